@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of the batched PursuitEvade hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the hot path over one batch: a single launch of the fused
+step kernel (pre-move reward, moves, catch resolution, observations, fused auto-reset)
+over `--envs` env instances per GPU (default 65 536 = BASELINE configs[1], PursuitEvade
+16x16, 8 pursuers / 30 evaders, obs_range 7, surround).  Inputs (the pursuer action
+tensors) are resident in HBM before the timed region starts; evader actions are drawn
+in-kernel (Philox).  N > 1: launched by torch.distributed.run, one rank per GPU, env
+index ranges sharded by rank (weak scaling), the compact trajectory (actions, rewards,
+dones) of the timed region is all-gathered over RCCL at the end, inside the timed region.
+
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` and
+`cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_env_step(P, E, D, rec_bytes):
+    """DESIGN.md "Algorithmic bytes": actions in, obs/rewards/done/removed out, packed state
+    record read + written once."""
+    return 4 * P + 4 * P * D + 4 * P + 1 + 4 + 2 * rec_bytes
+
+
+def cpu_baseline(maps, kw, budget_s=12.0):
+    """The C oracle (a port of the reference's algorithm) on the host cores, OpenMP over envs.
+    Bounded sample of the same workload: 4096 envs, free-running, ~budget_s seconds."""
+    import numpy as np
+    from oracle import pursuit as po
+    n = 4096
+    orc = po.PursuitOracle(maps, n_envs=n, seed=0, **kw)
+    orc.reset()
+    rng = np.random.RandomState(0)
+    acts = [rng.randint(5, size=(n, kw["n_pursuers"])).astype(np.int32) for _ in range(8)]
+    orc.step(acts[0])
+    t0 = time.time()
+    steps = 0
+    while time.time() - t0 < budget_s:
+        _, _, done, _ = orc.step(acts[steps % 8])
+        steps += 1
+        if steps % 500 == 0:
+            orc.reset()
+    dt = time.time() - t0
+    return dict(value=n * steps / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
+                sample="C oracle (oracle/pursuit_oracle.c, OpenMP), %d envs x %d steps, same config, %.1f s" % (n, steps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs", type=int, default=65536, help="env instances per GPU")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--horizon", type=int, default=500, help="max_path_length (runners/__init__.py:88)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from madrl_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with WORLD_SIZE=%d (got %d)" % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, P, E, R = args.envs, 8, 30, 7
+    maps = [rectangle_map(16, 16)]
+    kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, n_catch=2, surround=True, flatten=True, reward_mech="local")
+    env = BatchedPursuitEvade(maps, n_envs=N, device=dev, seed=0, env_id_base=rank * N, max_steps=args.horizon,
+                              auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw)
+    D = env.obs_dim
+    rec_bytes = env._state.numel() // N
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    n_act = 16
+    actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
+    K, W = args.steps, args.warmup
+    # compact trajectory of the timed region (what a sampler returns to the learner)
+    traj_act = torch.zeros((K, N, P), dtype=torch.uint8, device=dev)
+    traj_rew = torch.zeros((K, N, P), dtype=torch.float32, device=dev)
+    traj_done = torch.zeros((K, N), dtype=torch.uint8, device=dev)
+
+    L = _lib.lib()
+    h = env._handle
+    obs_p, rew_p, done_p, rem_p = (_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._removed))
+    act_p = [_lib.ptr(a) for a in actions]
+
+    def one_step(i, record):
+        _lib.check(L.madrl_pursuit_step(h, act_p[i % n_act], None, obs_p, rew_p, done_p, rem_p,
+                                        _lib.current_stream(dev)))
+        if record and world > 1:
+            traj_act[i].copy_(actions[i % n_act])
+            traj_rew[i].copy_(env._rew)
+            traj_done[i].copy_(env._done)
+
+    env.reset()
+    for i in range(W):
+        one_step(i, False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(K):
+        one_step(i, True)
+    ev1.record()  # events bracket exactly the K step launches on the launch stream
+    if world > 1:
+        from madrl_amd.dist import gather_trajectories
+        gathered = gather_trajectories(dict(actions=traj_act, rewards=traj_rew, dones=traj_done))
+        assert gathered["rewards"].shape[0] == world
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K  # average launch duration incl. inter-launch gaps
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
+        achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec at fixed batch (PursuitEvade 16x16, 8v30)",
+            "value": world * N * K / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
+            "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset)",
+            "config": {"workload": "PursuitEvade 16x16 rectangle_map, 8 pursuers / 30 evaders, obs_range 7, surround, "
+                                   "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (N, args.horizon),
+                       "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "pursuit_kernel<3>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_env_step": bytes_per},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(maps, kw)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

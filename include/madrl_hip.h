@@ -1,0 +1,144 @@
+/*
+ * madrl_hip.h -- C ABI of libmadrl_hip.so, the MI355X (gfx950) batched rollout
+ * engine for the sisl/MADRL environments.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its
+ * own -- it is pure Python -- so every entry point below replaces a *Python method*
+ * of the reference; the binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md (madrl_amd/_lib.py is that stub).  All buffers are plain device
+ * pointers (PyTorch tensors are only the transport), all sizes are explicit, no
+ * C++/torch types cross the boundary, nothing throws.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MADRL_E* code;
+ *     madrl_last_error() returns a thread-local message for the last failure;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work
+ *     is enqueued asynchronously, no host synchronisation inside reset/step;
+ *   - the caller owns every I/O and state buffer; the library owns only a small
+ *     host handle and a few KB of read-only device tables created in *_create;
+ *     no allocation happens in reset/step (graph-capture safe);
+ *   - a handle is not thread-safe; one handle per (process, device).
+ */
+#ifndef MADRL_HIP_H
+#define MADRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MADRL_ABI_VERSION 1
+
+#define MADRL_OK 0
+#define MADRL_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define MADRL_EHIP (-2)     /* a HIP runtime call failed */
+#define MADRL_ENOMEM (-3)
+
+int madrl_abi_version(void);
+const char *madrl_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * PursuitEvade  (reference: madrl_environments/pursuit/pursuit_evade.py)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Constructor kwargs of PursuitEvade.__init__ (pursuit_evade.py:49-148) plus the batching
+ * parameters.  Field names follow the reference kwargs. */
+typedef struct madrl_pursuit_config {
+    int32_t struct_size;   /* = sizeof(madrl_pursuit_config), ABI check */
+    int32_t xs, ys;        /* map_matrix.shape (:54) */
+    int32_t n_pursuers;    /* :61 */
+    int32_t n_evaders;     /* :60 */
+    int32_t obs_range;     /* :63 */
+    int32_t n_catch;       /* :79 */
+    int32_t surround;      /* :142 */
+    int32_t flatten;       /* :67  1: (3R^2[+1]) per agent, 0: (R,R,4) per agent */
+    int32_t include_id;    /* :100 */
+    int32_t reward_global; /* reward_mech == 'global' (:58, :260-261) */
+    int32_t sample_maps;   /* :49, :182-183 */
+    int32_t n_maps;        /* len(map_pool) */
+    int32_t max_steps;     /* 0 = none; else done bit1 is raised when the episode reaches it
+                              (the sampler's max_path_length, runners/__init__.py:88) */
+    int32_t auto_reset;    /* 1: an env whose step ends with done != 0 is reset inside the
+                              same launch and its obs row holds the new episode's first obs */
+    int32_t reserved0;
+    double catchr;            /* :92 */
+    double term_pursuit;      /* :95 */
+    double urgency_reward;    /* :98 */
+    double layer_norm;        /* :77 */
+    double constraint_window; /* :144 */
+    uint64_t seed;            /* Philox key (DESIGN.md "RNG contract") */
+    int64_t env_id_base;      /* global index of env 0 of this shard (multi-GPU: rank*n_envs) */
+} madrl_pursuit_config;
+
+typedef struct madrl_pursuit madrl_pursuit; /* opaque */
+
+/* Observation length per agent: 3R^2 (+1 with id) if flatten, else 4R^2
+ * (DiscreteAgent._obs_shape, utils/DiscreteAgent.py:50-53). */
+int madrl_pursuit_obs_dim(const madrl_pursuit_config *cfg, int32_t *out_dim);
+
+/* Bytes of packed per-env state the caller must allocate (and zero: an all-zero state is the
+ * reference's constructor state -- every agent at (0,0) on map 0, pursuit_evade.py:69-75). */
+int madrl_pursuit_state_bytes(const madrl_pursuit_config *cfg, int64_t n_envs, uint64_t *out_bytes);
+
+/* Replaces PursuitEvade.__init__ for n_envs instances.  map_pool_host: n_maps*xs*ys int8 on
+ * the HOST, row-major [map][x][y], 0 = free, -1 = building (utils/TwoDMaps.py:8-22).
+ * state_dev: device buffer of madrl_pursuit_state_bytes() bytes, zero-filled by the caller. */
+int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool_host,
+                         int64_t n_envs, int32_t device, void *state_dev, madrl_pursuit **out);
+void madrl_pursuit_destroy(madrl_pursuit *h);
+
+/* Launch shape: threads per workgroup (multiple of 64, 0 = heuristic) and the maximum number
+ * of workgroups (0 = one per env); workgroups stride over envs. */
+int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_blocks);
+
+/* Replaces PursuitEvade.reset (pursuit_evade.py:173-207) for every env with mask[n] != 0
+ * (mask_dev NULL = all).
+ *   inj_pos_dev  int32 [n_envs][P+E][2] or NULL: positions used instead of the rejection
+ *                sampler (agent_utils.py:31-47) -- parity harness hook, pursuers first;
+ *   inj_map_dev  int32 [n_envs] or NULL: map index used instead of the sample_maps draw;
+ *   obs_dev      float32 [n_envs][P][obs_dim], IN/OUT: this buffer is the reference's
+ *                persistent `local_obs` (pursuit_evade.py:119-120).  Cells of channels 1-2
+ *                that fall outside the map are left untouched, exactly as :438-439 leaves
+ *                them; pass the same zero-initialised buffer to every
+ *                reset/step call of a handle to get the reference's values. */
+int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t *inj_pos_dev,
+                        const int32_t *inj_map_dev, float *obs_dev, void *stream);
+
+/* Replaces PursuitEvade.step (pursuit_evade.py:209-262) for all envs.
+ *   actions_dev  int32 [n_envs][P], values 0..4 (utils/DiscreteAgent.py:28-38); anything
+ *                else is treated as 4 (stay) -- the reference raises IndexError instead;
+ *   inj_evader_actions_dev  int32 [n_envs][E] or NULL: entry k is the action of the k-th
+ *                REMAINING evader in layer order (one RandomPolicy.act per remaining evader,
+ *                pursuit_evade.py:238-241); NULL = in-kernel Philox draws;
+ *   obs_dev      as in reset (IN/OUT);
+ *   rew_dev      float32 [n_envs][P]  (computed in float64 like the reference, then rounded);
+ *   done_dev     uint8 [n_envs]: bit0 = is_terminal (:383-389), bit1 = max_steps reached;
+ *   removed_dev  int32 [n_envs]: info['removed'] (:261-262). */
+int madrl_pursuit_step(madrl_pursuit *h, const int32_t *actions_dev,
+                       const int32_t *inj_evader_actions_dev, float *obs_dev, float *rew_dev,
+                       uint8_t *done_dev, int32_t *removed_dev, void *stream);
+
+/* Unpacked view of the env state (device pointers; any may be NULL to skip).  This is the
+ * checkpoint / parity-injection hook (the reference pokes AgentLayer.set_position,
+ * pursuit/test_pursuit.py:22-51).  Evaders are in SLOT order; a removed evader has
+ * gone = 1 and position (-1,-1) on get.
+ *   pos_p int32 [N][P][2], pos_e int32 [N][E][2], gone uint8 [N][E],
+ *   term_p uint8 [N][P], term_e uint8 [N][E]  (DiscreteAgent.terminal, DiscreteAgent.py:45),
+ *   map_id int32 [N], tick uint32 [N] (RNG draw counter), t int32 [N] (episode step). */
+int madrl_pursuit_get_state(madrl_pursuit *h, int32_t *pos_p, int32_t *pos_e, uint8_t *gone,
+                            uint8_t *term_p, uint8_t *term_e, int32_t *map_id, uint32_t *tick,
+                            int32_t *t, void *stream);
+int madrl_pursuit_set_state(madrl_pursuit *h, const int32_t *pos_p, const int32_t *pos_e,
+                            const uint8_t *gone, const uint8_t *term_p, const uint8_t *term_e,
+                            const int32_t *map_id, const uint32_t *tick, const int32_t *t,
+                            void *stream);
+
+/* Philox4x32-10 on the host, exported so tests can pin the generator the kernels use
+ * against the published known-answer vectors. */
+void madrl_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADRL_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libmadrl_hip.so (include/madrl_hip.h).
+
+`import torch` happens BEFORE the library is dlopen'ed: PyTorch-ROCm bundles its own
+libamdhip64.so and the loader must reuse that already-mapped runtime, otherwise tensor
+data_ptr()s and torch's stream handles would not be valid inside our kernels
+("HIP runtime loading rule").
+
+There is no fallback: if the shared library is missing this module raises, and every
+environment class in madrl_amd fails loudly with it.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmadrl_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+
+class MadrlError(RuntimeError):
+    pass
+
+
+class PursuitConfig(C.Structure):
+    """mirror of madrl_pursuit_config (include/madrl_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "xs", "ys", "n_pursuers", "n_evaders", "obs_range", "n_catch", "surround",
+        "flatten", "include_id", "reward_global", "sample_maps", "n_maps", "max_steps",
+        "auto_reset", "reserved0")] + [(n, C.c_double) for n in (
+            "catchr", "term_pursuit", "urgency_reward", "layer_norm", "constraint_window")] + [
+                ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+
+
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); this table is also what tests use to check that the library
+# exports every symbol the header declares.
+SIGNATURES = {
+    "madrl_abi_version": (C.c_int, []),
+    "madrl_last_error": (C.c_char_p, []),
+    "madrl_philox4x32_10": (None, [_vp, _vp, _vp]),
+    "madrl_pursuit_obs_dim": (C.c_int, [_vp, _vp]),
+    "madrl_pursuit_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
+    "madrl_pursuit_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
+    "madrl_pursuit_destroy": (None, [_vp]),
+    "madrl_pursuit_set_launch": (C.c_int, [_vp, C.c_int32, C.c_int64]),
+    "madrl_pursuit_reset": (C.c_int, [_vp] * 6),
+    "madrl_pursuit_step": (C.c_int, [_vp] * 8),
+    "madrl_pursuit_get_state": (C.c_int, [_vp] * 10),
+    "madrl_pursuit_set_state": (C.c_int, [_vp] * 10),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise MadrlError(
+                "libmadrl_hip.so not found at %s -- build it with `python -m madrl_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if L.madrl_abi_version() != ABI_VERSION:
+            raise MadrlError("libmadrl_hip.so ABI %d != expected %d" % (L.madrl_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().madrl_last_error()
+        raise MadrlError("madrl error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor passed across the C ABI must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

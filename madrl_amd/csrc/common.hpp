@@ -1,0 +1,74 @@
+// common.hpp -- shared host/device helpers for libmadrl_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/madrl_hip.h"
+
+namespace madrl {
+
+// ---------------------------------------------------------------- error reporting
+char *last_error_buf();  // thread-local, defined in abi.hip
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define MADRL_HIP_TRY(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return ::madrl::fail(MADRL_EHIP, "%s failed: %s (%s:%d)", #expr,                 \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);                 \
+    } while (0)
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Counter-based generator (Salmon, Moraes, Dror, Shaw, SC'11).  One call = 4 x 32 random
+// bits addressed by (counter, key); no state to carry, so every (env, tick, agent) draw is
+// independent of launch shape and of the number of GPUs.
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+__host__ __device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// RNG contract tags: counter = (global env id, tick, index, tag | attempt << 8)
+enum : uint32_t { TAG_EVADER_ACT = 0, TAG_RESET_POS = 1, TAG_RESET_ENV = 2 };
+
+// uniform double in [0,1) from 53 random bits
+__host__ __device__ inline double u53(uint32_t hi, uint32_t lo) {
+    return (double)(((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace madrl

@@ -1,0 +1,796 @@
+// pursuit.hip -- batched PursuitEvade for MI355X (gfx950 / CDNA4).
+//
+// One workgroup owns one env instance at a time (workgroups stride over envs).  All of an
+// env's mutable state -- agent positions, alive/terminal bitmasks, the three observation
+// layers (map / pursuer counts / evader counts) as PADDED byte grids -- is staged in LDS;
+// HBM sees exactly one packed state record in, one record out, the action row in, and the
+// observation / reward / done rows out.  There is no dense contraction anywhere: this kernel
+// is HBM-write bound (the observation row is 94 % of the bytes), so the design
+// goals are (1) fully coalesced observation stores, (2) few instructions per stored dword,
+// (3) enough resident waves (64-thread workgroups, <4 KB LDS) to cover store latency.
+//
+// Reference semantics (file:line under /root/reference/madrl_environments/pursuit):
+//   step order ............... pursuit_evade.py:209-262      (A.1 in SURVEY.md)
+//   pre-move proximity reward  pursuit_evade.py:359-381
+//   agent motion ............. utils/DiscreteAgent.py:69-97
+//   catch resolution ......... pursuit_evade.py:463-521, need_to_surround :523-540
+//   observations ............. pursuit_evade.py:418-461 (stale out-of-map cells kept: the
+//                              obs buffer is IN/OUT and those cells are simply not stored)
+//   reset .................... pursuit_evade.py:173-207, utils/agent_utils.py:12-47
+#include "common.hpp"
+
+#include <new>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+using namespace madrl;
+
+// slot-code kinds (one code per element of an agent's observation row, built on the host)
+enum : uint32_t { K_GRID = 0, K_ID = 1, K_FILL = 2, K_SKIP = 3 };
+
+constexpr uint32_t PAD_MAP = 0xFEu;  // map layer outside the map  -> vtab[0xFE] = 1/layer_norm
+constexpr uint32_t PAD_CNT = 0xFFu;  // count layers outside the map -> "do not store" (Q2)
+constexpr int MAX_COUNT = 253;       // byte grids: per-cell agent counts must stay < PAD_MAP
+
+struct PursuitDev {
+    int32_t xs, ys, P, E, A, R, D;
+    int32_t pad, GW, GSZ;  // padded grid: width (y extent), bytes per layer (multiple of 16)
+    int32_t n_catch, surround, reward_global, sample_maps, n_maps, max_steps, auto_reset;
+    int32_t rec_bytes, off_gone, off_term, ngw, ntw;  // state record layout (byte offsets)
+    int32_t map_stride;                               // bytes per map entry in `maps`
+    uint32_t k0, k1, gid_base;
+    float fill32;
+    double catchr, term_pursuit, urgency, cw;
+    int64_t n_envs;
+    const uint8_t *maps;     // per map: padded wall layer [GSZ] then need_to_surround [xs*ys]
+    const uint8_t *cnt_tmpl; // padded count-layer template [GSZ]: 0 inside, 0xFF outside
+    const float *vtab;       // 256 floats: fl32(k / layer_norm), [0xFE] = fl32(1.0 / layer_norm)
+    const uint32_t *codes;   // D slot codes
+    uint8_t *state;
+};
+
+struct PursuitIO {
+    const uint8_t *mask;       // reset mode
+    const int32_t *inj_pos;    // reset mode
+    const int32_t *inj_map;    // reset mode
+    const int32_t *actions;    // step mode
+    const int32_t *inj_eact;   // step mode
+    float *obs;
+    float *rew;
+    uint8_t *done;
+    int32_t *removed;
+};
+
+// state record: [u32 tick][u32 t][u32 map_id][u32 spare][u8 xy[2A]][u32 gone[ngw]][u32 term[ntw]]
+constexpr int HDR_BYTES = 16;
+
+__device__ __forceinline__ void lds_byte_add(uint8_t *grid, int idx) {
+    atomicAdd(reinterpret_cast<unsigned *>(grid + (idx & ~3)), 1u << (8 * (idx & 3)));
+}
+__device__ __forceinline__ void lds_byte_sub(uint8_t *grid, int idx) {
+    atomicSub(reinterpret_cast<unsigned *>(grid + (idx & ~3)), 1u << (8 * (idx & 3)));
+}
+
+// numpy float64 add.reduce order (pairwise, 8-way unrolled base case), used by
+// `rewards.mean()` at pursuit_evade.py:261.  Base case: 8 <= n <= 128 (or n < 8).
+__device__ __forceinline__ double np_pairwise_base(const double *a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+// n <= 256 (n_pursuers <= 253): at most one level of numpy's recursive split
+__device__ __forceinline__ double np_pairwise_sum(const double *a, int n) {
+    if (n <= 128) return np_pairwise_base(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_base(a, n2) + np_pairwise_base(a + n2, n - n2);
+}
+
+// mode 0: reset(mask)   mode 1: step (+ fused auto-reset)
+template <int NT>
+__global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+
+    // ---- LDS carve (all offsets multiples of 16)
+    float *s_vtab = reinterpret_cast<float *>(smem);                   // 256 floats
+    uint8_t *g_map = smem + 1024;                                      // 3 layers, contiguous:
+    uint8_t *g_pc = g_map + d.GSZ;                                     //   map | pursuers | evaders
+    uint8_t *g_ec = g_pc + d.GSZ;
+    uint8_t *g_cr = g_ec + d.GSZ;                                      // credit layer (purs_sur)
+    const int A16 = (d.A + 15) & ~15;
+    uint8_t *s_ax = g_cr + d.GSZ;
+    uint8_t *s_ay = s_ax + A16;
+    uint32_t *s_gone = reinterpret_cast<uint32_t *>(s_ay + A16);       // ngw words
+    uint32_t *s_term = s_gone + ((d.ngw + 3) & ~3);                    // ntw words
+    uint32_t *s_misc = s_term + ((d.ntw + 3) & ~3);                    // [0..3] header, [4] removed
+    int32_t *s_kpre = reinterpret_cast<int32_t *>(s_misc + 8);         // P ints (pre-move counts)
+    double *s_rew = reinterpret_cast<double *>(s_kpre + ((d.P + 3) & ~3));  // P doubles
+
+    // ---- once per workgroup: value table and this thread's observation slot codes
+    for (int k = tid; k < 256; k += nthr) s_vtab[k] = d.vtab[k];
+    uint32_t code[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int r = tid + t * nthr;
+        code[t] = (r < d.D) ? d.codes[r] : (K_SKIP << 24);
+    }
+    const int GW = d.GW, pad = d.pad, GSZ = d.GSZ;
+    const int obs_off = (d.R - 1) / 2;  // pursuit_evade.py:65
+    const int gsz_words = GSZ >> 2;
+    int cached_map = -1;
+
+    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
+        if (mode == 0 && io.mask != nullptr && io.mask[env] == 0) continue;  // block-uniform
+        uint8_t *rec = d.state + env * (int64_t)d.rec_bytes;
+        __syncthreads();  // previous env's LDS reads are finished
+        // ------------------------------------------------------------ load state record
+        if (tid < 4) s_misc[tid] = reinterpret_cast<const uint32_t *>(rec)[tid];
+        if (tid == 4) s_misc[4] = 0;
+        for (int a = tid; a < d.A; a += nthr) {
+            const uint32_t xy = reinterpret_cast<const uint16_t *>(rec + HDR_BYTES)[a];
+            s_ax[a] = (uint8_t)(xy & 0xFF);
+            s_ay[a] = (uint8_t)(xy >> 8);
+        }
+        for (int w = tid; w < d.ngw; w += nthr)
+            s_gone[w] = reinterpret_cast<const uint32_t *>(rec + d.off_gone)[w];
+        for (int w = tid; w < d.ntw; w += nthr)
+            s_term[w] = reinterpret_cast<const uint32_t *>(rec + d.off_term)[w];
+        __syncthreads();
+        uint32_t tick = s_misc[0];
+        int32_t tstep = (int32_t)s_misc[1];
+        int32_t map_id = (int32_t)s_misc[2];
+        const uint32_t gid = d.gid_base + (uint32_t)env;
+        bool do_reset = (mode == 0);
+        uint32_t done_bits = 0;
+
+        // -------------------------------------------------------------- observations (:418-461)
+        // Element r of pursuer p's row: code[] says which padded-grid byte (relative to the
+        // window origin) feeds it.  Stores are lane-contiguous dwords; cells of the count
+        // layers outside the map read 0xFF and are NOT stored (reference leaves them stale).
+        auto write_obs = [&]() {
+            float *orow = io.obs + env * (int64_t)d.P * d.D;
+            for (int p = 0; p < d.P; ++p) {
+                const int base = (s_ax[p] - obs_off + pad) * GW + (s_ay[p] - obs_off + pad);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int r = tid + t * nthr;
+                    const uint32_t kind = code[t] >> 24;
+                    if (kind == K_GRID) {
+                        const uint32_t v = g_map[base + (int)(code[t] & 0xFFFFFFu)];
+                        if (v != PAD_CNT) orow[p * d.D + r] = s_vtab[v];
+                    } else if (kind == K_ID) {
+                        orow[p * d.D + r] = (float)((double)p / (double)d.P);  // :440-445
+                    } else if (kind == K_FILL) {
+                        orow[p * d.D + r] = d.fill32;  // even obs_range: never-copied channel-0 cells
+                    }
+                }
+            }
+        };
+
+
+        if (mode == 1) {
+            // -------------------------------------------------------- grids for this env
+            {
+                const uint32_t *mt = reinterpret_cast<const uint32_t *>(d.maps + (int64_t)map_id * d.map_stride);
+                const uint32_t *ct = reinterpret_cast<const uint32_t *>(d.cnt_tmpl);
+                for (int k = tid; k < gsz_words; k += nthr) {
+                    if (cached_map != map_id) reinterpret_cast<uint32_t *>(g_map)[k] = mt[k];
+                    const uint32_t c = ct[k];
+                    reinterpret_cast<uint32_t *>(g_pc)[k] = c;
+                    reinterpret_cast<uint32_t *>(g_ec)[k] = c;
+                    reinterpret_cast<uint32_t *>(g_cr)[k] = 0u;
+                }
+                cached_map = map_id;
+            }
+            __syncthreads();
+            // -------------------------------------------------------- pre-move evader counts (:364-365)
+            for (int i = tid; i < d.E; i += nthr) {
+                if (!((s_gone[i >> 5] >> (i & 31)) & 1u))
+                    lds_byte_add(g_ec, (s_ax[d.P + i] + pad) * GW + s_ay[d.P + i] + pad);
+            }
+            __syncthreads();
+            // proximity reward on the PRE-move state, np.clip keeps border pursuers on their
+            // own cell (pursuit_evade.py:374-380)
+            for (int p = tid; p < d.P; p += nthr) {
+                const int x = s_ax[p], y = s_ay[p];
+                const int xm = max(x - 1, 0), xp = min(x + 1, d.xs - 1);
+                const int ym = max(y - 1, 0), yp = min(y + 1, d.ys - 1);
+                s_kpre[p] = (int)g_ec[(xm + pad) * GW + y + pad] + (int)g_ec[(xp + pad) * GW + y + pad] +
+                            (int)g_ec[(x + pad) * GW + yp + pad] + (int)g_ec[(x + pad) * GW + ym + pad];
+            }
+            __syncthreads();
+            // -------------------------------------------------------- moves (:229-241)
+            for (int a = tid; a < d.A; a += nthr) {
+                const bool is_p = a < d.P;
+                const int i = a - d.P;
+                if (!is_p && ((s_gone[i >> 5] >> (i & 31)) & 1u)) continue;
+                int x = s_ax[a], y = s_ay[a];
+                int act;
+                if (is_p) {
+                    act = io.actions[env * d.P + a];
+                } else {
+                    lds_byte_sub(g_ec, (x + pad) * GW + y + pad);  // undo the pre-move count
+                    // k = index in the evader LAYER = alive evaders in slots below i
+                    int k = 0;
+                    for (int w = 0; w < (i >> 5); ++w) k += 32 - __popc(s_gone[w]);
+                    k += (i & 31) - __popc(s_gone[i >> 5] & ((1u << (i & 31)) - 1u));
+                    if (io.inj_eact != nullptr) {
+                        act = io.inj_eact[env * d.E + k];
+                    } else {
+                        const u32x4 r = philox4x32_10(gid, tick, (uint32_t)k, TAG_EVADER_ACT, d.k0, d.k1);
+                        act = (int)__umulhi(r.x, 5u);  // RandomPolicy.act, Controllers.py:15-16
+                    }
+                }
+                // DiscreteAgent.step, DiscreteAgent.py:69-97
+                const bool term = (s_term[a >> 5] >> (a & 31)) & 1u;
+                if (!term) {
+                    if (g_map[(x + pad) * GW + y + pad] == 1) {
+                        atomicOr(&s_term[a >> 5], 1u << (a & 31));  // standing in a building
+                    } else {
+                        int nx = x, ny = y;
+                        if (act == 0) nx = x - 1;
+                        else if (act == 1) nx = x + 1;
+                        else if (act == 2) ny = y + 1;
+                        else if (act == 3) ny = y - 1;
+                        // padded map layer: 0 = free, 1 = building, 0xFE = outside the map
+                        if (g_map[(nx + pad) * GW + ny + pad] == 0) {
+                            x = nx;
+                            y = ny;
+                        }
+                    }
+                }
+                s_ax[a] = (uint8_t)x;
+                s_ay[a] = (uint8_t)y;
+                lds_byte_add(is_p ? g_pc : g_ec, (x + pad) * GW + y + pad);  // :244-246
+            }
+            __syncthreads();
+            // -------------------------------------------------------- catch resolution (:463-521)
+            const uint8_t *need_tab = d.maps + (int64_t)map_id * d.map_stride + GSZ;
+            for (int i = tid; i < d.E; i += nthr) {
+                if ((s_gone[i >> 5] >> (i & 31)) & 1u) continue;
+                const int x = s_ax[d.P + i], y = s_ay[d.P + i];
+                const int c0 = (x + pad) * GW + y + pad;
+                bool caught;
+                if (d.surround) {
+                    // neighbour order of surround_mask (:150); pad cells hold 0xFF => never a hit
+                    const bool h0 = (uint8_t)(g_pc[c0 - GW] - 1) < 0xFEu;
+                    const bool h1 = (uint8_t)(g_pc[c0 + GW] - 1) < 0xFEu;
+                    const bool h2 = (uint8_t)(g_pc[c0 + 1] - 1) < 0xFEu;
+                    const bool h3 = (uint8_t)(g_pc[c0 - 1] - 1) < 0xFEu;
+                    const int cnt = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+                    caught = (cnt == (int)need_tab[x * d.ys + y]);  // need_to_surround :523-540
+                    if (caught) {  // pursuers standing on a matched neighbour get credit (:489-495)
+                        if (h0) g_cr[c0 - GW] = 1;
+                        if (h1) g_cr[c0 + GW] = 1;
+                        if (h2) g_cr[c0 + 1] = 1;
+                        if (h3) g_cr[c0 - 1] = 1;
+                    }
+                } else {
+                    caught = (int)g_pc[c0] >= d.n_catch;  // :498
+                    if (caught) g_cr[c0] = 1;             // :503-506
+                }
+                if (caught) {
+                    atomicOr(&s_gone[i >> 5], 1u << (i & 31));
+                    atomicAdd(&s_misc[4], 1u);
+                }
+            }
+            __syncthreads();
+            // -------------------------------------------------------- rewards (:254-262)
+            int n_alive = d.E;
+            for (int w = 0; w < d.ngw; ++w) n_alive -= __popc(s_gone[w]);
+            for (int p = tid; p < d.P; p += nthr) {
+                const int sur = g_cr[(s_ax[p] + pad) * GW + s_ay[p] + pad];
+                double r = d.catchr * (double)s_kpre[p];
+                r += d.term_pursuit * (sur ? 1.0 : 0.0);
+                r += d.urgency;
+                if (d.reward_global) s_rew[p] = r;
+                else io.rew[env * d.P + p] = (float)r;
+            }
+            if (d.reward_global) {
+                __syncthreads();
+                if (tid < d.P) {
+                    const double m = np_pairwise_sum(s_rew, d.P) / (double)d.P;
+                    for (int p = tid; p < d.P; p += nthr) io.rew[env * d.P + p] = (float)m;
+                }
+            }
+            tick += 1;
+            tstep += 1;
+            if (n_alive == 0) done_bits |= 1u;                               // :383-389
+            if (d.max_steps > 0 && tstep >= d.max_steps) done_bits |= 2u;
+            if (tid == 0) {
+                io.done[env] = (uint8_t)done_bits;
+                io.removed[env] = (int32_t)s_misc[4];
+            }
+            do_reset = d.auto_reset && done_bits != 0;
+        }
+
+        if (mode == 1 && do_reset) {
+            // auto-reset: the reference sequence is step() then reset(); both write the persistent
+            // observation buffer, and cells the second write skips keep the first one's values
+            write_obs();
+            __syncthreads();
+        }
+        if (do_reset) {
+            // ---------------------------------------------------------- reset (:173-207)
+            __syncthreads();
+            for (int w = tid; w < d.ngw; w += nthr) s_gone[w] = 0u;  // :175-176
+            for (int w = tid; w < d.ntw; w += nthr) s_term[w] = 0u;  // fresh agents
+            if (io.inj_map != nullptr && mode == 0) {
+                map_id = io.inj_map[env];
+            } else if (d.sample_maps) {  // :182-183
+                const u32x4 r = philox4x32_10(gid, tick, 0u, TAG_RESET_ENV, d.k0, d.k1);
+                map_id = (int)__umulhi(r.x, (uint32_t)d.n_maps);
+            }
+            {
+                const uint32_t *mt = reinterpret_cast<const uint32_t *>(d.maps + (int64_t)map_id * d.map_stride);
+                const uint32_t *ct = reinterpret_cast<const uint32_t *>(d.cnt_tmpl);
+                for (int k = tid; k < gsz_words; k += nthr) {
+                    if (cached_map != map_id) reinterpret_cast<uint32_t *>(g_map)[k] = mt[k];
+                    const uint32_t c = ct[k];
+                    reinterpret_cast<uint32_t *>(g_pc)[k] = c;
+                    reinterpret_cast<uint32_t *>(g_ec)[k] = c;
+                }
+                cached_map = map_id;
+            }
+            // constraint window (:185-191), float64 like the reference
+            const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, d.k0, d.k1);
+            const double sx = u53(rw.x, rw.y) * (1.0 - d.cw);
+            const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
+            const int xlb = (int)(d.xs * sx), xub = (int)(d.xs * (sx + d.cw));
+            const int ylb = (int)(d.ys * sy), yub = (int)(d.ys * (sy + d.cw));
+            __syncthreads();
+            for (int a = tid; a < d.A; a += nthr) {  // create_agents, agent_utils.py:12-28
+                int x = 0, y = 0;
+                if (io.inj_pos != nullptr && mode == 0) {
+                    x = io.inj_pos[(env * d.A + a) * 2];
+                    y = io.inj_pos[(env * d.A + a) * 2 + 1];
+                } else {
+                    // feasible_position: rejection sampling (agent_utils.py:37-47); bounded
+                    for (uint32_t att = 0; att < 1024u; ++att) {
+                        const u32x4 r = philox4x32_10(gid, tick, (uint32_t)a, TAG_RESET_POS | (att << 8), d.k0, d.k1);
+                        x = xlb + (int)__umulhi(r.x, (uint32_t)(xub - xlb));
+                        y = ylb + (int)__umulhi(r.y, (uint32_t)(yub - ylb));
+                        if (g_map[(x + pad) * GW + y + pad] != 1) break;
+                    }
+                }
+                s_ax[a] = (uint8_t)x;
+                s_ay[a] = (uint8_t)y;
+                lds_byte_add(a < d.P ? g_pc : g_ec, (x + pad) * GW + y + pad);  // :201-203
+            }
+            tick += 1;
+            tstep = 0;
+            __syncthreads();
+        }
+
+        write_obs();
+        // -------------------------------------------------------------- store state record
+        for (int a = tid; a < d.A; a += nthr)
+            reinterpret_cast<uint16_t *>(rec + HDR_BYTES)[a] = (uint16_t)(s_ax[a] | (s_ay[a] << 8));
+        for (int w = tid; w < d.ngw; w += nthr) reinterpret_cast<uint32_t *>(rec + d.off_gone)[w] = s_gone[w];
+        for (int w = tid; w < d.ntw; w += nthr) reinterpret_cast<uint32_t *>(rec + d.off_term)[w] = s_term[w];
+        if (tid == 0) {
+            uint32_t *h = reinterpret_cast<uint32_t *>(rec);
+            h[0] = tick;
+            h[1] = (uint32_t)tstep;
+            h[2] = (uint32_t)map_id;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ state (un)packing
+__global__ void pursuit_get_state_kernel(const PursuitDev d, int32_t *pos_p, int32_t *pos_e, uint8_t *gone,
+                                         uint8_t *term_p, uint8_t *term_e, int32_t *map_id, uint32_t *tick,
+                                         int32_t *t) {
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    const uint8_t *rec = d.state + env * (int64_t)d.rec_bytes;
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(rec);
+    const uint8_t *xy = rec + HDR_BYTES;
+    const uint32_t *gw = reinterpret_cast<const uint32_t *>(rec + d.off_gone);
+    const uint32_t *tw = reinterpret_cast<const uint32_t *>(rec + d.off_term);
+    if (tick) tick[env] = h[0];
+    if (t) t[env] = (int32_t)h[1];
+    if (map_id) map_id[env] = (int32_t)h[2];
+    for (int p = 0; p < d.P; ++p) {
+        if (pos_p) {
+            pos_p[(env * d.P + p) * 2] = xy[2 * p];
+            pos_p[(env * d.P + p) * 2 + 1] = xy[2 * p + 1];
+        }
+        if (term_p) term_p[env * d.P + p] = (tw[p >> 5] >> (p & 31)) & 1u;
+    }
+    for (int i = 0; i < d.E; ++i) {
+        const uint32_t g = (gw[i >> 5] >> (i & 31)) & 1u;
+        const int a = d.P + i;
+        if (gone) gone[env * d.E + i] = (uint8_t)g;
+        if (pos_e) {
+            pos_e[(env * d.E + i) * 2] = g ? -1 : (int32_t)xy[2 * a];
+            pos_e[(env * d.E + i) * 2 + 1] = g ? -1 : (int32_t)xy[2 * a + 1];
+        }
+        if (term_e) term_e[env * d.E + i] = g ? 0 : (uint8_t)((tw[a >> 5] >> (a & 31)) & 1u);
+    }
+}
+
+__global__ void pursuit_set_state_kernel(const PursuitDev d, const int32_t *pos_p, const int32_t *pos_e,
+                                         const uint8_t *gone, const uint8_t *term_p, const uint8_t *term_e,
+                                         const int32_t *map_id, const uint32_t *tick, const int32_t *t) {
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    uint8_t *rec = d.state + env * (int64_t)d.rec_bytes;
+    uint32_t *h = reinterpret_cast<uint32_t *>(rec);
+    uint8_t *xy = rec + HDR_BYTES;
+    uint32_t *gw = reinterpret_cast<uint32_t *>(rec + d.off_gone);
+    uint32_t *tw = reinterpret_cast<uint32_t *>(rec + d.off_term);
+    if (tick) h[0] = tick[env];
+    if (t) h[1] = (uint32_t)t[env];
+    if (map_id) h[2] = (uint32_t)map_id[env];
+    for (int p = 0; p < d.P; ++p) {
+        if (pos_p) {
+            xy[2 * p] = (uint8_t)pos_p[(env * d.P + p) * 2];
+            xy[2 * p + 1] = (uint8_t)pos_p[(env * d.P + p) * 2 + 1];
+        }
+        if (term_p) {
+            if (term_p[env * d.P + p]) tw[p >> 5] |= 1u << (p & 31);
+            else tw[p >> 5] &= ~(1u << (p & 31));
+        }
+    }
+    for (int i = 0; i < d.E; ++i) {
+        const int a = d.P + i;
+        bool g = (gw[i >> 5] >> (i & 31)) & 1u;
+        if (gone) {
+            g = gone[env * d.E + i] != 0;
+            if (g) gw[i >> 5] |= 1u << (i & 31);
+            else gw[i >> 5] &= ~(1u << (i & 31));
+        }
+        if (pos_e && !g) {
+            xy[2 * a] = (uint8_t)pos_e[(env * d.E + i) * 2];
+            xy[2 * a + 1] = (uint8_t)pos_e[(env * d.E + i) * 2 + 1];
+        }
+        if (term_e) {
+            if (term_e[env * d.E + i] && !g) tw[a >> 5] |= 1u << (a & 31);
+            else tw[a >> 5] &= ~(1u << (a & 31));
+        }
+    }
+}
+
+}  // namespace
+
+// =================================================================== host side / C ABI
+struct madrl_pursuit {
+    madrl_pursuit_config cfg;
+    PursuitDev dev;
+    int device;
+    int threads;
+    int nt;
+    int64_t max_blocks;
+    size_t lds_bytes;
+    void *tables;  // one device allocation holding maps | cnt_tmpl | vtab | codes
+};
+
+namespace {
+
+int validate(const madrl_pursuit_config *c) {
+    if (!c) return fail(MADRL_EINVAL, "config is NULL");
+    if (c->struct_size != (int32_t)sizeof(madrl_pursuit_config))
+        return fail(MADRL_EINVAL, "madrl_pursuit_config.struct_size=%d, library expects %d", c->struct_size,
+                    (int)sizeof(madrl_pursuit_config));
+    if (c->xs < 1 || c->ys < 1 || c->xs > 255 || c->ys > 255)
+        return fail(MADRL_EINVAL, "map size %dx%d unsupported (1..255)", c->xs, c->ys);
+    if (c->n_pursuers < 1 || c->n_evaders < 0 || c->n_pursuers > MAX_COUNT || c->n_evaders > MAX_COUNT)
+        return fail(MADRL_EINVAL, "n_pursuers=%d n_evaders=%d unsupported (pursuers 1..%d, evaders 0..%d: "
+                    "byte count grids)", c->n_pursuers, c->n_evaders, MAX_COUNT, MAX_COUNT);
+    if (c->obs_range < 1 || c->obs_range > 63) return fail(MADRL_EINVAL, "obs_range=%d unsupported", c->obs_range);
+    if (c->n_maps < 1) return fail(MADRL_EINVAL, "n_maps must be >= 1");
+    if (!(c->layer_norm > 0.0)) return fail(MADRL_EINVAL, "layer_norm must be > 0");
+    if (!(c->constraint_window > 0.0 && c->constraint_window <= 1.0))
+        return fail(MADRL_EINVAL, "constraint_window must be in (0,1]");
+    return MADRL_OK;
+}
+
+int obs_dim_of(const madrl_pursuit_config *c) {
+    const int R = c->obs_range;
+    return c->flatten ? 3 * R * R + (c->include_id ? 1 : 0) : 4 * R * R;
+}
+
+void layout(const madrl_pursuit_config *c, PursuitDev *d) {
+    memset(d, 0, sizeof(*d));
+    d->xs = c->xs; d->ys = c->ys; d->P = c->n_pursuers; d->E = c->n_evaders; d->A = d->P + d->E;
+    d->R = c->obs_range; d->D = obs_dim_of(c);
+    const int off = (c->obs_range - 1) / 2;
+    d->pad = off > 1 ? off : 1;
+    d->GW = c->ys + 2 * d->pad;
+    d->GSZ = (int)align_up((size_t)(c->xs + 2 * d->pad) * d->GW, 16);
+    d->n_catch = c->n_catch; d->surround = c->surround; d->reward_global = c->reward_global;
+    d->sample_maps = c->sample_maps; d->n_maps = c->n_maps; d->max_steps = c->max_steps;
+    d->auto_reset = c->auto_reset;
+    d->ngw = (d->E + 31) / 32; if (d->ngw < 1) d->ngw = 1;
+    d->ntw = (d->A + 31) / 32;
+    d->off_gone = (int)align_up(HDR_BYTES + 2 * (size_t)d->A, 4);
+    d->off_term = d->off_gone + 4 * d->ngw;
+    d->rec_bytes = (int)align_up((size_t)d->off_term + 4 * d->ntw, 16);
+    d->map_stride = (int)align_up((size_t)d->GSZ + (size_t)c->xs * c->ys, 16);
+    d->k0 = (uint32_t)c->seed; d->k1 = (uint32_t)(c->seed >> 32);
+    d->gid_base = (uint32_t)c->env_id_base;
+    d->catchr = c->catchr; d->term_pursuit = c->term_pursuit; d->urgency = c->urgency_reward;
+    d->cw = c->constraint_window;
+    d->fill32 = (float)(1.0 / c->layer_norm);  // local_obs[..][0].fill(1.0 / layer_norm), :433
+}
+
+// need_to_surround(x, y), pursuit_evade.py:523-540, tabulated per map cell
+int need_to_surround(const int8_t *map, int xs, int ys, int x, int y) {
+    static const int mx[4] = {-1, 1, 0, 0}, my[4] = {0, 0, 1, -1};
+    int tosur = 4;
+    if (x == 0 || x == xs - 1) tosur -= 1;
+    if (y == 0 || y == ys - 1) tosur -= 1;
+    for (int m = 0; m < 4; ++m) {
+        const int xn = x + mx[m], yn = y + my[m];
+        if (!(0 < xn && xn < xs) || !(0 < yn && yn < ys)) continue;  // sic: row/col 0 skipped
+        if (map[xn * ys + yn] == -1) tosur -= 1;
+    }
+    return tosur;
+}
+
+size_t lds_bytes_for(const PursuitDev &d) {
+    size_t b = 1024 + 4 * (size_t)d.GSZ;
+    b += 2 * align_up((size_t)d.A, 16);
+    b += 4 * align_up((size_t)d.ngw, 4) + 4 * align_up((size_t)d.ntw, 4) + 32;
+    b += 4 * align_up((size_t)d.P, 4);
+    b = align_up(b, 8);
+    b += 8 * (size_t)d.P;
+    return align_up(b, 16);
+}
+
+template <int NT>
+void launch_nt(const madrl_pursuit *h, const PursuitIO &io, int mode, hipStream_t s) {
+    int64_t blocks = h->dev.n_envs;
+    if (h->max_blocks > 0 && blocks > h->max_blocks) blocks = h->max_blocks;
+    hipLaunchKernelGGL(pursuit_kernel<NT>, dim3((unsigned)blocks), dim3((unsigned)h->threads), h->lds_bytes, s,
+                       h->dev, io, mode);
+}
+
+int launch(const madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    switch (h->nt) {
+        case 1: launch_nt<1>(h, io, mode, s); break;
+        case 2: launch_nt<2>(h, io, mode, s); break;
+        case 3: launch_nt<3>(h, io, mode, s); break;
+        case 4: launch_nt<4>(h, io, mode, s); break;
+        case 5: launch_nt<5>(h, io, mode, s); break;
+        case 6: launch_nt<6>(h, io, mode, s); break;
+        case 7: launch_nt<7>(h, io, mode, s); break;
+        case 8: launch_nt<8>(h, io, mode, s); break;
+        default: return fail(MADRL_EINVAL, "internal: nt=%d", h->nt);
+    }
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int pick_threads(const PursuitDev &d, int requested) {
+    int thr = requested;
+    if (thr <= 0) {
+        thr = 64;
+        while (thr < 1024 && (d.A > thr || (d.D + thr - 1) / thr > 4)) thr += 64;
+    }
+    return thr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int madrl_pursuit_obs_dim(const madrl_pursuit_config *cfg, int32_t *out_dim) {
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (!out_dim) return fail(MADRL_EINVAL, "out_dim is NULL");
+    *out_dim = obs_dim_of(cfg);
+    return MADRL_OK;
+}
+
+int madrl_pursuit_state_bytes(const madrl_pursuit_config *cfg, int64_t n_envs, uint64_t *out_bytes) {
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (n_envs < 1 || !out_bytes) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_bytes non-NULL");
+    PursuitDev d;
+    layout(cfg, &d);
+    *out_bytes = (uint64_t)d.rec_bytes * (uint64_t)n_envs;
+    return MADRL_OK;
+}
+
+int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool_host, int64_t n_envs,
+                         int32_t device, void *state_dev, madrl_pursuit **out) {
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (!map_pool_host || !state_dev || !out || n_envs < 1)
+        return fail(MADRL_EINVAL, "create: NULL argument or n_envs < 1");
+    if (n_envs + cfg->env_id_base > 0xFFFFFFFFll)
+        return fail(MADRL_EINVAL, "global env index must fit 32 bits");
+    MADRL_HIP_TRY(hipSetDevice(device));
+    madrl_pursuit *h = new (std::nothrow) madrl_pursuit();
+    if (!h) return fail(MADRL_ENOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    layout(cfg, &h->dev);
+    PursuitDev &d = h->dev;
+    d.n_envs = n_envs;
+    d.state = (uint8_t *)state_dev;
+    const int xs = d.xs, ys = d.ys, pad = d.pad, GW = d.GW;
+    const size_t cells = (size_t)xs * ys;
+
+    // ---- host-side tables
+    const size_t maps_bytes = (size_t)d.map_stride * d.n_maps;
+    const size_t off_cnt = align_up(maps_bytes, 16);
+    const size_t off_vtab = align_up(off_cnt + d.GSZ, 16);
+    const size_t off_codes = off_vtab + 256 * sizeof(float);
+    const size_t total = align_up(off_codes + sizeof(uint32_t) * d.D, 16);
+    std::vector<uint8_t> host(total, 0);
+    for (int m = 0; m < d.n_maps; ++m) {
+        const int8_t *map = map_pool_host + (size_t)m * cells;
+        uint8_t *wall = host.data() + (size_t)m * d.map_stride;
+        uint8_t *need = wall + d.GSZ;
+        memset(wall, PAD_MAP, d.GSZ);
+        for (int x = 0; x < xs; ++x)
+            for (int y = 0; y < ys; ++y) {
+                const int8_t v = map[x * ys + y];
+                if (v != 0 && v != -1) {
+                    delete h;
+                    return fail(MADRL_EINVAL, "map %d cell (%d,%d) = %d, expected 0 or -1", m, x, y, (int)v);
+                }
+                wall[(x + pad) * GW + y + pad] = (v == -1) ? 1 : 0;
+                need[x * ys + y] = (uint8_t)need_to_surround(map, xs, ys, x, y);
+            }
+    }
+    {
+        uint8_t *ct = host.data() + off_cnt;
+        memset(ct, PAD_CNT, d.GSZ);
+        for (int x = 0; x < xs; ++x)
+            for (int y = 0; y < ys; ++y) ct[(x + pad) * GW + y + pad] = 0;
+    }
+    {
+        // np.abs(model_state) / layer_norm is float32 / weak python scalar -> float32 (:438-439)
+        float *vt = reinterpret_cast<float *>(host.data() + off_vtab);
+        const float norm32 = (float)cfg->layer_norm;
+        for (int k = 0; k < 256; ++k) vt[k] = (float)k / norm32;
+        vt[PAD_MAP] = d.fill32;
+        vt[PAD_CNT] = 0.0f;
+    }
+    {
+        // slot codes: which padded-grid byte (relative to the window origin) feeds element r
+        uint32_t *codes = reinterpret_cast<uint32_t *>(host.data() + off_codes);
+        const int R = d.R, off = (R - 1) / 2, W = 2 * off + 1;  // W: copied window width (:451-461)
+        for (int r = 0; r < d.D; ++r) {
+            int c, i, j;
+            if (cfg->flatten) {
+                if (r == 3 * R * R) { codes[r] = K_ID << 24; continue; }  // :444-445
+                c = r / (R * R); i = (r % (R * R)) / R; j = r % R;
+            } else {
+                c = r % 4; i = (r / 4) / R; j = (r / 4) % R;  // rollaxis -> (R,R,4), :449
+                if (c == 3) {  // :440-441: only the centre of channel 3 is ever written
+                    codes[r] = ((i == R / 2 && j == R / 2) ? K_ID : K_SKIP) << 24;
+                    continue;
+                }
+            }
+            if (i < W && j < W) codes[r] = (K_GRID << 24) | (uint32_t)(c * d.GSZ + i * GW + j);
+            else codes[r] = (c == 0 ? K_FILL : K_SKIP) << 24;  // even obs_range (Q11)
+        }
+    }
+    hipError_t e = hipMalloc(&h->tables, total);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(MADRL_EHIP, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    }
+    e = hipMemcpy(h->tables, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(h->tables);
+        delete h;
+        return fail(MADRL_EHIP, "hipMemcpy tables failed: %s", hipGetErrorString(e));
+    }
+    uint8_t *tb = (uint8_t *)h->tables;
+    d.maps = tb;
+    d.cnt_tmpl = tb + off_cnt;
+    d.vtab = reinterpret_cast<const float *>(tb + off_vtab);
+    d.codes = reinterpret_cast<const uint32_t *>(tb + off_codes);
+
+    h->max_blocks = 0;
+    rc = madrl_pursuit_set_launch(h, 0, 0);
+    if (rc) {
+        (void)hipFree(h->tables);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return MADRL_OK;
+}
+
+int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_blocks) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const int thr = pick_threads(h->dev, threads);
+    if (thr % 64 != 0 || thr < 64 || thr > 1024) return fail(MADRL_EINVAL, "threads=%d must be a multiple of 64 in 64..1024", thr);
+    const int nt = (h->dev.D + thr - 1) / thr;
+    if (nt > 8) return fail(MADRL_EINVAL, "obs_dim=%d needs more than 8 slots per thread at %d threads", h->dev.D, thr);
+    const size_t lds = lds_bytes_for(h->dev);
+    if (lds > 160 * 1024) return fail(MADRL_EINVAL, "configuration needs %zu B of LDS (> 160 KiB)", lds);
+    if (max_blocks < 0) return fail(MADRL_EINVAL, "max_blocks < 0");
+    h->threads = thr;
+    h->nt = nt;
+    h->lds_bytes = lds;
+    h->max_blocks = max_blocks;
+    if (lds > 64 * 1024) {
+        // opt in to large dynamic LDS for every instantiation we may launch
+        const int bytes = (int)lds;
+#define MADRL_SET_LDS(NT) hipFuncSetAttribute((const void *)pursuit_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+        (void)MADRL_SET_LDS(1); (void)MADRL_SET_LDS(2); (void)MADRL_SET_LDS(3); (void)MADRL_SET_LDS(4);
+        (void)MADRL_SET_LDS(5); (void)MADRL_SET_LDS(6); (void)MADRL_SET_LDS(7); (void)MADRL_SET_LDS(8);
+#undef MADRL_SET_LDS
+    }
+    return MADRL_OK;
+}
+
+void madrl_pursuit_destroy(madrl_pursuit *h) {
+    if (!h) return;
+    if (h->tables) (void)hipFree(h->tables);
+    delete h;
+}
+
+int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t *inj_pos_dev,
+                        const int32_t *inj_map_dev, float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(MADRL_EINVAL, "reset: handle/obs is NULL");
+    PursuitIO io;
+    memset(&io, 0, sizeof(io));
+    io.mask = mask_dev;
+    io.inj_pos = inj_pos_dev;
+    io.inj_map = inj_map_dev;
+    io.obs = obs_dev;
+    return launch(h, io, 0, stream);
+}
+
+int madrl_pursuit_step(madrl_pursuit *h, const int32_t *actions_dev, const int32_t *inj_evader_actions_dev,
+                       float *obs_dev, float *rew_dev, uint8_t *done_dev, int32_t *removed_dev, void *stream) {
+    if (!h || !actions_dev || !obs_dev || !rew_dev || !done_dev || !removed_dev)
+        return fail(MADRL_EINVAL, "step: NULL argument");
+    PursuitIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = actions_dev;
+    io.inj_eact = inj_evader_actions_dev;
+    io.obs = obs_dev;
+    io.rew = rew_dev;
+    io.done = done_dev;
+    io.removed = removed_dev;
+    return launch(h, io, 1, stream);
+}
+
+int madrl_pursuit_get_state(madrl_pursuit *h, int32_t *pos_p, int32_t *pos_e, uint8_t *gone, uint8_t *term_p,
+                            uint8_t *term_e, int32_t *map_id, uint32_t *tick, int32_t *t, void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 127) / 128);
+    hipLaunchKernelGGL(pursuit_get_state_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, pos_p,
+                       pos_e, gone, term_p, term_e, map_id, tick, t);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_pursuit_set_state(madrl_pursuit *h, const int32_t *pos_p, const int32_t *pos_e, const uint8_t *gone,
+                            const uint8_t *term_p, const uint8_t *term_e, const int32_t *map_id,
+                            const uint32_t *tick, const int32_t *t, void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 127) / 128);
+    hipLaunchKernelGGL(pursuit_set_state_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, pos_p,
+                       pos_e, gone, term_p, term_e, map_id, tick, t);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+"""Batched PursuitEvade on MI355X -- host-side mirror of the reference class
+`madrl_environments.pursuit.PursuitEvade` (pursuit_evade.py:26-541).
+
+Two classes:
+
+* `BatchedPursuitEvade(map_pool, n_envs=..., device=..., **reference_kwargs)` -- the
+  vectorised env.  Same constructor kwargs / defaults, same `agents`, `reward_mech`,
+  `reset()`, `step()`, `seed()`, `is_terminal`, `set_param_values()`,
+  `update_curriculum()`, pickling by constructor arguments; tensors instead of lists:
+      reset()        -> obs  float32 [N, P, D]            (D = 3R^2(+1) or (R,R,4))
+      step(actions)  -> obs, rew float32 [N, P], done bool [N], {'removed': int32 [N], ...}
+* `PursuitEvade(map_pool, **reference_kwargs)` -- N == 1 drop-in with the reference's
+  exact return types (list of per-agent ndarrays, ndarray / list rewards, bool, dict), for
+  the in-tree callers: rllabwrapper/__init__.py:75-82, heuristics/pursuit.py:71-85,
+  madrl_environments/__init__.py:72-109.
+
+All arithmetic runs in the HIP kernels behind the C ABI (include/madrl_hip.h); this file
+only owns buffers (torch tensors) and argument checking.  No CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .base import AbstractMAEnv, Agent
+from .maps import as_map_pool
+from .spaces import Box, Discrete
+
+_DEFAULTS = dict(  # pursuit_evade.py:49-148
+    sample_maps=False, reward_mech="global", n_evaders=1, n_pursuers=1, obs_range=3,
+    flatten=True, layer_norm=10, n_catch=2, random_opponents=False, max_opponents=10,
+    catchr=0.01, caughtr=-0.01, term_pursuit=5.0, term_evade=-5.0, urgency_reward=0.0,
+    include_id=True, train_pursuit=True, initial_config=None, surround=True,
+    constraint_window=1.0, curriculum_remove_every=500, curriculum_constrain_rate=0.0,
+    curriculum_turn_off_shaping=np.inf)
+
+
+class PursuitAgent(Agent):
+    """utils/DiscreteAgent.py:11-66 (spaces only; dynamics live in the kernel)."""
+
+    def __init__(self, obs_shape):
+        self._obs_shape = tuple(obs_shape)
+
+    @property
+    def observation_space(self):
+        return Box(low=-np.inf, high=np.inf, shape=self._obs_shape)
+
+    @property
+    def action_space(self):
+        return Discrete(5)
+
+
+class BatchedPursuitEvade(AbstractMAEnv):
+
+    def __init__(self, map_pool, n_envs=1, device="cuda:0", seed=0, env_id_base=0, max_steps=0,
+                 auto_reset=False, threads=0, max_blocks=0, **kwargs):
+        self._ctor = dict(map_pool=map_pool, n_envs=n_envs, device=str(device), seed=seed,
+                          env_id_base=env_id_base, max_steps=max_steps, auto_reset=auto_reset,
+                          threads=threads, max_blocks=max_blocks, kwargs=dict(kwargs))
+        kw = dict(_DEFAULTS)
+        for k in list(kwargs):
+            if k in ("ally_layer", "opponent_layer", "evader_controller", "pursuer_controller"):
+                raise ValueError("%s is a Python object hook of the reference; the batched engine "
+                                 "injects evader actions through step(..., evader_actions=)" % k)
+            if k not in kw:
+                raise TypeError("unknown PursuitEvade kwarg %r" % k)
+            kw[k] = kwargs[k]
+        if kw["random_opponents"]:
+            raise NotImplementedError("random_opponents (pursuit_evade.py:177-181) is not supported")
+        if not kw["train_pursuit"]:
+            raise NotImplementedError("train_pursuit=False (controlling the evaders) is not supported")
+        for k, v in kw.items():
+            if k == "reward_mech":
+                self._reward_mech = v
+            else:
+                setattr(self, k, v)
+        self.map_pool = as_map_pool(map_pool)
+        self.map_matrix = self.map_pool[0]
+        self.xs, self.ys = self.map_matrix.shape
+        self.obs_offset = int((self.obs_range - 1) / 2)
+        self.n_envs = int(n_envs)
+        self.device = torch.device(device)
+        self._seed_value = int(seed)
+        self.env_id_base = int(env_id_base)
+        self.max_steps = int(max_steps)
+        self.auto_reset = bool(auto_reset)
+        self._threads, self._max_blocks = int(threads), int(max_blocks)
+        self._handle = None
+        self.setup()
+
+    # ------------------------------------------------------------------ plumbing
+    def _config(self):
+        c = _lib.PursuitConfig()
+        c.struct_size = C.sizeof(_lib.PursuitConfig)
+        c.xs, c.ys = self.xs, self.ys
+        c.n_pursuers, c.n_evaders = int(self.n_pursuers), int(self.n_evaders)
+        c.obs_range, c.n_catch = int(self.obs_range), int(self.n_catch)
+        c.surround, c.flatten, c.include_id = int(bool(self.surround)), int(bool(self.flatten)), int(bool(self.include_id))
+        c.reward_global = int(self._reward_mech == "global")
+        c.sample_maps, c.n_maps = int(bool(self.sample_maps)), int(self.map_pool.shape[0])
+        c.max_steps, c.auto_reset = self.max_steps, int(self.auto_reset)
+        c.catchr, c.term_pursuit = float(self.catchr), float(self.term_pursuit)
+        c.urgency_reward, c.layer_norm = float(self.urgency_reward), float(self.layer_norm)
+        c.constraint_window = float(self.constraint_window)
+        c.seed, c.env_id_base = self._seed_value, self.env_id_base
+        return c
+
+    def setup(self):
+        """(Re)build the native handle from the current attributes.  Called by __init__ and by
+        set_param_values (madrl_environments/__init__.py:64-67).  Buffers are kept when the
+        shapes did not change, so curriculum updates of catchr / constraint_window are cheap."""
+        L = _lib.lib()
+        if self.device.type != "cuda":
+            raise _lib.MadrlError("BatchedPursuitEvade needs a ROCm device (got %s); there is no "
+                                  "CPU path" % self.device)
+        cfg = self._config()
+        dim = C.c_int32()
+        _lib.check(L.madrl_pursuit_obs_dim(C.byref(cfg), C.byref(dim)))
+        nbytes = C.c_uint64()
+        _lib.check(L.madrl_pursuit_state_bytes(C.byref(cfg), self.n_envs, C.byref(nbytes)))
+        N, P, E, D = self.n_envs, int(self.n_pursuers), int(self.n_evaders), dim.value
+        shape_key = (N, P, E, D, nbytes.value)
+        if getattr(self, "_shape_key", None) != shape_key:
+            dev = self.device
+            self._state = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
+            # IN/OUT observation buffer == the reference's persistent local_obs (Q2)
+            self._obs = torch.zeros((N, P, D), dtype=torch.float32, device=dev)
+            self._rew = torch.zeros((N, P), dtype=torch.float32, device=dev)
+            self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
+            self._removed = torch.zeros(N, dtype=torch.int32, device=dev)
+            self._shape_key = shape_key
+        self.obs_dim = D
+        self._destroy()
+        h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(L.madrl_pursuit_create(C.byref(cfg), self.map_pool.ctypes.data_as(C.c_void_p), N,
+                                          dev_index, _lib.ptr(self._state), C.byref(h)))
+        self._handle = h
+        if self._threads or self._max_blocks:
+            _lib.check(L.madrl_pursuit_set_launch(h, self._threads, self._max_blocks))
+        obs_shape = (D,) if self.flatten else (self.obs_range, self.obs_range, 4)
+        self.pursuers = [PursuitAgent(obs_shape) for _ in range(P)]
+        self.act_dims = [5] * P
+
+    def set_launch(self, threads=0, max_blocks=0):
+        self._threads, self._max_blocks = int(threads), int(max_blocks)
+        _lib.check(_lib.lib().madrl_pursuit_set_launch(self._handle, self._threads, self._max_blocks))
+
+    def _destroy(self):
+        if getattr(self, "_handle", None):
+            _lib.lib().madrl_pursuit_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def _obs_view(self):
+        if self.flatten:
+            return self._obs
+        R = self.obs_range
+        return self._obs.view(self.n_envs, int(self.n_pursuers), R, R, 4)
+
+    def _i32(self, t, shape, name):
+        if t is None:
+            return None
+        t = torch.as_tensor(t, device=self.device)
+        if tuple(t.shape) != tuple(shape):
+            if t.numel() != int(np.prod(shape)):
+                raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+            t = t.reshape(shape)
+        return t.to(torch.int32).contiguous()
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def agents(self):
+        return self.pursuers
+
+    @property
+    def reward_mech(self):
+        return self._reward_mech
+
+    def seed(self, seed=None):
+        """pursuit_evade.py:166-168.  Here the seed keys every in-kernel Philox draw."""
+        if seed is None:
+            seed = int(np.random.randint(2**31 - 1))
+        self._seed_value = int(seed)
+        self.setup()
+        return [self._seed_value]
+
+    def get_param_values(self):
+        return self.__dict__
+
+    def n_agents(self):
+        return int(self.n_pursuers)
+
+    def reset(self, mask=None, positions=None, map_ids=None):
+        """pursuit_evade.py:173-207 for every env (or those with mask != 0).
+        positions int [N, P+E, 2] / map_ids int [N] replace the random draws (parity hook)."""
+        N, A = self.n_envs, int(self.n_pursuers) + int(self.n_evaders)
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device).reshape(N).to(torch.uint8).contiguous()
+        pos = self._i32(positions, (N, A, 2), "positions")
+        mid = self._i32(map_ids, (N,), "map_ids")
+        _lib.check(_lib.lib().madrl_pursuit_reset(self._handle, _lib.ptr(mask), _lib.ptr(pos), _lib.ptr(mid),
+                                                  _lib.ptr(self._obs), self._stream()))
+        return self._obs_view()
+
+    def step(self, actions, evader_actions=None):
+        """pursuit_evade.py:209-262.  actions: int [N, P] (0..4).  evader_actions: optional int
+        [N, E], entry k drives the k-th remaining evader (scripted evader_controller)."""
+        N, P, E = self.n_envs, int(self.n_pursuers), int(self.n_evaders)
+        act = self._i32(actions, (N, P), "actions")
+        eact = self._i32(evader_actions, (N, E), "evader_actions")
+        _lib.check(_lib.lib().madrl_pursuit_step(self._handle, _lib.ptr(act), _lib.ptr(eact), _lib.ptr(self._obs),
+                                                 _lib.ptr(self._rew), _lib.ptr(self._done), _lib.ptr(self._removed),
+                                                 self._stream()))
+        done = (self._done & 1).bool()
+        info = {"removed": self._removed, "truncated": (self._done & 2).bool(), "done_bits": self._done}
+        return self._obs_view(), self._rew, done, info
+
+    @property
+    def is_terminal(self):
+        """pursuit_evade.py:383-389 per env: no evaders left."""
+        return self.get_state()["gone"].bool().all(dim=1)
+
+    def update_curriculum(self, itr):
+        """pursuit_evade.py:264-272"""
+        self.constraint_window = float(np.clip(self.constraint_window + self.curriculum_constrain_rate, 0.0, 1.0))
+        if itr != 0 and itr % self.curriculum_remove_every == 0 and self.n_pursuers > 4:
+            self.n_evaders -= 1
+            self.n_pursuers -= 1
+        if itr > self.curriculum_turn_off_shaping:
+            self.catchr = 0.0
+        self.setup()
+
+    # ------------------------------------------------------------------ state exchange
+    def get_state(self):
+        N, P, E, dev = self.n_envs, int(self.n_pursuers), int(self.n_evaders), self.device
+        st = dict(pos_p=torch.zeros((N, P, 2), dtype=torch.int32, device=dev),
+                  pos_e=torch.zeros((N, E, 2), dtype=torch.int32, device=dev),
+                  gone=torch.zeros((N, E), dtype=torch.uint8, device=dev),
+                  term_p=torch.zeros((N, P), dtype=torch.uint8, device=dev),
+                  term_e=torch.zeros((N, E), dtype=torch.uint8, device=dev),
+                  map_id=torch.zeros(N, dtype=torch.int32, device=dev),
+                  tick=torch.zeros(N, dtype=torch.int32, device=dev),
+                  t=torch.zeros(N, dtype=torch.int32, device=dev))
+        _lib.check(_lib.lib().madrl_pursuit_get_state(
+            self._handle, *[_lib.ptr(st[k]) for k in ("pos_p", "pos_e", "gone", "term_p", "term_e", "map_id", "tick", "t")],
+            self._stream()))
+        return st
+
+    def set_state(self, st):
+        """Any subset of the get_state() keys.  (The reference's equivalent is poking
+        AgentLayer.set_position, pursuit/test_pursuit.py:22-51.)"""
+        N, P, E = self.n_envs, int(self.n_pursuers), int(self.n_evaders)
+        spec = (("pos_p", (N, P, 2), torch.int32), ("pos_e", (N, E, 2), torch.int32),
+                ("gone", (N, E), torch.uint8), ("term_p", (N, P), torch.uint8),
+                ("term_e", (N, E), torch.uint8), ("map_id", (N,), torch.int32),
+                ("tick", (N,), torch.int32), ("t", (N,), torch.int32))
+        args = []
+        for k, shape, dt in spec:
+            v = st.get(k)
+            if v is not None:
+                v = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v, device=self.device)
+                v = v.reshape(shape).to(dt).contiguous()
+            args.append(v)
+        self._keepalive = args
+        _lib.check(_lib.lib().madrl_pursuit_set_state(self._handle, *[_lib.ptr(a) for a in args], self._stream()))
+
+    @property
+    def obs_buffer(self):
+        """the persistent IN/OUT observation tensor (reference: self.local_obs)"""
+        return self._obs
+
+    # ------------------------------------------------------------------ pickling (EzPickle-style)
+    def __getstate__(self):
+        d = dict(self._ctor)
+        # curriculum attributes travel with the pickle (pursuit_evade.py:397-411)
+        d["curriculum"] = dict(constraint_window=self.constraint_window, n_evaders=self.n_evaders,
+                               n_pursuers=self.n_pursuers, catchr=self.catchr)
+        return d
+
+    def __setstate__(self, d):
+        cur = d.pop("curriculum", {})
+        kwargs = d.pop("kwargs")
+        kwargs.update(cur)
+        self.__init__(d.pop("map_pool"), **d, **kwargs)
+
+
+class PursuitEvade(AbstractMAEnv):
+    """N == 1 drop-in with the reference's return types (pursuit_evade.py:26)."""
+
+    def __init__(self, map_pool, device="cuda:0", **kwargs):
+        self._env = BatchedPursuitEvade(map_pool, n_envs=1, device=device, **kwargs)
+
+    def __getattr__(self, name):  # n_pursuers, catchr, map_matrix, ...
+        return getattr(self.__dict__["_env"], name)
+
+    @property
+    def agents(self):
+        return self._env.agents
+
+    @property
+    def reward_mech(self):
+        return self._env.reward_mech
+
+    def seed(self, seed=None):
+        return self._env.seed(seed)
+
+    def set_param_values(self, lut):
+        self._env.set_param_values(lut)
+
+    def update_curriculum(self, itr):
+        self._env.update_curriculum(itr)
+
+    def _obslist(self, obs):
+        o = obs[0].detach().cpu().numpy().astype(np.float64)
+        return [o[i] for i in range(o.shape[0])]
+
+    def reset(self):
+        return self._obslist(self._env.reset())
+
+    def step(self, actions):
+        P = int(self._env.n_pursuers)
+        if isinstance(actions, (list, np.ndarray)):  # pursuit_evade.py:227-230
+            act = np.asarray(actions).reshape(-1)
+            if act.shape[0] != P:
+                raise ValueError("expected %d actions, got %d" % (P, act.shape[0]))
+        else:  # joint scalar action, :231-235
+            act = np.asarray(np.unravel_index(int(actions), self._env.act_dims))
+        if ((act < -5) | (act > 4)).any():
+            raise IndexError("list index out of range")  # motion_range[a], DiscreteAgent.py:83
+        act = np.where(act < 0, act + 5, act)  # python list wrap-around
+        obs, rew, done, info = self._env.step(torch.as_tensor(act.reshape(1, P)))
+        r = rew[0].detach().cpu().numpy().astype(np.float64)
+        rewards = [float(r[0])] * P if self._env.reward_mech == "global" else r
+        return self._obslist(obs), rewards, bool(done[0].item()), {"removed": int(info["removed"][0].item())}
+
+    @property
+    def is_terminal(self):
+        return bool(self._env.is_terminal[0].item())

@@ -1,0 +1,111 @@
+"""CPU tests (-m "not gpu"): the C-ABI shared library loads without a GPU, exports every
+symbol include/madrl_hip.h declares, and its host-only entry points behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "madrl_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(madrl_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from madrl_amd import _lib
+    L = _lib.lib()
+    names = _declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), "libmadrl_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "madrl_amd/_lib.py has no signature for %s" % n
+    assert L.madrl_abi_version() == 1
+
+
+def test_host_philox_matches_published_vectors():
+    from madrl_amd import _lib
+    L = _lib.lib()
+    out = np.zeros(4, np.uint32)
+    ctr = np.array([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], np.uint32)
+    key = np.array([0xa4093822, 0x299f31d0], np.uint32)
+    L.madrl_philox4x32_10(ctr.ctypes.data_as(C.c_void_p), key.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert [hex(v) for v in out] == ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def _cfg(**over):
+    from madrl_amd import _lib
+    c = _lib.PursuitConfig()
+    c.struct_size = C.sizeof(_lib.PursuitConfig)
+    c.xs = c.ys = 16
+    c.n_pursuers, c.n_evaders, c.obs_range, c.n_catch = 8, 30, 7, 2
+    c.surround = c.flatten = c.include_id = 1
+    c.n_maps = 1
+    c.layer_norm, c.constraint_window = 10.0, 1.0
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_obs_dim_and_state_bytes():
+    from madrl_amd import _lib
+    L = _lib.lib()
+    d = C.c_int32()
+    assert L.madrl_pursuit_obs_dim(C.byref(_cfg()), C.byref(d)) == 0 and d.value == 148
+    assert L.madrl_pursuit_obs_dim(C.byref(_cfg(flatten=0)), C.byref(d)) == 0 and d.value == 196
+    assert L.madrl_pursuit_obs_dim(C.byref(_cfg(include_id=0)), C.byref(d)) == 0 and d.value == 147
+    b = C.c_uint64()
+    assert L.madrl_pursuit_state_bytes(C.byref(_cfg()), 65536, C.byref(b)) == 0
+    assert b.value == 65536 * 112  # 16 B header + 76 B positions + masks, 16-B aligned
+
+
+def test_invalid_configs_are_rejected_with_a_message():
+    from madrl_amd import _lib
+    L = _lib.lib()
+    d = C.c_int32()
+    for bad in (dict(struct_size=4), dict(xs=0), dict(n_pursuers=0), dict(n_evaders=300), dict(layer_norm=0.0),
+                dict(constraint_window=0.0), dict(obs_range=0)):
+        rc = L.madrl_pursuit_obs_dim(C.byref(_cfg(**bad)), C.byref(d))
+        assert rc == -1, bad
+        assert len(L.madrl_last_error()) > 0
+
+
+def test_product_never_touches_the_oracle():
+    """madrl_amd must not import / link / call anything under oracle/ (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "madrl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower() or f == "__init__.py" and "oracle" not in src, (dirpath, f)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from madrl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MadrlError):
+        _lib.lib()
+
+
+def test_env_refuses_cpu_device():
+    from madrl_amd import _lib
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from madrl_amd.maps import rectangle_map
+    with pytest.raises(_lib.MadrlError):
+        BatchedPursuitEvade([rectangle_map(16, 16)], n_envs=4, device="cpu", n_pursuers=2, n_evaders=2)
+
+
+def test_rectangle_map_matches_reference_fixture():
+    """maps.rectangle_map restates utils/TwoDMaps.py:8-22; golden files carry the reference's."""
+    from madrl_amd.maps import rectangle_map
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pursuit_c1_surround_local.npz"))
+    np.testing.assert_array_equal(rectangle_map(16, 16), g["maps"][0])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pursuit_c5_32x32.npz"))
+    np.testing.assert_array_equal(rectangle_map(32, 32), g["maps"][0])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pursuit_nonsquare_12x20.npz"))
+    np.testing.assert_array_equal(rectangle_map(12, 20), g["maps"][0])

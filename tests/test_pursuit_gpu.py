@@ -1,0 +1,240 @@
+"""GPU parity tests (-m gpu): the HIP PursuitEvade path, called through the C ABI, against
+(1) the golden vectors of the unmodified reference, (2) the C oracle on seeded free-running
+rollouts (independent Philox implementations), (3) size-independent properties at the
+BASELINE batch sizes.  Bit-exact everywhere: positions, flags, counts, observations; rewards
+are float32 roundings of the reference's float64 values."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import pursuit_golden_files, golden_id
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _mk(maps, n_envs, **kw):
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    return BatchedPursuitEvade(maps, n_envs=n_envs, device=DEV, **kw)
+
+
+def _cmp_state(st_gpu, st_ref, msg=""):
+    for k in ("pos_p", "pos_e", "gone", "term_p", "term_e", "map_id"):
+        a = st_gpu[k].cpu().numpy()
+        b = st_ref[k]
+        assert np.array_equal(a, b), "%s: state[%s] differs in %d entries" % (msg, k, int((a != b).sum()))
+    assert np.array_equal(st_gpu["tick"].cpu().numpy().view(np.uint32), st_ref["tick"]), msg + ": tick"
+
+
+@pytest.mark.parametrize("path", pursuit_golden_files(), ids=golden_id)
+@pytest.mark.parametrize("threads", [0, 128])
+def test_hip_matches_reference_golden(path, threads):
+    """Replay the reference's own recorded episodes (injected positions / evader actions)."""
+    from oracle import pursuit as po
+    g = np.load(path)
+    N = 3  # identical copies: also catches cross-env indexing mistakes
+    env = _mk(list(g["maps"]), N, threads=threads, **po.config_from_golden(g))
+    rep = lambda a: np.repeat(np.asarray(a)[None], N, axis=0)
+    for t in range(len(g["op"])):
+        want_obs = g["obs_f32"][t].reshape(env.n_pursuers, -1)
+        if g["op"][t] == 0:
+            pos = np.concatenate([g["init_p"][t], g["init_e"][t]])
+            obs = env.reset(positions=rep(pos), map_ids=np.full(N, g["map_id"][t]))
+            got = obs.reshape(N, env.n_pursuers, -1).cpu().numpy()
+            for n in range(N):
+                assert np.array_equal(got[n], want_obs), "%s reset obs op %d env %d" % (golden_id(path), t, n)
+        else:
+            obs, rew, done, info = env.step(rep(g["act_p"][t]), evader_actions=rep(g["act_e"][t]))
+            got = obs.reshape(N, env.n_pursuers, -1).cpu().numpy()
+            st = env.get_state()
+            for n in range(N):
+                tag = "%s op %d env %d" % (golden_id(path), t, n)
+                assert np.array_equal(got[n], want_obs), tag + ": obs (%d cells differ)" % int((got[n] != want_obs).sum())
+                assert np.array_equal(rew[n].cpu().numpy(), g["rew_f64"][t].astype(np.float32)), tag + ": rewards"
+                assert bool(done[n]) == bool(g["done"][t]), tag + ": done"
+                assert int(info["removed"][n]) == int(g["removed"][t]), tag + ": removed"
+                assert np.array_equal(st["pos_p"][n].cpu().numpy(), g["pos_p"][t]), tag + ": pursuer positions"
+                assert np.array_equal(st["pos_e"][n].cpu().numpy(), g["pos_e"][t]), tag + ": evader positions"
+                assert np.array_equal(st["gone"][n].cpu().numpy(), g["gone_e"][t]), tag + ": evaders_gone"
+
+
+CASES = {
+    "c2_surround": dict(maps="rect16", n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local"),
+    "c2_global_coloc": dict(maps="rect16", n_pursuers=8, n_evaders=30, obs_range=7, n_catch=1, surround=False, flatten=False,
+                            reward_mech="global", catchr=0.1, urgency_reward=-0.1),
+    "pool16": dict(maps="pool16", n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True,
+                   reward_mech="local", sample_maps=True),
+    "c5_32x32": dict(maps="rect32", n_pursuers=16, n_evaders=60, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local"),
+    "tiny_window": dict(maps="open6", n_pursuers=5, n_evaders=4, obs_range=5, n_catch=2, surround=True, flatten=True,
+                        reward_mech="global", constraint_window=0.5),
+}
+
+
+def _maps(name):
+    from madrl_amd.maps import rectangle_map
+    if name == "rect16":
+        return [rectangle_map(16, 16)]
+    if name == "rect32":
+        return [rectangle_map(32, 32)]
+    if name == "open6":
+        return [np.zeros((6, 6), np.int32)]
+    if name == "pool16":
+        g = np.load(pursuit_golden_files()[[golden_id(p) for p in pursuit_golden_files()].index("pursuit_pool16_sample_maps")])
+        return list(g["maps"])
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("case", sorted(CASES), ids=sorted(CASES))
+def test_hip_matches_oracle_free_running(case):
+    """Seeded free-running rollouts with auto-reset: HIP kernels and the C oracle each run their
+    own Philox; every output and the whole state must agree on every step."""
+    from oracle import pursuit as po
+    kw = dict(CASES[case])
+    maps = _maps(kw.pop("maps"))
+    N, T, H = 512, 120, 25
+    env = _mk(maps, N, seed=2024, env_id_base=1000, max_steps=H, auto_reset=True, **kw)
+    orc = po.PursuitOracle(maps, n_envs=N, seed=2024, env_id_base=1000, **kw)
+    obs = env.reset()
+    oobs = orc.reset().copy()
+    assert np.array_equal(obs.reshape(oobs.shape).cpu().numpy(), oobs), "reset obs"
+    _cmp_state(env.get_state(), orc.get_state(), "after reset")
+    rng = np.random.RandomState(5)
+    tstep = np.zeros(N, np.int64)
+    n_done = n_removed = 0
+    for t in range(T):
+        act = rng.randint(5, size=(N, env.n_pursuers))
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
+        oobs, orew, odone, orem = orc.step(act)
+        tstep += 1
+        bits = odone.astype(np.uint8) | ((tstep >= H).astype(np.uint8) << 1)
+        assert np.array_equal(info["done_bits"].cpu().numpy(), bits), "step %d done bits" % t
+        assert np.array_equal(info["removed"].cpu().numpy(), orem), "step %d removed" % t
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), "step %d rewards" % t
+        mask = (bits != 0).astype(np.uint8)
+        if mask.any():
+            orc.reset(mask=mask)  # rewrites the masked rows of orc.obs (shared persistent buffer)
+            tstep[mask != 0] = 0
+        n_done += int((bits & 1).sum())
+        n_removed += int(orem.sum())
+        got = obs.reshape(orc.obs.shape).cpu().numpy()
+        assert np.array_equal(got, orc.obs), "step %d obs: %d cells differ" % (t, int((got != orc.obs).sum()))
+        if t % 10 == 0 or t == T - 1:
+            _cmp_state(env.get_state(), orc.get_state(), "step %d" % t)
+            assert np.array_equal(env.get_state()["t"].cpu().numpy(), tstep), "episode step counter"
+    assert n_removed > 0
+
+
+def test_launch_shape_does_not_change_results():
+    from madrl_amd.maps import rectangle_map
+    kw = dict(n_pursuers=8, n_evaders=30, obs_range=7, surround=True, reward_mech="local", seed=9, max_steps=40, auto_reset=True)
+    outs = []
+    for threads, blocks in ((64, 0), (128, 0), (256, 7), (64, 300)):
+        env = _mk([rectangle_map(16, 16)], 1000, threads=threads, max_blocks=blocks, **kw)
+        env.reset()
+        g = torch.Generator(device="cpu").manual_seed(1)
+        for _ in range(60):
+            act = torch.randint(0, 5, (1000, 8), generator=g, dtype=torch.int32)
+            obs, rew, done, info = env.step(act.to(DEV))
+        st = env.get_state()
+        outs.append((obs.cpu().clone(), rew.cpu().clone(), {k: v.cpu() for k, v in st.items()}))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        for k in o[2]:
+            assert torch.equal(o[2][k], outs[0][2][k]), k
+
+
+def test_sharding_is_invisible_env_id_base():
+    """Env n of a shard with env_id_base=b behaves exactly like env b+n of one big batch
+    (this is what makes multi-GPU sharding need no communication)."""
+    from madrl_amd.maps import rectangle_map
+    kw = dict(n_pursuers=8, n_evaders=30, obs_range=7, surround=True, reward_mech="local", seed=3, max_steps=30, auto_reset=True)
+    full = _mk([rectangle_map(16, 16)], 512, **kw)
+    half = _mk([rectangle_map(16, 16)], 256, env_id_base=256, **kw)
+    full.reset(); half.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for _ in range(50):
+        act = torch.randint(0, 5, (512, 8), generator=g, dtype=torch.int32).to(DEV)
+        o1, r1, d1, _ = full.step(act)
+        o2, r2, d2, _ = half.step(act[256:].contiguous())
+    assert torch.equal(o1[256:], o2) and torch.equal(r1[256:], r2) and torch.equal(d1[256:], d2)
+
+
+def test_full_batch_invariants_c2():
+    """BASELINE C2 size (65 536 envs): size-independent properties of a free-running rollout."""
+    from madrl_amd.maps import rectangle_map
+    m = rectangle_map(16, 16)
+    N, P, E = 65536, 8, 30
+    env = _mk([m], N, n_pursuers=P, n_evaders=E, obs_range=7, surround=True, reward_mech="local", seed=11)
+    mt = torch.as_tensor(m, device=DEV)
+    obs = env.reset()
+    st = env.get_state()
+    assert (mt[st["pos_p"][..., 0].long(), st["pos_p"][..., 1].long()] == 0).all()
+    assert (mt[st["pos_e"][..., 0].long(), st["pos_e"][..., 1].long()] == 0).all()
+    # reset distribution: uniform over free cells (chi-square over 2M evader draws)
+    cnt = torch.zeros(256, device=DEV, dtype=torch.float64)
+    cell = (st["pos_e"][..., 0].long() * 16 + st["pos_e"][..., 1].long()).flatten()
+    cnt.scatter_add_(0, cell, torch.ones_like(cell, dtype=torch.float64))
+    free = (mt == 0).flatten()
+    exp = cnt.sum() / free.sum()
+    chi2 = float((((cnt[free] - exp) ** 2) / exp).sum())
+    dof = int(free.sum()) - 1
+    assert abs(chi2 - dof) < 6 * (2 * dof) ** 0.5, (chi2, dof)
+    assert float(cnt[~free].sum()) == 0
+    gone_prev = st["gone"].clone()
+    total_removed = torch.zeros(N, dtype=torch.int64, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for t in range(40):
+        act = torch.randint(0, 5, (N, P), generator=g, device=DEV, dtype=torch.int32)
+        obs, rew, done, info = env.step(act)
+        total_removed += info["removed"].long()
+    st = env.get_state()
+    alive = st["gone"] == 0
+    assert (st["gone"] >= gone_prev).all()                                  # evaders never come back
+    assert torch.equal(total_removed, st["gone"].long().sum(1))             # info['removed'] adds up
+    x, y = st["pos_e"][..., 0], st["pos_e"][..., 1]
+    assert ((x >= 0) & (x < 16) & (y >= 0) & (y < 16))[alive].all()
+    assert (mt[x.clamp(min=0).long(), y.clamp(min=0).long()] == 0)[alive].all()   # nobody inside a building
+    assert ((x == -1) & (y == -1))[~alive].all()
+    assert (mt[st["pos_p"][..., 0].long(), st["pos_p"][..., 1].long()] == 0).all()
+    # observation row structure: id column, channel-0 centre is the pursuer's own (free) cell,
+    # channel 1 centre counts at least the pursuer itself
+    o = obs.view(N, P, 148)
+    ids = torch.arange(P, device=DEV, dtype=torch.float64) / P
+    assert torch.equal(o[..., 147], ids.float().expand(N, P))
+    c = o[..., :147].view(N, P, 3, 7, 7)
+    assert (c[:, :, 0, 3, 3] == 0).all()
+    assert (c[:, :, 1, 3, 3] >= 0.1).all()
+    assert total_removed.sum() > 0
+
+
+def test_n1_dropin_api_matches_reference_types():
+    from madrl_amd.pursuit import PursuitEvade
+    from madrl_amd.maps import rectangle_map
+    env = PursuitEvade([rectangle_map(16, 16)], n_evaders=30, n_pursuers=8, obs_range=7, n_catch=2, surround=True,
+                       flatten=True, reward_mech="local")
+    assert len(env.agents) == 8 and env.agents[0].observation_space.shape == (148,) and env.agents[0].action_space.n == 5
+    obs = env.reset()
+    assert isinstance(obs, list) and len(obs) == 8 and obs[0].shape == (148,) and obs[0].dtype == np.float64
+    obs, rew, done, info = env.step([0, 1, 2, 3, 4, 0, 1, 2])
+    assert isinstance(obs, list) and isinstance(rew, np.ndarray) and rew.shape == (8,)
+    assert isinstance(done, bool) and set(info) == {"removed"} and isinstance(info["removed"], int)
+    obs, rew, done, info = env.step(np.array([4] * 8))
+    obs, rew, done, info = env.step(1234)  # joint scalar action, pursuit_evade.py:231-235
+    genv = PursuitEvade([rectangle_map(16, 16)], n_evaders=30, n_pursuers=8, obs_range=7, reward_mech="global")
+    genv.reset()
+    _, rew, _, _ = genv.step([4] * 8)
+    assert isinstance(rew, list) and len(rew) == 8 and len(set(rew)) == 1
+    with pytest.raises(IndexError):
+        env.step([7] * 8)
+
+
+def test_pickle_roundtrip_and_param_updates():
+    import pickle
+    from madrl_amd.maps import rectangle_map
+    env = _mk([rectangle_map(16, 16)], 16, n_pursuers=8, n_evaders=30, obs_range=7, reward_mech="local", seed=5)
+    env.set_param_values(dict(catchr=0.5, constraint_window=0.5))
+    env2 = pickle.loads(pickle.dumps(env))
+    assert env2.catchr == 0.5 and env2.constraint_window == 0.5 and env2.n_envs == 16
+    o1 = env.reset(); o2 = env2.reset()
+    assert torch.equal(o1, o2)
