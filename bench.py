@@ -165,7 +165,8 @@ def main():
                        "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "pursuit_kernel<3>", "kernel_ms": kernel_ms,
+                         "kernel": "pursuit_wave_kernel<16,16,8,30,7,1>" if env.kernel_kind == "wave" else "pursuit_kernel<3>",
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": bytes_per},
         }
         if not args.no_cpu_baseline:

@@ -88,8 +88,19 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
                          int64_t n_envs, int32_t device, void *state_dev, madrl_pursuit **out);
 void madrl_pursuit_destroy(madrl_pursuit *h);
 
-/* Launch shape: threads per workgroup (multiple of 64, 0 = heuristic) and the maximum number
- * of workgroups (0 = one per env); workgroups stride over envs. */
+/* Kernel selection.  Two implementations share the packed state and produce identical results:
+ * GENERIC (any configuration, one workgroup of `threads` lanes per env) and WAVE (one wavefront
+ * per env, compile-time specialised; only for the shapes listed in
+ * madrl_amd/csrc/pursuit_specializations.def).  AUTO = WAVE when available. */
+#define MADRL_KERNEL_AUTO 0
+#define MADRL_KERNEL_GENERIC 1
+#define MADRL_KERNEL_WAVE 2
+int madrl_pursuit_set_kernel(madrl_pursuit *h, int32_t kind);
+int madrl_pursuit_kernel_kind(const madrl_pursuit *h, int32_t *out_kind);
+
+/* Launch shape: threads per workgroup (GENERIC kernel only; multiple of 64, 0 = heuristic)
+ * and the maximum number of workgroups (0 = default: one per env for GENERIC, 4096 persistent
+ * workgroups for WAVE); workgroups stride over envs. */
 int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_blocks);
 
 /* Replaces PursuitEvade.reset (pursuit_evade.py:173-207) for every env with mask[n] != 0

@@ -17,6 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libmadrl_hip.so")
 ABI_VERSION = 1
 
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
+
 _lib = None
 
 
@@ -47,6 +49,8 @@ SIGNATURES = {
     "madrl_pursuit_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
     "madrl_pursuit_destroy": (None, [_vp]),
     "madrl_pursuit_set_launch": (C.c_int, [_vp, C.c_int32, C.c_int64]),
+    "madrl_pursuit_set_kernel": (C.c_int, [_vp, C.c_int32]),
+    "madrl_pursuit_kernel_kind": (C.c_int, [_vp, _vp]),
     "madrl_pursuit_reset": (C.c_int, [_vp] * 6),
     "madrl_pursuit_step": (C.c_int, [_vp] * 8),
     "madrl_pursuit_get_state": (C.c_int, [_vp] * 10),

@@ -18,6 +18,7 @@
 //                              obs buffer is IN/OUT and those cells are simply not stored)
 //   reset .................... pursuit_evade.py:173-207, utils/agent_utils.py:12-47
 #include "common.hpp"
+#include "pursuit_wave.hpp"
 
 #include <new>
 #include <string.h>
@@ -470,6 +471,8 @@ __global__ void pursuit_set_state_kernel(const PursuitDev d, const int32_t *pos_
 }  // namespace
 
 // =================================================================== host side / C ABI
+struct WaveEntry;  // one compiled specialisation of pursuit_wave_kernel
+
 struct madrl_pursuit {
     madrl_pursuit_config cfg;
     PursuitDev dev;
@@ -479,9 +482,57 @@ struct madrl_pursuit {
     int64_t max_blocks;
     size_t lds_bytes;
     void *tables;  // one device allocation holding maps | cnt_tmpl | vtab | codes
+    // one-wavefront-per-env fast path (pursuit_wave.hpp), when a specialisation matches
+    const WaveEntry *wave;
+    madrl::pw::WaveDev wdev;
+    void *wtables;
+    int kernel_kind;  // MADRL_KERNEL_AUTO / _GENERIC / _WAVE (requested)
 };
 
 namespace {
+
+// ------------------------------------------------------------------ wave-kernel specialisations
+struct WaveGeom {
+    int xs, ys, P, E, R, flatten;
+    int GW, PAD, GSZ, D, X_ID, X_SKIP;
+};
+}  // namespace
+
+struct WaveEntry {
+    WaveGeom g;
+    void (*launch)(const madrl::pw::WaveDev &, const madrl::pw::WaveIO &, int mode, int64_t blocks, hipStream_t s);
+};
+
+namespace {
+
+template <class S>
+void wave_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t blocks, hipStream_t s) {
+    hipLaunchKernelGGL(pw::pursuit_wave_kernel<S>, dim3((unsigned)blocks), dim3(64), 0, s, d, io, mode);
+}
+
+template <class S>
+constexpr WaveGeom wave_geom() {
+    return WaveGeom{S::XS, S::YS, S::P, S::E, S::R, S::FLATTEN, S::GW, S::PAD, S::GSZ, S::D, S::X_ID, S::X_SKIP};
+}
+
+#define X(XS, YS, NP, NE, R, FL) {wave_geom<pw::Shape<XS, YS, NP, NE, R, FL>>(), wave_launch<pw::Shape<XS, YS, NP, NE, R, FL>>},
+const WaveEntry WAVE_TABLE[] = {
+#include "pursuit_specializations.def"
+};
+#undef X
+
+const WaveEntry *find_wave(const madrl_pursuit_config *c) {
+    if (c->flatten && !c->include_id) return nullptr;
+    for (const WaveEntry &e : WAVE_TABLE) {
+        const WaveGeom &g = e.g;
+        if (g.xs == c->xs && g.ys == c->ys && g.P == c->n_pursuers && g.E == c->n_evaders && g.R == c->obs_range &&
+            g.flatten == (c->flatten ? 1 : 0))
+            return &e;
+    }
+    return nullptr;
+}
+
+constexpr int64_t WAVE_DEFAULT_BLOCKS = 256 * 16;  // persistent workgroups: 16 waves per CU
 
 int validate(const madrl_pursuit_config *c) {
     if (!c) return fail(MADRL_EINVAL, "config is NULL");
@@ -562,8 +613,22 @@ void launch_nt(const madrl_pursuit *h, const PursuitIO &io, int mode, hipStream_
                        h->dev, io, mode);
 }
 
+bool use_wave(const madrl_pursuit *h) {
+    return h->wave != nullptr && h->kernel_kind != MADRL_KERNEL_GENERIC;
+}
+
 int launch(const madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (use_wave(h)) {
+        pw::WaveIO w;
+        w.mask = io.mask; w.inj_pos = io.inj_pos; w.inj_map = io.inj_map; w.actions = io.actions;
+        w.inj_eact = io.inj_eact; w.obs = io.obs; w.rew = io.rew; w.done = io.done; w.removed = io.removed;
+        int64_t blocks = h->max_blocks > 0 ? h->max_blocks : WAVE_DEFAULT_BLOCKS;
+        if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
+        h->wave->launch(h->wdev, w, mode, blocks, s);
+        MADRL_HIP_TRY(hipGetLastError());
+        return MADRL_OK;
+    }
     switch (h->nt) {
         case 1: launch_nt<1>(h, io, mode, s); break;
         case 2: launch_nt<2>(h, io, mode, s); break;
@@ -704,9 +769,79 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
     d.vtab = reinterpret_cast<const float *>(tb + off_vtab);
     d.codes = reinterpret_cast<const uint32_t *>(tb + off_codes);
 
+    // ---- one-wavefront-per-env fast path tables (pursuit_wave.hpp)
+    h->wave = find_wave(cfg);
+    h->wtables = nullptr;
+    h->kernel_kind = MADRL_KERNEL_AUTO;
+    if (h->wave) {
+        const WaveGeom &g = h->wave->g;
+        const int need_words = ((int)cells + 3) / 4;
+        const int fstride = g.GSZ + need_words;
+        const size_t w_codes = (size_t)fstride * d.n_maps;
+        std::vector<uint32_t> wh(w_codes + d.D, 0u);
+        const float wallv = (float)1 / (float)cfg->layer_norm;  // |-1| / layer_norm in float32
+        uint32_t wall_bits, fill_bits;
+        memcpy(&wall_bits, &wallv, 4);
+        memcpy(&fill_bits, &d.fill32, 4);
+        for (int m = 0; m < d.n_maps; ++m) {
+            const int8_t *map = map_pool_host + (size_t)m * cells;
+            uint32_t *fm = wh.data() + (size_t)m * fstride;
+            uint8_t *need = reinterpret_cast<uint8_t *>(fm + g.GSZ);
+            for (int k = 0; k < g.GSZ; ++k) fm[k] = fill_bits;
+            for (int x = 0; x < xs; ++x)
+                for (int y = 0; y < ys; ++y) {
+                    fm[(x + g.PAD) * g.GW + y + g.PAD] = (map[x * ys + y] == -1) ? wall_bits : 0u;
+                    need[x * ys + y] = (uint8_t)need_to_surround(map, xs, ys, x, y);
+                }
+        }
+        uint32_t *wc = wh.data() + w_codes;
+        const int R = d.R;
+        bool eligible = (wall_bits != 0u) && (fill_bits != 0u);
+        for (int r = 0; r < d.D; ++r) {
+            int c, i, j;
+            if (cfg->flatten) {
+                if (r == 3 * R * R) { wc[r] = (uint32_t)g.X_ID; continue; }
+                c = r / (R * R); i = (r % (R * R)) / R; j = r % R;
+            } else {
+                c = r % 4; i = (r / 4) / R; j = (r / 4) % R;
+                if (c == 3) { wc[r] = (uint32_t)((i == R / 2 && j == R / 2) ? g.X_ID : g.X_SKIP); continue; }
+            }
+            wc[r] = 0x80000000u | (uint32_t)(c * g.GSZ + i * g.GW + j);
+        }
+        for (int r = 0; r < d.D; ++r)  // the kernel assumes only element 3 of a float4 can be absolute
+            if ((r & 3) != 3 && !(wc[r] >> 31)) eligible = false;
+        if (eligible) {
+            const size_t wbytes = wh.size() * sizeof(uint32_t);
+            e = hipMalloc(&h->wtables, wbytes);
+            if (e == hipSuccess) e = hipMemcpy(h->wtables, wh.data(), wbytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                if (h->wtables) (void)hipFree(h->wtables);
+                (void)hipFree(h->tables);
+                delete h;
+                return fail(MADRL_EHIP, "wave tables: %s", hipGetErrorString(e));
+            }
+            pw::WaveDev &w = h->wdev;
+            memset(&w, 0, sizeof(w));
+            w.n_catch = d.n_catch; w.surround = d.surround; w.reward_global = d.reward_global;
+            w.sample_maps = d.sample_maps; w.n_maps = d.n_maps; w.max_steps = d.max_steps; w.auto_reset = d.auto_reset;
+            w.rec_bytes = d.rec_bytes; w.off_gone = d.off_gone; w.off_term = d.off_term; w.ngw = d.ngw; w.ntw = d.ntw;
+            w.fmap_stride = fstride;
+            w.k0 = d.k0; w.k1 = d.k1; w.gid_base = d.gid_base;
+            w.catchr = d.catchr; w.term_pursuit = d.term_pursuit; w.urgency = d.urgency; w.cw = d.cw;
+            w.n_envs = d.n_envs;
+            w.fmaps = reinterpret_cast<const uint32_t *>(h->wtables);
+            w.vtab = d.vtab;
+            w.codes = reinterpret_cast<const uint32_t *>(h->wtables) + w_codes;
+            w.state = d.state;
+        } else {
+            h->wave = nullptr;
+        }
+    }
+
     h->max_blocks = 0;
     rc = madrl_pursuit_set_launch(h, 0, 0);
     if (rc) {
+        if (h->wtables) (void)hipFree(h->wtables);
         (void)hipFree(h->tables);
         delete h;
         return rc;
@@ -742,7 +877,25 @@ int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_bloc
 void madrl_pursuit_destroy(madrl_pursuit *h) {
     if (!h) return;
     if (h->tables) (void)hipFree(h->tables);
+    if (h->wtables) (void)hipFree(h->wtables);
     delete h;
+}
+
+int madrl_pursuit_set_kernel(madrl_pursuit *h, int32_t kind) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    if (kind != MADRL_KERNEL_AUTO && kind != MADRL_KERNEL_GENERIC && kind != MADRL_KERNEL_WAVE)
+        return fail(MADRL_EINVAL, "unknown kernel kind %d", kind);
+    if (kind == MADRL_KERNEL_WAVE && !h->wave)
+        return fail(MADRL_EINVAL, "no one-wavefront-per-env specialisation was compiled for this configuration "
+                    "(see madrl_amd/csrc/pursuit_specializations.def)");
+    h->kernel_kind = kind;
+    return MADRL_OK;
+}
+
+int madrl_pursuit_kernel_kind(const madrl_pursuit *h, int32_t *out_kind) {
+    if (!h || !out_kind) return fail(MADRL_EINVAL, "NULL argument");
+    *out_kind = use_wave(h) ? MADRL_KERNEL_WAVE : MADRL_KERNEL_GENERIC;
+    return MADRL_OK;
 }
 
 int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t *inj_pos_dev,

@@ -54,10 +54,11 @@ class PursuitAgent(Agent):
 class BatchedPursuitEvade(AbstractMAEnv):
 
     def __init__(self, map_pool, n_envs=1, device="cuda:0", seed=0, env_id_base=0, max_steps=0,
-                 auto_reset=False, threads=0, max_blocks=0, **kwargs):
+                 auto_reset=False, threads=0, max_blocks=0, kernel="auto", **kwargs):
         self._ctor = dict(map_pool=map_pool, n_envs=n_envs, device=str(device), seed=seed,
                           env_id_base=env_id_base, max_steps=max_steps, auto_reset=auto_reset,
-                          threads=threads, max_blocks=max_blocks, kwargs=dict(kwargs))
+                          threads=threads, max_blocks=max_blocks, kernel=kernel, kwargs=dict(kwargs))
+        self._kernel = kernel
         kw = dict(_DEFAULTS)
         for k in list(kwargs):
             if k in ("ally_layer", "opponent_layer", "evader_controller", "pursuer_controller"):
@@ -139,9 +140,23 @@ class BatchedPursuitEvade(AbstractMAEnv):
         self._handle = h
         if self._threads or self._max_blocks:
             _lib.check(L.madrl_pursuit_set_launch(h, self._threads, self._max_blocks))
+        if getattr(self, "_kernel", "auto") != "auto":
+            self.set_kernel(self._kernel)
         obs_shape = (D,) if self.flatten else (self.obs_range, self.obs_range, 4)
         self.pursuers = [PursuitAgent(obs_shape) for _ in range(P)]
         self.act_dims = [5] * P
+
+    def set_kernel(self, kind):
+        """'auto' | 'generic' | 'wave' (one wavefront per env, compile-time specialised shapes only)"""
+        k = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "wave": _lib.KERNEL_WAVE}[kind]
+        _lib.check(_lib.lib().madrl_pursuit_set_kernel(self._handle, k))
+        self._kernel = kind
+
+    @property
+    def kernel_kind(self):
+        out = C.c_int32()
+        _lib.check(_lib.lib().madrl_pursuit_kernel_kind(self._handle, C.byref(out)))
+        return {_lib.KERNEL_GENERIC: "generic", _lib.KERNEL_WAVE: "wave"}[out.value]
 
     def set_launch(self, threads=0, max_blocks=0):
         self._threads, self._max_blocks = int(threads), int(max_blocks)

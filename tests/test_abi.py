@@ -75,13 +75,18 @@ def test_invalid_configs_are_rejected_with_a_message():
 
 
 def test_product_never_touches_the_oracle():
-    """madrl_amd must not import / link / call anything under oracle/ (no CPU fallback)."""
+    """madrl_amd must not import / include / link / call anything under oracle/ (no CPU fallback)."""
     pkg = os.path.join(ROOT, "madrl_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|(#\s*include\s*[<\"][^>\"]*oracle)|(oracle/)|(madrl_oracle)|(\bpo_[a-z_]+\s*\()", re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".def")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.lower() or f == "__init__.py" and "oracle" not in src, (dirpath, f)
+                assert not bad.search(src), (dirpath, f, bad.search(src).group(0))
+    # and the shared library does not link it
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libmadrl_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -27,14 +27,28 @@ def _cmp_state(st_gpu, st_ref, msg=""):
     assert np.array_equal(st_gpu["tick"].cpu().numpy().view(np.uint32), st_ref["tick"]), msg + ": tick"
 
 
+WAVE_GOLDEN = {"pursuit_c1_surround_local", "pursuit_c1_surround_global", "pursuit_c1_colocate_hwc",
+               "pursuit_pool16_sample_maps", "pursuit_tiny5_dense", "pursuit_in_building",
+               "pursuit_nonsquare_12x20", "pursuit_window_gt_map"}
+
+
 @pytest.mark.parametrize("path", pursuit_golden_files(), ids=golden_id)
-@pytest.mark.parametrize("threads", [0, 128])
-def test_hip_matches_reference_golden(path, threads):
-    """Replay the reference's own recorded episodes (injected positions / evader actions)."""
+@pytest.mark.parametrize("kernel", ["generic64", "generic128", "wave"])
+def test_hip_matches_reference_golden(path, kernel):
+    """Replay the reference's own recorded episodes (injected positions / evader actions)
+    through both kernel implementations."""
     from oracle import pursuit as po
     g = np.load(path)
     N = 3  # identical copies: also catches cross-env indexing mistakes
-    env = _mk(list(g["maps"]), N, threads=threads, **po.config_from_golden(g))
+    if kernel == "wave":
+        if golden_id(path) not in WAVE_GOLDEN:
+            pytest.skip("no one-wavefront specialisation for this shape (generic kernel covers it)")
+        env = _mk(list(g["maps"]), N, kernel="wave", **po.config_from_golden(g))
+        assert env.kernel_kind == "wave"
+    else:
+        env = _mk(list(g["maps"]), N, kernel="generic", threads=0 if kernel == "generic64" else 128,
+                  **po.config_from_golden(g))
+        assert env.kernel_kind == "generic"
     rep = lambda a: np.repeat(np.asarray(a)[None], N, axis=0)
     for t in range(len(g["op"])):
         want_obs = g["obs_f32"][t].reshape(env.n_pursuers, -1)
@@ -86,14 +100,17 @@ def _maps(name):
 
 
 @pytest.mark.parametrize("case", sorted(CASES), ids=sorted(CASES))
-def test_hip_matches_oracle_free_running(case):
+@pytest.mark.parametrize("kernel", ["generic", "auto"])
+def test_hip_matches_oracle_free_running(case, kernel):
     """Seeded free-running rollouts with auto-reset: HIP kernels and the C oracle each run their
     own Philox; every output and the whole state must agree on every step."""
     from oracle import pursuit as po
     kw = dict(CASES[case])
     maps = _maps(kw.pop("maps"))
     N, T, H = 512, 120, 25
-    env = _mk(maps, N, seed=2024, env_id_base=1000, max_steps=H, auto_reset=True, **kw)
+    env = _mk(maps, N, seed=2024, env_id_base=1000, max_steps=H, auto_reset=True, kernel=kernel, **kw)
+    if kernel == "auto" and case != "c5_32x32":
+        assert env.kernel_kind == "wave"
     orc = po.PursuitOracle(maps, n_envs=N, seed=2024, env_id_base=1000, **kw)
     obs = env.reset()
     oobs = orc.reset().copy()
@@ -129,8 +146,9 @@ def test_launch_shape_does_not_change_results():
     from madrl_amd.maps import rectangle_map
     kw = dict(n_pursuers=8, n_evaders=30, obs_range=7, surround=True, reward_mech="local", seed=9, max_steps=40, auto_reset=True)
     outs = []
-    for threads, blocks in ((64, 0), (128, 0), (256, 7), (64, 300)):
-        env = _mk([rectangle_map(16, 16)], 1000, threads=threads, max_blocks=blocks, **kw)
+    for kernel, threads, blocks in (("generic", 64, 0), ("generic", 128, 0), ("generic", 256, 7), ("generic", 64, 300),
+                                    ("wave", 0, 0), ("wave", 0, 13)):
+        env = _mk([rectangle_map(16, 16)], 1000, kernel=kernel, threads=threads, max_blocks=blocks, **kw)
         env.reset()
         g = torch.Generator(device="cpu").manual_seed(1)
         for _ in range(60):
