@@ -34,6 +34,22 @@ def algorithmic_bytes_per_env_step(P, E, D, rec_bytes):
     return 4 * P + 4 * P * D + 4 * P + 1 + 4 + 2 * rec_bytes
 
 
+def measured_traffic(n_envs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/pmc_traffic.json,
+    FETCH_SIZE + WRITE_SIZE collected in separate runs by scripts/profile.sh); None if absent or
+    taken at another batch size.  bench.py cannot collect PMC counters on itself."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if int(j.get("envs", -1)) == int(n_envs):
+            best = (float(j["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT))
+    return best
+
+
 def cpu_baseline(maps, kw, budget_s=12.0):
     """The C oracle (a port of the reference's algorithm) on the host cores, OpenMP over envs.
     Bounded sample of the same workload: 4096 envs, free-running, ~budget_s seconds."""
@@ -147,6 +163,7 @@ def main():
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
         achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
+        traffic = measured_traffic(N)
         out = {
             "metric": "env-steps/sec at fixed batch (PursuitEvade 16x16, 8v30)",
             "value": world * N * K / dt,
@@ -164,7 +181,10 @@ def main():
                                    "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (N, args.horizon),
                        "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
+                         "algorithmic_bytes_per_launch": bytes_per * N,
                          "kernel": "pursuit_wave_kernel<16,16,8,30,7,1>" if env.kernel_kind == "wave" else "pursuit_kernel<3>",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": bytes_per},

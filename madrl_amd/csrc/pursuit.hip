@@ -21,6 +21,7 @@
 #include "pursuit_wave.hpp"
 
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -495,6 +496,7 @@ namespace {
 struct WaveGeom {
     int xs, ys, P, E, R, flatten;
     int GW, PAD, GSZ, D, X_ID, X_SKIP;
+    int rec_bytes, off_gone, off_term;
 };
 }  // namespace
 
@@ -507,12 +509,18 @@ namespace {
 
 template <class S>
 void wave_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t blocks, hipStream_t s) {
-    hipLaunchKernelGGL(pw::pursuit_wave_kernel<S>, dim3((unsigned)blocks), dim3(64), 0, s, d, io, mode);
+    if (mode == 0)
+        hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 0, false>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
+    else if (io.inj_eact != nullptr)
+        hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 1, true>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
+    else
+        hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 1, false>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
 }
 
 template <class S>
 constexpr WaveGeom wave_geom() {
-    return WaveGeom{S::XS, S::YS, S::P, S::E, S::R, S::FLATTEN, S::GW, S::PAD, S::GSZ, S::D, S::X_ID, S::X_SKIP};
+    return WaveGeom{S::XS, S::YS, S::P, S::E, S::R, S::FLATTEN, S::GW, S::PAD, S::GSZ, S::D, S::X_ID, S::X_SKIP,
+                    S::REC_BYTES, S::OFF_GONE, S::OFF_TERM};
 }
 
 #define X(XS, YS, NP, NE, R, FL) {wave_geom<pw::Shape<XS, YS, NP, NE, R, FL>>(), wave_launch<pw::Shape<XS, YS, NP, NE, R, FL>>},
@@ -532,7 +540,7 @@ const WaveEntry *find_wave(const madrl_pursuit_config *c) {
     return nullptr;
 }
 
-constexpr int64_t WAVE_DEFAULT_BLOCKS = 256 * 16;  // persistent workgroups: 16 waves per CU
+constexpr int64_t WAVE_DEFAULT_BLOCKS = 256 * 24;  // persistent workgroups: 24 waves per CU (6 per SIMD)
 
 int validate(const madrl_pursuit_config *c) {
     if (!c) return fail(MADRL_EINVAL, "config is NULL");
@@ -796,7 +804,8 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         }
         uint32_t *wc = wh.data() + w_codes;
         const int R = d.R;
-        bool eligible = (wall_bits != 0u) && (fill_bits != 0u);
+        bool eligible = (wall_bits != 0u) && (fill_bits != 0u) && g.rec_bytes == d.rec_bytes &&
+                        g.off_gone == d.off_gone && g.off_term == d.off_term && g.D == d.D;
         for (int r = 0; r < d.D; ++r) {
             int c, i, j;
             if (cfg->flatten) {
@@ -824,8 +833,8 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             memset(&w, 0, sizeof(w));
             w.n_catch = d.n_catch; w.surround = d.surround; w.reward_global = d.reward_global;
             w.sample_maps = d.sample_maps; w.n_maps = d.n_maps; w.max_steps = d.max_steps; w.auto_reset = d.auto_reset;
-            w.rec_bytes = d.rec_bytes; w.off_gone = d.off_gone; w.off_term = d.off_term; w.ngw = d.ngw; w.ntw = d.ntw;
             w.fmap_stride = fstride;
+            w.ablate = getenv("MADRL_PURSUIT_ABLATE") ? atoi(getenv("MADRL_PURSUIT_ABLATE")) : 0;
             w.k0 = d.k0; w.k1 = d.k1; w.gid_base = d.gid_base;
             w.catchr = d.catchr; w.term_pursuit = d.term_pursuit; w.urgency = d.urgency; w.cw = d.cw;
             w.n_envs = d.n_envs;

@@ -37,8 +37,8 @@ constexpr uint32_t CAUGHT = 0x10000u;    // added to an evader-count cell by a c
 
 struct WaveDev {
     int32_t n_catch, surround, reward_global, sample_maps, n_maps, max_steps, auto_reset;
-    int32_t rec_bytes, off_gone, off_term, ngw, ntw;
     int32_t fmap_stride;  // dwords per map entry in fmaps
+    int32_t ablate;       // profiling only (MADRL_PURSUIT_ABLATE): 1 no obs stores, 2 no obs pass, 4 no Philox, 8 nt stores
     uint32_t k0, k1, gid_base;
     double catchr, term_pursuit, urgency, cw;
     int64_t n_envs;
@@ -79,6 +79,14 @@ struct Shape {
     static constexpr int NVT = 72;
     static constexpr int X_NEED = X_VTAB + NVT;                  // XS*YS bytes, as dwords
     static constexpr int LDS_DWORDS = X_NEED + (XS * YS + 3) / 4;
+    // packed state record, identical to the generic kernel's layout() in pursuit.hip
+    static constexpr int NGW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
+    static constexpr int NTW = (A + 31) / 32;
+    static constexpr int OFF_GONE = (16 + 2 * A + 3) / 4 * 4;
+    static constexpr int OFF_TERM = OFF_GONE + 4 * NGW;
+    static constexpr int REC_BYTES = (OFF_TERM + 4 * NTW + 15) / 16 * 16;
+    static constexpr int REC_DW = REC_BYTES / 4;
+    static_assert(REC_DW <= 64, "the whole record must fit one dword per lane");
     static_assert(A <= 64, "one wavefront per env: n_pursuers + n_evaders must fit 64 lanes");
     static_assert(R % 2 == 1, "odd obs_range only (even ranges run on the generic kernel)");
     static_assert(D % 4 == 0, "observation row must be a whole number of float4");
@@ -114,13 +122,28 @@ __device__ __forceinline__ double np_sum_regs(const double (&a)[P]) {
     }
 }
 
-template <class S>
-__global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const WaveIO io, const int mode) {
+// Wave-local synchronisation.  A workgroup is one wavefront, its DS (LDS) instructions are
+// executed in issue order, so cross-lane LDS hand-offs only need the COMPILER to keep the
+// order; unlike __syncthreads() this emits no s_waitcnt vmcnt(0), i.e. the wave never waits
+// for its observation stores to reach HBM.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// MODE 0: reset(mask)      MODE 1: step (+ fused auto-reset)
+// INJECT (step only): evader actions come from io.inj_eact (parity harness) instead of Philox.
+// It is a template parameter because a conditional global load in the hot loop makes the
+// compiler's s_waitcnt pass put a vmcnt(0) on the common path (see "pipeline hinge" below).
+template <class S, int MODE, bool INJECT>
+__global__ __launch_bounds__(64, 6) void pursuit_wave_kernel(const WaveDev d, const WaveIO io) {
     constexpr int P = S::P, E = S::E, A = S::A, GW = S::GW, PAD = S::PAD, GSZ = S::GSZ, NS = S::NS;
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int lane = threadIdx.x;
     const bool is_p = lane < P;
     const bool is_agent = lane < A;
+    const bool is_e = is_agent && !is_p;
     const int eslot = lane - P;
 
     // ---------------------------------------------------------------- once per workgroup
@@ -135,9 +158,9 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
     }
     if (lane < P) L[S::X_ID + lane] = __float_as_uint((float)((double)lane / (double)P));  // :440-445
     for (int k = lane; k < S::NVT; k += 64) L[S::X_VTAB + k] = __float_as_uint(d.vtab[k]);
-    // observation slot constants
+    // observation slot constants (registers, live across the env loop)
     int s_cst[NS][4];
-    int s_rel3[NS];   // 1: element 3 is window-relative, 0: absolute (id / skip / fill cell)
+    int s_rel3[NS];   // 1: element 3 is window-relative, 0: absolute (id / skip cell)
     int s_src[NS];    // ds_bpermute byte address of the owning pursuer's lane
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -155,250 +178,286 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
         }
     }
     int cached_map = -1;
-    __syncthreads();
-
-    auto load_map = [&](int map_id) {
-        if (cached_map == map_id) return;
-        const uint32_t *src = d.fmaps + (int64_t)map_id * d.fmap_stride;
-        for (int k = lane; k < GSZ; k += 64) L[k] = src[k];
-        for (int k = lane; k < (S::XS * S::YS + 3) / 4; k += 64) L[S::X_NEED + k] = src[GSZ + k];
-        cached_map = map_id;
-        __syncthreads();
-    };
     const uint8_t *need_tab = reinterpret_cast<const uint8_t *>(&L[S::X_NEED]);
+    uint32_t *const layer = &L[is_p ? GSZ : 2 * GSZ];  // this lane's count layer
+    // which lanes feed my dword of the packed state record (agents 2j and 2j+1 for dword 4+j)
+    const int rec_src0 = (lane >= 4 ? 2 * (lane - 4) : 0) * 4, rec_src1 = rec_src0 + 4;
+
+    // ---------------------------------------------------------------- software pipeline
+    // The whole packed state record (S::REC_DW dwords) is fetched by ONE coalesced load, lane k
+    // holding dword k, together with the pursuer action of the same env; both are issued one
+    // env ahead so their HBM latency hides behind the current env's work.
+    auto fetch_rec = [&](int64_t env) -> uint32_t {
+        return (lane < S::REC_DW) ? reinterpret_cast<const uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] : 0u;
+    };
+    auto fetch_act = [&](int64_t env) -> int {
+        if constexpr (MODE == 1) return is_p ? io.actions[env * P + lane] : 4;
+        else return 4;
+    };
+    uint32_t cur_rec = 0;
+    int cur_act = 4;
+    if ((int64_t)blockIdx.x < d.n_envs) {
+        cur_rec = fetch_rec(blockIdx.x);
+        cur_act = fetch_act(blockIdx.x);
+    }
+    asm volatile("" : "+v"(cur_rec), "+v"(cur_act));  // loads complete before the loop (see hinge below)
+    wave_sync();
 
     for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
-        if (mode == 0 && io.mask != nullptr && io.mask[env] == 0) continue;
-        uint8_t *rec = d.state + env * (int64_t)d.rec_bytes;
-        // ------------------------------------------------------------ state record -> registers
-        const uint32_t *hdr = reinterpret_cast<const uint32_t *>(rec);
-        uint32_t tick = __builtin_amdgcn_readfirstlane(hdr[0]);
-        int32_t tstep = (int32_t)__builtin_amdgcn_readfirstlane(hdr[1]);
-        int32_t map_id = (int32_t)__builtin_amdgcn_readfirstlane(hdr[2]);
-        int x = 0, y = 0;
-        if (is_agent) {
-            const uint32_t xy = reinterpret_cast<const uint16_t *>(rec + 16)[lane];
-            x = (int)(xy & 0xFF);
-            y = (int)(xy >> 8);
+        const int64_t nenv = env + gridDim.x;
+        uint32_t nxt_rec = 0;
+        int nxt_act = 4;
+        if (nenv < d.n_envs) {
+            nxt_rec = fetch_rec(nenv);
+            nxt_act = fetch_act(nenv);
         }
-        uint64_t gone = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(rec + d.off_gone)[0]);
-        if (d.ngw > 1)
-            gone |= (uint64_t)__builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(rec + d.off_gone)[1]) << 32;
-        uint64_t term = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(rec + d.off_term)[0]);
-        if (d.ntw > 1)
-            term |= (uint64_t)__builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(rec + d.off_term)[1]) << 32;
-        const uint32_t gid = d.gid_base + (uint32_t)env;
-        bool do_reset = (mode == 0);
-        uint32_t done_bits = 0;
-        bool alive = is_p || (is_agent && !((gone >> eslot) & 1ull));
-        uint32_t *layer = &L[is_p ? GSZ : 2 * GSZ];  // this lane's count layer
-        int cell = (x + PAD) * GW + y + PAD;
+        bool skip = false;
+        if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
+        if (!skip) {
+            // -------------------------------------------------------- unpack the record
+            uint32_t tick = __builtin_amdgcn_readlane(cur_rec, 0);
+            int32_t tstep = (int32_t)__builtin_amdgcn_readlane(cur_rec, 1);
+            int32_t map_id = (int32_t)__builtin_amdgcn_readlane(cur_rec, 2);
+            const uint32_t xyw = (uint32_t)__shfl((int)cur_rec, 4 + (lane >> 1));
+            const uint32_t xy = (lane & 1) ? (xyw >> 16) : (xyw & 0xFFFFu);
+            int x = (int)(xy & 0xFF), y = (int)(xy >> 8);
+            uint64_t gone = __builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4);
+            if constexpr (S::NGW > 1) gone |= (uint64_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4 + 1) << 32;
+            uint64_t term = __builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4);
+            if constexpr (S::NTW > 1) term |= (uint64_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4 + 1) << 32;
+            const uint32_t gid = d.gid_base + (uint32_t)env;
+            bool do_reset = (MODE == 0);
+            uint32_t done_bits = 0;
+            float rew_out = 0.0f;
+            int n_removed = 0;
+            bool alive = is_p || (is_e && !((gone >> eslot) & 1ull));
+            int cell = (x + PAD) * GW + y + PAD;
 
-        // ------------------------------------------------------------ observations (:418-461)
-        auto write_obs = [&]() {
-            // integer counts -> float32 observation values, in place (all reads precede all writes:
-            // one wave executes the ds_read for every lane before the ds_write)
-            uint32_t cnt = 0;
-            if (alive) cnt = layer[cell] & 0xFFFFu;
-            __syncthreads();
-            if (alive) layer[cell] = L[S::X_VTAB + cnt];
-            __syncthreads();
-            const int origin = is_p ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
-            float4 *orow = reinterpret_cast<float4 *>(io.obs + env * (int64_t)(P * S::D));
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int q = lane + 64 * s;
-                const int base = __builtin_amdgcn_ds_bpermute(s_src[s], origin);
-                const uint32_t v0 = L[base + s_cst[s][0]];
-                const uint32_t v1 = L[base + s_cst[s][1]];
-                const uint32_t v2 = L[base + s_cst[s][2]];
-                const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
-                if (q < S::NQ) {
-                    if ((v0 != SENT) & (v1 != SENT) & (v2 != SENT) & (v3 != SENT)) {
-                        orow[q] = make_float4(__uint_as_float(v0), __uint_as_float(v1), __uint_as_float(v2),
-                                              __uint_as_float(v3));
-                    } else {  // some cell is outside the map in a count layer: leave it stale (Q2)
-                        float *o = reinterpret_cast<float *>(orow + q);
-                        if (v0 != SENT) o[0] = __uint_as_float(v0);
-                        if (v1 != SENT) o[1] = __uint_as_float(v1);
-                        if (v2 != SENT) o[2] = __uint_as_float(v2);
-                        if (v3 != SENT) o[3] = __uint_as_float(v3);
-                    }
+            auto load_map = [&](int mid) {
+                if (cached_map == mid) return;
+                const uint32_t *src = d.fmaps + (int64_t)mid * d.fmap_stride;
+                for (int k = lane; k < GSZ; k += 64) L[k] = src[k];
+                for (int k = lane; k < (S::XS * S::YS + 3) / 4; k += 64) L[S::X_NEED + k] = src[GSZ + k];
+                cached_map = mid;
+                wave_sync();
+            };
+            load_map(map_id);
+
+            if constexpr (MODE == 1) {
+                const bool e_alive = is_e && alive;
+                // ---------------------------------------------------- pre-move reward (:359-381)
+                if (e_alive) atomicAdd(&layer[cell], 1u);
+                wave_sync();
+                int kpre = 0;
+                if (is_p) {  // np.clip keeps a border pursuer on its own cell (:374-380)
+                    const int dxm = (x > 0) ? GW : 0, dxp = (x < S::XS - 1) ? GW : 0;
+                    const int dym = (y > 0) ? 1 : 0, dyp = (y < S::YS - 1) ? 1 : 0;
+                    const uint32_t *ec = &L[2 * GSZ];
+                    kpre = (int)(ec[cell - dxm] + ec[cell + dxp] + ec[cell + dyp] + ec[cell - dym]);
                 }
-            }
-            __syncthreads();
-            if (alive) layer[cell] = 0u;  // restore the layers for the next env
-            // an evader caught this step is no longer `alive` but still owns a mark + count
-        };
-
-        load_map(map_id);
-
-        if (mode == 1) {
-            // -------------------------------------------------------- pre-move reward (:359-381)
-            if (is_agent && !is_p && alive) atomicAdd(&layer[cell], 1u);
-            __syncthreads();
-            int kpre = 0;
-            if (is_p) {
-                const int xm = max(x - 1, 0), xp = min(x + 1, S::XS - 1);
-                const int ym = max(y - 1, 0), yp = min(y + 1, S::YS - 1);
-                const uint32_t *ec = &L[2 * GSZ];
-                kpre = (int)(ec[(xm + PAD) * GW + y + PAD] + ec[(xp + PAD) * GW + y + PAD] +
-                             ec[(x + PAD) * GW + yp + PAD] + ec[(x + PAD) * GW + ym + PAD]);
-            }
-            __syncthreads();
-            if (is_agent && !is_p && alive) atomicSub(&layer[cell], 1u);
-            // -------------------------------------------------------- moves (:229-241)
-            bool newterm = false;
-            if (alive) {
-                int act;
-                if (is_p) {
-                    act = io.actions[env * P + lane];
+                wave_sync();
+                if (e_alive) atomicSub(&layer[cell], 1u);
+                // ---------------------------------------------------- moves (:229-241), branch-free
+                // evader draw: index in the evader layer = alive evaders in lower slots
+                const int kidx = __popcll((~gone) & ((1ull << (eslot & 63)) - 1ull));
+                int act = cur_act;
+                if constexpr (INJECT) {
+                    if (e_alive) act = io.inj_eact[env * E + kidx];
                 } else {
-                    // index in the evader layer = alive evaders in lower slots
-                    const uint64_t below = (~gone) & ((1ull << eslot) - 1ull);
-                    const int k = __popcll(below);
-                    if (io.inj_eact != nullptr) {
-                        act = io.inj_eact[env * E + k];
-                    } else {
-                        const u32x4 r = philox4x32_10(gid, tick, (uint32_t)k, TAG_EVADER_ACT, d.k0, d.k1);
-                        act = (int)__umulhi(r.x, 5u);
-                    }
+                    const u32x4 r = philox4x32_10(gid, tick, (uint32_t)kidx, TAG_EVADER_ACT, d.k0, d.k1);
+                    if (!is_p) act = (int)__umulhi(r.x, 5u);  // RandomPolicy.act, Controllers.py:15-16
                 }
+                // DiscreteAgent.step, DiscreteAgent.py:69-97
+                const int dcell = (act == 0 ? -GW : 0) + (act == 1 ? GW : 0) + (act == 2 ? 1 : 0) + (act == 3 ? -1 : 0);
                 const bool tflag = (term >> lane) & 1ull;
-                if (!tflag) {  // DiscreteAgent.step, DiscreteAgent.py:69-97
-                    if (L[cell] != 0u) {
-                        newterm = true;  // standing in a building
+                const bool in_building = L[cell] != 0u;          // layer 0 is +0.0f only on free in-map cells
+                const bool target_free = L[cell + dcell] == 0u;  // building or outside the map otherwise
+                const bool newterm = alive && !tflag && in_building;
+                if (alive && !tflag && !in_building && target_free) {
+                    cell += dcell;
+                    x += (act == 1) - (act == 0);
+                    y += (act == 2) - (act == 3);
+                }
+                term |= __ballot(newterm);
+                if (alive) atomicAdd(&layer[cell], 1u);  // :244-246
+                wave_sync();
+                // ---------------------------------------------------- catch resolution (:463-521)
+                bool caught = false;
+                if (e_alive) {
+                    const uint32_t *pc = &L[GSZ];
+                    if (d.surround) {
+                        const uint32_t n0 = pc[cell - GW], n1 = pc[cell + GW], n2 = pc[cell + 1], n3 = pc[cell - 1];
+                        const int cnt = (int)(n0 - 1u < SENT - 1u) + (int)(n1 - 1u < SENT - 1u) +
+                                        (int)(n2 - 1u < SENT - 1u) + (int)(n3 - 1u < SENT - 1u);
+                        caught = cnt == (int)need_tab[x * S::YS + y];  // need_to_surround :523-540
                     } else {
-                        int nx = x, ny = y;
-                        if (act == 0) nx = x - 1;
-                        else if (act == 1) nx = x + 1;
-                        else if (act == 2) ny = y + 1;
-                        else if (act == 3) ny = y - 1;
-                        const int ncell = (nx + PAD) * GW + ny + PAD;
-                        if (L[ncell] == 0u) {  // layer 0 is +0.0f only on free in-map cells
-                            x = nx;
-                            y = ny;
-                            cell = ncell;
+                        caught = (int)pc[cell] >= d.n_catch;  // :498
+                    }
+                    if (caught) atomicAdd(&layer[cell], CAUGHT);
+                }
+                const uint64_t caught_mask = __ballot(caught) >> P;
+                gone |= caught_mask;
+                wave_sync();
+                // ---------------------------------------------------- rewards (:254-262)
+                double r = 0.0;
+                if (is_p) {
+                    const uint32_t *ec = &L[2 * GSZ];
+                    bool sur;
+                    if (d.surround) {  // a caught evader on one of my four neighbour cells (:489-495)
+                        const uint32_t n0 = ec[cell - GW], n1 = ec[cell + GW], n2 = ec[cell + 1], n3 = ec[cell - 1];
+                        sur = ((n0 != SENT) & (n0 >= CAUGHT)) | ((n1 != SENT) & (n1 >= CAUGHT)) |
+                              ((n2 != SENT) & (n2 >= CAUGHT)) | ((n3 != SENT) & (n3 >= CAUGHT));
+                    } else {
+                        sur = ec[cell] >= CAUGHT;  // :503-506
+                    }
+                    r = d.catchr * (double)kpre;
+                    r += d.term_pursuit * (sur ? 1.0 : 0.0);
+                    r += d.urgency;
+                }
+                if (d.reward_global) {  // [rewards.mean()] * n_pursuers, numpy summation order
+                    double all[P];
+#pragma unroll
+                    for (int k = 0; k < P; ++k) all[k] = __shfl(r, k);
+                    r = np_sum_regs<P>(all) / (double)P;
+                }
+                tick += 1;
+                tstep += 1;
+                constexpr uint64_t all_e = (1ull << E) - 1ull;
+                if ((gone & all_e) == all_e) done_bits |= 1u;  // :383-389
+                if (d.max_steps > 0 && tstep >= d.max_steps) done_bits |= 2u;
+                do_reset = d.auto_reset && done_bits != 0;
+                rew_out = (float)r;
+                n_removed = __popcll(caught_mask);
+            }
+
+            // Pipeline hinge: everything above only LOADS from HBM (issued one env ago), everything
+            // below only STORES.  Touching the prefetched registers here makes the compiler wait
+            // for the next env's record now -- when only loads and the previous env's long-issued
+            // stores are outstanding -- instead of at the loop back-edge, where an in-order
+            // vmcnt(0) would also wait for this env's observation stores to reach HBM.
+            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act));
+
+            if constexpr (MODE == 1) {
+                if (is_p) io.rew[env * P + lane] = rew_out;
+                if (lane == 0) {
+                    io.done[env] = (uint8_t)done_bits;
+                    io.removed[env] = n_removed;
+                }
+            }
+
+            // One observation pass normally.  On auto-reset two: the reference sequence is step()
+            // then reset(), both write the persistent observation buffer and the cells the second
+            // write skips keep the first one's values.  `alive` is the PRE-catch set in the first
+            // pass: a just-caught evader is still drawn in channel 2 (Q6) and its cell (count +
+            // CAUGHT mark) is zeroed with the others.
+            const int npass = (MODE == 1 && do_reset) ? 2 : 1;
+            for (int pass = 0; pass < npass; ++pass) {
+                if (do_reset && pass == npass - 1) {
+                    // -------------------------------------------------- reset (:173-207)
+                    gone = 0ull;
+                    term = 0ull;
+                    bool inj_map = false, inj_pos = false;
+                    if constexpr (MODE == 0) {
+                        inj_map = io.inj_map != nullptr;
+                        inj_pos = io.inj_pos != nullptr;
+                    }
+                    if (inj_map) {
+                        map_id = __builtin_amdgcn_readfirstlane(io.inj_map[env]);
+                    } else if (d.sample_maps) {  // :182-183
+                        const u32x4 rm = philox4x32_10(gid, tick, 0u, TAG_RESET_ENV, d.k0, d.k1);
+                        map_id = (int)__umulhi(rm.x, (uint32_t)d.n_maps);
+                    }
+                    load_map(map_id);
+                    const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, d.k0, d.k1);
+                    const double sx = u53(rw.x, rw.y) * (1.0 - d.cw);  // :185-191, float64
+                    const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
+                    const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + d.cw));
+                    const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + d.cw));
+                    if (is_agent) {  // create_agents / feasible_position, agent_utils.py:12-47
+                        if (inj_pos) {
+                            x = io.inj_pos[(env * A + lane) * 2];
+                            y = io.inj_pos[(env * A + lane) * 2 + 1];
+                        } else {
+                            for (uint32_t att = 0; att < 1024u; ++att) {
+                                const u32x4 rp = philox4x32_10(gid, tick, (uint32_t)lane, TAG_RESET_POS | (att << 8), d.k0, d.k1);
+                                x = xlb + (int)__umulhi(rp.x, (uint32_t)(xub - xlb));
+                                y = ylb + (int)__umulhi(rp.y, (uint32_t)(yub - ylb));
+                                // building cells hold fl32(1/norm) != 0; window cells are inside the map
+                                if (L[(x + PAD) * GW + y + PAD] == 0u) break;
+                            }
+                        }
+                        cell = (x + PAD) * GW + y + PAD;
+                        atomicAdd(&layer[cell], 1u);  // :201-203
+                    }
+                    alive = is_agent;
+                    tick += 1;
+                    tstep = 0;
+                    wave_sync();
+                }
+                // ------------------------------------------------------ observations (:418-461)
+                // integer counts -> float32 observation values, in place (a wave executes the
+                // ds_read of every lane before the ds_write of any lane)
+                uint32_t cnt = 0;
+                if (alive) cnt = layer[cell] & 0xFFFFu;
+                wave_sync();
+                if (alive) layer[cell] = L[S::X_VTAB + cnt];
+                wave_sync();
+                if (!(d.ablate & 2)) {
+                    const int origin = is_p ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f *orow = reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D));
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const int q = lane + 64 * s;
+                        const int base = __builtin_amdgcn_ds_bpermute(s_src[s], origin);
+                        const uint32_t v0 = L[base + s_cst[s][0]];
+                        const uint32_t v1 = L[base + s_cst[s][1]];
+                        const uint32_t v2 = L[base + s_cst[s][2]];
+                        const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
+                        if (q < S::NQ && !(d.ablate & 1)) {
+                            if (((v0 != SENT) & (v1 != SENT) & (v2 != SENT) & (v3 != SENT)) || (d.ablate & 16)) {
+                                const v4f val = {__uint_as_float(v0), __uint_as_float(v1), __uint_as_float(v2),
+                                                 __uint_as_float(v3)};
+                                if (d.ablate & 8) orow[q] = val;
+                                else __builtin_nontemporal_store(val, &orow[q]);
+                            } else {  // a count-layer cell outside the map: leave it stale (Q2).
+                                // Plain (L2-cached) stores: partial lines must merge in L2 -- nontemporal
+                                // partial writes cost a read-modify-write at the memory side (3x slower).
+                                float *o = reinterpret_cast<float *>(orow + q);
+                                if (v0 != SENT) o[0] = __uint_as_float(v0);
+                                if (v1 != SENT) o[1] = __uint_as_float(v1);
+                                if (v2 != SENT) o[2] = __uint_as_float(v2);
+                                if (v3 != SENT) o[3] = __uint_as_float(v3);
+                            }
                         }
                     }
                 }
-                atomicAdd(&layer[cell], 1u);  // :244-246
+                wave_sync();
+                if (alive) layer[cell] = 0u;  // restore the count layers for the next pass / env
+                wave_sync();
             }
-            term |= __ballot(newterm);
-            __syncthreads();
-            // -------------------------------------------------------- catch resolution (:463-521)
-            bool caught = false;
-            if (is_agent && !is_p && alive) {
-                const uint32_t *pc = &L[GSZ];
-                if (d.surround) {
-                    const uint32_t n0 = pc[cell - GW], n1 = pc[cell + GW], n2 = pc[cell + 1], n3 = pc[cell - 1];
-                    const int cnt = (int)(n0 - 1u < SENT - 1u) + (int)(n1 - 1u < SENT - 1u) +
-                                    (int)(n2 - 1u < SENT - 1u) + (int)(n3 - 1u < SENT - 1u);
-                    caught = cnt == (int)need_tab[x * S::YS + y];
-                } else {
-                    caught = (int)pc[cell] >= d.n_catch;
-                }
-                if (caught) atomicAdd(&layer[cell], CAUGHT);
-            }
-            const uint64_t caught_mask = __ballot(caught) >> P;
-            gone |= caught_mask;
-            const int n_removed = __popcll(caught_mask);
-            __syncthreads();
-            // -------------------------------------------------------- rewards (:254-262)
-            double r = 0.0;
-            if (is_p) {
-                const uint32_t *ec = &L[2 * GSZ];
-                bool sur;
-                if (d.surround) {
-                    const uint32_t n0 = ec[cell - GW], n1 = ec[cell + GW], n2 = ec[cell + 1], n3 = ec[cell - 1];
-                    sur = ((n0 != SENT) & (n0 >= CAUGHT)) | ((n1 != SENT) & (n1 >= CAUGHT)) |
-                          ((n2 != SENT) & (n2 >= CAUGHT)) | ((n3 != SENT) & (n3 >= CAUGHT));
-                } else {
-                    sur = ec[cell] >= CAUGHT;
-                }
-                r = d.catchr * (double)kpre;
-                r += d.term_pursuit * (sur ? 1.0 : 0.0);
-                r += d.urgency;
-            }
-            if (d.reward_global) {
-                double all[P];
-#pragma unroll
-                for (int k = 0; k < P; ++k) all[k] = __shfl(r, k);
-                r = np_sum_regs<P>(all) / (double)P;
-            }
-            if (is_p) io.rew[env * P + lane] = (float)r;
-            tick += 1;
-            tstep += 1;
-            const uint64_t all_e = (E >= 64) ? ~0ull : ((1ull << E) - 1ull);
-            if ((gone & all_e) == all_e) done_bits |= 1u;
-            if (d.max_steps > 0 && tstep >= d.max_steps) done_bits |= 2u;
-            if (lane == 0) {
-                io.done[env] = (uint8_t)done_bits;
-                io.removed[env] = n_removed;
-            }
-            do_reset = d.auto_reset && done_bits != 0;
-            if (do_reset) {
-                // the final step's observation lands in the persistent buffer first; write_obs also
-                // zeroes the cell of every agent counted in this step (`alive` still includes the
-                // evaders caught just now, which is what clears their count and CAUGHT mark)
-                write_obs();
-                __syncthreads();
+            // ---------------------------------------------------------- registers -> state record
+            // one coalesced dword store: lane k writes dword k of the record
+            {
+                const int myxy = x | (y << 8);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(rec_src0, myxy);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(rec_src1, myxy);
+                uint32_t w = (lo & 0xFFFFu) | (hi << 16);
+                if (lane == 0) w = tick;
+                if (lane == 1) w = (uint32_t)tstep;
+                if (lane == 2) w = (uint32_t)map_id;
+                if (lane == 3) w = 0u;
+                if (lane == S::OFF_GONE / 4) w = (uint32_t)gone;
+                if (S::NGW > 1 && lane == S::OFF_GONE / 4 + 1) w = (uint32_t)(gone >> 32);
+                if (lane == S::OFF_TERM / 4) w = (uint32_t)term;
+                if (S::NTW > 1 && lane == S::OFF_TERM / 4 + 1) w = (uint32_t)(term >> 32);
+                if (lane > S::OFF_TERM / 4 + S::NTW - 1) w = 0u;  // padding dwords
+                if (lane < S::REC_DW)
+                    reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] = w;
             }
         }
-
-        if (do_reset) {
-            // ---------------------------------------------------------- reset (:173-207)
-            gone = 0ull;
-            term = 0ull;
-            if (io.inj_map != nullptr && mode == 0) {
-                map_id = __builtin_amdgcn_readfirstlane(io.inj_map[env]);
-            } else if (d.sample_maps) {
-                const u32x4 rm = philox4x32_10(gid, tick, 0u, TAG_RESET_ENV, d.k0, d.k1);
-                map_id = (int)__umulhi(rm.x, (uint32_t)d.n_maps);
-            }
-            load_map(map_id);
-            const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, d.k0, d.k1);
-            const double sx = u53(rw.x, rw.y) * (1.0 - d.cw);
-            const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
-            const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + d.cw));
-            const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + d.cw));
-            if (is_agent) {
-                if (io.inj_pos != nullptr && mode == 0) {
-                    x = io.inj_pos[(env * A + lane) * 2];
-                    y = io.inj_pos[(env * A + lane) * 2 + 1];
-                } else {
-                    for (uint32_t att = 0; att < 1024u; ++att) {
-                        const u32x4 rp = philox4x32_10(gid, tick, (uint32_t)lane, TAG_RESET_POS | (att << 8), d.k0, d.k1);
-                        x = xlb + (int)__umulhi(rp.x, (uint32_t)(xub - xlb));
-                        y = ylb + (int)__umulhi(rp.y, (uint32_t)(yub - ylb));
-                        // building cells hold fl32(1/norm) != 0; in-window cells are never outside the map
-                        if (L[(x + PAD) * GW + y + PAD] == 0u) break;
-                    }
-                }
-                cell = (x + PAD) * GW + y + PAD;
-                atomicAdd(&layer[cell], 1u);
-            }
-            alive = is_agent;
-            tick += 1;
-            tstep = 0;
-            __syncthreads();
-        }
-
-        // `alive` is the pre-catch set in step mode: a just-caught evader is still drawn in channel 2
-        // of this observation (Q6) and its cell (count + CAUGHT mark) is zeroed with the others
-        write_obs();
-        // ------------------------------------------------------------ registers -> state record
-        if (is_agent) reinterpret_cast<uint16_t *>(rec + 16)[lane] = (uint16_t)(x | (y << 8));
-        if (lane == 0) {
-            uint32_t *h = reinterpret_cast<uint32_t *>(rec);
-            h[0] = tick;
-            h[1] = (uint32_t)tstep;
-            h[2] = (uint32_t)map_id;
-            reinterpret_cast<uint32_t *>(rec + d.off_gone)[0] = (uint32_t)gone;
-            if (d.ngw > 1) reinterpret_cast<uint32_t *>(rec + d.off_gone)[1] = (uint32_t)(gone >> 32);
-            reinterpret_cast<uint32_t *>(rec + d.off_term)[0] = (uint32_t)term;
-            if (d.ntw > 1) reinterpret_cast<uint32_t *>(rec + d.off_term)[1] = (uint32_t)(term >> 32);
-        }
+        cur_rec = nxt_rec;
+        cur_act = nxt_act;
     }
 }
 

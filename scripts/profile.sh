@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline"
+ARGS="--steps 200 --warmup 20 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o pursuit -- python bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pursuit -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
