@@ -1,0 +1,47 @@
+"""Worker for tests/test_dist_cpu.py: world_size-2 gloo run of the multi-GPU layer on CPU tensors."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from madrl_amd.dist import shard_range, gather_trajectories, gather_episode_stats
+    n_total = 1001
+    lo, hi = shard_range(n_total)
+    sizes = torch.zeros(world, dtype=torch.int64)
+    sizes[rank] = hi - lo
+    dist.all_reduce(sizes)
+    assert int(sizes.sum()) == n_total and int(sizes.max() - sizes.min()) <= 1
+    los = [shard_range(n_total, r, world)[0] for r in range(world)] + [n_total]
+    assert all(shard_range(n_total, r, world)[1] == los[r + 1] for r in range(world))  # contiguous, disjoint
+    # compact trajectory gather: every rank ends up with every rank's buffers, in rank order
+    T, N, P = 7, 16, 3
+    g = torch.Generator().manual_seed(100 + rank)
+    local = dict(actions=torch.randint(0, 5, (T, N, P), generator=g, dtype=torch.uint8),
+                 rewards=torch.randn((T, N, P), generator=g),
+                 dones=torch.randint(0, 2, (T, N), generator=g, dtype=torch.uint8))
+    out = gather_trajectories(local)
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        exp = dict(actions=torch.randint(0, 5, (T, N, P), generator=gr, dtype=torch.uint8),
+                   rewards=torch.randn((T, N, P), generator=gr),
+                   dones=torch.randint(0, 2, (T, N), generator=gr, dtype=torch.uint8))
+        for k in exp:
+            assert out[k].shape == (world,) + tuple(exp[k].shape)
+            assert torch.equal(out[k][r], exp[k]), (k, r)
+    st = gather_episode_stats(torch.full((4, P), float(rank)), torch.full((4,), rank, dtype=torch.int32))
+    assert torch.equal(st["lengths"][:, 0], torch.arange(world, dtype=torch.int32))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()
