@@ -145,6 +145,58 @@ int madrl_pursuit_set_state(madrl_pursuit *h, const int32_t *pos_p, const int32_
                             const int32_t *map_id, const uint32_t *tick, const int32_t *t,
                             void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MAWaterWorld  (reference: madrl_environments/pursuit/waterworld.py), float32 arithmetic
+ * ---------------------------------------------------------------------------------------- */
+
+/* Constructor arguments of MAWaterWorld.__init__ (waterworld.py:77-118). */
+typedef struct madrl_waterworld_config {
+    int32_t struct_size;     /* = sizeof(madrl_waterworld_config) */
+    int32_t n_pursuers, n_evaders, n_coop, n_poison, n_sensors;   /* :77-81 */
+    int32_t addid, speed_features;                                 /* :81 */
+    int32_t reward_global;   /* reward_mech == 'global' */
+    int32_t obstacle_fixed;  /* 1: obstacle at obstacle_loc; 0: obstacle_loc=None, random per reset (:147-151) */
+    int32_t max_steps;       /* 0 = the reference's timestep_limit of 1000 (:124-126) */
+    int32_t auto_reset;      /* 1: an env whose step ends with done is reset in the same launch */
+    int32_t reserved0;
+    double radius, obstacle_radius, ev_speed, poison_speed, sensor_range, action_scale;
+    double poison_reward, food_reward, encounter_reward, control_penalty;
+    double obstacle_loc[2];
+    uint64_t seed;
+    int64_t env_id_base;
+} madrl_waterworld_config;
+
+typedef struct madrl_waterworld madrl_waterworld; /* opaque */
+
+/* n_sensors * (7 or 4) + 2 + (1 if addid)  (Archea.__init__, waterworld.py:18-24) */
+int madrl_waterworld_obs_dim(const madrl_waterworld_config *cfg, int32_t *out_dim);
+/* packed state per env: float32 pos[NP][2] vel[NP][2] obstacle[2], int32 t, uint32 tick
+ * (NP = pursuers + evaders + poisons, in that order) */
+int madrl_waterworld_state_bytes(const madrl_waterworld_config *cfg, int64_t n_envs, uint64_t *out_bytes);
+/* sensors_host: float64 [n_sensors][2] unit vectors, np.c_[cos, sin] of linspace(0, 2pi, K+1)[:-1]
+ * (Archea.__init__ :29-31), rounded to float32 once by the library. */
+int madrl_waterworld_create(const madrl_waterworld_config *cfg, const double *sensors_host, int64_t n_envs,
+                            int32_t device, void *state_dev, madrl_waterworld **out);
+void madrl_waterworld_destroy(madrl_waterworld *h);
+int madrl_waterworld_set_launch(madrl_waterworld *h, int64_t max_blocks);
+
+/* MAWaterWorld.reset (:144-172) incl. its trailing zero-action step; obs float32 [N][Np][obs_dim]. */
+int madrl_waterworld_reset(madrl_waterworld *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
+/* MAWaterWorld.step (:220-436).
+ *   actions_dev       float32 [N][Np][2]  (any layout that reshapes to it, :221-222)
+ *   inj_respawn_dev   float32 [N][NP][4] or NULL: for a particle caught in this step, (x, y) is the
+ *                     accepted respawn position and (u0, u1) the two velocity uniforms -- parity hook
+ *                     replacing the np_random draws of :355-374; NULL = in-kernel Philox
+ *   rew_dev float32 [N][Np]; done_dev uint8 [N] (:174-178); info_dev int32 [N][2] = evcatches, pocatches */
+int madrl_waterworld_step(madrl_waterworld *h, const float *actions_dev, const float *inj_respawn_dev,
+                          float *obs_dev, float *rew_dev, uint8_t *done_dev, int32_t *info_dev, void *stream);
+/* teacher-forcing / checkpoint hook: float32 pos [N][NP][2], vel [N][NP][2], obst [N][2], int32 t [N],
+ * uint32 tick [N]; any pointer may be NULL */
+int madrl_waterworld_get_state(madrl_waterworld *h, float *pos, float *vel, float *obst, int32_t *t,
+                               uint32_t *tick, void *stream);
+int madrl_waterworld_set_state(madrl_waterworld *h, const float *pos, const float *vel, const float *obst,
+                               const int32_t *t, const uint32_t *tick, void *stream);
+
 /* Philox4x32-10 on the host, exported so tests can pin the generator the kernels use
  * against the published known-answer vectors. */
 void madrl_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

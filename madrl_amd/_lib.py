@@ -36,6 +36,17 @@ class PursuitConfig(C.Structure):
                 ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 
 
+class WaterworldConfig(C.Structure):
+    """mirror of madrl_waterworld_config (include/madrl_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "n_pursuers", "n_evaders", "n_coop", "n_poison", "n_sensors", "addid",
+        "speed_features", "reward_global", "obstacle_fixed", "max_steps", "auto_reset", "reserved0")] + [
+            (n, C.c_double) for n in (
+                "radius", "obstacle_radius", "ev_speed", "poison_speed", "sensor_range", "action_scale",
+                "poison_reward", "food_reward", "encounter_reward", "control_penalty")] + [
+                    ("obstacle_loc", C.c_double * 2), ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+
+
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); this table is also what tests use to check that the library
@@ -55,6 +66,15 @@ SIGNATURES = {
     "madrl_pursuit_step": (C.c_int, [_vp] * 8),
     "madrl_pursuit_get_state": (C.c_int, [_vp] * 10),
     "madrl_pursuit_set_state": (C.c_int, [_vp] * 10),
+    "madrl_waterworld_obs_dim": (C.c_int, [_vp, _vp]),
+    "madrl_waterworld_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
+    "madrl_waterworld_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
+    "madrl_waterworld_destroy": (None, [_vp]),
+    "madrl_waterworld_set_launch": (C.c_int, [_vp, C.c_int64]),
+    "madrl_waterworld_reset": (C.c_int, [_vp] * 4),
+    "madrl_waterworld_step": (C.c_int, [_vp] * 8),
+    "madrl_waterworld_get_state": (C.c_int, [_vp] * 7),
+    "madrl_waterworld_set_state": (C.c_int, [_vp] * 7),
 }
 
 

@@ -1,0 +1,591 @@
+// waterworld.hip -- batched MAWaterWorld for MI355X (gfx950 / CDNA4), float32.
+//
+// One wavefront owns one env at a time (64-thread workgroups, persistent, striding over
+// envs).  The env's particles (pursuers | evaders | poisons: position + velocity), the
+// obstacle and the assembled observation rows live in LDS; HBM sees one packed state record
+// in / out, the action row in and observation / reward / done / info rows out.
+//
+// Lane roles change per phase:
+//   particle phases   lane j < NP owns particle j (integration, walls, obstacle rebound,
+//                     respawn, evader/poison motion);
+//   collision phase   lane = (pursuer, evader) / (pursuer, poison) pair;
+//   sensing phase     lane = (pursuer, sensor) pair, looping over the <= ~26 objects whose
+//                     coordinates are LDS broadcasts -- the only O(Np*K*N) part (~4k ray tests).
+// No dense contraction -> no MFMA.  ~40 kFLOP and 5.2 KB of HBM traffic per env-step: the
+// kernel is VALU/LDS-issue bound, not HBM bound.
+//
+// Reference semantics (file:line under /root/reference/madrl_environments/pursuit/waterworld.py):
+//   step phases ........ MAWaterWorld.step :220-436      sensing ...... Archea.sensed :64-72
+//   catch rule ......... _caught :180-193                 respawn ...... _respawn :139-142, :355-374
+//   reset .............. :144-172 (ends with a zero-action step, W11)
+// Arithmetic is float32 (north_star tolerance 1e-5 against the float64 reference); every
+// expression keeps the statement order of the reference's step() so that a float32 CPU restatement agrees bit for bit.
+#include "common.hpp"
+
+#include <math.h>
+#include <new>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+using namespace madrl;
+
+enum : uint32_t { WW_TAG_RESPAWN = 16, WW_TAG_RESET = 17, WW_TAG_OBSTACLE = 18 };
+
+struct WwDev {
+    int32_t Np, Ne, Npo, NP, K, D, nfeat;
+    int32_t n_coop, addid, speed_features, reward_global, obstacle_fixed, max_steps, auto_reset;
+    int32_t rec_dw;  // dwords per packed state record: pos[NP][2] vel[NP][2] obst[2] t tick
+    uint32_t k0, k1, gid_base;
+    float r_pu, r_ev, r_po, obst_r, ev_speed, poison_speed, sensor_range, action_scale;
+    float poison_reward, food_reward, encounter_reward, control_penalty;
+    float obst_x, obst_y;
+    int64_t n_envs;
+    const float *sensors;  // [K][2]
+    float *state;
+};
+
+struct WwIO {
+    const uint8_t *mask;    // reset mode
+    const float *actions;   // [N][Np][2]
+    const float *inj_resp;  // [N][NP][4] or NULL
+    float *obs;             // [N][Np][D]
+    float *rew;             // [N][Np]
+    uint8_t *done;          // [N]
+    int32_t *info;          // [N][2]  evcatches, pocatches
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float u24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) {
+    const float dx = ax - bx, dy = ay - by;
+    return sqrtf(dx * dx + dy * dy);  // scipy cdist 'euclidean'
+}
+
+// MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
+template <int MODE>
+__global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwIO io) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int Np = d.Np, Ne = d.Ne, Npo = d.Npo, NP = d.NP, K = d.K, D = d.D;
+    // ---- LDS carve
+    float *S = smem;                                    // packed record: X[NP][2] | V[NP][2] | obst[2] | t | tick
+    float *X = S, *V = S + 2 * NP;
+    float *OB = S + 4 * NP;
+    float *O = S + ((d.rec_dw + 3) & ~3);               // observation staging [Np][D]
+    float *SEN = O + ((Np * D + 3) & ~3);               // sensor unit vectors [K][2]
+    uint8_t *COL = reinterpret_cast<uint8_t *>(SEN + ((2 * K + 3) & ~3));  // col_ev[Np][Ne] | col_po[Np][Npo]
+    uint8_t *COLP = COL + Np * Ne;
+    uint8_t *FLG = COLP + Np * Npo;                     // caught_ev[Ne] | enc_ev[Ne] | caught_po[Npo]
+
+    for (int k = lane; k < 2 * K; k += 64) SEN[k] = d.sensors[k];
+    const int rec_dw = d.rec_dw;
+    const int nreg = (rec_dw + 63) >> 6;  // <= 4 (NP <= 62)
+
+    // ---- software pipeline: next env's record + action row are fetched one env ahead
+    uint32_t cur[4] = {0, 0, 0, 0};
+    float cur_act = 0.0f;
+    auto fetch = [&](int64_t env, uint32_t (&r)[4], float &a) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(d.state) + env * (int64_t)rec_dw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lane + 64 * q;
+            r[q] = (q < nreg && k < rec_dw) ? src[k] : 0u;
+        }
+        if constexpr (MODE == 1) a = (lane < 2 * Np) ? io.actions[env * 2 * Np + lane] : 0.0f;
+        else a = 0.0f;
+    };
+    if ((int64_t)blockIdx.x < d.n_envs) fetch(blockIdx.x, cur, cur_act);
+    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur_act));
+    wave_sync();
+
+    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
+        const int64_t nenv = env + gridDim.x;
+        uint32_t nxt[4] = {0, 0, 0, 0};
+        float nxt_act = 0.0f;
+        if (nenv < d.n_envs) fetch(nenv, nxt, nxt_act);
+        bool skip = false;
+        if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
+        if (!skip) {
+            // record -> LDS
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = lane + 64 * q;
+                if (q < nreg && k < rec_dw) reinterpret_cast<uint32_t *>(S)[k] = cur[q];
+            }
+            wave_sync();
+            int32_t tstep = reinterpret_cast<int32_t *>(S)[4 * NP + 2];
+            uint32_t tick = reinterpret_cast<uint32_t *>(S)[4 * NP + 3];
+            const uint32_t gid = d.gid_base + (uint32_t)env;
+            float act_lane = cur_act;  // lane 2i / 2i+1 hold pursuer i's action components
+
+            bool do_init = (MODE == 0);
+            int npass = 1;
+            for (int pass = 0; pass < npass; ++pass) {
+                if (do_init) {
+                    // ------------------------------------------------ reset (:144-172)
+                    tstep = 0;
+                    if (lane == 0) {
+                        float ox = d.obst_x, oy = d.obst_y;
+                        if (!d.obstacle_fixed) {  // :147-148
+                            const u32x4 r = philox4x32_10(gid, tick, 0u, WW_TAG_OBSTACLE, d.k0, d.k1);
+                            ox = u24(r.x);
+                            oy = u24(r.y);
+                        }
+                        OB[0] = ox;
+                        OB[1] = oy;
+                    }
+                    wave_sync();
+                    if (lane < NP) {  // :153-170 each particle: uniform position, redrawn while too close to the obstacle
+                        const float pr = lane < Np ? d.r_pu : (lane < Np + Ne ? d.r_ev : d.r_po);
+                        const float thr = pr * 2.0f + d.obst_r;
+                        const float ox = OB[0], oy = OB[1];
+                        float x = 0.f, y = 0.f, u0 = 0.f, u1 = 0.f;
+                        for (uint32_t att = 0; att < 1024u; ++att) {
+                            const u32x4 r = philox4x32_10(gid, tick, (uint32_t)lane, WW_TAG_RESET | (att << 8), d.k0, d.k1);
+                            x = u24(r.x);
+                            y = u24(r.y);
+                            if (att == 0) { u0 = u24(r.z); u1 = u24(r.w); }
+                            if (!(dist2d(x, y, ox, oy) <= thr)) break;
+                        }
+                        X[2 * lane] = x;
+                        X[2 * lane + 1] = y;
+                        V[2 * lane] = lane < Np ? 0.0f : (u0 - 0.5f) * d.ev_speed;      // :164, :170 (W9)
+                        V[2 * lane + 1] = lane < Np ? 0.0f : (u1 - 0.5f) * d.ev_speed;
+                    }
+                    tick += 1;
+                    act_lane = 0.0f;  // reset ends with step(zeros) (:172, W11)
+                    wave_sync();
+                }
+                // ---------------------------------------------------- step (:220-436)
+                const float ox = OB[0], oy = OB[1];
+                // phase A: particles
+                float reward = 0.0f;
+                {
+                    const float a_raw0 = __shfl(act_lane, 2 * (lane < Np ? lane : 0));
+                    const float a_raw1 = __shfl(act_lane, 2 * (lane < Np ? lane : 0) + 1);
+                    const float a0 = a_raw0 * d.action_scale, a1 = a_raw1 * d.action_scale;  // :224
+                    float pen_local = d.control_penalty * (a0 * a0 + a1 * a1);
+                    if (d.reward_global) {  // (actions**2).sum(), row-major (:234-235, W12)
+                        float s = 0.0f;
+                        for (int i = 0; i < Np; ++i) {
+                            const float b0 = __shfl(a0, i), b1 = __shfl(a1, i);
+                            s += b0 * b0;
+                            s += b1 * b1;
+                        }
+                        pen_local = d.control_penalty * s;
+                    }
+                    if (lane < NP) {
+                        float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
+                        float pr = d.r_po, f = -1.0f;
+                        if (lane < Np) {
+                            vx = vx + a0; vy = vy + a1;  // :229-231
+                            x = x + vx; y = y + vy;
+                            reward = 0.0f + pen_local;   // :233-237
+                            const float cx = x < 0.f ? 0.f : (x > 1.f ? 1.f : x);  // :239-245
+                            const float cy = y < 0.f ? 0.f : (y > 1.f ? 1.f : y);
+                            if (x != cx) vx = 0.f;
+                            if (y != cy) vy = 0.f;
+                            x = cx; y = cy;
+                            pr = d.r_pu; f = -0.5f;
+                        } else if (lane < Np + Ne) {
+                            pr = d.r_ev; f = -0.5f;
+                        }
+                        if (dist2d(x, y, ox, oy) <= pr + d.obst_r) {  // :247-270 (W1, W2)
+                            vx = f * vx;
+                            vy = f * vy;
+                        }
+                        X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
+                    }
+                }
+                wave_sync();
+                // phase B: collisions (:272-293)
+                for (int idx = lane; idx < Np * (Ne + Npo); idx += 64) {
+                    const bool is_ev = idx < Np * Ne;
+                    const int r = is_ev ? idx : idx - Np * Ne;
+                    const int n2 = is_ev ? Ne : Npo;
+                    const int i = r / n2, m = r % n2;
+                    const int j = (is_ev ? Np : Np + Ne) + m;
+                    const float thr = d.r_pu + (is_ev ? d.r_ev : d.r_po);
+                    COL[idx] = dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= thr;
+                }
+                wave_sync();
+                // _caught (:180-193): evader lanes / poison lanes count their column
+                bool my_caught = false, my_enc = false;
+                if (lane >= Np && lane < NP) {
+                    const bool is_ev = lane < Np + Ne;
+                    const int m = is_ev ? lane - Np : lane - Np - Ne;
+                    const uint8_t *col = is_ev ? COL : COLP;
+                    const int n2 = is_ev ? Ne : Npo;
+                    int s = 0;
+                    for (int i = 0; i < Np; ++i) s += col[i * n2 + m];
+                    my_caught = s >= (is_ev ? d.n_coop : 1);
+                    my_enc = is_ev && s >= 1;
+                    if (is_ev) { FLG[m] = my_caught; FLG[Ne + m] = my_enc; }
+                    else FLG[2 * Ne + m] = my_caught;
+                }
+                const uint64_t ev_lanes = ((Ne >= 64) ? ~0ull : ((1ull << Ne) - 1ull)) << Np;
+                const uint64_t caught_mask = __ballot(my_caught);
+                const uint64_t enc_mask = __ballot(my_enc);
+                const int n_evc = __popcll(caught_mask & ev_lanes);
+                const int n_poc = __popcll(caught_mask & ~ev_lanes);
+                const int n_enc = __popcll(enc_mask);
+                wave_sync();
+                // phase C: sensing (:295-353).  lane = (pursuer i, sensor k)
+                const float srange = d.sensor_range, rad2 = d.r_pu * d.r_pu;  // W3
+                for (int idx = lane; idx < Np * K; idx += 64) {
+                    const int i = idx / K, k = idx - i * K;
+                    const float sx = SEN[2 * k], sy = SEN[2 * k + 1];
+                    const float px = X[2 * i], py = X[2 * i + 1], pvx = V[2 * i], pvy = V[2 * i + 1];
+                    float *o = O + i * D;
+                    float feat_d[4];
+                    int arg[4];
+#pragma unroll
+                    for (int cls = 0; cls < 4; ++cls) {
+                        const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
+                        const int cnt = cls == 0 ? 1 : (cls == 1 ? Ne : (cls == 2 ? Npo : Np));
+                        float b = INFINITY;
+                        int bi = 0;
+                        for (int m = 0; m < cnt; ++m) {
+                            const float qx = cls == 0 ? ox : X[2 * (lo + m)], qy = cls == 0 ? oy : X[2 * (lo + m) + 1];
+                            const float rx = qx - px, ry = qy - py;
+                            float sv = sx * rx + sy * ry;
+                            const float d2 = rx * rx + ry * ry;
+                            if ((sv < 0.f) || (sv > srange) || (d2 - sv * sv > rad2)) sv = INFINITY;
+                            if (cls == 3 && m == i) sv = INFINITY;
+                            if (sv < b) { b = sv; bi = m; }
+                        }
+                        feat_d[cls] = b;
+                        arg[cls] = bi;
+                    }
+                    const float f_ob = (feat_d[0] < INFINITY) ? feat_d[0] : 0.f;  // W4: raw distance or 0
+                    float fd[3], fs[3];
+#pragma unroll
+                    for (int cls = 1; cls < 4; ++cls) {
+                        const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
+                        const bool fin = feat_d[cls] < INFINITY;
+                        fd[cls - 1] = fin ? feat_d[cls] : 0.f;
+                        const int j = lo + arg[cls];
+                        fs[cls - 1] = fin ? (sx * (V[2 * j] - pvx) + sy * (V[2 * j + 1] - pvy)) : 0.f;  // W5
+                    }
+                    if (d.speed_features) {
+                        o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fs[0]; o[3 * K + k] = fd[1];
+                        o[4 * K + k] = fs[1]; o[5 * K + k] = fd[2]; o[6 * K + k] = fs[2];
+                    } else {
+                        o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fd[1]; o[3 * K + k] = fd[2];
+                    }
+                }
+                // pursuer lanes: collision flags, id, who-caught tests for the local rewards
+                bool wc = false, wp = false, we = false;
+                if (lane < Np) {
+                    bool tev = false, tpo = false;
+                    for (int e = 0; e < Ne; ++e) {
+                        const bool c = COL[lane * Ne + e];
+                        tev |= c;
+                        wc |= c && FLG[e];
+                        we |= c && FLG[Ne + e];
+                    }
+                    for (int p = 0; p < Npo; ++p) {
+                        const bool c = COLP[lane * Npo + p];
+                        tpo |= c;
+                        wp |= c && FLG[2 * Ne + p];
+                    }
+                    float *o = O + lane * D + d.nfeat * K;  // :411-428
+                    o[0] = tev ? 1.f : 0.f;
+                    o[1] = tpo ? 1.f : 0.f;
+                    if (d.addid) o[2] = (float)(lane + 1);  // W10
+                }
+                wave_sync();
+                // phase E: respawn caught evaders / poisons (:355-374)
+                if (lane >= Np && lane < NP && my_caught) {
+                    const bool is_ev = lane < Np + Ne;
+                    float x, y, u0, u1;
+                    if (MODE == 1 && io.inj_resp != nullptr && !do_init) {
+                        const float *r = io.inj_resp + (env * NP + lane) * 4;
+                        x = r[0]; y = r[1]; u0 = r[2]; u1 = r[3];
+                    } else {
+                        const float thr = (is_ev ? d.r_ev : d.r_po) * 2.0f + d.obst_r;
+                        x = y = u0 = u1 = 0.f;
+                        for (uint32_t att = 0; att < 1024u; ++att) {
+                            const u32x4 r = philox4x32_10(gid, tick, (uint32_t)lane, WW_TAG_RESPAWN | (att << 8), d.k0, d.k1);
+                            x = u24(r.x);
+                            y = u24(r.y);
+                            if (att == 0) { u0 = u24(r.z); u1 = u24(r.w); }
+                            if (!(dist2d(x, y, ox, oy) <= thr)) break;
+                        }
+                    }
+                    const float sp = is_ev ? d.ev_speed : d.poison_speed;  // W9
+                    X[2 * lane] = x; X[2 * lane + 1] = y;
+                    V[2 * lane] = (u0 - 0.5f) * sp;
+                    V[2 * lane + 1] = (u1 - 0.5f) * sp;
+                }
+                tick += 1;
+                // phase F: rewards (:376-385)
+                if (lane < Np) {
+                    if (d.reward_global) {
+                        reward += ((float)n_evc * d.food_reward) + ((float)n_poc * d.poison_reward) +
+                                  ((float)n_enc * d.encounter_reward);
+                    } else {  // fancy-index += pays a pursuer once per kind (W7)
+                        if (wc) reward += d.food_reward;
+                        if (wp) reward += d.poison_reward;
+                        if (we) reward += d.encounter_reward;
+                    }
+                }
+                wave_sync();
+                // phase G: evaders / poisons move; velocity flips only if BOTH coordinates left [0,1] (W6)
+                if (lane >= Np && lane < NP) {
+                    float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
+                    x = x + vx; y = y + vy;
+                    const bool outx = !(x >= 0.f && x <= 1.f), outy = !(y >= 0.f && y <= 1.f);
+                    if (outx && outy) { vx = -1.0f * vx; vy = -1.0f * vy; }
+                    X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
+                }
+                tstep += 1;  // :433
+                const int limit = d.max_steps > 0 ? d.max_steps : 1000;  // timestep_limit :124-126
+                const bool is_done = tstep >= limit;                     // :174-178
+                wave_sync();
+
+                if (pass == 0) asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_act));  // pipeline hinge
+                // ---------------------------------------------------- outputs
+                if (MODE == 1 && !do_init) {
+                    if (lane < Np) io.rew[env * Np + lane] = reward;
+                    if (lane == 0) {
+                        io.done[env] = (uint8_t)is_done;
+                        io.info[2 * env] = n_evc;
+                        io.info[2 * env + 1] = n_poc;
+                    }
+                    if (is_done && d.auto_reset) {  // wave-uniform: run the reset pass next
+                        npass = 2;
+                        do_init = true;
+                    }
+                }
+                if (pass == npass - 1) {
+                    float *orow = io.obs + env * (int64_t)(Np * D);
+                    for (int e = lane; e < Np * D; e += 64) orow[e] = O[e];
+                }
+                wave_sync();
+            }
+            // ---------------------------------------------------------- LDS -> record
+            if (lane == 0) {
+                reinterpret_cast<int32_t *>(S)[4 * NP + 2] = tstep;
+                reinterpret_cast<uint32_t *>(S)[4 * NP + 3] = tick;
+            }
+            wave_sync();
+            {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(d.state) + env * (int64_t)rec_dw;
+                for (int k = lane; k < rec_dw; k += 64) dst[k] = reinterpret_cast<const uint32_t *>(S)[k];
+            }
+            wave_sync();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        cur_act = nxt_act;
+    }
+}
+
+}  // namespace
+
+// =================================================================== host side / C ABI
+struct madrl_waterworld {
+    madrl_waterworld_config cfg;
+    WwDev dev;
+    int device;
+    int64_t max_blocks;
+    size_t lds_bytes;
+    void *tables;
+};
+
+namespace {
+
+int ww_validate(const madrl_waterworld_config *c) {
+    if (!c) return fail(MADRL_EINVAL, "config is NULL");
+    if (c->struct_size != (int32_t)sizeof(madrl_waterworld_config))
+        return fail(MADRL_EINVAL, "madrl_waterworld_config.struct_size=%d, library expects %d", c->struct_size,
+                    (int)sizeof(madrl_waterworld_config));
+    if (c->n_pursuers < 1 || c->n_evaders < 1 || c->n_poison < 1)
+        return fail(MADRL_EINVAL, "n_pursuers, n_evaders, n_poison must be >= 1");
+    if (c->n_pursuers + c->n_evaders + c->n_poison > 62)
+        return fail(MADRL_EINVAL, "at most 62 particles per env (one wavefront per env)");
+    if (2 * c->n_pursuers > 64) return fail(MADRL_EINVAL, "n_pursuers must be <= 32");
+    if (c->n_sensors < 1 || c->n_sensors > 256) return fail(MADRL_EINVAL, "n_sensors must be in 1..256");
+    if (c->n_coop < 1) return fail(MADRL_EINVAL, "n_coop must be >= 1");
+    return MADRL_OK;
+}
+
+int ww_obs_dim_of(const madrl_waterworld_config *c) {
+    return c->n_sensors * (c->speed_features ? 7 : 4) + 2 + (c->addid ? 1 : 0);  // Archea.__init__ :18-24
+}
+
+void ww_layout(const madrl_waterworld_config *c, WwDev *d) {
+    memset(d, 0, sizeof(*d));
+    d->Np = c->n_pursuers; d->Ne = c->n_evaders; d->Npo = c->n_poison; d->NP = d->Np + d->Ne + d->Npo;
+    d->K = c->n_sensors; d->D = ww_obs_dim_of(c); d->nfeat = c->speed_features ? 7 : 4;
+    d->n_coop = c->n_coop; d->addid = c->addid; d->speed_features = c->speed_features;
+    d->reward_global = c->reward_global; d->obstacle_fixed = c->obstacle_fixed; d->max_steps = c->max_steps;
+    d->auto_reset = c->auto_reset;
+    d->rec_dw = (int)align_up((size_t)4 * d->NP + 4, 4);
+    d->k0 = (uint32_t)c->seed; d->k1 = (uint32_t)(c->seed >> 32); d->gid_base = (uint32_t)c->env_id_base;
+    // radii: pursuer r, evader 2r, poison 3r/4, evaluated in float64 like the reference (:108-118)
+    d->r_pu = (float)c->radius; d->r_ev = (float)(c->radius * 2); d->r_po = (float)(c->radius * 3 / 4);
+    d->obst_r = (float)c->obstacle_radius; d->ev_speed = (float)c->ev_speed; d->poison_speed = (float)c->poison_speed;
+    d->sensor_range = (float)c->sensor_range; d->action_scale = (float)c->action_scale;
+    d->poison_reward = (float)c->poison_reward; d->food_reward = (float)c->food_reward;
+    d->encounter_reward = (float)c->encounter_reward; d->control_penalty = (float)c->control_penalty;
+    d->obst_x = (float)c->obstacle_loc[0]; d->obst_y = (float)c->obstacle_loc[1];
+}
+
+size_t ww_lds_bytes(const WwDev &d) {
+    size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)d.Np * d.D, 4) + align_up((size_t)2 * d.K, 4);
+    size_t b = f * 4 + (size_t)d.Np * (d.Ne + d.Npo) + 2 * (size_t)d.Ne + d.Npo;
+    return align_up(b, 16);
+}
+
+int ww_launch(const madrl_waterworld *h, const WwIO &io, int mode, void *stream) {
+    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 16;
+    if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0)
+        hipLaunchKernelGGL(waterworld_kernel<0>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    else
+        hipLaunchKernelGGL(waterworld_kernel<1>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+__global__ void ww_state_copy_kernel(const WwDev d, float *pos, float *vel, float *obst, int32_t *t, uint32_t *tick,
+                                     const int to_state) {
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    float *rec = d.state + env * (int64_t)d.rec_dw;
+    const int NP = d.NP;
+    for (int k = 0; k < 2 * NP; ++k) {
+        if (pos) { if (to_state) rec[k] = pos[env * 2 * NP + k]; else pos[env * 2 * NP + k] = rec[k]; }
+        if (vel) { if (to_state) rec[2 * NP + k] = vel[env * 2 * NP + k]; else vel[env * 2 * NP + k] = rec[2 * NP + k]; }
+    }
+    for (int k = 0; k < 2; ++k)
+        if (obst) { if (to_state) rec[4 * NP + k] = obst[env * 2 + k]; else obst[env * 2 + k] = rec[4 * NP + k]; }
+    int32_t *ti = reinterpret_cast<int32_t *>(rec) + 4 * NP + 2;
+    uint32_t *tk = reinterpret_cast<uint32_t *>(rec) + 4 * NP + 3;
+    if (t) { if (to_state) *ti = t[env]; else t[env] = *ti; }
+    if (tick) { if (to_state) *tk = tick[env]; else tick[env] = *tk; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int madrl_waterworld_obs_dim(const madrl_waterworld_config *cfg, int32_t *out_dim) {
+    int rc = ww_validate(cfg);
+    if (rc) return rc;
+    if (!out_dim) return fail(MADRL_EINVAL, "out_dim is NULL");
+    *out_dim = ww_obs_dim_of(cfg);
+    return MADRL_OK;
+}
+
+int madrl_waterworld_state_bytes(const madrl_waterworld_config *cfg, int64_t n_envs, uint64_t *out_bytes) {
+    int rc = ww_validate(cfg);
+    if (rc) return rc;
+    if (n_envs < 1 || !out_bytes) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_bytes non-NULL");
+    WwDev d;
+    ww_layout(cfg, &d);
+    *out_bytes = (uint64_t)d.rec_dw * 4u * (uint64_t)n_envs;
+    return MADRL_OK;
+}
+
+int madrl_waterworld_create(const madrl_waterworld_config *cfg, const double *sensors_host, int64_t n_envs,
+                            int32_t device, void *state_dev, madrl_waterworld **out) {
+    int rc = ww_validate(cfg);
+    if (rc) return rc;
+    if (!sensors_host || !state_dev || !out || n_envs < 1) return fail(MADRL_EINVAL, "create: NULL argument or n_envs < 1");
+    if (n_envs + cfg->env_id_base > 0xFFFFFFFFll) return fail(MADRL_EINVAL, "global env index must fit 32 bits");
+    MADRL_HIP_TRY(hipSetDevice(device));
+    madrl_waterworld *h = new (std::nothrow) madrl_waterworld();
+    if (!h) return fail(MADRL_ENOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    ww_layout(cfg, &h->dev);
+    h->dev.n_envs = n_envs;
+    h->dev.state = (float *)state_dev;
+    h->lds_bytes = ww_lds_bytes(h->dev);
+    h->max_blocks = 0;
+    if (h->lds_bytes > 64 * 1024) {
+        delete h;
+        return fail(MADRL_EINVAL, "configuration needs %zu B of LDS (> 64 KiB)", h->lds_bytes);
+    }
+    std::vector<float> sens(2 * (size_t)cfg->n_sensors);
+    for (size_t k = 0; k < sens.size(); ++k) sens[k] = (float)sensors_host[k];  // float64 cos/sin rounded once
+    hipError_t e = hipMalloc(&h->tables, sens.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->tables, sens.data(), sens.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->tables) (void)hipFree(h->tables);
+        delete h;
+        return fail(MADRL_EHIP, "sensor table upload failed: %s", hipGetErrorString(e));
+    }
+    h->dev.sensors = (const float *)h->tables;
+    *out = h;
+    return MADRL_OK;
+}
+
+void madrl_waterworld_destroy(madrl_waterworld *h) {
+    if (!h) return;
+    if (h->tables) (void)hipFree(h->tables);
+    delete h;
+}
+
+int madrl_waterworld_set_launch(madrl_waterworld *h, int64_t max_blocks) {
+    if (!h || max_blocks < 0) return fail(MADRL_EINVAL, "set_launch: bad argument");
+    h->max_blocks = max_blocks;
+    return MADRL_OK;
+}
+
+int madrl_waterworld_reset(madrl_waterworld *h, const uint8_t *mask_dev, float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(MADRL_EINVAL, "reset: handle/obs is NULL");
+    WwIO io;
+    memset(&io, 0, sizeof(io));
+    io.mask = mask_dev;
+    io.obs = obs_dev;
+    return ww_launch(h, io, 0, stream);
+}
+
+int madrl_waterworld_step(madrl_waterworld *h, const float *actions_dev, const float *inj_respawn_dev, float *obs_dev,
+                          float *rew_dev, uint8_t *done_dev, int32_t *info_dev, void *stream) {
+    if (!h || !actions_dev || !obs_dev || !rew_dev || !done_dev || !info_dev) return fail(MADRL_EINVAL, "step: NULL argument");
+    WwIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = actions_dev;
+    io.inj_resp = inj_respawn_dev;
+    io.obs = obs_dev;
+    io.rew = rew_dev;
+    io.done = done_dev;
+    io.info = info_dev;
+    return ww_launch(h, io, 1, stream);
+}
+
+int madrl_waterworld_get_state(madrl_waterworld *h, float *pos, float *vel, float *obst, int32_t *t, uint32_t *tick,
+                               void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 127) / 128);
+    hipLaunchKernelGGL(ww_state_copy_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, pos, vel, obst, t,
+                       tick, 0);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_waterworld_set_state(madrl_waterworld *h, const float *pos, const float *vel, const float *obst,
+                               const int32_t *t, const uint32_t *tick, void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 127) / 128);
+    hipLaunchKernelGGL(ww_state_copy_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, (float *)pos,
+                       (float *)vel, (float *)obst, (int32_t *)t, (uint32_t *)tick, 1);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+}  // extern "C"
