@@ -197,6 +197,50 @@ int madrl_waterworld_get_state(madrl_waterworld *h, float *pos, float *vel, floa
 int madrl_waterworld_set_state(madrl_waterworld *h, const float *pos, const float *vel, const float *obst,
                                const int32_t *t, const uint32_t *tick, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MultiWalkerEnv  (reference: madrl_environments/walker/multi_walker.py), float32.
+ * The rigid-body dynamics the reference delegates to Box2D (`world.Step(1/50, 180, 60)`,
+ * multi_walker.py:365) are restated from scratch; parity with Box2D itself is UNPINNED
+ * (DESIGN.md "MultiWalker").
+ * ---------------------------------------------------------------------------------------- */
+
+/* Constructor arguments of MultiWalkerEnv.__init__ (multi_walker.py:256-270). */
+typedef struct madrl_multiwalker_config {
+    int32_t struct_size;      /* = sizeof(madrl_multiwalker_config) */
+    int32_t n_walkers;        /* 1..4 */
+    int32_t reward_global;    /* reward_mech != 'local' (:426-428) */
+    int32_t terminate_on_fall;
+    int32_t one_hot;          /* must be 0 */
+    int32_t max_steps;        /* 0 = none; else done bit1 when the episode reaches it */
+    int32_t auto_reset;
+    int32_t reserved0;
+    double position_noise, angle_noise, forward_reward, fall_reward, drop_reward;
+    uint64_t seed;
+    int64_t env_id_base;
+} madrl_multiwalker_config;
+
+typedef struct madrl_multiwalker madrl_multiwalker; /* opaque */
+
+int madrl_multiwalker_obs_dim(const madrl_multiwalker_config *cfg, int32_t *out_dim);        /* 32 (:243) */
+/* one opaque world struct per env (bodies, joints, manifold cache, terrain); caller allocates + zeroes */
+int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n_envs, uint64_t *out_bytes);
+int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device, void *state_dev,
+                             madrl_multiwalker **out);
+void madrl_multiwalker_destroy(madrl_multiwalker *h);
+int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks);
+int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain);
+/* MultiWalkerEnv.reset (:330-357) incl. its trailing zero-action step; obs float32 [N][W][32] */
+int madrl_multiwalker_reset(madrl_multiwalker *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
+/* MultiWalkerEnv.step (:359-428): actions float32 [N][W][4]; rew float32 [N][W]; done uint8 [N]
+ * (bit0 = the reference's done, bit1 = max_steps reached) */
+int madrl_multiwalker_step(madrl_multiwalker *h, const float *actions_dev, float *obs_dev, float *rew_dev,
+                           uint8_t *done_dev, void *stream);
+/* inspection: bodies float32 [N][NB][6] = centre x, y, angle, vx, vy, w (body 0 = package, then per walker hull,
+ * upper/lower left leg, upper/lower right leg); flags uint8 [N][1+3W] = game_over, fallen[W], ground_contact[W][2];
+ * terrain float32 [N][NT] heights.  Any pointer may be NULL. */
+int madrl_multiwalker_get_bodies(madrl_multiwalker *h, float *bodies_dev, uint8_t *flags_dev, float *terrain_dev,
+                                 void *stream);
+
 /* Philox4x32-10 on the host, exported so tests can pin the generator the kernels use
  * against the published known-answer vectors. */
 void madrl_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

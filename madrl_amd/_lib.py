@@ -47,6 +47,15 @@ class WaterworldConfig(C.Structure):
                     ("obstacle_loc", C.c_double * 2), ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 
 
+class MultiWalkerConfig(C.Structure):
+    """mirror of madrl_multiwalker_config (include/madrl_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "n_walkers", "reward_global", "terminate_on_fall", "one_hot", "max_steps", "auto_reset",
+        "reserved0")] + [(n, C.c_double) for n in (
+            "position_noise", "angle_noise", "forward_reward", "fall_reward", "drop_reward")] + [
+                ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+
+
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); this table is also what tests use to check that the library
@@ -75,6 +84,15 @@ SIGNATURES = {
     "madrl_waterworld_step": (C.c_int, [_vp] * 8),
     "madrl_waterworld_get_state": (C.c_int, [_vp] * 7),
     "madrl_waterworld_set_state": (C.c_int, [_vp] * 7),
+    "madrl_multiwalker_obs_dim": (C.c_int, [_vp, _vp]),
+    "madrl_multiwalker_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
+    "madrl_multiwalker_create": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
+    "madrl_multiwalker_destroy": (None, [_vp]),
+    "madrl_multiwalker_set_launch": (C.c_int, [_vp, C.c_int64]),
+    "madrl_multiwalker_dims": (C.c_int, [_vp, _vp, _vp]),
+    "madrl_multiwalker_reset": (C.c_int, [_vp] * 4),
+    "madrl_multiwalker_step": (C.c_int, [_vp] * 6),
+    "madrl_multiwalker_get_bodies": (C.c_int, [_vp] * 5),
 }
 
 

@@ -1,0 +1,260 @@
+// multiwalker.hip -- batched MultiWalkerEnv for MI355X (gfx950 / CDNA4), float32.
+//
+// One workgroup (one wavefront) owns one env at a time; the whole rigid-body world of the env
+// (16 bodies, 12 revolute joints, manifold cache, terrain: mw::World, 6 KB) and the per-step
+// solver workspace (mw::Scratch, ~8 KB) live in LDS for the 180 + 60 Gauss-Seidel sweeps of
+// Box2D's `Step(1/50, 180, 60)`; HBM sees the world struct in/out once per step, the action row
+// in and observation / reward / done rows out.
+//
+// v1 mapping: the solver (multiwalker_core.hpp, shared host/device source) runs on lane 0 of the
+// wavefront; the other lanes move the world struct and the outputs (coalesced dword copies).
+// The path is bound by dependent FP32 VALU latency inside one wavefront, not by HBM
+// (~3 KB per env-step against ~1 MFLOP of serial work) -- DESIGN.md "MultiWalker".
+//
+// PARITY UNPINNED (Box2D is not available to pin against) -- see multiwalker_core.hpp.
+#include "common.hpp"
+#include "multiwalker_core.hpp"
+
+#include <new>
+#include <string.h>
+
+namespace {
+
+using namespace madrl;
+
+struct MwDev {
+    mw::EnvCfg cfg;
+    uint32_t gid_base;
+    int32_t world_dw;  // dwords per env in the state buffer
+    int64_t n_envs;
+    const mw::Model *model;
+    uint32_t *state;
+};
+struct MwIO {
+    const uint8_t *mask;
+    const float *actions;  // [N][W][4]
+    float *obs;            // [N][W][32]
+    float *rew;            // [N][W]
+    uint8_t *done;         // [N]
+};
+
+__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+
+// MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
+template <int MODE>
+__global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const MwIO io) {
+    __shared__ mw::Model M;
+    __shared__ mw::World Wd;
+    __shared__ mw::Scratch S;
+    __shared__ float s_obs[mw::MAX_WALKERS * mw::OBS_DIM], s_rew[mw::MAX_WALKERS], s_act[4 * mw::MAX_WALKERS];
+    __shared__ uint32_t s_done;
+    const int lane = threadIdx.x;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(d.model);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&M);
+        for (int k = lane; k < (int)(sizeof(mw::Model) / 4); k += 64) dst[k] = src[k];
+    }
+    lds_sync();
+    const int W = M.W;
+    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
+        if (MODE == 0 && io.mask != nullptr && io.mask[env] == 0) continue;
+        uint32_t *rec = d.state + env * (int64_t)d.world_dw;
+        {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
+            for (int k = lane; k < (int)(sizeof(mw::World) / 4); k += 64) dst[k] = rec[k];
+            if (MODE == 1 && lane < 4 * W) s_act[lane] = io.actions[env * 4 * W + lane];
+        }
+        lds_sync();
+        const uint32_t gid = d.gid_base + (uint32_t)env;
+        if (lane == 0) {
+            uint8_t dn = 0;
+            if (MODE == 1) {
+                mw::env_step(M, d.cfg, Wd, S, gid, s_act, s_obs, s_rew, &dn);
+                if (d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) dn |= 2;
+            }
+            if (MODE == 0 || (dn != 0 && d.cfg.auto_reset)) {  // MultiWalkerEnv.reset (:330-357) ends with step(zeros)
+                float zero[4 * mw::MAX_WALKERS];
+                for (int k = 0; k < 4 * mw::MAX_WALKERS; ++k) zero[k] = 0.0f;
+                mw::env_reset_world(M, d.cfg, Wd, gid);
+                mw::env_step(M, d.cfg, Wd, S, gid, zero, s_obs, nullptr, nullptr);
+                Wd.t = 0;
+            }
+            s_done = dn;
+        }
+        lds_sync();
+        for (int k = lane; k < W * mw::OBS_DIM; k += 64) io.obs[env * W * mw::OBS_DIM + k] = s_obs[k];
+        if (MODE == 1) {
+            if (lane < W) io.rew[env * W + lane] = s_rew[lane];
+            if (lane == 0) io.done[env] = (uint8_t)s_done;
+        }
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
+            for (int k = lane; k < (int)(sizeof(mw::World) / 4); k += 64) rec[k] = src[k];
+        }
+        lds_sync();
+    }
+}
+
+__global__ void mw_get_bodies_kernel(const MwDev d, float *bodies, uint8_t *flags, float *terrain) {
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    const mw::World *w = reinterpret_cast<const mw::World *>(d.state + env * (int64_t)d.world_dw);
+    const int NB = d.model->NB, W = d.model->W, NT = d.model->NT;
+    if (bodies)
+        for (int b = 0; b < NB; ++b) {
+            float *p = bodies + (env * NB + b) * 6;
+            p[0] = w->b[b].c.x; p[1] = w->b[b].c.y; p[2] = w->b[b].a; p[3] = w->b[b].v.x; p[4] = w->b[b].v.y; p[5] = w->b[b].w;
+        }
+    if (flags) {
+        uint8_t *f = flags + env * (1 + 3 * W);
+        f[0] = w->game_over;
+        for (int k = 0; k < W; ++k) { f[1 + k] = w->fallen[k]; f[1 + W + 2 * k] = w->ground[k][0]; f[1 + W + 2 * k + 1] = w->ground[k][1]; }
+    }
+    if (terrain) for (int i = 0; i < NT; ++i) terrain[env * NT + i] = w->ty[i];
+}
+
+}  // namespace
+
+struct madrl_multiwalker {
+    madrl_multiwalker_config cfg;
+    MwDev dev;
+    int device;
+    int64_t max_blocks;
+    void *model_dev;
+    int NB, NT;
+};
+
+namespace {
+
+int mw_validate(const madrl_multiwalker_config *c) {
+    if (!c) return fail(MADRL_EINVAL, "config is NULL");
+    if (c->struct_size != (int32_t)sizeof(madrl_multiwalker_config))
+        return fail(MADRL_EINVAL, "madrl_multiwalker_config.struct_size=%d, library expects %d", c->struct_size,
+                    (int)sizeof(madrl_multiwalker_config));
+    if (c->n_walkers < 1 || c->n_walkers > mw::MAX_WALKERS)
+        return fail(MADRL_EINVAL, "n_walkers=%d unsupported (1..%d)", c->n_walkers, mw::MAX_WALKERS);
+    if (c->one_hot) return fail(MADRL_EINVAL, "one_hot ids (multi_walker.py:397-398) are not supported");
+    return MADRL_OK;
+}
+
+int mw_launch(const madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
+    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 8;
+    if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(multiwalker_kernel<0>, dim3((unsigned)blocks), dim3(64), 0, s, h->dev, io);
+    else hipLaunchKernelGGL(multiwalker_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, s, h->dev, io);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int madrl_multiwalker_obs_dim(const madrl_multiwalker_config *cfg, int32_t *out_dim) {
+    int rc = mw_validate(cfg);
+    if (rc) return rc;
+    if (!out_dim) return fail(MADRL_EINVAL, "out_dim is NULL");
+    *out_dim = mw::OBS_DIM;
+    return MADRL_OK;
+}
+
+int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n_envs, uint64_t *out_bytes) {
+    int rc = mw_validate(cfg);
+    if (rc) return rc;
+    if (n_envs < 1 || !out_bytes) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_bytes non-NULL");
+    *out_bytes = (uint64_t)align_up(sizeof(mw::World), 16) * (uint64_t)n_envs;
+    return MADRL_OK;
+}
+
+int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device, void *state_dev,
+                             madrl_multiwalker **out) {
+    int rc = mw_validate(cfg);
+    if (rc) return rc;
+    if (!state_dev || !out || n_envs < 1) return fail(MADRL_EINVAL, "create: NULL argument or n_envs < 1");
+    if (n_envs + cfg->env_id_base > 0xFFFFFFFFll) return fail(MADRL_EINVAL, "global env index must fit 32 bits");
+    MADRL_HIP_TRY(hipSetDevice(device));
+    madrl_multiwalker *h = new (std::nothrow) madrl_multiwalker();
+    if (!h) return fail(MADRL_ENOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    h->max_blocks = 0;
+    mw::Model M;
+    memset(&M, 0, sizeof(M));
+    mw::build_model(M, cfg->n_walkers);
+    h->NB = M.NB; h->NT = M.NT;
+    hipError_t e = hipMalloc(&h->model_dev, sizeof(M));
+    if (e == hipSuccess) e = hipMemcpy(h->model_dev, &M, sizeof(M), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->model_dev) (void)hipFree(h->model_dev);
+        delete h;
+        return fail(MADRL_EHIP, "model upload failed: %s", hipGetErrorString(e));
+    }
+    MwDev &d = h->dev;
+    memset(&d, 0, sizeof(d));
+    d.cfg.n_walkers = cfg->n_walkers; d.cfg.reward_global = cfg->reward_global; d.cfg.terminate_on_fall = cfg->terminate_on_fall;
+    d.cfg.one_hot = 0; d.cfg.max_steps = cfg->max_steps; d.cfg.auto_reset = cfg->auto_reset;
+    d.cfg.position_noise = (float)cfg->position_noise; d.cfg.angle_noise = (float)cfg->angle_noise;
+    d.cfg.forward_reward = (float)cfg->forward_reward; d.cfg.fall_reward = (float)cfg->fall_reward;
+    d.cfg.drop_reward = (float)cfg->drop_reward;
+    d.cfg.k0 = (uint32_t)cfg->seed; d.cfg.k1 = (uint32_t)(cfg->seed >> 32);
+    d.gid_base = (uint32_t)cfg->env_id_base;
+    d.world_dw = (int32_t)(align_up(sizeof(mw::World), 16) / 4);
+    d.n_envs = n_envs;
+    d.model = (const mw::Model *)h->model_dev;
+    d.state = (uint32_t *)state_dev;
+    *out = h;
+    return MADRL_OK;
+}
+
+void madrl_multiwalker_destroy(madrl_multiwalker *h) {
+    if (!h) return;
+    if (h->model_dev) (void)hipFree(h->model_dev);
+    delete h;
+}
+
+int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks) {
+    if (!h || max_blocks < 0) return fail(MADRL_EINVAL, "set_launch: bad argument");
+    h->max_blocks = max_blocks;
+    return MADRL_OK;
+}
+
+int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    if (n_bodies) *n_bodies = h->NB;
+    if (n_terrain) *n_terrain = h->NT;
+    return MADRL_OK;
+}
+
+int madrl_multiwalker_reset(madrl_multiwalker *h, const uint8_t *mask_dev, float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(MADRL_EINVAL, "reset: handle/obs is NULL");
+    MwIO io;
+    memset(&io, 0, sizeof(io));
+    io.mask = mask_dev;
+    io.obs = obs_dev;
+    return mw_launch(h, io, 0, stream);
+}
+
+int madrl_multiwalker_step(madrl_multiwalker *h, const float *actions_dev, float *obs_dev, float *rew_dev,
+                           uint8_t *done_dev, void *stream) {
+    if (!h || !actions_dev || !obs_dev || !rew_dev || !done_dev) return fail(MADRL_EINVAL, "step: NULL argument");
+    MwIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = actions_dev;
+    io.obs = obs_dev;
+    io.rew = rew_dev;
+    io.done = done_dev;
+    return mw_launch(h, io, 1, stream);
+}
+
+int madrl_multiwalker_get_bodies(madrl_multiwalker *h, float *bodies_dev, uint8_t *flags_dev, float *terrain_dev,
+                                 void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 63) / 64);
+    hipLaunchKernelGGL(mw_get_bodies_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->dev, bodies_dev, flags_dev,
+                       terrain_dev);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1170 @@
+// multiwalker_core.hpp -- MultiWalkerEnv dynamics: a from-scratch float32 restatement of the
+// subset of Box2D 2.3.x that madrl_environments/walker/multi_walker.py drives
+// (`self.world.Step(1.0 / FPS, 6 * 30, 2 * 30)`, multi_walker.py:365), plus the env logic
+// around it.  Written once as host/device code: the HIP kernel (multiwalker.hip) runs it with the
+// world resident in LDS.
+//
+// PARITY UNPINNED: the arithmetic lives in third-party Box2D (pybox2d /
+// box2d-py, Box2D 2.3.x; no version pin anywhere in the reference tree, the module is not
+// installable here and the reference has no golden vectors at that boundary).  What follows
+// restates Box2D's published algorithms from their documented structure:
+//   b2World::Step -> Collide -> Solve(islands) ; b2ContactSolver (sequential impulses, block
+//   solver for 2-point manifolds, Baumgarte position correction) ; b2RevoluteJoint (point
+//   constraint + motor + limit) ; b2CollidePolygons ; b2CollideEdgeAndPolygon ; b2EdgeShape::RayCast.
+// Known, deliberate differences from Box2D (documented in DESIGN.md): no TOI / continuous pass,
+// no sleeping, constraint order = this file's deterministic order (Box2D: creation/DFS order),
+// lidar returns the closest terrain hit (Box2D reports the first hit in tree order).
+//
+// Reference call sites (file:line in /root/reference/madrl_environments/walker/multi_walker.py):
+//   constants :17-47 ; BipedalWalker._reset :113-192 ; apply_action :194-203 ;
+//   get_observation :205-237 ; ContactDetector :50-84 ; MultiWalkerEnv.setup/reset :276-357 ;
+//   step :359-428 ; _generate_package :499-514 ; _generate_terrain :516-628.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MW_HD __host__ __device__ inline
+#else
+#define MW_HD inline
+#endif
+
+namespace mw {
+
+// ---------------------------------------------------------------- env constants (:17-47)
+constexpr float FPS = 50.0f, SCALE = 30.0f;
+constexpr float MOTORS_TORQUE = 80.0f, SPEED_HIP = 4.0f, SPEED_KNEE = 6.0f;
+constexpr float LIDAR_RANGE = 160.0f / SCALE, INITIAL_RANDOM = 5.0f;
+constexpr float LEG_DOWN = -8.0f / SCALE, LEG_W = 8.0f / SCALE, LEG_H = 34.0f / SCALE;
+constexpr float PACKAGE_LENGTH = 240.0f;
+constexpr float VIEWPORT_W = 600.0f, VIEWPORT_H = 400.0f;
+constexpr float TERRAIN_STEP = 14.0f / SCALE;
+constexpr int TERRAIN_LENGTH = 200, TERRAIN_GRASS = 10, TERRAIN_STARTPAD = 20;
+constexpr float TERRAIN_HEIGHT = VIEWPORT_H / SCALE / 4.0f, FRICTION = 2.5f;
+constexpr int WALKER_SEPERATION = 10;
+
+// ---------------------------------------------------------------- Box2D constants (b2Settings.h)
+constexpr float B2_PI = 3.14159265359f;
+constexpr float LINEAR_SLOP = 0.005f, ANGULAR_SLOP = 2.0f / 180.0f * B2_PI, POLY_RADIUS = 2.0f * LINEAR_SLOP;
+constexpr float MAX_LINEAR_CORRECTION = 0.2f, MAX_ANGULAR_CORRECTION = 8.0f / 180.0f * B2_PI;
+constexpr float MAX_TRANSLATION = 2.0f, MAX_ROTATION = 0.5f * B2_PI, BAUMGARTE = 0.2f;
+constexpr float GRAVITY_Y = -10.0f;  // b2World() default in pybox2d: gravity=(0,-10)
+constexpr int VEL_ITERS = 6 * 30, POS_ITERS = 2 * 30;
+
+constexpr int MAX_WALKERS = 4;
+constexpr int MAXB = 5 * MAX_WALKERS + 1;        // package + 5 bodies per walker
+constexpr int MAXJ = 4 * MAX_WALKERS;
+constexpr int MAXT = TERRAIN_LENGTH * MAX_WALKERS / 8;  // terrain points (:301)
+constexpr int EDGE_SLOTS_SMALL = 6, EDGE_SLOTS_PKG = 36;
+constexpr int MAXSLOT = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
+constexpr int MAXM = 40;  // active manifolds per step
+
+struct V2 { float x, y; };
+MW_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+MW_HD V2 operator+(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
+MW_HD V2 operator-(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
+MW_HD V2 operator-(V2 a) { return v2(-a.x, -a.y); }
+MW_HD V2 operator*(float s, V2 a) { return v2(s * a.x, s * a.y); }
+MW_HD float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+MW_HD float cross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+MW_HD V2 cross(V2 a, float s) { return v2(s * a.y, -s * a.x); }
+MW_HD V2 cross(float s, V2 a) { return v2(-s * a.y, s * a.x); }
+MW_HD float clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
+struct Rot { float s, c; };
+// sin/cos from +,-,* only (Cody-Waite reduction by pi/2, cephes single-precision minimax
+// polynomials on [-pi/4, pi/4]): the host build and the device build of this file then agree
+// bit for bit, which libm's and the device library's sinf/cosf (each within an ulp or two of
+// the true value, but not of each other) do not.
+MW_HD void sincos_det(float a, float &sn, float &cs) {
+    const float kf = floorf(a * 0.636619772f + 0.5f);  // nearest multiple of pi/2
+    const int k = (int)kf;
+    float r = (a - kf * 1.5703125f) - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.549789948768648e-8f;
+    const float z = r * r;
+    const float ps = r + r * z * ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f);
+    const float pc = (1.0f - 0.5f * z) + z * z * ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f);
+    switch (k & 3) {
+        case 0: sn = ps; cs = pc; break;
+        case 1: sn = pc; cs = -ps; break;
+        case 2: sn = -ps; cs = -pc; break;
+        default: sn = -pc; cs = ps; break;
+    }
+}
+MW_HD Rot rot(float a) { Rot q; sincos_det(a, q.s, q.c); return q; }
+MW_HD V2 mul(Rot q, V2 v) { return v2(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }
+MW_HD V2 mulT(Rot q, V2 v) { return v2(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); }
+struct Xf { V2 p; Rot q; };
+MW_HD V2 mul(Xf t, V2 v) { return mul(t.q, v) + t.p; }
+MW_HD V2 mulT(Xf t, V2 v) { return mulT(t.q, v - t.p); }
+MW_HD Rot mulT(Rot q, Rot r) { Rot o; o.s = q.c * r.s - q.s * r.c; o.c = q.c * r.c + q.s * r.s; return o; }
+MW_HD Xf mulT(Xf A, Xf B) { Xf C; C.q = mulT(A.q, B.q); C.p = mulT(A.q, B.p - A.p); return C; }
+
+// ---------------------------------------------------------------- static model (per n_walkers)
+enum { SH_PACKAGE = 0, SH_HULL = 1, SH_UPPER = 2, SH_LOWER = 3, N_SHAPES = 4 };
+struct Shape {
+    int n;
+    V2 v[5], nrm[5];
+    V2 centroid;      // = body localCenter (one fixture per body)
+    float inv_mass, inv_I, friction;
+    uint16_t category, mask;
+};
+struct JointDef {  // revoluteJointDef, multi_walker.py:145-179
+    int bA, bB;
+    V2 lA, lB;        // local anchors
+    float lower, upper;
+};
+struct Model {
+    int W, NB, NJ, NT;  // walkers, bodies, joints, terrain points
+    Shape shape[N_SHAPES];
+    JointDef jd[MAXJ];
+    float package_length, package_scale;
+    float start_x[MAX_WALKERS];
+    int slot_base[MAXB], slot_cap[MAXB];  // body-vs-terrain manifold cache ranges
+    int dyn_slot_base, n_dyn_pairs;
+    int dyn_a[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS], dyn_b[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
+};
+MW_HD int shape_of_body(int b) { return b == 0 ? SH_PACKAGE : (((b - 1) % 5 == 0) ? SH_HULL : (((b - 1) % 5) % 2 == 1 ? SH_UPPER : SH_LOWER)); }
+MW_HD int hull_of(int w) { return 1 + 5 * w; }
+
+// b2PolygonShape::Set (gift wrapping from the right-most, lowest vertex, CCW) + normals
+inline void poly_set(Shape &s, const V2 *pts, int count) {
+    int i0 = 0;
+    float x0 = pts[0].x;
+    for (int i = 1; i < count; ++i) {
+        const float x = pts[i].x;
+        if (x > x0 || (x == x0 && pts[i].y < pts[i0].y)) { i0 = i; x0 = x; }
+    }
+    int hull[8], m = 0, ih = i0;
+    for (;;) {
+        hull[m] = ih;
+        int ie = 0;
+        for (int j = 1; j < count; ++j) {
+            if (ie == ih) { ie = j; continue; }
+            const V2 r = pts[ie] - pts[hull[m]], v = pts[j] - pts[hull[m]];
+            const float c = cross(r, v);
+            if (c < 0.0f) ie = j;
+            if (c == 0.0f && dot(v, v) > dot(r, r)) ie = j;
+        }
+        ++m;
+        ih = ie;
+        if (ie == i0) break;
+    }
+    s.n = m;
+    for (int i = 0; i < m; ++i) s.v[i] = pts[hull[i]];
+    for (int i = 0; i < m; ++i) {
+        const V2 e = s.v[(i + 1) % m] - s.v[i];
+        const float len = sqrtf(dot(e, e));
+        s.nrm[i] = v2(e.y / len, -e.x / len);
+    }
+}
+// b2PolygonShape::ComputeMass + b2Body::ResetMassData for a single-fixture body
+inline void poly_mass(Shape &s, float density) {
+    V2 center = v2(0, 0), ref = v2(0, 0);
+    float area = 0.0f, I = 0.0f;
+    for (int i = 0; i < s.n; ++i) ref = ref + s.v[i];
+    ref = (1.0f / s.n) * ref;
+    const float inv3 = 1.0f / 3.0f;
+    for (int i = 0; i < s.n; ++i) {
+        const V2 e1 = s.v[i] - ref, e2 = s.v[(i + 1) % s.n] - ref;
+        const float D = cross(e1, e2), ta = 0.5f * D;
+        area += ta;
+        center = center + (ta * inv3) * (e1 + e2);
+        const float intx2 = e1.x * e1.x + e2.x * e1.x + e2.x * e2.x, inty2 = e1.y * e1.y + e2.y * e1.y + e2.y * e2.y;
+        I += (0.25f * inv3 * D) * (intx2 + inty2);
+    }
+    const float mass = density * area;
+    center = (1.0f / area) * center;
+    const V2 c = center + ref;
+    float Io = density * I + mass * (dot(c, c) - dot(center, center));  // about the body origin
+    Io -= mass * dot(c, c);                                              // about the centre of mass
+    s.centroid = c;
+    s.inv_mass = 1.0f / mass;
+    s.inv_I = 1.0f / Io;
+}
+
+inline void build_model(Model &M, int n_walkers) {
+    M.W = n_walkers; M.NB = 5 * n_walkers + 1; M.NJ = 4 * n_walkers;
+    M.NT = (int)(TERRAIN_LENGTH * n_walkers * 1 / 8.0);          // :301
+    M.package_scale = n_walkers / 1.75f;                          // :293
+    M.package_length = PACKAGE_LENGTH / SCALE * M.package_scale;  // :294
+    const float init_x = TERRAIN_STEP * TERRAIN_STARTPAD / 2;
+    for (int w = 0; w < n_walkers; ++w) M.start_x[w] = init_x + WALKER_SEPERATION * w * TERRAIN_STEP;  // :285-287
+    {   // package :499-514
+        const float hx = 120.0f * M.package_scale / SCALE, hy = 5.0f / SCALE;
+        const V2 p[4] = {v2(-hx, hy), v2(hx, hy), v2(hx, -hy), v2(-hx, -hy)};
+        poly_set(M.shape[SH_PACKAGE], p, 4);
+        poly_mass(M.shape[SH_PACKAGE], 1.0f);
+        M.shape[SH_PACKAGE].friction = 0.5f; M.shape[SH_PACKAGE].category = 0x004; M.shape[SH_PACKAGE].mask = 0xFFFF;
+    }
+    {   // hull :118-127
+        const V2 p[5] = {v2(-30 / SCALE, 9 / SCALE), v2(6 / SCALE, 9 / SCALE), v2(34 / SCALE, 1 / SCALE), v2(34 / SCALE, -8 / SCALE), v2(-30 / SCALE, -8 / SCALE)};
+        poly_set(M.shape[SH_HULL], p, 5);
+        poly_mass(M.shape[SH_HULL], 5.0f);
+        M.shape[SH_HULL].friction = 0.1f; M.shape[SH_HULL].category = 0x002; M.shape[SH_HULL].mask = 0xFFFF;
+    }
+    for (int k = 0; k < 2; ++k) {  // legs :136-163: SetAsBox order, default friction 0.2
+        Shape &s = M.shape[k == 0 ? SH_UPPER : SH_LOWER];
+        const float hx = (k == 0 ? 1.0f : 0.8f) * LEG_W / 2, hy = LEG_H / 2;
+        s.n = 4;
+        s.v[0] = v2(-hx, -hy); s.v[1] = v2(hx, -hy); s.v[2] = v2(hx, hy); s.v[3] = v2(-hx, hy);
+        s.nrm[0] = v2(0, -1); s.nrm[1] = v2(1, 0); s.nrm[2] = v2(0, 1); s.nrm[3] = v2(-1, 0);
+        poly_mass(s, 1.0f);
+        s.friction = 0.2f; s.category = k == 0 ? 0x002 : 0x0020; s.mask = 0x001;
+    }
+    for (int w = 0; w < n_walkers; ++w)
+        for (int side = 0; side < 2; ++side) {
+            JointDef &hip = M.jd[4 * w + 2 * side], &knee = M.jd[4 * w + 2 * side + 1];
+            hip.bA = hull_of(w); hip.bB = hull_of(w) + 1 + 2 * side;
+            hip.lA = v2(0, LEG_DOWN); hip.lB = v2(0, LEG_H / 2); hip.lower = -0.8f; hip.upper = 1.1f;
+            knee.bA = hip.bB; knee.bB = hip.bB + 1;
+            knee.lA = v2(0, -LEG_H / 2); knee.lB = v2(0, LEG_H / 2); knee.lower = -1.6f; knee.upper = -0.1f;
+        }
+    int base = 0;
+    for (int b = 0; b < M.NB; ++b) { M.slot_base[b] = base; M.slot_cap[b] = (b == 0) ? EDGE_SLOTS_PKG : EDGE_SLOTS_SMALL; base += M.slot_cap[b]; }
+    M.dyn_slot_base = base;
+    int np = 0;
+    for (int w = 0; w < n_walkers; ++w) { M.dyn_a[np] = 0; M.dyn_b[np] = hull_of(w); ++np; }          // package (A) - hull
+    for (int i = 0; i < n_walkers; ++i) for (int j = i + 1; j < n_walkers; ++j) { M.dyn_a[np] = hull_of(i); M.dyn_b[np] = hull_of(j); ++np; }
+    M.n_dyn_pairs = np;
+}
+
+// ---------------------------------------------------------------- dynamic state
+struct Body { V2 c; float a; V2 v; float w; };  // centre of mass, angle, velocities
+struct Joint {
+    float ix, iy, iz, motor_impulse;  // accumulated impulses (warm start)
+    float motor_speed, max_torque;
+    int limit_state;                  // 0 inactive, 1 at lower, 2 at upper, 3 equal
+};
+struct Slot {       // persistent manifold cache of one candidate pair (b2Contact)
+    int16_t edge;   // terrain edge index, or -1: free slot (dyn pairs: always used)
+    uint8_t npts, touching;
+    uint32_t id[2];
+    float ni[2], ti[2];
+};
+struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositionConstraint
+    int16_t bA, bB, slot;  // bA = -1: static terrain
+    uint8_t npts, type;    // type 0: faceA, 1: faceB
+    V2 local_normal, local_point, lp[2];  // b2Manifold (lp in the other body's frame)
+    V2 normal, rA[2], rB[2];
+    float friction, nm[2], tm[2], ni[2], ti[2];
+    float k11, k12, k22, im11, im12, im22;  // block solver K and K^-1
+    uint8_t block;
+};
+struct World {
+    Body b[MAXB];
+    Joint j[MAXJ];
+    Slot slot[MAXSLOT];
+    float ty[MAXT];               // terrain heights (x = i * TERRAIN_STEP)
+    float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
+    float prev_shaping[MAX_WALKERS], prev_package_shaping;
+    uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, pad_;
+    uint32_t tick;
+    int32_t t;
+};
+struct Scratch {  // per-step workspace (LDS on the GPU)
+    Manifold m[MAXM];
+    int nm;
+    float jrAx[MAXJ], jrAy[MAXJ], jrBx[MAXJ], jrBy[MAXJ], jmotor_mass[MAXJ];
+    float jk[MAXJ][9];
+    // per-body constants gathered once per step (avoid shape lookups in the solver loops)
+    float bim[MAXB], bii[MAXB];
+    V2 blc[MAXB];
+    int8_t node[MAXB];  // island graph node of a body: walker index, or W for the package
+};
+
+MW_HD Xf body_xf(const Model &M, const Body &b, int bi) {
+    Xf t; t.q = rot(b.a);
+    t.p = b.c - mul(t.q, M.shape[shape_of_body(bi)].centroid);
+    return t;
+}
+MW_HD Xf xf_from(V2 c, float a, V2 local_center) { Xf t; t.q = rot(a); t.p = c - mul(t.q, local_center); return t; }
+
+// ---------------------------------------------------------------- narrow phase
+struct ClipV { V2 v; uint32_t id; };
+// contact feature id: indexA | indexB << 8 | typeA << 16 | typeB << 24  (type 0 vertex, 1 face)
+MW_HD uint32_t mk_id(int ia, int ib, int ta, int tb) { return (uint32_t)ia | ((uint32_t)ib << 8) | ((uint32_t)ta << 16) | ((uint32_t)tb << 24); }
+MW_HD uint32_t swap_id(uint32_t id) { return ((id >> 8) & 0xFF) | ((id & 0xFF) << 8) | (((id >> 24) & 0xFF) << 16) | (((id >> 16) & 0xFF) << 24); }
+
+MW_HD int clip_segment(ClipV out[2], const ClipV in[2], V2 normal, float offset, int vertexIndexA) {
+    int n = 0;
+    const float d0 = dot(normal, in[0].v) - offset, d1 = dot(normal, in[1].v) - offset;
+    if (d0 <= 0.0f) out[n++] = in[0];
+    if (d1 <= 0.0f) out[n++] = in[1];
+    if (d0 * d1 < 0.0f) {
+        const float interp = d0 / (d0 - d1);
+        out[n].v = in[0].v + interp * (in[1].v - in[0].v);
+        out[n].id = mk_id(vertexIndexA, (in[0].id >> 8) & 0xFF, 0, 1);
+        ++n;
+    }
+    return n;
+}
+
+struct ManifoldOut { int npts, type; V2 local_normal, local_point, lp[2]; uint32_t id[2]; };
+
+MW_HD float find_max_separation(int *edge, const Shape &p1, Xf xf1, const Shape &p2, Xf xf2) {
+    const Xf xf = mulT(xf2, xf1);
+    int best = 0;
+    float maxsep = -3.0e38f;
+    for (int i = 0; i < p1.n; ++i) {
+        const V2 n = mul(xf.q, p1.nrm[i]), v1 = mul(xf, p1.v[i]);
+        float si = 3.0e38f;
+        for (int j = 0; j < p2.n; ++j) { const float sij = dot(n, p2.v[j] - v1); if (sij < si) si = sij; }
+        if (si > maxsep) { maxsep = si; best = i; }
+    }
+    *edge = best;
+    return maxsep;
+}
+
+// b2CollidePolygons
+MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shape &pB, Xf xfB) {
+    mo.npts = 0;
+    const float total_radius = 2.0f * POLY_RADIUS;
+    int edgeA = 0, edgeB = 0;
+    const float sepA = find_max_separation(&edgeA, pA, xfA, pB, xfB);
+    if (sepA > total_radius) return;
+    const float sepB = find_max_separation(&edgeB, pB, xfB, pA, xfA);
+    if (sepB > total_radius) return;
+    const Shape *p1, *p2; Xf xf1, xf2; int edge1, flip;
+    const float k_tol = 0.1f * LINEAR_SLOP;
+    if (sepB > sepA + k_tol) { p1 = &pB; p2 = &pA; xf1 = xfB; xf2 = xfA; edge1 = edgeB; mo.type = 1; flip = 1; }
+    else { p1 = &pA; p2 = &pB; xf1 = xfA; xf2 = xfB; edge1 = edgeA; mo.type = 0; flip = 0; }
+    ClipV inc[2];
+    {   // b2FindIncidentEdge
+        const V2 normal1 = mulT(xf2.q, mul(xf1.q, p1->nrm[edge1]));
+        int index = 0; float mind = 3.0e38f;
+        for (int i = 0; i < p2->n; ++i) { const float dd = dot(normal1, p2->nrm[i]); if (dd < mind) { mind = dd; index = i; } }
+        const int i1 = index, i2 = (i1 + 1 < p2->n) ? i1 + 1 : 0;
+        inc[0].v = mul(xf2, p2->v[i1]); inc[0].id = mk_id(edge1, i1, 1, 0);
+        inc[1].v = mul(xf2, p2->v[i2]); inc[1].id = mk_id(edge1, i2, 1, 0);
+    }
+    const int iv1 = edge1, iv2 = (edge1 + 1 < p1->n) ? edge1 + 1 : 0;
+    V2 v11 = p1->v[iv1], v12 = p1->v[iv2];
+    V2 local_tangent = v12 - v11;
+    { const float len = sqrtf(dot(local_tangent, local_tangent)); local_tangent = (1.0f / len) * local_tangent; }
+    const V2 local_normal = cross(local_tangent, 1.0f), plane_point = 0.5f * (v11 + v12);
+    const V2 tangent = mul(xf1.q, local_tangent), normal = cross(tangent, 1.0f);
+    v11 = mul(xf1, v11); v12 = mul(xf1, v12);
+    const float front_offset = dot(normal, v11);
+    const float side1 = -dot(tangent, v11) + total_radius, side2 = dot(tangent, v12) + total_radius;
+    ClipV c1[2], c2[2];
+    if (clip_segment(c1, inc, -tangent, side1, iv1) < 2) return;
+    if (clip_segment(c2, c1, tangent, side2, iv2) < 2) return;
+    mo.local_normal = local_normal; mo.local_point = plane_point;
+    int n = 0;
+    for (int i = 0; i < 2; ++i) {
+        const float sep = dot(normal, c2[i].v) - front_offset;
+        if (sep <= total_radius) {
+            mo.lp[n] = mulT(xf2, c2[i].v);
+            mo.id[n] = flip ? swap_id(c2[i].id) : c2[i].id;
+            ++n;
+        }
+    }
+    mo.npts = n;
+}
+
+// b2CollideEdgeAndPolygon (b2EPCollider::Collide); edge = shape A, whose body frame is the world.
+// The terrain edges are given their neighbours' vertices (v0 before v1, v3 after v2) like the
+// ghost vertices of a b2ChainShape.  The reference builds plain b2EdgeShapes; Box2D protects those
+// from deep penetration with its continuous (TOI) pass, which this restatement does not have, and
+// without it a foot pressed into a terrain vertex gets wedged by the internal-edge side normals.
+// The adjacency test below is Box2D's own remedy for exactly that artefact.
+MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB, Xf xfB, bool has0, V2 v0, bool has3, V2 v3) {
+    mo.npts = 0;
+    const Xf xf = xfB;  // edge body transform is identity
+    const V2 centroidB = mul(xf, pB.centroid);
+    V2 edge1 = v2e - v1;
+    { const float len = sqrtf(dot(edge1, edge1)); edge1 = (1.0f / len) * edge1; }
+    const V2 normal1 = v2(edge1.y, -edge1.x);
+    const float offset1 = dot(normal1, centroidB - v1);
+    float offset0 = 0.0f, offset2 = 0.0f;
+    bool convex1 = false, convex2 = false;
+    V2 normal0 = v2(0, 0), normal2 = v2(0, 0);
+    if (has0) {
+        V2 edge0 = v1 - v0;
+        { const float len = sqrtf(dot(edge0, edge0)); edge0 = (1.0f / len) * edge0; }
+        normal0 = v2(edge0.y, -edge0.x);
+        convex1 = cross(edge0, edge1) >= 0.0f;
+        offset0 = dot(normal0, centroidB - v0);
+    }
+    if (has3) {
+        V2 edge2 = v3 - v2e;
+        { const float len = sqrtf(dot(edge2, edge2)); edge2 = (1.0f / len) * edge2; }
+        normal2 = v2(edge2.y, -edge2.x);
+        convex2 = cross(edge1, edge2) > 0.0f;
+        offset2 = dot(normal2, centroidB - v2e);
+    }
+    bool front;
+    V2 m_normal, lower, upper;
+    if (has0 && has3) {
+        if (convex1 && convex2) {
+            front = offset0 >= 0.0f || offset1 >= 0.0f || offset2 >= 0.0f;
+            if (front) { m_normal = normal1; lower = normal0; upper = normal2; } else { m_normal = -normal1; lower = -normal1; upper = -normal1; }
+        } else if (convex1) {
+            front = offset0 >= 0.0f || (offset1 >= 0.0f && offset2 >= 0.0f);
+            if (front) { m_normal = normal1; lower = normal0; upper = normal1; } else { m_normal = -normal1; lower = -normal2; upper = -normal1; }
+        } else if (convex2) {
+            front = offset2 >= 0.0f || (offset0 >= 0.0f && offset1 >= 0.0f);
+            if (front) { m_normal = normal1; lower = normal1; upper = normal2; } else { m_normal = -normal1; lower = -normal1; upper = -normal0; }
+        } else {
+            front = offset0 >= 0.0f && offset1 >= 0.0f && offset2 >= 0.0f;
+            if (front) { m_normal = normal1; lower = normal1; upper = normal1; } else { m_normal = -normal1; lower = -normal2; upper = -normal0; }
+        }
+    } else if (has0) {
+        if (convex1) {
+            front = offset0 >= 0.0f || offset1 >= 0.0f;
+            if (front) { m_normal = normal1; lower = normal0; upper = -normal1; } else { m_normal = -normal1; lower = normal1; upper = -normal1; }
+        } else {
+            front = offset0 >= 0.0f && offset1 >= 0.0f;
+            if (front) { m_normal = normal1; lower = normal1; upper = -normal1; } else { m_normal = -normal1; lower = normal1; upper = -normal0; }
+        }
+    } else if (has3) {
+        if (convex2) {
+            front = offset1 >= 0.0f || offset2 >= 0.0f;
+            if (front) { m_normal = normal1; lower = -normal1; upper = normal2; } else { m_normal = -normal1; lower = -normal1; upper = normal1; }
+        } else {
+            front = offset1 >= 0.0f && offset2 >= 0.0f;
+            if (front) { m_normal = normal1; lower = -normal1; upper = normal1; } else { m_normal = -normal1; lower = -normal2; upper = normal1; }
+        }
+    } else {
+        front = offset1 >= 0.0f;
+        if (front) { m_normal = normal1; lower = -normal1; upper = -normal1; } else { m_normal = -normal1; lower = normal1; upper = normal1; }
+    }
+    V2 bv[5], bn[5];
+    for (int i = 0; i < pB.n; ++i) { bv[i] = mul(xf, pB.v[i]); bn[i] = mul(xf.q, pB.nrm[i]); }
+    const float radius = 2.0f * POLY_RADIUS;
+    // edge axis
+    float edge_sep = 3.0e38f;
+    for (int i = 0; i < pB.n; ++i) { const float s = dot(m_normal, bv[i] - v1); if (s < edge_sep) edge_sep = s; }
+    if (edge_sep > radius) return;
+    // polygon axis
+    int poly_type = 0, poly_index = -1; float poly_sep = -3.0e38f;
+    const V2 perp = v2(-m_normal.y, m_normal.x);
+    for (int i = 0; i < pB.n; ++i) {
+        const V2 n = -bn[i];
+        const float s1 = dot(n, bv[i] - v1), s2 = dot(n, bv[i] - v2e), s = fminf(s1, s2);
+        if (s > radius) { poly_type = 2; poly_index = i; poly_sep = s; break; }
+        if (dot(n, perp) >= 0.0f) { if (dot(n - upper, m_normal) < -ANGULAR_SLOP) continue; }
+        else { if (dot(n - lower, m_normal) < -ANGULAR_SLOP) continue; }
+        if (s > poly_sep) { poly_type = 2; poly_index = i; poly_sep = s; }
+    }
+    if (poly_type != 0 && poly_sep > radius) return;
+    const float k_rel = 0.98f, k_abs = 0.001f;
+    const bool primary_edge = (poly_type == 0) || !(poly_sep > k_rel * edge_sep + k_abs);
+    ClipV ie[2];
+    int rf_i1, rf_i2; V2 rf_v1, rf_v2, rf_normal;
+    if (primary_edge) {
+        mo.type = 0;
+        int best = 0; float bestv = dot(m_normal, bn[0]);
+        for (int i = 1; i < pB.n; ++i) { const float val = dot(m_normal, bn[i]); if (val < bestv) { bestv = val; best = i; } }
+        const int i1 = best, i2 = (i1 + 1 < pB.n) ? i1 + 1 : 0;
+        ie[0].v = bv[i1]; ie[0].id = mk_id(0, i1, 1, 0);
+        ie[1].v = bv[i2]; ie[1].id = mk_id(0, i2, 1, 0);
+        if (front) { rf_i1 = 0; rf_i2 = 1; rf_v1 = v1; rf_v2 = v2e; rf_normal = normal1; }
+        else { rf_i1 = 1; rf_i2 = 0; rf_v1 = v2e; rf_v2 = v1; rf_normal = -normal1; }
+    } else {
+        mo.type = 1;
+        ie[0].v = v1; ie[0].id = mk_id(0, poly_index, 0, 1);
+        ie[1].v = v2e; ie[1].id = mk_id(0, poly_index, 0, 1);
+        rf_i1 = poly_index; rf_i2 = (rf_i1 + 1 < pB.n) ? rf_i1 + 1 : 0;
+        rf_v1 = bv[rf_i1]; rf_v2 = bv[rf_i2]; rf_normal = bn[rf_i1];
+    }
+    const V2 side_n1 = v2(rf_normal.y, -rf_normal.x), side_n2 = -side_n1;
+    const float so1 = dot(side_n1, rf_v1), so2 = dot(side_n2, rf_v2);
+    ClipV c1[2], c2[2];
+    if (clip_segment(c1, ie, side_n1, so1, rf_i1) < 2) return;
+    if (clip_segment(c2, c1, side_n2, so2, rf_i2) < 2) return;
+    if (primary_edge) { mo.local_normal = rf_normal; mo.local_point = rf_v1; }
+    else { mo.local_normal = pB.nrm[rf_i1]; mo.local_point = pB.v[rf_i1]; }
+    int n = 0;
+    for (int i = 0; i < 2; ++i) {
+        const float sep = dot(rf_normal, c2[i].v - rf_v1);
+        if (sep <= radius) {
+            if (primary_edge) { mo.lp[n] = mulT(xf, c2[i].v); mo.id[n] = c2[i].id; }
+            else { mo.lp[n] = c2[i].v; mo.id[n] = swap_id(c2[i].id); }
+            ++n;
+        }
+    }
+    mo.npts = n;
+}
+
+MW_HD void body_aabb(const Model &M, const World &Wd, int bi, float &xmin, float &xmax, float &ymin, float &ymax) {
+    const Shape &s = M.shape[shape_of_body(bi)];
+    const Xf t = body_xf(M, Wd.b[bi], bi);
+    xmin = ymin = 3.0e38f; xmax = ymax = -3.0e38f;
+    for (int i = 0; i < s.n; ++i) {
+        const V2 p = mul(t, s.v[i]);
+        xmin = fminf(xmin, p.x); xmax = fmaxf(xmax, p.x); ymin = fminf(ymin, p.y); ymax = fmaxf(ymax, p.y);
+    }
+    xmin -= POLY_RADIUS; xmax += POLY_RADIUS; ymin -= POLY_RADIUS; ymax += POLY_RADIUS;
+}
+
+// ContactDetector.BeginContact / EndContact (:50-84) for one pair whose touching state changed
+MW_HD void contact_event(const Model &M, World &Wd, int bA, int bB, bool begin) {
+    // bA == -1: terrain
+    for (int w = 0; w < M.W; ++w) {
+        const int hull = hull_of(w);
+        if (begin) {
+            if (hull == bA && bB != 0) Wd.fallen[w] = 1;   // hull touches anything but the package
+            if (hull == bB && bA != 0) Wd.fallen[w] = 1;
+        }
+        for (int k = 0; k < 2; ++k) {                      // legs[1], legs[3]: the lower legs
+            const int leg = hull + 2 + 2 * k;
+            if (leg == bA || leg == bB) Wd.ground[w][k] = begin ? 1 : 0;
+        }
+    }
+    if (begin) {
+        if (bA == 0 && !(bB >= 1 && (bB - 1) % 5 == 0)) Wd.game_over = 1;   // package touches a non-hull
+        if (bB == 0 && !(bA >= 1 && (bA - 1) % 5 == 0)) Wd.game_over = 1;
+    }
+}
+
+// push an active manifold into the solver list, carrying impulses over from the cached contact
+MW_HD void emit_manifold(const Model &M, World &Wd, Scratch &S, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction) {
+    float ni[2] = {0, 0}, ti[2] = {0, 0};
+    for (int i = 0; i < mo.npts; ++i)  // b2Contact::Update: match ids with the old manifold
+        for (int k = 0; k < sl.npts; ++k)
+            if (sl.id[k] == mo.id[i]) { ni[i] = sl.ni[k]; ti[i] = sl.ti[k]; break; }
+    const bool touching = mo.npts > 0;
+    if (touching != (sl.touching != 0)) contact_event(M, Wd, bA, bB, touching);
+    sl.touching = touching; sl.npts = (uint8_t)mo.npts;
+    for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
+    if (!touching || S.nm >= MAXM) return;
+    Manifold &m = S.m[S.nm++];
+    m.bA = (int16_t)bA; m.bB = (int16_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)mo.type;
+    m.local_normal = mo.local_normal; m.local_point = mo.local_point;
+    for (int i = 0; i < mo.npts; ++i) { m.lp[i] = mo.lp[i]; m.ni[i] = ni[i]; m.ti[i] = ti[i]; }
+    m.friction = friction;
+}
+
+// b2ContactManager::Collide restated over the candidate pairs of this model
+MW_HD void collide(const Model &M, World &Wd, Scratch &S) {
+    S.nm = 0;
+    // bodies against the terrain polyline: edge e spans x in [e, e+1] * TERRAIN_STEP
+    for (int bi = 0; bi < M.NB; ++bi) {
+        const Shape &s = M.shape[shape_of_body(bi)];
+        float xmin, xmax, ymin, ymax;
+        body_aabb(M, Wd, bi, xmin, xmax, ymin, ymax);
+        int e0 = (int)floorf(xmin / TERRAIN_STEP), e1 = (int)floorf(xmax / TERRAIN_STEP);
+        if (e0 < 0) e0 = 0;
+        if (e1 > M.NT - 2) e1 = M.NT - 2;
+        Slot *slots = Wd.slot + M.slot_base[bi];
+        const int cap = M.slot_cap[bi];
+        // contacts whose edge left the candidate range are destroyed (EndContact if touching)
+        for (int k = 0; k < cap; ++k) {
+            Slot &sl = slots[k];
+            if (sl.edge >= 0 && (sl.edge < e0 || sl.edge > e1)) {
+                if (sl.touching) contact_event(M, Wd, -1, bi, false);
+                sl.edge = -1; sl.npts = 0; sl.touching = 0;
+            }
+        }
+        const Xf xfB = body_xf(M, Wd.b[bi], bi);
+        for (int e = e0; e <= e1; ++e) {
+            int k = -1;
+            for (int q = 0; q < cap; ++q) if (slots[q].edge == e) { k = q; break; }
+            if (k < 0) { for (int q = 0; q < cap; ++q) if (slots[q].edge < 0) { k = q; break; } }
+            if (k < 0) continue;  // cache full: pair ignored this step
+            Slot &sl = slots[k];
+            if (sl.edge != e) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; }
+            const V2 p1 = v2(e * TERRAIN_STEP, Wd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Wd.ty[e + 1]);
+            ManifoldOut mo; mo.npts = 0;
+            const float elo = fminf(p1.y, p2.y) - POLY_RADIUS, ehi = fmaxf(p1.y, p2.y) + POLY_RADIUS;
+            if (!(ymin > ehi + 0.2f || ymax < elo - 0.2f)) {
+                const bool has0 = e > 0, has3 = e < M.NT - 2;
+                const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Wd.ty[e - 1]) : p1;
+                const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Wd.ty[e + 2]) : p2;
+                collide_edge_polygon(mo, p1, p2, s, xfB, has0, p0, has3, p3);
+            }
+            emit_manifold(M, Wd, S, sl, M.slot_base[bi] + k, mo, -1, bi, sqrtf(FRICTION * s.friction));
+        }
+    }
+    // package - hull and hull - hull
+    for (int p = 0; p < M.n_dyn_pairs; ++p) {
+        const int bA = M.dyn_a[p], bB = M.dyn_b[p];
+        const Shape &sA = M.shape[shape_of_body(bA)], &sB = M.shape[shape_of_body(bB)];
+        Slot &sl = Wd.slot[M.dyn_slot_base + p];
+        sl.edge = 0;
+        float ax0, ax1, ay0, ay1, bx0, bx1, by0, by1;
+        body_aabb(M, Wd, bA, ax0, ax1, ay0, ay1);
+        body_aabb(M, Wd, bB, bx0, bx1, by0, by1);
+        ManifoldOut mo; mo.npts = 0;
+        if (!(ax0 > bx1 + 0.2f || bx0 > ax1 + 0.2f || ay0 > by1 + 0.2f || by0 > ay1 + 0.2f))
+            collide_polygons(mo, sA, body_xf(M, Wd.b[bA], bA), sB, body_xf(M, Wd.b[bB], bB));
+        emit_manifold(M, Wd, S, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction));
+    }
+}
+
+// ---------------------------------------------------------------- island solver (b2Island::Solve)
+#define inv_mass_of(M_, b_, im_, ii_) do { const int _b = (b_); if (_b < 0) { im_ = 0.0f; ii_ = 0.0f; } else { im_ = S.bim[_b]; ii_ = S.bii[_b]; } } while (0)
+#define local_center_of(M_, b_) ((b_) < 0 ? v2(0, 0) : S.blc[(b_)])
+
+MW_HD void solve33(const float *k, float bx, float by, float bz, float &x, float &y, float &z) {
+    // k = [ex.x ex.y ex.z ey.x ey.y ey.z ez.x ez.y ez.z]; Cramer's rule as b2Mat33::Solve33
+    const float exx = k[0], exy = k[1], exz = k[2], eyx = k[3], eyy = k[4], eyz = k[5], ezx = k[6], ezy = k[7], ezz = k[8];
+    const float cx = eyy * ezz - eyz * ezy, cy = eyz * ezx - eyx * ezz, cz = eyx * ezy - eyy * ezx;  // cross(ey, ez)
+    float det = exx * cx + exy * cy + exz * cz;
+    if (det != 0.0f) det = 1.0f / det;
+    x = det * (bx * cx + by * cy + bz * cz);
+    const float dx = by * ezz - bz * ezy, dy = bz * ezx - bx * ezz, dz = bx * ezy - by * ezx;        // cross(b, ez)
+    y = det * (exx * dx + exy * dy + exz * dz);
+    const float fx = eyy * bz - eyz * by, fy = eyz * bx - eyx * bz, fz = eyx * by - eyy * bx;        // cross(ey, b)
+    z = det * (exx * fx + exy * fy + exz * fz);
+}
+MW_HD void solve22(const float *k, float bx, float by, float &x, float &y) {
+    const float a11 = k[0], a12 = k[3], a21 = k[1], a22 = k[4];
+    float det = a11 * a22 - a12 * a21;
+    if (det != 0.0f) det = 1.0f / det;
+    x = det * (a22 * bx - a12 * by);
+    y = det * (a11 * by - a21 * bx);
+}
+
+MW_HD void world_step(const Model &M, World &Wd, Scratch &S) {
+    const float h = 1.0f / FPS;
+    for (int bi = 0; bi < M.NB; ++bi) {
+        const Shape &sh = M.shape[shape_of_body(bi)];
+        S.bim[bi] = sh.inv_mass; S.bii[bi] = sh.inv_I; S.blc[bi] = sh.centroid;
+        S.node[bi] = (int8_t)(bi == 0 ? M.W : (bi - 1) / 5);
+    }
+    collide(M, Wd, S);
+    // ---- islands: walkers (+ package) joined by touching hull-hull / hull-package contacts
+    int comp[MAX_WALKERS + 1];  // index W = package
+    for (int i = 0; i <= M.W; ++i) comp[i] = i;
+    for (int k = 0; k < S.nm; ++k) {
+        const Manifold &m = S.m[k];
+        if (m.bA < 0) continue;
+        const int na = S.node[m.bA], nb = S.node[m.bB];
+        const int ca = comp[na], cb = comp[nb];
+        if (ca != cb) for (int i = 0; i <= M.W; ++i) if (comp[i] == cb) comp[i] = ca;
+    }
+    // ---- integrate velocities (gravity + the pending initial push)
+    for (int bi = 0; bi < M.NB; ++bi) {
+        Body &b = Wd.b[bi];
+        float fx = 0.0f;
+        if (bi >= 1 && (bi - 1) % 5 == 0) { const int w = (bi - 1) / 5; fx = Wd.push_x[w]; }
+        const float im = S.bim[bi];
+        b.v.x += h * (im * fx);
+        b.v.y += h * (GRAVITY_Y + im * 0.0f);
+        // linear/angular damping are 0: v *= 1/(1 + h*0)
+    }
+    for (int w = 0; w < M.W; ++w) Wd.push_x[w] = 0.0f;  // ClearForces
+    // ---- contact velocity constraints: b2ContactSolver::InitializeVelocityConstraints + WarmStart
+    for (int k = 0; k < S.nm; ++k) {
+        Manifold &m = S.m[k];
+        float mA, iA, mB, iB;
+        inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+        const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
+        Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = body_xf(M, Wd.b[m.bA], m.bA);
+        const Xf xfB = body_xf(M, Wd.b[m.bB], m.bB);
+        // b2WorldManifold::Initialize
+        V2 normal, pts[2];
+        if (m.type == 0) {
+            normal = mul(xfA.q, m.local_normal);
+            const V2 plane = mul(xfA, m.local_point);
+            for (int i = 0; i < m.npts; ++i) {
+                const V2 clip = mul(xfB, m.lp[i]);
+                const V2 a = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, bb = clip - POLY_RADIUS * normal;
+                pts[i] = 0.5f * (a + bb);
+            }
+        } else {
+            normal = mul(xfB.q, m.local_normal);
+            const V2 plane = mul(xfB, m.local_point);
+            for (int i = 0; i < m.npts; ++i) {
+                const V2 clip = mul(xfA, m.lp[i]);
+                const V2 bb = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, a = clip - POLY_RADIUS * normal;
+                pts[i] = 0.5f * (a + bb);
+            }
+            normal = -normal;
+        }
+        m.normal = normal;
+        const V2 tangent = cross(normal, 1.0f);
+        for (int i = 0; i < m.npts; ++i) {
+            m.rA[i] = pts[i] - cA; m.rB[i] = pts[i] - cB;
+            const float rnA = cross(m.rA[i], normal), rnB = cross(m.rB[i], normal);
+            const float kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+            m.nm[i] = kn > 0.0f ? 1.0f / kn : 0.0f;
+            const float rtA = cross(m.rA[i], tangent), rtB = cross(m.rB[i], tangent);
+            const float kt = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+            m.tm[i] = kt > 0.0f ? 1.0f / kt : 0.0f;
+        }
+        m.block = 0;
+        if (m.npts == 2) {
+            const float rn1A = cross(m.rA[0], normal), rn1B = cross(m.rB[0], normal), rn2A = cross(m.rA[1], normal), rn2B = cross(m.rB[1], normal);
+            const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B, k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+            const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+            if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+                m.k11 = k11; m.k12 = k12; m.k22 = k22;
+                float det = k11 * k22 - k12 * k12;
+                if (det != 0.0f) det = 1.0f / det;
+                m.im11 = det * k22; m.im12 = -det * k12; m.im22 = det * k11;
+                m.block = 1;
+            } else {
+                m.npts = 1;  // the constraints are redundant, just use one
+            }
+        }
+        // warm start
+        V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
+        float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
+        for (int i = 0; i < m.npts; ++i) {
+            const V2 P = m.ni[i] * normal + m.ti[i] * tangent;
+            wA -= iA * cross(m.rA[i], P); vA = vA - mA * P;
+            wB += iB * cross(m.rB[i], P); vB = vB + mB * P;
+        }
+        if (m.bA >= 0) { Wd.b[m.bA].v = vA; Wd.b[m.bA].w = wA; }
+        Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
+    }
+    // ---- joints: b2RevoluteJoint::InitVelocityConstraints (+ warm start)
+    for (int ji = 0; ji < M.NJ; ++ji) {
+        const JointDef &jd = M.jd[ji];
+        Joint &j = Wd.j[ji];
+        Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
+        float mA, iA, mB, iB;
+        inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+        const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
+        S.jrAx[ji] = rA.x; S.jrAy[ji] = rA.y; S.jrBx[ji] = rB.x; S.jrBy[ji] = rB.y;
+        float *k = S.jk[ji];
+        k[0] = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+        k[3] = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+        k[6] = -rA.y * iA - rB.y * iB;
+        k[1] = k[3];
+        k[4] = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+        k[7] = rA.x * iA + rB.x * iB;
+        k[2] = k[6]; k[5] = k[7];
+        k[8] = iA + iB;
+        float mm = iA + iB;
+        if (mm > 0.0f) mm = 1.0f / mm;
+        S.jmotor_mass[ji] = mm;
+        const float angle = B.a - A.a;  // referenceAngle = 0 (the def is built from kwargs, not Initialize())
+        if (fabsf(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP) j.limit_state = 3;
+        else if (angle <= jd.lower) { if (j.limit_state != 1) j.iz = 0.0f; j.limit_state = 1; }
+        else if (angle >= jd.upper) { if (j.limit_state != 2) j.iz = 0.0f; j.limit_state = 2; }
+        else { j.limit_state = 0; j.iz = 0.0f; }
+        const V2 P = v2(j.ix, j.iy);  // dtRatio = 1
+        A.v = A.v - mA * P; A.w -= iA * (cross(rA, P) + j.motor_impulse + j.iz);
+        B.v = B.v + mB * P; B.w += iB * (cross(rB, P) + j.motor_impulse + j.iz);
+    }
+    // ---- per island: velocity iterations, integrate positions, position iterations
+    for (int isl = 0; isl <= M.W; ++isl) {
+        bool any = false;
+        for (int i = 0; i <= M.W; ++i) any |= (comp[i] == isl);
+        if (!any) continue;
+        #define MW_NODE_OF(bi) ((int)S.node[(bi)])
+        for (int it = 0; it < VEL_ITERS; ++it) {
+            for (int ji = 0; ji < M.NJ; ++ji) {  // b2RevoluteJoint::SolveVelocityConstraints
+                const JointDef &jd = M.jd[ji];
+                if (comp[MW_NODE_OF(jd.bA)] != isl) continue;
+                Joint &j = Wd.j[ji];
+                Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
+                float mA, iA, mB, iB;
+                inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+                const V2 rA = v2(S.jrAx[ji], S.jrAy[ji]), rB = v2(S.jrBx[ji], S.jrBy[ji]);
+                V2 vA = A.v, vB = B.v; float wA = A.w, wB = B.w;
+                if (j.limit_state != 3) {  // motor (enableMotor is always true)
+                    const float Cdot = wB - wA - j.motor_speed;
+                    float imp = -S.jmotor_mass[ji] * Cdot;
+                    const float old = j.motor_impulse, maxi = h * j.max_torque;
+                    j.motor_impulse = clampf(old + imp, -maxi, maxi);
+                    imp = j.motor_impulse - old;
+                    wA -= iA * imp; wB += iB * imp;
+                }
+                if (j.limit_state != 0) {  // limit + point constraint (3x3)
+                    const V2 Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA);
+                    const float Cdot2 = wB - wA;
+                    float ix, iy, iz;
+                    solve33(S.jk[ji], Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
+                    ix = -ix; iy = -iy; iz = -iz;
+                    bool reduce = false;
+                    if (j.limit_state == 3) { j.ix += ix; j.iy += iy; j.iz += iz; }
+                    else if (j.limit_state == 1) { reduce = (j.iz + iz) < 0.0f; }
+                    else { reduce = (j.iz + iz) > 0.0f; }
+                    if (j.limit_state != 3) {
+                        if (reduce) {
+                            const float rx = -Cdot1.x + j.iz * S.jk[ji][6], ry = -Cdot1.y + j.iz * S.jk[ji][7];
+                            float qx, qy;
+                            solve22(S.jk[ji], rx, ry, qx, qy);
+                            ix = qx; iy = qy; iz = -j.iz;
+                            j.ix += qx; j.iy += qy; j.iz = 0.0f;
+                        } else { j.ix += ix; j.iy += iy; j.iz += iz; }
+                    }
+                    const V2 P = v2(ix, iy);
+                    vA = vA - mA * P; wA -= iA * (cross(rA, P) + iz);
+                    vB = vB + mB * P; wB += iB * (cross(rB, P) + iz);
+                } else {  // point-to-point only
+                    const V2 Cdot = vB + cross(wB, rB) - vA - cross(wA, rA);
+                    float ix, iy;
+                    solve22(S.jk[ji], -Cdot.x, -Cdot.y, ix, iy);
+                    j.ix += ix; j.iy += iy;
+                    const V2 P = v2(ix, iy);
+                    vA = vA - mA * P; wA -= iA * cross(rA, P);
+                    vB = vB + mB * P; wB += iB * cross(rB, P);
+                }
+                A.v = vA; A.w = wA; B.v = vB; B.w = wB;
+            }
+            for (int k = 0; k < S.nm; ++k) {  // b2ContactSolver::SolveVelocityConstraints
+                Manifold &m = S.m[k];
+                if (comp[MW_NODE_OF(m.bB)] != isl) continue;
+                float mA, iA, mB, iB;
+                inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+                V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
+                float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
+                const V2 normal = m.normal, tangent = cross(normal, 1.0f);
+                for (int i = 0; i < m.npts; ++i) {  // friction first
+                    const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
+                    const float vt = dot(dv, tangent);
+                    float lambda = m.tm[i] * (-vt);
+                    const float maxf = m.friction * m.ni[i];
+                    const float newi = clampf(m.ti[i] + lambda, -maxf, maxf);
+                    lambda = newi - m.ti[i];
+                    m.ti[i] = newi;
+                    const V2 P = lambda * tangent;
+                    vA = vA - mA * P; wA -= iA * cross(m.rA[i], P);
+                    vB = vB + mB * P; wB += iB * cross(m.rB[i], P);
+                }
+                if (m.npts == 1 || !m.block) {
+                    for (int i = 0; i < m.npts; ++i) {
+                        const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
+                        const float vn = dot(dv, normal);
+                        float lambda = -m.nm[i] * (vn - 0.0f);  // restitution 0 -> velocityBias 0
+                        const float newi = fmaxf(m.ni[i] + lambda, 0.0f);
+                        lambda = newi - m.ni[i];
+                        m.ni[i] = newi;
+                        const V2 P = lambda * normal;
+                        vA = vA - mA * P; wA -= iA * cross(m.rA[i], P);
+                        vB = vB + mB * P; wB += iB * cross(m.rB[i], P);
+                    }
+                } else {  // block solver
+                    const float a1 = m.ni[0], a2 = m.ni[1];
+                    const V2 dv1 = vB + cross(wB, m.rB[0]) - vA - cross(wA, m.rA[0]);
+                    const V2 dv2 = vB + cross(wB, m.rB[1]) - vA - cross(wA, m.rA[1]);
+                    float b1 = dot(dv1, normal), b2 = dot(dv2, normal);
+                    b1 -= m.k11 * a1 + m.k12 * a2;
+                    b2 -= m.k12 * a1 + m.k22 * a2;
+                    float x1 = 0, x2 = 0; bool ok = false;
+                    x1 = -(m.im11 * b1 + m.im12 * b2); x2 = -(m.im12 * b1 + m.im22 * b2);
+                    if (x1 >= 0.0f && x2 >= 0.0f) ok = true;
+                    if (!ok) { x1 = -m.nm[0] * b1; x2 = 0.0f; const float vn2 = m.k12 * x1 + b2; if (x1 >= 0.0f && vn2 >= 0.0f) ok = true; }
+                    if (!ok) { x1 = 0.0f; x2 = -m.nm[1] * b2; const float vn1 = m.k12 * x2 + b1; if (x2 >= 0.0f && vn1 >= 0.0f) ok = true; }
+                    if (!ok) { x1 = 0.0f; x2 = 0.0f; if (b1 >= 0.0f && b2 >= 0.0f) ok = true; }
+                    if (ok) {
+                        const float d1 = x1 - a1, d2 = x2 - a2;
+                        const V2 P1 = d1 * normal, P2 = d2 * normal;
+                        vA = vA - mA * (P1 + P2); wA -= iA * (cross(m.rA[0], P1) + cross(m.rA[1], P2));
+                        vB = vB + mB * (P1 + P2); wB += iB * (cross(m.rB[0], P1) + cross(m.rB[1], P2));
+                        m.ni[0] = x1; m.ni[1] = x2;
+                    }
+                }
+                if (m.bA >= 0) { Wd.b[m.bA].v = vA; Wd.b[m.bA].w = wA; }
+                Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
+            }
+        }
+        // integrate positions
+        for (int bi = 0; bi < M.NB; ++bi) {
+            if (comp[MW_NODE_OF(bi)] != isl) continue;
+            Body &b = Wd.b[bi];
+            V2 tr = h * b.v;
+            if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) { const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr)); b.v = ratio * b.v; }
+            const float ro = h * b.w;
+            if (ro * ro > MAX_ROTATION * MAX_ROTATION) { const float ratio = MAX_ROTATION / fabsf(ro); b.w *= ratio; }
+            b.c = b.c + h * b.v;
+            b.a += h * b.w;
+        }
+        // position iterations
+        for (int it = 0; it < POS_ITERS; ++it) {
+            float min_sep = 0.0f;
+            for (int k = 0; k < S.nm; ++k) {  // b2ContactSolver::SolvePositionConstraints
+                const Manifold &m = S.m[k];
+                if (comp[MW_NODE_OF(m.bB)] != isl) continue;
+                float mA, iA, mB, iB;
+                inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+                V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
+                float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a, aB = Wd.b[m.bB].a;
+                const V2 lcA = local_center_of(M, m.bA), lcB = local_center_of(M, m.bB);
+                for (int i = 0; i < m.npts; ++i) {
+                    const Xf xfA = xf_from(cA, aA, lcA), xfB = xf_from(cB, aB, lcB);
+                    V2 normal, point; float sep;
+                    if (m.type == 0) {
+                        normal = mul(xfA.q, m.local_normal);
+                        const V2 plane = mul(xfA, m.local_point), clip = mul(xfB, m.lp[i]);
+                        sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+                    } else {
+                        normal = mul(xfB.q, m.local_normal);
+                        const V2 plane = mul(xfB, m.local_point), clip = mul(xfA, m.lp[i]);
+                        sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+                        normal = -normal;
+                    }
+                    const V2 rA = point - cA, rB = point - cB;
+                    min_sep = fminf(min_sep, sep);
+                    const float C = clampf(BAUMGARTE * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);
+                    const float rnA = cross(rA, normal), rnB = cross(rB, normal);
+                    const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+                    const float imp = K > 0.0f ? -C / K : 0.0f;
+                    const V2 P = imp * normal;
+                    cA = cA - mA * P; aA -= iA * cross(rA, P);
+                    cB = cB + mB * P; aB += iB * cross(rB, P);
+                }
+                if (m.bA >= 0) { Wd.b[m.bA].c = cA; Wd.b[m.bA].a = aA; }
+                Wd.b[m.bB].c = cB; Wd.b[m.bB].a = aB;
+            }
+            const bool contacts_ok = min_sep >= -3.0f * LINEAR_SLOP;
+            bool joints_ok = true;
+            for (int ji = 0; ji < M.NJ; ++ji) {  // b2RevoluteJoint::SolvePositionConstraints
+                const JointDef &jd = M.jd[ji];
+                if (comp[MW_NODE_OF(jd.bA)] != isl) continue;
+                const Joint &j = Wd.j[ji];
+                Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
+                float mA, iA, mB, iB;
+                inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+                float ang_err = 0.0f;
+                if (j.limit_state != 0) {
+                    const float angle = B.a - A.a;
+                    float limit_imp = 0.0f;
+                    if (j.limit_state == 3) {
+                        const float C = clampf(angle - jd.lower, -MAX_ANGULAR_CORRECTION, MAX_ANGULAR_CORRECTION);
+                        limit_imp = -S.jmotor_mass[ji] * C; ang_err = fabsf(C);
+                    } else if (j.limit_state == 1) {
+                        float C = angle - jd.lower; ang_err = -C;
+                        C = clampf(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION, 0.0f);
+                        limit_imp = -S.jmotor_mass[ji] * C;
+                    } else {
+                        float C = angle - jd.upper; ang_err = C;
+                        C = clampf(C - ANGULAR_SLOP, 0.0f, MAX_ANGULAR_CORRECTION);
+                        limit_imp = -S.jmotor_mass[ji] * C;
+                    }
+                    A.a -= iA * limit_imp; B.a += iB * limit_imp;
+                }
+                const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
+                const V2 C = B.c + rB - A.c - rA;
+                const float pos_err = sqrtf(dot(C, C));
+                const float kxx = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y, kxy = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+                const float kyy = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+                float det = kxx * kyy - kxy * kxy;
+                if (det != 0.0f) det = 1.0f / det;
+                const V2 imp = v2(-(det * (kyy * C.x - kxy * C.y)), -(det * (kxx * C.y - kxy * C.x)));
+                A.c = A.c - mA * imp; A.a -= iA * cross(rA, imp);
+                B.c = B.c + mB * imp; B.a += iB * cross(rB, imp);
+                joints_ok = joints_ok && (pos_err <= LINEAR_SLOP && ang_err <= ANGULAR_SLOP);
+            }
+            if (contacts_ok && joints_ok) break;
+        }
+        #undef MW_NODE_OF
+    }
+    // b2ContactSolver::StoreImpulses -> manifold cache (warm start of the next step)
+    for (int k = 0; k < S.nm; ++k) {
+        const Manifold &m = S.m[k];
+        Slot &sl = Wd.slot[m.slot];
+        for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
+    }
+}
+#undef inv_mass_of
+#undef local_center_of
+
+// ---------------------------------------------------------------- lidar: b2EdgeShape::RayCast over the terrain
+MW_HD float lidar_fraction(const Model &M, const World &Wd, V2 p1, V2 p2) {
+    const V2 d = p2 - p1;
+    float best = 1.0f;  // LidarCallback.fraction starts at 1.0 (:210)
+    int e0 = (int)floorf(fminf(p1.x, p2.x) / TERRAIN_STEP), e1 = (int)floorf(fmaxf(p1.x, p2.x) / TERRAIN_STEP);
+    if (e0 < 0) e0 = 0;
+    if (e1 > M.NT - 2) e1 = M.NT - 2;
+    for (int e = e0; e <= e1; ++e) {
+        const V2 v1 = v2(e * TERRAIN_STEP, Wd.ty[e]), v2e = v2((e + 1) * TERRAIN_STEP, Wd.ty[e + 1]);
+        const V2 ee = v2e - v1;
+        V2 normal = v2(ee.y, -ee.x);
+        { const float len = sqrtf(dot(normal, normal)); normal = (1.0f / len) * normal; }
+        const float num = dot(normal, v1 - p1), den = dot(normal, d);
+        if (den == 0.0f) continue;
+        const float t = num / den;
+        if (t < 0.0f || 1.0f < t) continue;
+        const V2 q = p1 + t * d;
+        const float rr = dot(ee, ee);
+        if (rr == 0.0f) continue;
+        const float s = dot(q - v1, ee) / rr;
+        if (s < 0.0f || 1.0f < s) continue;
+        if (t < best) best = t;
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------- env: reset / step
+struct EnvCfg {
+    int n_walkers, reward_global, terminate_on_fall, one_hot, max_steps, auto_reset;
+    float position_noise, angle_noise, forward_reward, fall_reward, drop_reward;
+    uint32_t k0, k1;
+};
+constexpr int OBS_DIM = 24 + 4 + 3 + 1;  // :243 (one_hot unsupported)
+
+MW_HD void philox10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+enum : uint32_t { TAG_MW_TERRAIN = 32, TAG_MW_PUSH = 33, TAG_MW_NOISE = 34 };
+MW_HD float u24f(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid, float *obs, float *rew, uint8_t *done);
+
+// MultiWalkerEnv.reset (:330-357) without its trailing step
+MW_HD void env_reset_world(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid) {
+    const uint32_t tick = Wd.tick;
+    Wd.game_over = 0; Wd.prev_package_shaping = 0.0f; Wd.t = 0;
+    for (int w = 0; w < M.W; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0f; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
+    for (int k = 0; k < MAXSLOT; ++k) { Wd.slot[k].edge = -1; Wd.slot[k].npts = 0; Wd.slot[k].touching = 0; }
+    // _generate_terrain, non-hardcore branch (:516-612)
+    {
+        float velocity = 0.0f, y = TERRAIN_HEIGHT;
+        int counter = TERRAIN_STARTPAD;
+        bool oneshot = false;
+        for (int i = 0; i < M.NT; ++i) {
+            uint32_t r[4];
+            philox10(gid, tick, (uint32_t)i, TAG_MW_TERRAIN, C.k0, C.k1, r);
+            if (!oneshot) {
+                const float sgn = (TERRAIN_HEIGHT - y) > 0.0f ? 1.0f : ((TERRAIN_HEIGHT - y) < 0.0f ? -1.0f : 0.0f);
+                velocity = 0.8f * velocity + 0.01f * sgn;
+                if (i > TERRAIN_STARTPAD) velocity += (2.0f * u24f(r[0]) - 1.0f) / SCALE;  // np_random.uniform(-1, 1) / SCALE
+                y += velocity;
+            }
+            oneshot = false;
+            Wd.ty[i] = y;
+            counter -= 1;
+            if (counter == 0) {
+                counter = TERRAIN_GRASS / 2 + (int)(((uint64_t)r[1] * (uint64_t)(TERRAIN_GRASS - TERRAIN_GRASS / 2)) >> 32);  // randint(5, 10)
+                oneshot = true;
+            }
+        }
+    }
+    // _generate_package (:499-514)
+    float sx = 0.0f;
+    for (int w = 0; w < M.W; ++w) sx += M.start_x[w];
+    sx /= (float)M.W;
+    {
+        Body &b = Wd.b[0];
+        b.a = 0.0f; b.v = v2(0, 0); b.w = 0.0f;
+        b.c = v2(sx, TERRAIN_HEIGHT + 3 * LEG_H) + M.shape[SH_PACKAGE].centroid;
+    }
+    // BipedalWalker._reset (:113-192)
+    const float init_y = TERRAIN_HEIGHT + 2 * LEG_H;
+    for (int w = 0; w < M.W; ++w) {
+        const float init_x = M.start_x[w];
+        Body &hull = Wd.b[hull_of(w)];
+        hull.a = 0.0f; hull.v = v2(0, 0); hull.w = 0.0f;
+        hull.c = v2(init_x, init_y) + M.shape[SH_HULL].centroid;
+        uint32_t r[4];
+        philox10(gid, tick, (uint32_t)w, TAG_MW_PUSH, C.k0, C.k1, r);
+        Wd.push_x[w] = (2.0f * u24f(r[0]) - 1.0f) * INITIAL_RANDOM;  // uniform(-INITIAL_RANDOM, INITIAL_RANDOM)
+        for (int side = 0; side < 2; ++side) {
+            const float sgn = side == 0 ? -1.0f : 1.0f;
+            Body &up = Wd.b[hull_of(w) + 1 + 2 * side], &lo = Wd.b[hull_of(w) + 2 + 2 * side];
+            up.a = sgn * 0.05f; up.v = v2(0, 0); up.w = 0.0f;
+            up.c = v2(init_x, init_y - LEG_H / 2 - LEG_DOWN) + mul(rot(up.a), M.shape[SH_UPPER].centroid);
+            lo.a = sgn * 0.05f; lo.v = v2(0, 0); lo.w = 0.0f;
+            lo.c = v2(init_x, init_y - LEG_H * 3 / 2 - LEG_DOWN) + mul(rot(lo.a), M.shape[SH_LOWER].centroid);
+            Joint &hip = Wd.j[4 * w + 2 * side], &knee = Wd.j[4 * w + 2 * side + 1];
+            hip.ix = hip.iy = hip.iz = hip.motor_impulse = 0.0f; hip.limit_state = 0;
+            hip.motor_speed = sgn; hip.max_torque = MOTORS_TORQUE;
+            knee.ix = knee.iy = knee.iz = knee.motor_impulse = 0.0f; knee.limit_state = 0;
+            knee.motor_speed = 1.0f; knee.max_torque = MOTORS_TORQUE;
+        }
+    }
+    Wd.tick = tick + 1;
+}
+
+// MultiWalkerEnv.step (:359-428).  obs: [W][32], rew: [W]
+MW_HD void env_step(const Model &M, const EnvCfg &C, World &Wd, Scratch &S, uint32_t gid, const float *actions, float *obs,
+                    float *rew, uint8_t *done) {
+    for (int w = 0; w < M.W; ++w) {  // apply_action (:194-203)
+        for (int k = 0; k < 4; ++k) {
+            const float a = actions[4 * w + k];
+            Joint &j = Wd.j[4 * w + k];
+            const float sp = (k % 2 == 0) ? SPEED_HIP : SPEED_KNEE;
+            j.motor_speed = sp * (a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f));
+            j.max_torque = MOTORS_TORQUE * clampf(fabsf(a), 0.0f, 1.0f);
+        }
+    }
+    world_step(M, Wd, S);  // :365
+    env_observe(M, C, Wd, gid, obs, rew, done);
+    Wd.t += 1;
+    Wd.tick += 1;
+}
+
+MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
+    const Body &pkg = Wd.b[0];
+    const V2 pkg_pos = body_xf(M, pkg, 0).p;
+    float rewards[MAX_WALKERS];
+    V2 hull_pos[MAX_WALKERS];
+    for (int w = 0; w < M.W; ++w) hull_pos[w] = body_xf(M, Wd.b[hull_of(w)], hull_of(w)).p;
+    for (int w = 0; w < M.W; ++w) {
+        const Body &hull = Wd.b[hull_of(w)];
+        const V2 pos = hull_pos[w];
+        float *o = obs + w * OBS_DIM;
+        // get_observation (:205-237)
+        o[0] = hull.a;
+        o[1] = 2.0f * hull.w / FPS;
+        o[2] = 0.3f * hull.v.x * (VIEWPORT_W / SCALE) / FPS;
+        o[3] = 0.3f * hull.v.y * (VIEWPORT_H / SCALE) / FPS;
+        for (int side = 0; side < 2; ++side) {
+            const Body &up = Wd.b[hull_of(w) + 1 + 2 * side], &lo = Wd.b[hull_of(w) + 2 + 2 * side];
+            o[4 + 5 * side + 0] = up.a - hull.a;                       // joints[0/2].angle
+            o[4 + 5 * side + 1] = (up.w - hull.w) / SPEED_HIP;          // .speed / SPEED_HIP
+            o[4 + 5 * side + 2] = (lo.a - up.a) + 1.0f;                 // joints[1/3].angle + 1.0
+            o[4 + 5 * side + 3] = (lo.w - up.w) / SPEED_KNEE;
+            o[4 + 5 * side + 4] = Wd.ground[w][side] ? 1.0f : 0.0f;
+        }
+        for (int i = 0; i < 10; ++i) {  // lidar (:209-214)
+            float ls, lc;
+            sincos_det(1.5f * i / 10.0f, ls, lc);
+            const V2 p2 = v2(pos.x + ls * LIDAR_RANGE, pos.y - lc * LIDAR_RANGE);
+            o[14 + i] = lidar_fraction(M, Wd, pos, p2);
+        }
+        // neighbours and package (:380-400), gaussian noise via Box-Muller on keyed uniforms
+        float nz[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (C.position_noise != 0.0f || C.angle_noise != 0.0f) {
+            for (int q = 0; q < 4; ++q) {
+                uint32_t r[4];
+                philox10(gid, Wd.tick, (uint32_t)(w * 4 + q), TAG_MW_NOISE, C.k0, C.k1, r);
+                const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u24f(r[1]);
+                const float rad = sqrtf(-2.0f * logf(u1));
+                float bs, bc;
+                sincos_det(2.0f * B2_PI * u2, bs, bc);
+                nz[2 * q] = rad * bc;
+                if (2 * q + 1 < 7) nz[2 * q + 1] = rad * bs;
+            }
+        }
+        int n = 24, zi = 0;
+        for (int dj = -1; dj <= 1; dj += 2) {
+            const int j = w + dj;
+            if (j < 0 || j == M.W) { o[n++] = 0.0f; o[n++] = 0.0f; }
+            else {
+                const float xm = (hull_pos[j].x - pos.x) / M.package_length, ym = (hull_pos[j].y - pos.y) / M.package_length;
+                o[n++] = xm + C.position_noise * nz[zi++];
+                o[n++] = ym + C.position_noise * nz[zi++];
+            }
+        }
+        const float xd = (pkg_pos.x - pos.x) / M.package_length, yd = (pkg_pos.y - pos.y) / M.package_length;
+        o[n++] = xd + C.position_noise * nz[4];
+        o[n++] = yd + C.position_noise * nz[5];
+        o[n++] = pkg.a + C.angle_noise * nz[6];
+        o[n++] = (float)w / (float)M.W;  // :400
+        // shaping (:403-407)
+        const float shaping = 0.0f - 5.0f * fabsf(o[0]);
+        rewards[w] = shaping - Wd.prev_shaping[w];
+        Wd.prev_shaping[w] = shaping;
+    }
+    const float package_shaping = C.forward_reward * 130.0f * pkg_pos.x / SCALE;  // :409-411
+    for (int w = 0; w < M.W; ++w) rewards[w] += (package_shaping - Wd.prev_package_shaping);
+    Wd.prev_package_shaping = package_shaping;
+    bool dn = false;
+    const float last_x = hull_pos[M.W - 1].x;  // `pos` leaks out of the loop: the LAST walker (:417, :420)
+    if (Wd.game_over || last_x < 0.0f) { for (int w = 0; w < M.W; ++w) rewards[w] += C.drop_reward; dn = true; }
+    if (last_x > (M.NT - TERRAIN_GRASS) * TERRAIN_STEP) dn = true;
+    int nfallen = 0;
+    for (int w = 0; w < M.W; ++w) { rewards[w] += C.fall_reward * (Wd.fallen[w] ? 1.0f : 0.0f); nfallen += Wd.fallen[w]; }
+    if (C.terminate_on_fall && nfallen > 0) dn = true;
+    if (rew) {
+        if (C.reward_global) { float s = 0.0f; for (int w = 0; w < M.W; ++w) s += rewards[w]; s /= (float)M.W; for (int w = 0; w < M.W; ++w) rew[w] = s; }
+        else for (int w = 0; w < M.W; ++w) rew[w] = rewards[w];
+    }
+    if (done) *done = dn ? 1 : 0;
+}
+
+}  // namespace mw

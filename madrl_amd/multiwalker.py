@@ -1,0 +1,199 @@
+"""Batched MultiWalkerEnv on MI355X -- host-side mirror of the reference class
+`madrl_environments.walker.multi_walker.MultiWalkerEnv` (multi_walker.py:250-641).
+
+Same constructor arguments / defaults (:256-258), `agents`, `reward_mech`, `reset()`, `step()`:
+    reset()        -> obs float32 [N, W, 32]
+    step(actions)  -> obs, rew float32 [N, W], done bool [N], {}      actions float [N, W, 4]
+`MultiWalkerEnv(...)` is the N == 1 drop-in with the reference's return types.
+
+The rigid-body dynamics (Box2D in the reference) are restated from scratch in
+madrl_amd/csrc/multiwalker_core.hpp; parity with Box2D is UNPINNED.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .base import AbstractMAEnv, Agent
+from .spaces import Box
+
+
+class BipedalWalker(Agent):
+    """multi_walker.py:87-247 (spaces only)."""
+
+    @property
+    def observation_space(self):
+        return Box(low=-np.inf, high=np.inf, shape=(24 + 4 + 3 + 1,))  # :243
+
+    @property
+    def action_space(self):
+        return Box(low=-1, high=1, shape=(4,))
+
+
+class BatchedMultiWalkerEnv(AbstractMAEnv):
+
+    def __init__(self, n_walkers=2, position_noise=1e-3, angle_noise=1e-3, reward_mech='local', forward_reward=1.0,
+                 fall_reward=-100.0, drop_reward=-100.0, terminate_on_fall=True, one_hot=False,
+                 n_envs=1, device="cuda:0", seed=0, env_id_base=0, max_steps=0, auto_reset=False, max_blocks=0):
+        self._ctor = dict(locals())
+        self._ctor.pop("self"); self._ctor.pop("__class__", None)
+        if one_hot:
+            raise NotImplementedError("one_hot ids (multi_walker.py:397-398) are not supported")
+        self.n_walkers, self.position_noise, self.angle_noise = n_walkers, position_noise, angle_noise
+        self._reward_mech, self.forward_reward, self.fall_reward = reward_mech, forward_reward, fall_reward
+        self.drop_reward, self.terminate_on_fall, self.one_hot = drop_reward, terminate_on_fall, one_hot
+        self.n_envs, self.device = int(n_envs), torch.device(device)
+        self._seed_value, self.env_id_base = int(seed), int(env_id_base)
+        self.max_steps, self.auto_reset, self._max_blocks = int(max_steps), bool(auto_reset), int(max_blocks)
+        self._handle = None
+        self.setup()
+
+    def _config(self):
+        c = _lib.MultiWalkerConfig()
+        c.struct_size = C.sizeof(_lib.MultiWalkerConfig)
+        c.n_walkers, c.reward_global = int(self.n_walkers), int(self._reward_mech != "local")
+        c.terminate_on_fall, c.one_hot = int(bool(self.terminate_on_fall)), 0
+        c.max_steps, c.auto_reset = self.max_steps, int(self.auto_reset)
+        c.position_noise, c.angle_noise = float(self.position_noise), float(self.angle_noise)
+        c.forward_reward, c.fall_reward, c.drop_reward = float(self.forward_reward), float(self.fall_reward), float(self.drop_reward)
+        c.seed, c.env_id_base = self._seed_value, self.env_id_base
+        return c
+
+    def setup(self):
+        """multi_walker.py:276-303 (called by set_param_values for curriculum updates)."""
+        L = _lib.lib()
+        if self.device.type != "cuda":
+            raise _lib.MadrlError("BatchedMultiWalkerEnv needs a ROCm device (got %s); there is no CPU path" % self.device)
+        cfg = self._config()
+        nbytes = C.c_uint64()
+        _lib.check(L.madrl_multiwalker_state_bytes(C.byref(cfg), self.n_envs, C.byref(nbytes)))
+        N, W, dev = self.n_envs, int(self.n_walkers), self.device
+        if getattr(self, "_shape_key", None) != (N, W, nbytes.value):
+            self._state = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
+            self._obs = torch.zeros((N, W, 32), dtype=torch.float32, device=dev)
+            self._rew = torch.zeros((N, W), dtype=torch.float32, device=dev)
+            self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
+            self._shape_key = (N, W, nbytes.value)
+        self._destroy()
+        h = C.c_void_p()
+        dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        _lib.check(L.madrl_multiwalker_create(C.byref(cfg), N, dev_index, _lib.ptr(self._state), C.byref(h)))
+        self._handle = h
+        if self._max_blocks:
+            _lib.check(L.madrl_multiwalker_set_launch(h, self._max_blocks))
+        nb, nt = C.c_int32(), C.c_int32()
+        _lib.check(L.madrl_multiwalker_dims(h, C.byref(nb), C.byref(nt)))
+        self.n_bodies, self.n_terrain = nb.value, nt.value
+        self.world_bytes = nbytes.value // N
+        self.walkers = [BipedalWalker() for _ in range(W)]
+        self.package_scale = W / 1.75
+        self.package_length = 240 / 30.0 * self.package_scale
+        self.total_agents = W
+
+    def set_launch(self, max_blocks=0):
+        self._max_blocks = int(max_blocks)
+        _lib.check(_lib.lib().madrl_multiwalker_set_launch(self._handle, self._max_blocks))
+
+    def _destroy(self):
+        if getattr(self, "_handle", None):
+            _lib.lib().madrl_multiwalker_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    @property
+    def agents(self):
+        return self.walkers
+
+    @property
+    def reward_mech(self):
+        return self._reward_mech
+
+    def get_param_values(self):
+        return self.__dict__
+
+    def seed(self, seed=None):
+        if seed is None:
+            seed = int(np.random.randint(2**31 - 1))
+        self._seed_value = int(seed)
+        self.setup()
+        return [self._seed_value]
+
+    def reset(self, mask=None):
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device).reshape(self.n_envs).to(torch.uint8).contiguous()
+        _lib.check(_lib.lib().madrl_multiwalker_reset(self._handle, _lib.ptr(mask), _lib.ptr(self._obs),
+                                                      _lib.current_stream(self.device)))
+        return self._obs
+
+    def step(self, actions):
+        N, W = self.n_envs, int(self.n_walkers)
+        a = torch.as_tensor(actions, device=self.device)
+        if a.numel() != N * W * 4:
+            raise AssertionError("actions have %d elements, expected %d" % (a.numel(), N * W * 4))  # :360-361
+        a = a.reshape(N, W, 4).to(torch.float32).contiguous()
+        _lib.check(_lib.lib().madrl_multiwalker_step(self._handle, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._rew),
+                                                     _lib.ptr(self._done), _lib.current_stream(self.device)))
+        return self._obs, self._rew, (self._done & 1).bool(), {}
+
+    def bodies(self):
+        N, W, dev = self.n_envs, int(self.n_walkers), self.device
+        b = torch.zeros((N, self.n_bodies, 6), dtype=torch.float32, device=dev)
+        f = torch.zeros((N, 1 + 3 * W), dtype=torch.uint8, device=dev)
+        t = torch.zeros((N, self.n_terrain), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().madrl_multiwalker_get_bodies(self._handle, _lib.ptr(b), _lib.ptr(f), _lib.ptr(t),
+                                                           _lib.current_stream(self.device)))
+        return b, f, t
+
+    @property
+    def state_buffer(self):
+        """raw per-env world structs, uint8 [N, world_bytes] (checkpoint / teacher-forcing hook)"""
+        return self._state.view(self.n_envs, self.world_bytes)
+
+    def __getstate__(self):
+        return dict(self._ctor)
+
+    def __setstate__(self, d):
+        self.__init__(**d)
+
+
+class MultiWalkerEnv(AbstractMAEnv):
+    """N == 1 drop-in with the reference's return types (multi_walker.py:250)."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.pop("n_envs", None)
+        self._env = BatchedMultiWalkerEnv(*args, n_envs=1, **kwargs)
+        self.reset()  # the reference constructor ends in setup() -> reset() (:271, :303)
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["_env"], name)
+
+    @property
+    def agents(self):
+        return self._env.agents
+
+    @property
+    def reward_mech(self):
+        return self._env.reward_mech
+
+    def seed(self, seed=None):
+        return self._env.seed(seed)
+
+    def _obslist(self, obs):
+        o = obs[0].detach().cpu().numpy().astype(np.float64)
+        return [o[i] for i in range(o.shape[0])]
+
+    def reset(self):
+        return self._obslist(self._env.reset())
+
+    def step(self, actions):
+        act_vec = np.reshape(np.asarray(actions, dtype=np.float64), (self._env.n_walkers, 4))  # :360
+        obs, rew, done, info = self._env.step(act_vec[None])
+        r = rew[0].detach().cpu().numpy().astype(np.float64)
+        rewards = r if self._env.reward_mech == "local" else [float(r[0])] * self._env.n_walkers  # :426-428
+        return self._obslist(obs), rewards, bool(done[0].item()), {}

@@ -1,0 +1,77 @@
+"""ctypes wrapper over oracle/multiwalker_oracle.cpp (CPU build of the MultiWalker solver source).
+TEST INFRASTRUCTURE ONLY; parity unpinned -- see the header of multiwalker_oracle.cpp."""
+import ctypes as C
+
+import numpy as np
+
+from . import pursuit as _po
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class MultiWalkerOracle(object):
+    def __init__(self, n_walkers=2, position_noise=1e-3, angle_noise=1e-3, reward_mech="local", forward_reward=1.0,
+                 fall_reward=-100.0, drop_reward=-100.0, terminate_on_fall=True, one_hot=False, n_envs=1, seed=0,
+                 env_id_base=0):
+        assert not one_hot
+        L = _po.lib()
+        self.L = L
+        L.mwo_create.restype = C.c_void_p
+        L.mwo_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int64, C.c_uint64, C.c_int64]
+        for name, n in (("mwo_destroy", 1), ("mwo_reset", 3), ("mwo_step", 5), ("mwo_get_worlds", 2), ("mwo_set_worlds", 2),
+                        ("mwo_get_bodies", 3), ("mwo_get_terrain", 2), ("mwo_num_terrain", 1), ("mwo_num_bodies", 1),
+                        ("mwo_model_masses", 2)):
+            getattr(L, name).argtypes = [C.c_void_p] * n
+        self.N, self.W = int(n_envs), n_walkers
+        self.h = L.mwo_create(n_walkers, int(reward_mech == "global"), int(terminate_on_fall), position_noise, angle_noise,
+                              forward_reward, fall_reward, drop_reward, self.N, int(seed), int(env_id_base))
+        self.D = L.mwo_obs_dim()
+        self.NB, self.NT = L.mwo_num_bodies(self.h), L.mwo_num_terrain(self.h)
+        self.world_bytes = L.mwo_world_bytes()
+        self.obs = np.zeros((self.N, self.W, self.D), np.float32)
+        self.rew = np.zeros((self.N, self.W), np.float32)
+        self.done = np.zeros(self.N, np.uint8)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.mwo_destroy(self.h)
+            self.h = None
+
+    def reset(self, mask=None):
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+        self.L.mwo_reset(self.h, _p(mask), _p(self.obs))
+        return self.obs
+
+    def step(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.N, self.W, 4))
+        self.L.mwo_step(self.h, _p(a), _p(self.obs), _p(self.rew), _p(self.done))
+        return self.obs, self.rew, self.done
+
+    def bodies(self):
+        out = np.zeros((self.N, self.NB, 6), np.float32)
+        flags = np.zeros((self.N, 1 + 3 * self.W), np.uint8)
+        self.L.mwo_get_bodies(self.h, _p(out), _p(flags))
+        return out, flags
+
+    def terrain(self):
+        out = np.zeros((self.N, self.NT), np.float32)
+        self.L.mwo_get_terrain(self.h, _p(out))
+        return out
+
+    def worlds(self):
+        out = np.zeros((self.N, self.world_bytes), np.uint8)
+        self.L.mwo_get_worlds(self.h, _p(out))
+        return out
+
+    def set_worlds(self, w):
+        w = np.ascontiguousarray(w, np.uint8).reshape(self.N, self.world_bytes)
+        self.L.mwo_set_worlds(self.h, _p(w))
+
+    def masses(self):
+        out = np.zeros(8, np.float32)
+        self.L.mwo_model_masses(self.h, _p(out))
+        return out

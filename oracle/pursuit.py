@@ -13,7 +13,8 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "_build", "libmadrl_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith("_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(("_oracle.c", "_oracle.cpp"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "madrl_amd", "csrc", "multiwalker_core.hpp"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
     return so
