@@ -540,7 +540,7 @@ const WaveEntry *find_wave(const madrl_pursuit_config *c) {
     return nullptr;
 }
 
-constexpr int64_t WAVE_DEFAULT_BLOCKS = 256 * 24;  // persistent workgroups: 24 waves per CU (6 per SIMD)
+constexpr int64_t WAVE_DEFAULT_BLOCKS = 256 * 16;  // persistent workgroups: 16 waves per CU (4 per SIMD at ~98 VGPRs)
 
 int validate(const madrl_pursuit_config *c) {
     if (!c) return fail(MADRL_EINVAL, "config is NULL");
@@ -834,7 +834,6 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             w.n_catch = d.n_catch; w.surround = d.surround; w.reward_global = d.reward_global;
             w.sample_maps = d.sample_maps; w.n_maps = d.n_maps; w.max_steps = d.max_steps; w.auto_reset = d.auto_reset;
             w.fmap_stride = fstride;
-            w.ablate = getenv("MADRL_PURSUIT_ABLATE") ? atoi(getenv("MADRL_PURSUIT_ABLATE")) : 0;
             w.k0 = d.k0; w.k1 = d.k1; w.gid_base = d.gid_base;
             w.catchr = d.catchr; w.term_pursuit = d.term_pursuit; w.urgency = d.urgency; w.cw = d.cw;
             w.n_envs = d.n_envs;

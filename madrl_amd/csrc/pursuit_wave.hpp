@@ -38,7 +38,6 @@ constexpr uint32_t CAUGHT = 0x10000u;    // added to an evader-count cell by a c
 struct WaveDev {
     int32_t n_catch, surround, reward_global, sample_maps, n_maps, max_steps, auto_reset;
     int32_t fmap_stride;  // dwords per map entry in fmaps
-    int32_t ablate;       // profiling only (MADRL_PURSUIT_ABLATE): 1 no obs stores, 2 no obs pass, 4 no Philox, 8 nt stores
     uint32_t k0, k1, gid_base;
     double catchr, term_pursuit, urgency, cw;
     int64_t n_envs;
@@ -137,7 +136,7 @@ __device__ __forceinline__ void wave_sync() {
 // It is a template parameter because a conditional global load in the hot loop makes the
 // compiler's s_waitcnt pass put a vmcnt(0) on the common path (see "pipeline hinge" below).
 template <class S, int MODE, bool INJECT>
-__global__ __launch_bounds__(64, 6) void pursuit_wave_kernel(const WaveDev d, const WaveIO io) {
+__global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const WaveIO io) {
     constexpr int P = S::P, E = S::E, A = S::A, GW = S::GW, PAD = S::PAD, GSZ = S::GSZ, NS = S::NS;
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int lane = threadIdx.x;
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(64, 6) void pursuit_wave_kernel(const WaveDev d, co
                 wave_sync();
                 if (alive) layer[cell] = L[S::X_VTAB + cnt];
                 wave_sync();
-                if (!(d.ablate & 2)) {
+                {
                     const int origin = is_p ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f *orow = reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D));
@@ -414,12 +413,11 @@ __global__ __launch_bounds__(64, 6) void pursuit_wave_kernel(const WaveDev d, co
                         const uint32_t v1 = L[base + s_cst[s][1]];
                         const uint32_t v2 = L[base + s_cst[s][2]];
                         const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
-                        if (q < S::NQ && !(d.ablate & 1)) {
-                            if (((v0 != SENT) & (v1 != SENT) & (v2 != SENT) & (v3 != SENT)) || (d.ablate & 16)) {
+                        if (q < S::NQ) {
+                            if ((v0 != SENT) & (v1 != SENT) & (v2 != SENT) & (v3 != SENT)) {
                                 const v4f val = {__uint_as_float(v0), __uint_as_float(v1), __uint_as_float(v2),
                                                  __uint_as_float(v3)};
-                                if (d.ablate & 8) orow[q] = val;
-                                else __builtin_nontemporal_store(val, &orow[q]);
+                                __builtin_nontemporal_store(val, &orow[q]);
                             } else {  // a count-layer cell outside the map: leave it stale (Q2).
                                 // Plain (L2-cached) stores: partial lines must merge in L2 -- nontemporal
                                 // partial writes cost a read-modify-write at the memory side (3x slower).

@@ -27,7 +27,7 @@ for blocks in [int(b) for b in sys.argv[1].split(",")]:
     print("ablate=%%s blocks=%%6d  %%.1f us/step  %%.3e env-steps/s  %%.0f GB/s" %% (os.environ.get("MADRL_PURSUIT_ABLATE", "0"), blocks, ms * 1e3, N / ms * 1e3, 5029 * N / ms / 1e6))
 ''' % ROOT
 import sys as _s
-SETS = (("0", "4096,6144"), ("16", "4096,6144"), ("24", "4096,6144"), ("1", "4096"), ("2", "4096"))
+SETS = (("0", "3072,4096,6144,8192"),)
 for ab, blocks in SETS:
     env = dict(os.environ, MADRL_PURSUIT_ABLATE=ab)
     subprocess.run([sys.executable, "-c", CHILD, blocks], env=env)
