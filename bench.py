@@ -73,12 +73,116 @@ def cpu_baseline(maps, kw, budget_s=12.0):
                 sample="C oracle (oracle/pursuit_oracle.c, OpenMP), %d envs x %d steps, same config, %.1f s" % (n, steps, dt))
 
 
+def bench_other(args, rank, local_rank, world, dev):
+    """Waterworld (BASELINE configs[2]) and MultiWalker (configs[3]) on the same contract."""
+    import numpy as np
+    import torch
+    from madrl_amd import _lib
+    L = _lib.lib()
+    K, W = args.steps, args.warmup
+    if args.workload == "waterworld":
+        from madrl_amd.waterworld import BatchedMAWaterWorld
+        N = args.envs or 32768
+        env = BatchedMAWaterWorld(5, 10, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
+                                  max_blocks=args.max_blocks)
+        acts = [(torch.rand((N, 5, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)]
+        outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
+        step = lambda i: _lib.check(L.madrl_waterworld_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
+        bytes_per = 40 + 4 * 5 * env.obs_dim + 20 + 1 + 8 + 2 * (env._state.numel() // N)
+        kernel, binding = "waterworld_kernel<1>", "VALU / LDS issue (about 4 000 ray tests per env-step), not HBM"
+        workload = "MAWaterWorld 5 pursuers / 10 evaders / 10 poison / 30 sensors, n_coop 2, %d envs per GPU, timestep_limit 1000" % N
+
+        def cpu():
+            from oracle import waterworld as ww
+            n = 4096
+            o = ww.WaterworldOracle(5, 10, n_envs=n, seed=0, dtype=np.float32)
+            o.reset()
+            a = np.random.RandomState(0).uniform(-1, 1, (n, 5, 2)).astype(np.float32)
+            t0 = time.time(); k = 0
+            while time.time() - t0 < 10:
+                o.step(a); k += 1
+            dt = time.time() - t0
+            from oracle import pursuit as po
+            return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
+                        sample="float32 C oracle (oracle/waterworld_oracle.c, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
+    else:
+        from madrl_amd.multiwalker import BatchedMultiWalkerEnv
+        N = args.envs or 16384
+        env = BatchedMultiWalkerEnv(n_walkers=3, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
+                                    max_steps=500, max_blocks=args.max_blocks)
+        acts = [(torch.rand((N, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)]
+        outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done)]
+        step = lambda i: _lib.check(L.madrl_multiwalker_step(env._handle, _lib.ptr(acts[i % 8]), *outs, _lib.current_stream(dev)))
+        bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * env.world_bytes
+        kernel, binding = "multiwalker_kernel<1>", "dependent FP32 VALU latency of the serial Gauss-Seidel sweeps in one lane, not HBM"
+        workload = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, parity unpinned)" % N
+        K, W = min(K, 20), min(W, 3)
+
+        def cpu():
+            from oracle import multiwalker as mwo
+            from oracle import pursuit as po
+            n = 1024
+            o = mwo.MultiWalkerOracle(n_walkers=3, n_envs=n, seed=0)
+            o.reset()
+            a = np.random.RandomState(0).uniform(-1, 1, (n, 3, 4)).astype(np.float32)
+            t0 = time.time(); k = 0
+            while time.time() - t0 < 10:
+                _, _, d = o.step(a); k += 1
+                if d.any():
+                    o.reset(mask=d)
+            dt = time.time() - t0
+            return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
+                        sample="CPU build of the solver source (oracle/multiwalker_oracle.cpp, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
+    if world > 1:
+        import torch.distributed as dist
+    env.reset()
+    for i in range(W):
+        step(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(K):
+        step(i)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
+        out = {"metric": "env-steps/sec at fixed batch (%s)" % args.workload, "value": world * N * K / dt, "unit": "env-steps/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform random actions resident in HBM, in-kernel Philox, fused auto-reset)",
+               "config": {"workload": workload, "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                            "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per,
+                            "binding_resource": binding}}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs", type=int, default=65536, help="env instances per GPU")
+    ap.add_argument("--envs", type=int, default=0, help="env instances per GPU (0 = the BASELINE config's batch)")
+    ap.add_argument("--workload", default="pursuit", choices=["pursuit", "waterworld", "multiwalker"],
+                    help="pursuit = BASELINE.json's metric (default); the other two are the remaining north_star envs")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,7 +206,9 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    N, P, E, R = args.envs, 8, 30, 7
+    if args.workload != "pursuit":
+        return bench_other(args, rank, local_rank, world, dev)
+    N, P, E, R = (args.envs or 65536), 8, 30, 7
     maps = [rectangle_map(16, 16)]
     kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, n_catch=2, surround=True, flatten=True, reward_mech="local")
     env = BatchedPursuitEvade(maps, n_envs=N, device=dev, seed=0, env_id_base=rank * N, max_steps=args.horizon,
