@@ -219,10 +219,14 @@ def main():
     n_act = 16
     actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
     K, W = args.steps, args.warmup
-    # compact trajectory of the timed region (what a sampler returns to the learner)
-    traj_act = torch.zeros((K, N, P), dtype=torch.uint8, device=dev)
-    traj_rew = torch.zeros((K, N, P), dtype=torch.float32, device=dev)
-    traj_done = torch.zeros((K, N), dtype=torch.uint8, device=dev)
+    # compact trajectory of the timed region (what a sampler returns to the learner), cut into
+    # chunks whose all-gather over RCCL/xGMI overlaps with the stepping of the next chunk
+    CH = 50
+    n_chunks = (K + CH - 1) // CH
+    chunk_len = [min(CH, K - c * CH) for c in range(n_chunks)]
+    traj = [dict(actions=torch.zeros((chunk_len[c], N, P), dtype=torch.uint8, device=dev),
+                 rewards=torch.zeros((chunk_len[c], N, P), dtype=torch.float32, device=dev),
+                 dones=torch.zeros((chunk_len[c], N), dtype=torch.uint8, device=dev)) for c in range(n_chunks)] if world > 1 else []
 
     L = _lib.lib()
     h = env._handle
@@ -233,9 +237,10 @@ def main():
         _lib.check(L.madrl_pursuit_step(h, act_p[i % n_act], None, obs_p, rew_p, done_p, rem_p,
                                         _lib.current_stream(dev)))
         if record and world > 1:
-            traj_act[i].copy_(actions[i % n_act])
-            traj_rew[i].copy_(env._rew)
-            traj_done[i].copy_(env._done)
+            c, j = divmod(i, CH)
+            traj[c]["actions"][j].copy_(actions[i % n_act])
+            traj[c]["rewards"][j].copy_(env._rew)
+            traj[c]["dones"][j].copy_(env._done)
 
     env.reset()
     for i in range(W):
@@ -246,17 +251,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gatherer = None
+    if world > 1:
+        from madrl_amd.dist import ChunkedTrajectoryGather
+        gatherer = ChunkedTrajectoryGather()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(K):
         one_step(i, True)
-    ev1.record()  # events bracket exactly the K step launches on the launch stream
-    if world > 1:
-        from madrl_amd.dist import gather_trajectories
-        gathered = gather_trajectories(dict(actions=traj_act, rewards=traj_rew, dones=traj_done))
-        assert gathered["rewards"].shape[0] == world
+        if gatherer is not None and (i + 1) % CH == 0:
+            gatherer.submit(traj[i // CH])      # async: overlaps with the next chunk's steps
+    ev1.record()  # events bracket the K step launches (and the small trajectory copies when N > 1)
+    if gatherer is not None:
+        if K % CH:
+            gatherer.submit(traj[-1])
+        gathered = gatherer.finish()            # episode end: every rank holds every rank's trajectory
+        assert sum(t.shape[1] for t in gathered["rewards"]) == K and gathered["rewards"][0].shape[0] == world
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K  # average launch duration incl. inter-launch gaps

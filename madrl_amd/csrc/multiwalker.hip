@@ -6,8 +6,11 @@
 // Box2D's `Step(1/50, 180, 60)`; HBM sees the world struct in/out once per step, the action row
 // in and observation / reward / done rows out.
 //
-// v1 mapping: the solver (multiwalker_core.hpp, shared host/device source) runs on lane 0 of the
-// wavefront; the other lanes move the world struct and the outputs (coalesced dword copies).
+// Lane mapping (multiwalker_core.hpp `Par`): collision detection by body, joints by walker,
+// terrain contacts by body, the package/hull contacts on one lane, with wave-local syncs between
+// the phases of each Gauss-Seidel sweep; lanes working concurrently never share a body, so the
+// result equals the serial sweep bit for bit.  The remaining lanes move the world struct and the
+// outputs (coalesced dword copies).
 // The path is bound by dependent FP32 VALU latency inside one wavefront, not by HBM
 // (~3 KB per env-step against ~1 MFLOP of serial work) -- DESIGN.md "MultiWalker".
 //
@@ -38,7 +41,20 @@ struct MwIO {
     uint8_t *done;         // [N]
 };
 
-__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the cooperating lanes of multiwalker_core.hpp's `Par` = the 64 lanes of the wavefront
+struct WavePar {
+    int l;
+    __device__ __forceinline__ int lane() const { return l; }
+    __device__ __forceinline__ int n() const { return 64; }
+    __device__ __forceinline__ void sync() const { lds_sync(); }
+    __device__ __forceinline__ int alloc(int *counter) const { return atomicAdd(counter, 1); }
+};
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 template <int MODE>
@@ -47,8 +63,9 @@ __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const Mw
     __shared__ mw::World Wd;
     __shared__ mw::Scratch S;
     __shared__ float s_obs[mw::MAX_WALKERS * mw::OBS_DIM], s_rew[mw::MAX_WALKERS], s_act[4 * mw::MAX_WALKERS];
-    __shared__ uint32_t s_done;
+    __shared__ uint8_t s_done;
     const int lane = threadIdx.x;
+    const WavePar par{lane};
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(d.model);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&M);
@@ -62,30 +79,29 @@ __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const Mw
         {
             uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
             for (int k = lane; k < (int)(sizeof(mw::World) / 4); k += 64) dst[k] = rec[k];
-            if (MODE == 1 && lane < 4 * W) s_act[lane] = io.actions[env * 4 * W + lane];
+            if (lane < 4 * mw::MAX_WALKERS) s_act[lane] = (MODE == 1 && lane < 4 * W) ? io.actions[env * 4 * W + lane] : 0.0f;
+            if (lane == 0) s_done = 0;
         }
         lds_sync();
         const uint32_t gid = d.gid_base + (uint32_t)env;
-        if (lane == 0) {
-            uint8_t dn = 0;
-            if (MODE == 1) {
-                mw::env_step(M, d.cfg, Wd, S, gid, s_act, s_obs, s_rew, &dn);
-                if (d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) dn |= 2;
-            }
-            if (MODE == 0 || (dn != 0 && d.cfg.auto_reset)) {  // MultiWalkerEnv.reset (:330-357) ends with step(zeros)
-                float zero[4 * mw::MAX_WALKERS];
-                for (int k = 0; k < 4 * mw::MAX_WALKERS; ++k) zero[k] = 0.0f;
-                mw::env_reset_world(M, d.cfg, Wd, gid);
-                mw::env_step(M, d.cfg, Wd, S, gid, zero, s_obs, nullptr, nullptr);
-                Wd.t = 0;
-            }
-            s_done = dn;
+        if (MODE == 1) {
+            mw::env_step(M, d.cfg, Wd, S, par, gid, s_act, s_obs, s_rew, &s_done);   // all lanes cooperate
+            if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) s_done |= 2;
+            lds_sync();
         }
-        lds_sync();
+        const uint32_t dn = s_done;  // wave-uniform
+        if (MODE == 0 || (dn != 0 && d.cfg.auto_reset)) {  // MultiWalkerEnv.reset (:330-357) ends with step(zeros)
+            if (lane < 4 * mw::MAX_WALKERS) s_act[lane] = 0.0f;
+            if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, gid);
+            lds_sync();
+            mw::env_step(M, d.cfg, Wd, S, par, gid, s_act, s_obs, (float *)nullptr, (uint8_t *)nullptr);
+            if (lane == 0) Wd.t = 0;
+            lds_sync();
+        }
         for (int k = lane; k < W * mw::OBS_DIM; k += 64) io.obs[env * W * mw::OBS_DIM + k] = s_obs[k];
         if (MODE == 1) {
             if (lane < W) io.rew[env * W + lane] = s_rew[lane];
-            if (lane == 0) io.done[env] = (uint8_t)s_done;
+            if (lane == 0) io.done[env] = (uint8_t)dn;
         }
         {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
@@ -138,7 +154,8 @@ int mw_validate(const madrl_multiwalker_config *c) {
 }
 
 int mw_launch(const madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
-    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 8;
+    // default: one workgroup per env (measured best: the step is latency bound, 17 KB of LDS per env)
+    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : h->dev.n_envs;
     if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(multiwalker_kernel<0>, dim3((unsigned)blocks), dim3(64), 0, s, h->dev, io);

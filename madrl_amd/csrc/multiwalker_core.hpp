@@ -58,7 +58,7 @@ constexpr int MAXJ = 4 * MAX_WALKERS;
 constexpr int MAXT = TERRAIN_LENGTH * MAX_WALKERS / 8;  // terrain points (:301)
 constexpr int EDGE_SLOTS_SMALL = 6, EDGE_SLOTS_PKG = 36;
 constexpr int MAXSLOT = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
-constexpr int MAXM = 40;  // active manifolds per step
+constexpr int MAXM = 48;  // active manifolds per step (pool)
 
 struct V2 { float x, y; };
 MW_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
@@ -271,6 +271,12 @@ struct Scratch {  // per-step workspace (LDS on the GPU)
     float bim[MAXB], bii[MAXB];
     V2 blc[MAXB];
     int8_t node[MAXB];  // island graph node of a body: walker index, or W for the package
+    // solver schedule: manifold indices per body (terrain contacts) and per dynamic pair
+    uint8_t bm_cnt[MAXB], bm_idx[MAXB][EDGE_SLOTS_PKG];
+    int8_t dyn_midx[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
+    int8_t comp[MAX_WALKERS + 1];
+    uint8_t isl_done[MAX_WALKERS + 1], walker_ok[MAX_WALKERS], all_done;
+    float body_minsep[MAXB], dyn_minsep[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
 };
 
 MW_HD Xf body_xf(const Model &M, const Body &b, int bi) {
@@ -519,8 +525,23 @@ MW_HD void contact_event(const Model &M, World &Wd, int bA, int bB, bool begin) 
     }
 }
 
-// push an active manifold into the solver list, carrying impulses over from the cached contact
-MW_HD void emit_manifold(const Model &M, World &Wd, Scratch &S, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction) {
+// ---------------------------------------------------------------- lane parallelism
+// The step is written once for a group of cooperating lanes (`Par`): SerialPar (CPU build: one
+// lane, no-op sync) or the wavefront of the HIP kernel.  Work is split so that lanes running
+// concurrently never touch the same body: joints by walker, terrain contacts by body, the
+// package-hull / hull-hull contacts by one lane after a sync.  Constraints that share a body keep
+// their serial Gauss-Seidel order, constraints that do not commute trivially -- so the lane-parallel
+// schedule produces bit-identical results to the serial one.
+struct SerialPar {
+    MW_HD int lane() const { return 0; }
+    MW_HD int n() const { return 1; }
+    MW_HD void sync() const {}
+    MW_HD int alloc(int *counter) const { return (*counter)++; }
+};
+
+// push an active manifold into the solver pool, carrying impulses over from the cached contact
+template <class Par>
+MW_HD int emit_manifold(const Model &M, World &Wd, Scratch &S, Par par, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction) {
     float ni[2] = {0, 0}, ti[2] = {0, 0};
     for (int i = 0; i < mo.npts; ++i)  // b2Contact::Update: match ids with the old manifold
         for (int k = 0; k < sl.npts; ++k)
@@ -529,69 +550,74 @@ MW_HD void emit_manifold(const Model &M, World &Wd, Scratch &S, Slot &sl, int sl
     if (touching != (sl.touching != 0)) contact_event(M, Wd, bA, bB, touching);
     sl.touching = touching; sl.npts = (uint8_t)mo.npts;
     for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
-    if (!touching || S.nm >= MAXM) return;
-    Manifold &m = S.m[S.nm++];
+    if (!touching) return -1;
+    const int idx = par.alloc(&S.nm);
+    if (idx >= MAXM) return -1;  // pool exhausted: the pair is ignored this step
+    Manifold &m = S.m[idx];
     m.bA = (int16_t)bA; m.bB = (int16_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)mo.type;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
     for (int i = 0; i < mo.npts; ++i) { m.lp[i] = mo.lp[i]; m.ni[i] = ni[i]; m.ti[i] = ti[i]; }
     m.friction = friction;
+    return idx;
 }
 
-// b2ContactManager::Collide restated over the candidate pairs of this model
-MW_HD void collide(const Model &M, World &Wd, Scratch &S) {
-    S.nm = 0;
-    // bodies against the terrain polyline: edge e spans x in [e, e+1] * TERRAIN_STEP
-    for (int bi = 0; bi < M.NB; ++bi) {
-        const Shape &s = M.shape[shape_of_body(bi)];
-        float xmin, xmax, ymin, ymax;
-        body_aabb(M, Wd, bi, xmin, xmax, ymin, ymax);
-        int e0 = (int)floorf(xmin / TERRAIN_STEP), e1 = (int)floorf(xmax / TERRAIN_STEP);
-        if (e0 < 0) e0 = 0;
-        if (e1 > M.NT - 2) e1 = M.NT - 2;
-        Slot *slots = Wd.slot + M.slot_base[bi];
-        const int cap = M.slot_cap[bi];
-        // contacts whose edge left the candidate range are destroyed (EndContact if touching)
-        for (int k = 0; k < cap; ++k) {
-            Slot &sl = slots[k];
-            if (sl.edge >= 0 && (sl.edge < e0 || sl.edge > e1)) {
-                if (sl.touching) contact_event(M, Wd, -1, bi, false);
-                sl.edge = -1; sl.npts = 0; sl.touching = 0;
-            }
-        }
-        const Xf xfB = body_xf(M, Wd.b[bi], bi);
-        for (int e = e0; e <= e1; ++e) {
-            int k = -1;
-            for (int q = 0; q < cap; ++q) if (slots[q].edge == e) { k = q; break; }
-            if (k < 0) { for (int q = 0; q < cap; ++q) if (slots[q].edge < 0) { k = q; break; } }
-            if (k < 0) continue;  // cache full: pair ignored this step
-            Slot &sl = slots[k];
-            if (sl.edge != e) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; }
-            const V2 p1 = v2(e * TERRAIN_STEP, Wd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Wd.ty[e + 1]);
-            ManifoldOut mo; mo.npts = 0;
-            const float elo = fminf(p1.y, p2.y) - POLY_RADIUS, ehi = fmaxf(p1.y, p2.y) + POLY_RADIUS;
-            if (!(ymin > ehi + 0.2f || ymax < elo - 0.2f)) {
-                const bool has0 = e > 0, has3 = e < M.NT - 2;
-                const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Wd.ty[e - 1]) : p1;
-                const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Wd.ty[e + 2]) : p2;
-                collide_edge_polygon(mo, p1, p2, s, xfB, has0, p0, has3, p3);
-            }
-            emit_manifold(M, Wd, S, sl, M.slot_base[bi] + k, mo, -1, bi, sqrtf(FRICTION * s.friction));
+// b2ContactManager::Collide for body `bi` against the terrain polyline (edge e spans x in [e, e+1] * TERRAIN_STEP)
+template <class Par>
+MW_HD void collide_body_terrain(const Model &M, World &Wd, Scratch &S, Par par, int bi) {
+    const Shape &s = M.shape[shape_of_body(bi)];
+    float xmin, xmax, ymin, ymax;
+    body_aabb(M, Wd, bi, xmin, xmax, ymin, ymax);
+    int e0 = (int)floorf(xmin / TERRAIN_STEP), e1 = (int)floorf(xmax / TERRAIN_STEP);
+    if (e0 < 0) e0 = 0;
+    if (e1 > M.NT - 2) e1 = M.NT - 2;
+    Slot *slots = Wd.slot + M.slot_base[bi];
+    const int cap = M.slot_cap[bi];
+    int cnt = 0;
+    // contacts whose edge left the candidate range are destroyed (EndContact if touching)
+    for (int k = 0; k < cap; ++k) {
+        Slot &sl = slots[k];
+        if (sl.edge >= 0 && (sl.edge < e0 || sl.edge > e1)) {
+            if (sl.touching) contact_event(M, Wd, -1, bi, false);
+            sl.edge = -1; sl.npts = 0; sl.touching = 0;
         }
     }
-    // package - hull and hull - hull
-    for (int p = 0; p < M.n_dyn_pairs; ++p) {
-        const int bA = M.dyn_a[p], bB = M.dyn_b[p];
-        const Shape &sA = M.shape[shape_of_body(bA)], &sB = M.shape[shape_of_body(bB)];
-        Slot &sl = Wd.slot[M.dyn_slot_base + p];
-        sl.edge = 0;
-        float ax0, ax1, ay0, ay1, bx0, bx1, by0, by1;
-        body_aabb(M, Wd, bA, ax0, ax1, ay0, ay1);
-        body_aabb(M, Wd, bB, bx0, bx1, by0, by1);
+    const Xf xfB = body_xf(M, Wd.b[bi], bi);
+    for (int e = e0; e <= e1; ++e) {
+        int k = -1;
+        for (int q = 0; q < cap; ++q) if (slots[q].edge == e) { k = q; break; }
+        if (k < 0) { for (int q = 0; q < cap; ++q) if (slots[q].edge < 0) { k = q; break; } }
+        if (k < 0) continue;  // cache full: pair ignored this step
+        Slot &sl = slots[k];
+        if (sl.edge != e) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; }
+        const V2 p1 = v2(e * TERRAIN_STEP, Wd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Wd.ty[e + 1]);
         ManifoldOut mo; mo.npts = 0;
-        if (!(ax0 > bx1 + 0.2f || bx0 > ax1 + 0.2f || ay0 > by1 + 0.2f || by0 > ay1 + 0.2f))
-            collide_polygons(mo, sA, body_xf(M, Wd.b[bA], bA), sB, body_xf(M, Wd.b[bB], bB));
-        emit_manifold(M, Wd, S, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction));
+        const float elo = fminf(p1.y, p2.y) - POLY_RADIUS, ehi = fmaxf(p1.y, p2.y) + POLY_RADIUS;
+        if (!(ymin > ehi + 0.2f || ymax < elo - 0.2f)) {
+            const bool has0 = e > 0, has3 = e < M.NT - 2;
+            const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Wd.ty[e - 1]) : p1;
+            const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Wd.ty[e + 2]) : p2;
+            collide_edge_polygon(mo, p1, p2, s, xfB, has0, p0, has3, p3);
+        }
+        const int idx = emit_manifold(M, Wd, S, par, sl, M.slot_base[bi] + k, mo, -1, bi, sqrtf(FRICTION * s.friction));
+        if (idx >= 0 && cnt < EDGE_SLOTS_PKG) S.bm_idx[bi][cnt++] = (uint8_t)idx;
     }
+    S.bm_cnt[bi] = (uint8_t)cnt;
+}
+
+// package - hull and hull - hull pair p
+template <class Par>
+MW_HD void collide_dyn_pair(const Model &M, World &Wd, Scratch &S, Par par, int p) {
+    const int bA = M.dyn_a[p], bB = M.dyn_b[p];
+    const Shape &sA = M.shape[shape_of_body(bA)], &sB = M.shape[shape_of_body(bB)];
+    Slot &sl = Wd.slot[M.dyn_slot_base + p];
+    sl.edge = 0;
+    float ax0, ax1, ay0, ay1, bx0, bx1, by0, by1;
+    body_aabb(M, Wd, bA, ax0, ax1, ay0, ay1);
+    body_aabb(M, Wd, bB, bx0, bx1, by0, by1);
+    ManifoldOut mo; mo.npts = 0;
+    if (!(ax0 > bx1 + 0.2f || bx0 > ax1 + 0.2f || ay0 > by1 + 0.2f || by0 > ay1 + 0.2f))
+        collide_polygons(mo, sA, body_xf(M, Wd.b[bA], bA), sB, body_xf(M, Wd.b[bB], bB));
+    S.dyn_midx[p] = (int8_t)emit_manifold(M, Wd, S, par, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction));
 }
 
 // ---------------------------------------------------------------- island solver (b2Island::Solve)
@@ -618,26 +644,312 @@ MW_HD void solve22(const float *k, float bx, float by, float &x, float &y) {
     y = det * (a11 * by - a21 * bx);
 }
 
-MW_HD void world_step(const Model &M, World &Wd, Scratch &S) {
+// b2ContactSolver::InitializeVelocityConstraints + WarmStart for manifold k
+MW_HD void contact_init_warm(const Model &M, World &Wd, Scratch &S, int k) {
+    Manifold &m = S.m[k];
+    float mA, iA, mB, iB;
+    inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+    const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
+    Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = body_xf(M, Wd.b[m.bA], m.bA);
+    const Xf xfB = body_xf(M, Wd.b[m.bB], m.bB);
+    V2 normal, pts[2];  // b2WorldManifold::Initialize
+    if (m.type == 0) {
+        normal = mul(xfA.q, m.local_normal);
+        const V2 plane = mul(xfA, m.local_point);
+        for (int i = 0; i < m.npts; ++i) {
+            const V2 clip = mul(xfB, m.lp[i]);
+            const V2 a = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, bb = clip - POLY_RADIUS * normal;
+            pts[i] = 0.5f * (a + bb);
+        }
+    } else {
+        normal = mul(xfB.q, m.local_normal);
+        const V2 plane = mul(xfB, m.local_point);
+        for (int i = 0; i < m.npts; ++i) {
+            const V2 clip = mul(xfA, m.lp[i]);
+            const V2 bb = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, a = clip - POLY_RADIUS * normal;
+            pts[i] = 0.5f * (a + bb);
+        }
+        normal = -normal;
+    }
+    m.normal = normal;
+    const V2 tangent = cross(normal, 1.0f);
+    for (int i = 0; i < m.npts; ++i) {
+        m.rA[i] = pts[i] - cA; m.rB[i] = pts[i] - cB;
+        const float rnA = cross(m.rA[i], normal), rnB = cross(m.rB[i], normal);
+        const float kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        m.nm[i] = kn > 0.0f ? 1.0f / kn : 0.0f;
+        const float rtA = cross(m.rA[i], tangent), rtB = cross(m.rB[i], tangent);
+        const float kt = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+        m.tm[i] = kt > 0.0f ? 1.0f / kt : 0.0f;
+    }
+    m.block = 0;
+    if (m.npts == 2) {
+        const float rn1A = cross(m.rA[0], normal), rn1B = cross(m.rB[0], normal), rn2A = cross(m.rA[1], normal), rn2B = cross(m.rB[1], normal);
+        const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B, k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+        const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+        if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+            m.k11 = k11; m.k12 = k12; m.k22 = k22;
+            float det = k11 * k22 - k12 * k12;
+            if (det != 0.0f) det = 1.0f / det;
+            m.im11 = det * k22; m.im12 = -det * k12; m.im22 = det * k11;
+            m.block = 1;
+        } else {
+            m.npts = 1;  // the constraints are redundant, just use one
+        }
+    }
+    V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
+    float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
+    for (int i = 0; i < m.npts; ++i) {  // warm start
+        const V2 P = m.ni[i] * normal + m.ti[i] * tangent;
+        wA -= iA * cross(m.rA[i], P); vA = vA - mA * P;
+        wB += iB * cross(m.rB[i], P); vB = vB + mB * P;
+    }
+    if (m.bA >= 0) { Wd.b[m.bA].v = vA; Wd.b[m.bA].w = wA; }
+    Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
+}
+
+// b2RevoluteJoint::InitVelocityConstraints (+ warm start)
+MW_HD void joint_init_warm(const Model &M, World &Wd, Scratch &S, int ji) {
+    const JointDef &jd = M.jd[ji];
+    Joint &j = Wd.j[ji];
+    Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
+    float mA, iA, mB, iB;
+    inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+    const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
+    S.jrAx[ji] = rA.x; S.jrAy[ji] = rA.y; S.jrBx[ji] = rB.x; S.jrBy[ji] = rB.y;
+    float *k = S.jk[ji];
+    k[0] = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+    k[3] = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+    k[6] = -rA.y * iA - rB.y * iB;
+    k[1] = k[3];
+    k[4] = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+    k[7] = rA.x * iA + rB.x * iB;
+    k[2] = k[6]; k[5] = k[7];
+    k[8] = iA + iB;
+    float mm = iA + iB;
+    if (mm > 0.0f) mm = 1.0f / mm;
+    S.jmotor_mass[ji] = mm;
+    const float angle = B.a - A.a;  // referenceAngle = 0 (the def is built from kwargs, not Initialize())
+    if (fabsf(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP) j.limit_state = 3;
+    else if (angle <= jd.lower) { if (j.limit_state != 1) j.iz = 0.0f; j.limit_state = 1; }
+    else if (angle >= jd.upper) { if (j.limit_state != 2) j.iz = 0.0f; j.limit_state = 2; }
+    else { j.limit_state = 0; j.iz = 0.0f; }
+    const V2 P = v2(j.ix, j.iy);  // dtRatio = 1
+    A.v = A.v - mA * P; A.w -= iA * (cross(rA, P) + j.motor_impulse + j.iz);
+    B.v = B.v + mB * P; B.w += iB * (cross(rB, P) + j.motor_impulse + j.iz);
+}
+
+// b2RevoluteJoint::SolveVelocityConstraints
+MW_HD void joint_solve_velocity(const Model &M, World &Wd, Scratch &S, int ji, float h) {
+    const JointDef &jd = M.jd[ji];
+    Joint &j = Wd.j[ji];
+    Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
+    float mA, iA, mB, iB;
+    inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+    const V2 rA = v2(S.jrAx[ji], S.jrAy[ji]), rB = v2(S.jrBx[ji], S.jrBy[ji]);
+    V2 vA = A.v, vB = B.v; float wA = A.w, wB = B.w;
+    if (j.limit_state != 3) {  // motor (enableMotor is always true)
+        const float Cdot = wB - wA - j.motor_speed;
+        float imp = -S.jmotor_mass[ji] * Cdot;
+        const float old = j.motor_impulse, maxi = h * j.max_torque;
+        j.motor_impulse = clampf(old + imp, -maxi, maxi);
+        imp = j.motor_impulse - old;
+        wA -= iA * imp; wB += iB * imp;
+    }
+    if (j.limit_state != 0) {  // limit + point constraint (3x3)
+        const V2 Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA);
+        const float Cdot2 = wB - wA;
+        float ix, iy, iz;
+        solve33(S.jk[ji], Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
+        ix = -ix; iy = -iy; iz = -iz;
+        bool reduce = false;
+        if (j.limit_state == 3) { j.ix += ix; j.iy += iy; j.iz += iz; }
+        else if (j.limit_state == 1) { reduce = (j.iz + iz) < 0.0f; }
+        else { reduce = (j.iz + iz) > 0.0f; }
+        if (j.limit_state != 3) {
+            if (reduce) {
+                const float rx = -Cdot1.x + j.iz * S.jk[ji][6], ry = -Cdot1.y + j.iz * S.jk[ji][7];
+                float qx, qy;
+                solve22(S.jk[ji], rx, ry, qx, qy);
+                ix = qx; iy = qy; iz = -j.iz;
+                j.ix += qx; j.iy += qy; j.iz = 0.0f;
+            } else { j.ix += ix; j.iy += iy; j.iz += iz; }
+        }
+        const V2 P = v2(ix, iy);
+        vA = vA - mA * P; wA -= iA * (cross(rA, P) + iz);
+        vB = vB + mB * P; wB += iB * (cross(rB, P) + iz);
+    } else {  // point-to-point only
+        const V2 Cdot = vB + cross(wB, rB) - vA - cross(wA, rA);
+        float ix, iy;
+        solve22(S.jk[ji], -Cdot.x, -Cdot.y, ix, iy);
+        j.ix += ix; j.iy += iy;
+        const V2 P = v2(ix, iy);
+        vA = vA - mA * P; wA -= iA * cross(rA, P);
+        vB = vB + mB * P; wB += iB * cross(rB, P);
+    }
+    A.v = vA; A.w = wA; B.v = vB; B.w = wB;
+}
+
+// b2ContactSolver::SolveVelocityConstraints for manifold k
+MW_HD void contact_solve_velocity(const Model &M, World &Wd, Scratch &S, int k) {
+    Manifold &m = S.m[k];
+    float mA, iA, mB, iB;
+    inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+    V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
+    float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
+    const V2 normal = m.normal, tangent = cross(normal, 1.0f);
+    for (int i = 0; i < m.npts; ++i) {  // friction first
+        const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
+        const float vt = dot(dv, tangent);
+        float lambda = m.tm[i] * (-vt);
+        const float maxf = m.friction * m.ni[i];
+        const float newi = clampf(m.ti[i] + lambda, -maxf, maxf);
+        lambda = newi - m.ti[i];
+        m.ti[i] = newi;
+        const V2 P = lambda * tangent;
+        vA = vA - mA * P; wA -= iA * cross(m.rA[i], P);
+        vB = vB + mB * P; wB += iB * cross(m.rB[i], P);
+    }
+    if (m.npts == 1 || !m.block) {
+        for (int i = 0; i < m.npts; ++i) {
+            const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
+            const float vn = dot(dv, normal);
+            float lambda = -m.nm[i] * (vn - 0.0f);  // restitution 0 -> velocityBias 0
+            const float newi = fmaxf(m.ni[i] + lambda, 0.0f);
+            lambda = newi - m.ni[i];
+            m.ni[i] = newi;
+            const V2 P = lambda * normal;
+            vA = vA - mA * P; wA -= iA * cross(m.rA[i], P);
+            vB = vB + mB * P; wB += iB * cross(m.rB[i], P);
+        }
+    } else {  // block solver
+        const float a1 = m.ni[0], a2 = m.ni[1];
+        const V2 dv1 = vB + cross(wB, m.rB[0]) - vA - cross(wA, m.rA[0]);
+        const V2 dv2 = vB + cross(wB, m.rB[1]) - vA - cross(wA, m.rA[1]);
+        float b1 = dot(dv1, normal), b2 = dot(dv2, normal);
+        b1 -= m.k11 * a1 + m.k12 * a2;
+        b2 -= m.k12 * a1 + m.k22 * a2;
+        float x1 = 0, x2 = 0; bool ok = false;
+        x1 = -(m.im11 * b1 + m.im12 * b2); x2 = -(m.im12 * b1 + m.im22 * b2);
+        if (x1 >= 0.0f && x2 >= 0.0f) ok = true;
+        if (!ok) { x1 = -m.nm[0] * b1; x2 = 0.0f; const float vn2 = m.k12 * x1 + b2; if (x1 >= 0.0f && vn2 >= 0.0f) ok = true; }
+        if (!ok) { x1 = 0.0f; x2 = -m.nm[1] * b2; const float vn1 = m.k12 * x2 + b1; if (x2 >= 0.0f && vn1 >= 0.0f) ok = true; }
+        if (!ok) { x1 = 0.0f; x2 = 0.0f; if (b1 >= 0.0f && b2 >= 0.0f) ok = true; }
+        if (ok) {
+            const float d1 = x1 - a1, d2 = x2 - a2;
+            const V2 P1 = d1 * normal, P2 = d2 * normal;
+            vA = vA - mA * (P1 + P2); wA -= iA * (cross(m.rA[0], P1) + cross(m.rA[1], P2));
+            vB = vB + mB * (P1 + P2); wB += iB * (cross(m.rB[0], P1) + cross(m.rB[1], P2));
+            m.ni[0] = x1; m.ni[1] = x2;
+        }
+    }
+    if (m.bA >= 0) { Wd.b[m.bA].v = vA; Wd.b[m.bA].w = wA; }
+    Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
+}
+
+// b2ContactSolver::SolvePositionConstraints for manifold k; returns its minimum separation
+MW_HD float contact_solve_position(const Model &M, World &Wd, Scratch &S, int k) {
+    const Manifold &m = S.m[k];
+    float min_sep = 0.0f;
+    float mA, iA, mB, iB;
+    inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+    V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
+    float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a, aB = Wd.b[m.bB].a;
+    const V2 lcA = local_center_of(M, m.bA), lcB = local_center_of(M, m.bB);
+    for (int i = 0; i < m.npts; ++i) {
+        const Xf xfA = xf_from(cA, aA, lcA), xfB = xf_from(cB, aB, lcB);
+        V2 normal, point; float sep;
+        if (m.type == 0) {
+            normal = mul(xfA.q, m.local_normal);
+            const V2 plane = mul(xfA, m.local_point), clip = mul(xfB, m.lp[i]);
+            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+        } else {
+            normal = mul(xfB.q, m.local_normal);
+            const V2 plane = mul(xfB, m.local_point), clip = mul(xfA, m.lp[i]);
+            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+            normal = -normal;
+        }
+        const V2 rA = point - cA, rB = point - cB;
+        min_sep = fminf(min_sep, sep);
+        const float C = clampf(BAUMGARTE * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);
+        const float rnA = cross(rA, normal), rnB = cross(rB, normal);
+        const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        const float imp = K > 0.0f ? -C / K : 0.0f;
+        const V2 P = imp * normal;
+        cA = cA - mA * P; aA -= iA * cross(rA, P);
+        cB = cB + mB * P; aB += iB * cross(rB, P);
+    }
+    if (m.bA >= 0) { Wd.b[m.bA].c = cA; Wd.b[m.bA].a = aA; }
+    Wd.b[m.bB].c = cB; Wd.b[m.bB].a = aB;
+    return min_sep;
+}
+
+// b2RevoluteJoint::SolvePositionConstraints; returns whether the joint is within tolerance
+MW_HD bool joint_solve_position(const Model &M, World &Wd, Scratch &S, int ji) {
+    const JointDef &jd = M.jd[ji];
+    const Joint &j = Wd.j[ji];
+    Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
+    float mA, iA, mB, iB;
+    inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+    float ang_err = 0.0f;
+    if (j.limit_state != 0) {
+        const float angle = B.a - A.a;
+        float limit_imp = 0.0f;
+        if (j.limit_state == 3) {
+            const float C = clampf(angle - jd.lower, -MAX_ANGULAR_CORRECTION, MAX_ANGULAR_CORRECTION);
+            limit_imp = -S.jmotor_mass[ji] * C; ang_err = fabsf(C);
+        } else if (j.limit_state == 1) {
+            float C = angle - jd.lower; ang_err = -C;
+            C = clampf(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION, 0.0f);
+            limit_imp = -S.jmotor_mass[ji] * C;
+        } else {
+            float C = angle - jd.upper; ang_err = C;
+            C = clampf(C - ANGULAR_SLOP, 0.0f, MAX_ANGULAR_CORRECTION);
+            limit_imp = -S.jmotor_mass[ji] * C;
+        }
+        A.a -= iA * limit_imp; B.a += iB * limit_imp;
+    }
+    const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
+    const V2 C = B.c + rB - A.c - rA;
+    const float pos_err = sqrtf(dot(C, C));
+    const float kxx = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y, kxy = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+    const float kyy = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+    float det = kxx * kyy - kxy * kxy;
+    if (det != 0.0f) det = 1.0f / det;
+    const V2 imp = v2(-(det * (kyy * C.x - kxy * C.y)), -(det * (kxx * C.y - kxy * C.x)));
+    A.c = A.c - mA * imp; A.a -= iA * cross(rA, imp);
+    B.c = B.c + mB * imp; B.a += iB * cross(rB, imp);
+    return pos_err <= LINEAR_SLOP && ang_err <= ANGULAR_SLOP;
+}
+
+// b2World::Step(1/50, 180, 60) for the lanes of `par`
+template <class Par>
+MW_HD void world_step(const Model &M, World &Wd, Scratch &S, Par par) {
     const float h = 1.0f / FPS;
-    for (int bi = 0; bi < M.NB; ++bi) {
+    const int L0 = par.lane(), LN = par.n();
+    const int NODES = M.W + 1;  // island graph nodes: walkers, then the package
+    for (int bi = L0; bi < M.NB; bi += LN) {
         const Shape &sh = M.shape[shape_of_body(bi)];
         S.bim[bi] = sh.inv_mass; S.bii[bi] = sh.inv_I; S.blc[bi] = sh.centroid;
         S.node[bi] = (int8_t)(bi == 0 ? M.W : (bi - 1) / 5);
     }
-    collide(M, Wd, S);
-    // ---- islands: walkers (+ package) joined by touching hull-hull / hull-package contacts
-    int comp[MAX_WALKERS + 1];  // index W = package
-    for (int i = 0; i <= M.W; ++i) comp[i] = i;
-    for (int k = 0; k < S.nm; ++k) {
-        const Manifold &m = S.m[k];
-        if (m.bA < 0) continue;
-        const int na = S.node[m.bA], nb = S.node[m.bB];
-        const int ca = comp[na], cb = comp[nb];
-        if (ca != cb) for (int i = 0; i <= M.W; ++i) if (comp[i] == cb) comp[i] = ca;
+    if (L0 == 0) S.nm = 0;
+    par.sync();
+    // ---- Collide: terrain candidates by body, then the dynamic pairs
+    for (int bi = L0; bi < M.NB; bi += LN) collide_body_terrain(M, Wd, S, par, bi);
+    par.sync();
+    for (int p = L0; p < M.n_dyn_pairs; p += LN) collide_dyn_pair(M, Wd, S, par, p);
+    par.sync();
+    if (L0 == 0) {  // islands: walkers (+ package) joined by touching hull-hull / hull-package contacts
+        for (int i = 0; i < NODES; ++i) { S.comp[i] = (int8_t)i; S.isl_done[i] = 0; }
+        for (int p = 0; p < M.n_dyn_pairs; ++p) {
+            if (S.dyn_midx[p] < 0) continue;
+            const int ca = S.comp[S.node[M.dyn_a[p]]], cb = S.comp[S.node[M.dyn_b[p]]];
+            if (ca != cb) for (int i = 0; i < NODES; ++i) if (S.comp[i] == cb) S.comp[i] = (int8_t)ca;
+        }
     }
     // ---- integrate velocities (gravity + the pending initial push)
-    for (int bi = 0; bi < M.NB; ++bi) {
+    for (int bi = L0; bi < M.NB; bi += LN) {
         Body &b = Wd.b[bi];
         float fx = 0.0f;
         if (bi >= 1 && (bi - 1) % 5 == 0) { const int w = (bi - 1) / 5; fx = Wd.push_x[w]; }
@@ -646,313 +958,89 @@ MW_HD void world_step(const Model &M, World &Wd, Scratch &S) {
         b.v.y += h * (GRAVITY_Y + im * 0.0f);
         // linear/angular damping are 0: v *= 1/(1 + h*0)
     }
-    for (int w = 0; w < M.W; ++w) Wd.push_x[w] = 0.0f;  // ClearForces
-    // ---- contact velocity constraints: b2ContactSolver::InitializeVelocityConstraints + WarmStart
-    for (int k = 0; k < S.nm; ++k) {
-        Manifold &m = S.m[k];
-        float mA, iA, mB, iB;
-        inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
-        const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
-        Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = body_xf(M, Wd.b[m.bA], m.bA);
-        const Xf xfB = body_xf(M, Wd.b[m.bB], m.bB);
-        // b2WorldManifold::Initialize
-        V2 normal, pts[2];
-        if (m.type == 0) {
-            normal = mul(xfA.q, m.local_normal);
-            const V2 plane = mul(xfA, m.local_point);
-            for (int i = 0; i < m.npts; ++i) {
-                const V2 clip = mul(xfB, m.lp[i]);
-                const V2 a = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, bb = clip - POLY_RADIUS * normal;
-                pts[i] = 0.5f * (a + bb);
-            }
-        } else {
-            normal = mul(xfB.q, m.local_normal);
-            const V2 plane = mul(xfB, m.local_point);
-            for (int i = 0; i < m.npts; ++i) {
-                const V2 clip = mul(xfA, m.lp[i]);
-                const V2 bb = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, a = clip - POLY_RADIUS * normal;
-                pts[i] = 0.5f * (a + bb);
-            }
-            normal = -normal;
-        }
-        m.normal = normal;
-        const V2 tangent = cross(normal, 1.0f);
-        for (int i = 0; i < m.npts; ++i) {
-            m.rA[i] = pts[i] - cA; m.rB[i] = pts[i] - cB;
-            const float rnA = cross(m.rA[i], normal), rnB = cross(m.rB[i], normal);
-            const float kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
-            m.nm[i] = kn > 0.0f ? 1.0f / kn : 0.0f;
-            const float rtA = cross(m.rA[i], tangent), rtB = cross(m.rB[i], tangent);
-            const float kt = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
-            m.tm[i] = kt > 0.0f ? 1.0f / kt : 0.0f;
-        }
-        m.block = 0;
-        if (m.npts == 2) {
-            const float rn1A = cross(m.rA[0], normal), rn1B = cross(m.rB[0], normal), rn2A = cross(m.rA[1], normal), rn2B = cross(m.rB[1], normal);
-            const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B, k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
-            const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
-            if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
-                m.k11 = k11; m.k12 = k12; m.k22 = k22;
-                float det = k11 * k22 - k12 * k12;
-                if (det != 0.0f) det = 1.0f / det;
-                m.im11 = det * k22; m.im12 = -det * k12; m.im22 = det * k11;
-                m.block = 1;
-            } else {
-                m.npts = 1;  // the constraints are redundant, just use one
-            }
-        }
-        // warm start
-        V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
-        float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
-        for (int i = 0; i < m.npts; ++i) {
-            const V2 P = m.ni[i] * normal + m.ti[i] * tangent;
-            wA -= iA * cross(m.rA[i], P); vA = vA - mA * P;
-            wB += iB * cross(m.rB[i], P); vB = vB + mB * P;
-        }
-        if (m.bA >= 0) { Wd.b[m.bA].v = vA; Wd.b[m.bA].w = wA; }
-        Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
+    par.sync();
+    for (int w = L0; w < M.W; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces
+    // ---- contact constraints: init + warm start (terrain contacts by body, then the dynamic pairs)
+    for (int bi = L0; bi < M.NB; bi += LN)
+        for (int q = 0; q < S.bm_cnt[bi]; ++q) contact_init_warm(M, Wd, S, S.bm_idx[bi][q]);
+    par.sync();
+    if (L0 == 0) for (int p = 0; p < M.n_dyn_pairs; ++p) if (S.dyn_midx[p] >= 0) contact_init_warm(M, Wd, S, S.dyn_midx[p]);
+    par.sync();
+    // ---- joints: init + warm start, by walker
+    for (int w = L0; w < M.W; w += LN) for (int q = 0; q < 4; ++q) joint_init_warm(M, Wd, S, 4 * w + q);
+    par.sync();
+    // ---- velocity iterations (islands are disjoint, so iterating them together changes nothing)
+    for (int it = 0; it < VEL_ITERS; ++it) {
+        for (int w = L0; w < M.W; w += LN) for (int q = 0; q < 4; ++q) joint_solve_velocity(M, Wd, S, 4 * w + q, h);
+        par.sync();
+        for (int bi = L0; bi < M.NB; bi += LN)
+            for (int q = 0; q < S.bm_cnt[bi]; ++q) contact_solve_velocity(M, Wd, S, S.bm_idx[bi][q]);
+        par.sync();
+        if (L0 == 0) for (int p = 0; p < M.n_dyn_pairs; ++p) if (S.dyn_midx[p] >= 0) contact_solve_velocity(M, Wd, S, S.dyn_midx[p]);
+        par.sync();
     }
-    // ---- joints: b2RevoluteJoint::InitVelocityConstraints (+ warm start)
-    for (int ji = 0; ji < M.NJ; ++ji) {
-        const JointDef &jd = M.jd[ji];
-        Joint &j = Wd.j[ji];
-        Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
-        float mA, iA, mB, iB;
-        inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
-        const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
-        S.jrAx[ji] = rA.x; S.jrAy[ji] = rA.y; S.jrBx[ji] = rB.x; S.jrBy[ji] = rB.y;
-        float *k = S.jk[ji];
-        k[0] = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
-        k[3] = -rA.y * rA.x * iA - rB.y * rB.x * iB;
-        k[6] = -rA.y * iA - rB.y * iB;
-        k[1] = k[3];
-        k[4] = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
-        k[7] = rA.x * iA + rB.x * iB;
-        k[2] = k[6]; k[5] = k[7];
-        k[8] = iA + iB;
-        float mm = iA + iB;
-        if (mm > 0.0f) mm = 1.0f / mm;
-        S.jmotor_mass[ji] = mm;
-        const float angle = B.a - A.a;  // referenceAngle = 0 (the def is built from kwargs, not Initialize())
-        if (fabsf(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP) j.limit_state = 3;
-        else if (angle <= jd.lower) { if (j.limit_state != 1) j.iz = 0.0f; j.limit_state = 1; }
-        else if (angle >= jd.upper) { if (j.limit_state != 2) j.iz = 0.0f; j.limit_state = 2; }
-        else { j.limit_state = 0; j.iz = 0.0f; }
-        const V2 P = v2(j.ix, j.iy);  // dtRatio = 1
-        A.v = A.v - mA * P; A.w -= iA * (cross(rA, P) + j.motor_impulse + j.iz);
-        B.v = B.v + mB * P; B.w += iB * (cross(rB, P) + j.motor_impulse + j.iz);
+    // ---- integrate positions
+    for (int bi = L0; bi < M.NB; bi += LN) {
+        Body &b = Wd.b[bi];
+        V2 tr = h * b.v;
+        if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) { const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr)); b.v = ratio * b.v; }
+        const float ro = h * b.w;
+        if (ro * ro > MAX_ROTATION * MAX_ROTATION) { const float ratio = MAX_ROTATION / fabsf(ro); b.w *= ratio; }
+        b.c = b.c + h * b.v;
+        b.a += h * b.w;
     }
-    // ---- per island: velocity iterations, integrate positions, position iterations
-    for (int isl = 0; isl <= M.W; ++isl) {
-        bool any = false;
-        for (int i = 0; i <= M.W; ++i) any |= (comp[i] == isl);
-        if (!any) continue;
-        #define MW_NODE_OF(bi) ((int)S.node[(bi)])
-        for (int it = 0; it < VEL_ITERS; ++it) {
-            for (int ji = 0; ji < M.NJ; ++ji) {  // b2RevoluteJoint::SolveVelocityConstraints
-                const JointDef &jd = M.jd[ji];
-                if (comp[MW_NODE_OF(jd.bA)] != isl) continue;
-                Joint &j = Wd.j[ji];
-                Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
-                float mA, iA, mB, iB;
-                inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
-                const V2 rA = v2(S.jrAx[ji], S.jrAy[ji]), rB = v2(S.jrBx[ji], S.jrBy[ji]);
-                V2 vA = A.v, vB = B.v; float wA = A.w, wB = B.w;
-                if (j.limit_state != 3) {  // motor (enableMotor is always true)
-                    const float Cdot = wB - wA - j.motor_speed;
-                    float imp = -S.jmotor_mass[ji] * Cdot;
-                    const float old = j.motor_impulse, maxi = h * j.max_torque;
-                    j.motor_impulse = clampf(old + imp, -maxi, maxi);
-                    imp = j.motor_impulse - old;
-                    wA -= iA * imp; wB += iB * imp;
-                }
-                if (j.limit_state != 0) {  // limit + point constraint (3x3)
-                    const V2 Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA);
-                    const float Cdot2 = wB - wA;
-                    float ix, iy, iz;
-                    solve33(S.jk[ji], Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
-                    ix = -ix; iy = -iy; iz = -iz;
-                    bool reduce = false;
-                    if (j.limit_state == 3) { j.ix += ix; j.iy += iy; j.iz += iz; }
-                    else if (j.limit_state == 1) { reduce = (j.iz + iz) < 0.0f; }
-                    else { reduce = (j.iz + iz) > 0.0f; }
-                    if (j.limit_state != 3) {
-                        if (reduce) {
-                            const float rx = -Cdot1.x + j.iz * S.jk[ji][6], ry = -Cdot1.y + j.iz * S.jk[ji][7];
-                            float qx, qy;
-                            solve22(S.jk[ji], rx, ry, qx, qy);
-                            ix = qx; iy = qy; iz = -j.iz;
-                            j.ix += qx; j.iy += qy; j.iz = 0.0f;
-                        } else { j.ix += ix; j.iy += iy; j.iz += iz; }
-                    }
-                    const V2 P = v2(ix, iy);
-                    vA = vA - mA * P; wA -= iA * (cross(rA, P) + iz);
-                    vB = vB + mB * P; wB += iB * (cross(rB, P) + iz);
-                } else {  // point-to-point only
-                    const V2 Cdot = vB + cross(wB, rB) - vA - cross(wA, rA);
-                    float ix, iy;
-                    solve22(S.jk[ji], -Cdot.x, -Cdot.y, ix, iy);
-                    j.ix += ix; j.iy += iy;
-                    const V2 P = v2(ix, iy);
-                    vA = vA - mA * P; wA -= iA * cross(rA, P);
-                    vB = vB + mB * P; wB += iB * cross(rB, P);
-                }
-                A.v = vA; A.w = wA; B.v = vB; B.w = wB;
-            }
-            for (int k = 0; k < S.nm; ++k) {  // b2ContactSolver::SolveVelocityConstraints
-                Manifold &m = S.m[k];
-                if (comp[MW_NODE_OF(m.bB)] != isl) continue;
-                float mA, iA, mB, iB;
-                inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
-                V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
-                float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
-                const V2 normal = m.normal, tangent = cross(normal, 1.0f);
-                for (int i = 0; i < m.npts; ++i) {  // friction first
-                    const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
-                    const float vt = dot(dv, tangent);
-                    float lambda = m.tm[i] * (-vt);
-                    const float maxf = m.friction * m.ni[i];
-                    const float newi = clampf(m.ti[i] + lambda, -maxf, maxf);
-                    lambda = newi - m.ti[i];
-                    m.ti[i] = newi;
-                    const V2 P = lambda * tangent;
-                    vA = vA - mA * P; wA -= iA * cross(m.rA[i], P);
-                    vB = vB + mB * P; wB += iB * cross(m.rB[i], P);
-                }
-                if (m.npts == 1 || !m.block) {
-                    for (int i = 0; i < m.npts; ++i) {
-                        const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
-                        const float vn = dot(dv, normal);
-                        float lambda = -m.nm[i] * (vn - 0.0f);  // restitution 0 -> velocityBias 0
-                        const float newi = fmaxf(m.ni[i] + lambda, 0.0f);
-                        lambda = newi - m.ni[i];
-                        m.ni[i] = newi;
-                        const V2 P = lambda * normal;
-                        vA = vA - mA * P; wA -= iA * cross(m.rA[i], P);
-                        vB = vB + mB * P; wB += iB * cross(m.rB[i], P);
-                    }
-                } else {  // block solver
-                    const float a1 = m.ni[0], a2 = m.ni[1];
-                    const V2 dv1 = vB + cross(wB, m.rB[0]) - vA - cross(wA, m.rA[0]);
-                    const V2 dv2 = vB + cross(wB, m.rB[1]) - vA - cross(wA, m.rA[1]);
-                    float b1 = dot(dv1, normal), b2 = dot(dv2, normal);
-                    b1 -= m.k11 * a1 + m.k12 * a2;
-                    b2 -= m.k12 * a1 + m.k22 * a2;
-                    float x1 = 0, x2 = 0; bool ok = false;
-                    x1 = -(m.im11 * b1 + m.im12 * b2); x2 = -(m.im12 * b1 + m.im22 * b2);
-                    if (x1 >= 0.0f && x2 >= 0.0f) ok = true;
-                    if (!ok) { x1 = -m.nm[0] * b1; x2 = 0.0f; const float vn2 = m.k12 * x1 + b2; if (x1 >= 0.0f && vn2 >= 0.0f) ok = true; }
-                    if (!ok) { x1 = 0.0f; x2 = -m.nm[1] * b2; const float vn1 = m.k12 * x2 + b1; if (x2 >= 0.0f && vn1 >= 0.0f) ok = true; }
-                    if (!ok) { x1 = 0.0f; x2 = 0.0f; if (b1 >= 0.0f && b2 >= 0.0f) ok = true; }
-                    if (ok) {
-                        const float d1 = x1 - a1, d2 = x2 - a2;
-                        const V2 P1 = d1 * normal, P2 = d2 * normal;
-                        vA = vA - mA * (P1 + P2); wA -= iA * (cross(m.rA[0], P1) + cross(m.rA[1], P2));
-                        vB = vB + mB * (P1 + P2); wB += iB * (cross(m.rB[0], P1) + cross(m.rB[1], P2));
-                        m.ni[0] = x1; m.ni[1] = x2;
-                    }
-                }
-                if (m.bA >= 0) { Wd.b[m.bA].v = vA; Wd.b[m.bA].w = wA; }
-                Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
-            }
+    par.sync();
+    // ---- position iterations, each island stops on its own (b2Island::Solve early exit)
+    for (int it = 0; it < POS_ITERS; ++it) {
+        for (int bi = L0; bi < M.NB; bi += LN) {
+            float ms = 0.0f;
+            if (!S.isl_done[S.comp[S.node[bi]]])
+                for (int q = 0; q < S.bm_cnt[bi]; ++q) ms = fminf(ms, contact_solve_position(M, Wd, S, S.bm_idx[bi][q]));
+            S.body_minsep[bi] = ms;
         }
-        // integrate positions
-        for (int bi = 0; bi < M.NB; ++bi) {
-            if (comp[MW_NODE_OF(bi)] != isl) continue;
-            Body &b = Wd.b[bi];
-            V2 tr = h * b.v;
-            if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) { const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr)); b.v = ratio * b.v; }
-            const float ro = h * b.w;
-            if (ro * ro > MAX_ROTATION * MAX_ROTATION) { const float ratio = MAX_ROTATION / fabsf(ro); b.w *= ratio; }
-            b.c = b.c + h * b.v;
-            b.a += h * b.w;
-        }
-        // position iterations
-        for (int it = 0; it < POS_ITERS; ++it) {
-            float min_sep = 0.0f;
-            for (int k = 0; k < S.nm; ++k) {  // b2ContactSolver::SolvePositionConstraints
-                const Manifold &m = S.m[k];
-                if (comp[MW_NODE_OF(m.bB)] != isl) continue;
-                float mA, iA, mB, iB;
-                inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
-                V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
-                float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a, aB = Wd.b[m.bB].a;
-                const V2 lcA = local_center_of(M, m.bA), lcB = local_center_of(M, m.bB);
-                for (int i = 0; i < m.npts; ++i) {
-                    const Xf xfA = xf_from(cA, aA, lcA), xfB = xf_from(cB, aB, lcB);
-                    V2 normal, point; float sep;
-                    if (m.type == 0) {
-                        normal = mul(xfA.q, m.local_normal);
-                        const V2 plane = mul(xfA, m.local_point), clip = mul(xfB, m.lp[i]);
-                        sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
-                    } else {
-                        normal = mul(xfB.q, m.local_normal);
-                        const V2 plane = mul(xfB, m.local_point), clip = mul(xfA, m.lp[i]);
-                        sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
-                        normal = -normal;
-                    }
-                    const V2 rA = point - cA, rB = point - cB;
-                    min_sep = fminf(min_sep, sep);
-                    const float C = clampf(BAUMGARTE * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);
-                    const float rnA = cross(rA, normal), rnB = cross(rB, normal);
-                    const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
-                    const float imp = K > 0.0f ? -C / K : 0.0f;
-                    const V2 P = imp * normal;
-                    cA = cA - mA * P; aA -= iA * cross(rA, P);
-                    cB = cB + mB * P; aB += iB * cross(rB, P);
-                }
-                if (m.bA >= 0) { Wd.b[m.bA].c = cA; Wd.b[m.bA].a = aA; }
-                Wd.b[m.bB].c = cB; Wd.b[m.bB].a = aB;
+        par.sync();
+        if (L0 == 0)
+            for (int p = 0; p < M.n_dyn_pairs; ++p) {
+                float ms = 0.0f;
+                if (S.dyn_midx[p] >= 0 && !S.isl_done[S.comp[S.node[M.dyn_b[p]]]]) ms = contact_solve_position(M, Wd, S, S.dyn_midx[p]);
+                S.dyn_minsep[p] = ms;
             }
-            const bool contacts_ok = min_sep >= -3.0f * LINEAR_SLOP;
-            bool joints_ok = true;
-            for (int ji = 0; ji < M.NJ; ++ji) {  // b2RevoluteJoint::SolvePositionConstraints
-                const JointDef &jd = M.jd[ji];
-                if (comp[MW_NODE_OF(jd.bA)] != isl) continue;
-                const Joint &j = Wd.j[ji];
-                Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
-                float mA, iA, mB, iB;
-                inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
-                float ang_err = 0.0f;
-                if (j.limit_state != 0) {
-                    const float angle = B.a - A.a;
-                    float limit_imp = 0.0f;
-                    if (j.limit_state == 3) {
-                        const float C = clampf(angle - jd.lower, -MAX_ANGULAR_CORRECTION, MAX_ANGULAR_CORRECTION);
-                        limit_imp = -S.jmotor_mass[ji] * C; ang_err = fabsf(C);
-                    } else if (j.limit_state == 1) {
-                        float C = angle - jd.lower; ang_err = -C;
-                        C = clampf(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION, 0.0f);
-                        limit_imp = -S.jmotor_mass[ji] * C;
-                    } else {
-                        float C = angle - jd.upper; ang_err = C;
-                        C = clampf(C - ANGULAR_SLOP, 0.0f, MAX_ANGULAR_CORRECTION);
-                        limit_imp = -S.jmotor_mass[ji] * C;
-                    }
-                    A.a -= iA * limit_imp; B.a += iB * limit_imp;
-                }
-                const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
-                const V2 C = B.c + rB - A.c - rA;
-                const float pos_err = sqrtf(dot(C, C));
-                const float kxx = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y, kxy = -iA * rA.x * rA.y - iB * rB.x * rB.y;
-                const float kyy = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
-                float det = kxx * kyy - kxy * kxy;
-                if (det != 0.0f) det = 1.0f / det;
-                const V2 imp = v2(-(det * (kyy * C.x - kxy * C.y)), -(det * (kxx * C.y - kxy * C.x)));
-                A.c = A.c - mA * imp; A.a -= iA * cross(rA, imp);
-                B.c = B.c + mB * imp; B.a += iB * cross(rB, imp);
-                joints_ok = joints_ok && (pos_err <= LINEAR_SLOP && ang_err <= ANGULAR_SLOP);
-            }
-            if (contacts_ok && joints_ok) break;
+        par.sync();
+        for (int w = L0; w < M.W; w += LN) {
+            bool ok = true;
+            if (!S.isl_done[S.comp[w]])
+                for (int q = 0; q < 4; ++q) ok = joint_solve_position(M, Wd, S, 4 * w + q) && ok;
+            S.walker_ok[w] = ok ? 1 : 0;
         }
-        #undef MW_NODE_OF
+        par.sync();
+        if (L0 == 0) {
+            bool all_done = true;
+            for (int c = 0; c < NODES; ++c) {
+                bool any = false;
+                for (int i = 0; i < NODES; ++i) any |= (S.comp[i] == c);
+                if (!any || S.isl_done[c]) continue;
+                float ms = 0.0f;
+                bool jok = true;
+                for (int bi = 0; bi < M.NB; ++bi) if (S.comp[S.node[bi]] == c) ms = fminf(ms, S.body_minsep[bi]);
+                for (int p = 0; p < M.n_dyn_pairs; ++p) if (S.comp[S.node[M.dyn_b[p]]] == c) ms = fminf(ms, S.dyn_minsep[p]);
+                for (int w = 0; w < M.W; ++w) if (S.comp[w] == c) jok = jok && S.walker_ok[w];
+                if (ms >= -3.0f * LINEAR_SLOP && jok) S.isl_done[c] = 1;
+                else all_done = false;
+            }
+            S.all_done = all_done ? 1 : 0;
+        }
+        par.sync();
+        if (S.all_done) break;
     }
+    par.sync();
     // b2ContactSolver::StoreImpulses -> manifold cache (warm start of the next step)
-    for (int k = 0; k < S.nm; ++k) {
+    const int nm = S.nm < MAXM ? S.nm : MAXM;
+    for (int k = L0; k < nm; k += LN) {
         const Manifold &m = S.m[k];
         Slot &sl = Wd.slot[m.slot];
         for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
     }
+    par.sync();
 }
 #undef inv_mass_of
 #undef local_center_of
@@ -1070,9 +1158,10 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, World &Wd, uint32_t 
 }
 
 // MultiWalkerEnv.step (:359-428).  obs: [W][32], rew: [W]
-MW_HD void env_step(const Model &M, const EnvCfg &C, World &Wd, Scratch &S, uint32_t gid, const float *actions, float *obs,
+template <class Par>
+MW_HD void env_step(const Model &M, const EnvCfg &C, World &Wd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
                     float *rew, uint8_t *done) {
-    for (int w = 0; w < M.W; ++w) {  // apply_action (:194-203)
+    for (int w = par.lane(); w < M.W; w += par.n()) {  // apply_action (:194-203)
         for (int k = 0; k < 4; ++k) {
             const float a = actions[4 * w + k];
             Joint &j = Wd.j[4 * w + k];
@@ -1081,10 +1170,14 @@ MW_HD void env_step(const Model &M, const EnvCfg &C, World &Wd, Scratch &S, uint
             j.max_torque = MOTORS_TORQUE * clampf(fabsf(a), 0.0f, 1.0f);
         }
     }
-    world_step(M, Wd, S);  // :365
-    env_observe(M, C, Wd, gid, obs, rew, done);
-    Wd.t += 1;
-    Wd.tick += 1;
+    par.sync();
+    world_step(M, Wd, S, par);  // :365
+    if (par.lane() == 0) {
+        env_observe(M, C, Wd, gid, obs, rew, done);
+        Wd.t += 1;
+        Wd.tick += 1;
+    }
+    par.sync();
 }
 
 MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid, float *obs, float *rew, uint8_t *done) {

@@ -40,6 +40,48 @@ def gather_trajectories(local, group=None):
     return out
 
 
+class ChunkedTrajectoryGather(object):
+    """Overlaps the trajectory exchange with stepping.
+
+    A rollout of T steps is cut into chunks; as soon as a chunk's compact trajectory
+    (actions / rewards / dones tensors of shape [chunk, ...]) is complete its all-gather is
+    issued with async_op=True -- RCCL runs it on its own HIP stream over xGMI while the step
+    kernels of the next chunk run on the compute stream -- and `finish()` waits for all of them
+    at episode end.  With ~95 us per 65 536-env step a rank produces ~28 GB/s of trajectory, so a
+    single blocking gather at the end would cost ~30 % of the rollout; chunking hides it.
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self.pending = []   # (name, buffer, work)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def submit(self, local):
+        """local: dict name -> tensor (a finished chunk; must not be written again)."""
+        out = {}
+        for k in sorted(local):
+            v = local[k].contiguous()
+            if self.world == 1:
+                out[k] = v.unsqueeze(0)
+                self.pending.append((k, out[k], None))
+                continue
+            buf = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+            work = dist.all_gather_into_tensor(buf.view(-1), v.view(-1), group=self.group, async_op=True)
+            self.pending.append((k, buf, work))
+            out[k] = buf
+        return out
+
+    def finish(self):
+        """Waits for every outstanding gather; returns dict name -> list of [world, chunk, ...] tensors."""
+        res = {}
+        for k, buf, work in self.pending:
+            if work is not None:
+                work.wait()
+            res.setdefault(k, []).append(buf)
+        self.pending = []
+        return res
+
+
 def gather_episode_stats(returns, lengths, group=None):
     """Per-episode returns/lengths (KBs) to every rank: float32 [n_local_episodes, A], int32 [n]."""
     return gather_trajectories(dict(returns=returns, lengths=lengths), group=group)

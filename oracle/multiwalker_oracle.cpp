@@ -53,7 +53,7 @@ void mwo_reset(MwOracle *o, const uint8_t *mask, float *obs) {
         float zero[4 * mw::MAX_WALKERS] = {0};
         const uint32_t gid = (uint32_t)(o->env_id_base + n);
         mw::env_reset_world(o->M, o->C, o->worlds[n], gid);
-        mw::env_step(o->M, o->C, o->worlds[n], S, gid, zero, obs + n * W * mw::OBS_DIM, nullptr, nullptr);
+        mw::env_step(o->M, o->C, o->worlds[n], S, mw::SerialPar(), gid, zero, obs + n * W * mw::OBS_DIM, nullptr, nullptr);
         o->worlds[n].t = 0;
     }
 }
@@ -63,7 +63,7 @@ void mwo_step(MwOracle *o, const float *actions, float *obs, float *rew, uint8_t
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < o->n_envs; ++n) {
         mw::Scratch S;
-        mw::env_step(o->M, o->C, o->worlds[n], S, (uint32_t)(o->env_id_base + n), actions + n * W * 4,
+        mw::env_step(o->M, o->C, o->worlds[n], S, mw::SerialPar(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
                      obs + n * W * mw::OBS_DIM, rew + n * W, done + n);
     }
 }

@@ -36,6 +36,22 @@ def main():
         for k in exp:
             assert out[k].shape == (world,) + tuple(exp[k].shape)
             assert torch.equal(out[k][r], exp[k]), (k, r)
+    from madrl_amd.dist import ChunkedTrajectoryGather
+    cg = ChunkedTrajectoryGather()
+    chunks = []
+    for c in range(3):
+        gc = torch.Generator().manual_seed(1000 * rank + c)
+        ch = dict(rewards=torch.randn((5, N, P), generator=gc), dones=torch.randint(0, 2, (5, N), generator=gc, dtype=torch.uint8))
+        chunks.append(ch)
+        cg.submit(ch)
+    got = cg.finish()
+    assert len(got["rewards"]) == 3 and got["rewards"][0].shape == (world, 5, N, P)
+    for c in range(3):
+        for r in range(world):
+            gr = torch.Generator().manual_seed(1000 * r + c)
+            exp_r = torch.randn((5, N, P), generator=gr)
+            exp_d = torch.randint(0, 2, (5, N), generator=gr, dtype=torch.uint8)
+            assert torch.equal(got["rewards"][c][r], exp_r) and torch.equal(got["dones"][c][r], exp_d), (c, r)
     st = gather_episode_stats(torch.full((4, P), float(rank)), torch.full((4,), rank, dtype=torch.int32))
     assert torch.equal(st["lengths"][:, 0], torch.arange(world, dtype=torch.int32))
     dist.barrier()
