@@ -241,6 +241,28 @@ int madrl_multiwalker_step(madrl_multiwalker *h, const float *actions_dev, float
 int madrl_multiwalker_get_bodies(madrl_multiwalker *h, float *bodies_dev, uint8_t *flags_dev, float *terrain_dev,
                                  void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Env wrappers as epilogue kernels (reference: madrl_environments/__init__.py:143-389).
+ * Every env instance carries its own wrapper state (caller-owned device buffers, zero / one
+ * initialised as noted); `mask` / `reset_mask` are uint8 [n_envs] or NULL.
+ * ---------------------------------------------------------------------------------------- */
+/* StandardizedEnv.standardize_obs (:242-263): mean/var float64 [n_elems] (init 0 / 1, :229-230) */
+int madrl_wrap_obsnorm(const float *obs_in, double *mean, double *var, float *obs_out, int64_t n_elems,
+                       int64_t elems_per_env, const uint8_t *mask, double alpha, double eps, void *stream);
+/* StandardizedEnv.standardize_rew + scale_reward (:251-271, :290): mean/var float64 [n] (init 0 / 1) */
+int madrl_wrap_rewnorm(const float *rew_in, double *mean, double *var, float *rew_out, int64_t n, int64_t per_env,
+                       const uint8_t *mask, double alpha, double eps, double scale, int32_t enable_norm, void *stream);
+/* ObservationBuffer (:176-195): buf float32 [n_elems][k]; envs flagged in reset_mask fill all k slots */
+int madrl_wrap_obsbuffer(const float *obs, float *buf, int64_t n_elems, int64_t elems_per_env, int32_t k,
+                         const uint8_t *reset_mask, void *stream);
+/* DiagnosticsWrapper.step (:335-369): per-env accumulators ep_reward float64 [N][A], ep_len int32 [N],
+ * disc_ret / disc_pow float64 [N] (all init 0); on episode end (done bit0 or max_traj_len) the out_* rows
+ * receive episode_reward_agent*, episode_disc_return, episode_length and out_finished = 1 */
+int madrl_wrap_diagnostics(const float *rew, const uint8_t *done, double *ep_reward, int32_t *ep_len,
+                           double *disc_ret, double *disc_pow, int64_t n_envs, int32_t n_agents, double discount,
+                           int32_t max_traj_len, double *out_ep_reward, double *out_disc, int32_t *out_len,
+                           uint8_t *out_finished, void *stream);
+
 /* Philox4x32-10 on the host, exported so tests can pin the generator the kernels use
  * against the published known-answer vectors. */
 void madrl_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

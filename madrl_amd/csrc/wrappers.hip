@@ -1,0 +1,134 @@
+// wrappers.hip -- the reference's env wrappers as elementwise epilogue kernels over the batched
+// observation / reward tensors.  Each env instance keeps its own wrapper
+// state, exactly as if N wrapped reference envs ran side by side.
+//
+// Reference (file:line in /root/reference/madrl_environments/__init__.py):
+//   ObservationBuffer.step/reset :176-195 ; StandardizedEnv.update_*_estimate / standardize_* :242-271,
+//   step :283-291 ; DiagnosticsWrapper.step :335-369, _discount_sum :392-393.
+// HBM-bound streaming kernels: grid-stride, one element per lane, running statistics in float64
+// like the reference (a float32 EMA with alpha = 1e-3 drifts by ~6e-5, beyond the 1e-5 tolerance).
+#include "common.hpp"
+
+namespace {
+using namespace madrl;
+
+__global__ void obsnorm_kernel(const float *obs_in, double *mean, double *var, float *obs_out, int64_t n,
+                               int64_t per_env, const uint8_t *mask, double alpha, double eps) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mask != nullptr && mask[i / per_env] == 0) continue;
+        const double x = (double)obs_in[i];
+        const double m = (1.0 - alpha) * mean[i] + alpha * x;              // :245-246
+        const double d = x - m;
+        const double v = (1.0 - alpha) * var[i] + alpha * (d * d);         // :247-249
+        mean[i] = m;
+        var[i] = v;
+        obs_out[i] = (float)((x - m) / (sqrt(v) + eps));                   // :262-263
+    }
+}
+
+__global__ void rewnorm_kernel(const float *rew_in, double *mean, double *var, float *rew_out, int64_t n, int64_t per_env,
+                               const uint8_t *mask, double alpha, double eps, double scale, int enable) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mask != nullptr && mask[i / per_env] == 0) continue;
+        double r = (double)rew_in[i];
+        if (enable) {
+            const double m = (1.0 - alpha) * mean[i] + alpha * r;          // :253-254
+            const double d = r - m;
+            const double v = (1.0 - alpha) * var[i] + alpha * (d * d);     // :255-257
+            mean[i] = m;
+            var[i] = v;
+            r = r / (sqrt(v) + eps);                                       // :268-271 (the mean is not subtracted)
+        }
+        rew_out[i] = (float)(scale * r);                                   // :290
+    }
+}
+
+__global__ void obsbuffer_kernel(const float *obs, float *buf, int64_t n, int64_t per_env, int k, const uint8_t *reset_mask) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float *b = buf + i * k;
+        const float x = obs[i];
+        if (reset_mask != nullptr && reset_mask[i / per_env] != 0) {
+            for (int j = 0; j < k; ++j) b[j] = x;                           // reset :190-192
+        } else {
+            for (int j = 0; j + 1 < k; ++j) b[j] = b[j + 1];               // step :179-181
+            b[k - 1] = x;
+        }
+    }
+}
+
+__global__ void diagnostics_kernel(const float *rew, const uint8_t *done, double *ep_reward, int32_t *ep_len, double *disc_ret,
+                                   double *disc_pow, int64_t N, int A, double discount, int max_traj_len, double *out_ep_reward,
+                                   double *out_disc, int32_t *out_len, uint8_t *out_finished) {
+    const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0;
+    for (int a = 0; a < A; ++a) {
+        const double r = (double)rew[n * A + a];
+        ep_reward[n * A + a] += r;                                          // :350
+        s += r;
+    }
+    if (ep_len[n] == 0) disc_pow[n] = 1.0;
+    disc_ret[n] += (s / (double)A) * disc_pow[n];                           // :360-361 accumulated step by step
+    disc_pow[n] *= discount;
+    ep_len[n] += 1;                                                         // :351
+    const bool fin = (done[n] != 0) || ep_len[n] >= max_traj_len;           // :354
+    out_finished[n] = fin ? 1 : 0;
+    if (fin) {
+        for (int a = 0; a < A; ++a) { out_ep_reward[n * A + a] = ep_reward[n * A + a]; ep_reward[n * A + a] = 0.0; }
+        out_disc[n] = disc_ret[n];
+        out_len[n] = ep_len[n];
+        disc_ret[n] = 0.0;
+        ep_len[n] = 0;                                                      // :365-367
+    }
+}
+
+inline unsigned grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+}  // namespace
+
+extern "C" {
+
+int madrl_wrap_obsnorm(const float *obs_in, double *mean, double *var, float *obs_out, int64_t n_elems, int64_t elems_per_env,
+                       const uint8_t *mask, double alpha, double eps, void *stream) {
+    if (!obs_in || !mean || !var || !obs_out || n_elems < 1 || elems_per_env < 1) return fail(MADRL_EINVAL, "obsnorm: bad argument");
+    hipLaunchKernelGGL(obsnorm_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, obs_in, mean, var, obs_out,
+                       n_elems, elems_per_env, mask, alpha, eps);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_wrap_rewnorm(const float *rew_in, double *mean, double *var, float *rew_out, int64_t n, int64_t per_env,
+                       const uint8_t *mask, double alpha, double eps, double scale, int32_t enable_norm, void *stream) {
+    if (!rew_in || !rew_out || n < 1 || per_env < 1 || (enable_norm && (!mean || !var))) return fail(MADRL_EINVAL, "rewnorm: bad argument");
+    hipLaunchKernelGGL(rewnorm_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, rew_in, mean, var, rew_out, n, per_env,
+                       mask, alpha, eps, scale, (int)enable_norm);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_wrap_obsbuffer(const float *obs, float *buf, int64_t n_elems, int64_t elems_per_env, int32_t k, const uint8_t *reset_mask,
+                         void *stream) {
+    if (!obs || !buf || n_elems < 1 || elems_per_env < 1 || k < 1) return fail(MADRL_EINVAL, "obsbuffer: bad argument");
+    hipLaunchKernelGGL(obsbuffer_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, obs, buf, n_elems,
+                       elems_per_env, (int)k, reset_mask);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_wrap_diagnostics(const float *rew, const uint8_t *done, double *ep_reward, int32_t *ep_len, double *disc_ret,
+                           double *disc_pow, int64_t n_envs, int32_t n_agents, double discount, int32_t max_traj_len,
+                           double *out_ep_reward, double *out_disc, int32_t *out_len, uint8_t *out_finished, void *stream) {
+    if (!rew || !done || !ep_reward || !ep_len || !disc_ret || !disc_pow || !out_ep_reward || !out_disc || !out_len || !out_finished ||
+        n_envs < 1 || n_agents < 1)
+        return fail(MADRL_EINVAL, "diagnostics: bad argument");
+    hipLaunchKernelGGL(diagnostics_kernel, dim3((unsigned)((n_envs + 127) / 128)), dim3(128), 0, (hipStream_t)stream, rew, done,
+                       ep_reward, ep_len, disc_ret, disc_pow, n_envs, (int)n_agents, discount, (int)max_traj_len, out_ep_reward,
+                       out_disc, out_len, out_finished);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+}  // extern "C"
