@@ -256,12 +256,26 @@ int madrl_wrap_rewnorm(const float *rew_in, double *mean, double *var, float *re
 int madrl_wrap_obsbuffer(const float *obs, float *buf, int64_t n_elems, int64_t elems_per_env, int32_t k,
                          const uint8_t *reset_mask, void *stream);
 /* DiagnosticsWrapper.step (:335-369): per-env accumulators ep_reward float64 [N][A], ep_len int32 [N],
- * disc_ret / disc_pow float64 [N] (all init 0); on episode end (done bit0 or max_traj_len) the out_* rows
+ * disc_ret / disc_pow float64 [N] (all init 0); on episode end (any done bit or max_traj_len) the out_* rows
  * receive episode_reward_agent*, episode_disc_return, episode_length and out_finished = 1 */
 int madrl_wrap_diagnostics(const float *rew, const uint8_t *done, double *ep_reward, int32_t *ep_len,
                            double *disc_ret, double *disc_pow, int64_t n_envs, int32_t n_agents, double discount,
                            int32_t max_traj_len, double *out_ep_reward, double *out_disc, int32_t *out_len,
                            uint8_t *out_finished, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rollout post-processing: what the external samplers the runners hand the env to do with a batch of
+ * paths (runners/rurllab.py:298-305 discount / gae_lambda; runners/rurltools.py:196-209), as one reverse
+ * scan in time over the time-major trajectory tensors of the collector.
+ *   rew float32 [T][N][A], done uint8 [T][N] (any bit = episode boundary after step t),
+ *   values float32 [T+1][N][A] or NULL (baseline predictions; row T bootstraps the unfinished tail),
+ *   returns[t] = rew[t] + gamma * (done[t] ? 0 : returns[t+1]),      returns[T] = values[T] or 0
+ *   delta[t]   = rew[t] + gamma * (done[t] ? 0 : values[t+1]) - values[t]
+ *   adv[t]     = delta[t] + gamma * lambda * (done[t] ? 0 : adv[t+1])       (adv may be NULL; needs values)
+ * Accumulation in float64, results float32 [T][N][A].
+ * ---------------------------------------------------------------------------------------- */
+int madrl_rollout_gae(const float *rew, const uint8_t *done, const float *values, int64_t T, int64_t n_envs,
+                      int32_t n_agents, double gamma, double lambda, float *returns, float *adv, void *stream);
 
 /* Philox4x32-10 on the host, exported so tests can pin the generator the kernels use
  * against the published known-answer vectors. */

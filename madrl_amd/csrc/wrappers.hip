@@ -89,6 +89,32 @@ inline unsigned grid_for(int64_t n) {
 }
 }  // namespace
 
+// One thread per (env, agent) column; each time row is one coalesced sweep over [N][A].  HBM-bound:
+// 4 (rew) + 4 (values) + 4 + 4 (returns, adv) bytes per element and step, the done byte is shared by A lanes.
+__global__ void gae_kernel(const float *__restrict__ rew, const uint8_t *__restrict__ done, const float *__restrict__ values, int64_t T,
+                           int64_t n_envs, int n_agents, double gamma, double lambda, float *__restrict__ returns,
+                           float *__restrict__ adv) {
+    const int64_t row = n_envs * n_agents;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row) return;
+    const int64_t n = i / n_agents;
+    double ret = values ? (double)values[T * row + i] : 0.0, a = 0.0;
+    double vnext = ret;
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const bool cut = done[t * n_envs + n] != 0;
+        const double r = (double)rew[t * row + i];
+        ret = r + (cut ? 0.0 : gamma * ret);
+        returns[t * row + i] = (float)ret;
+        if (adv) {
+            const double v = (double)values[t * row + i];
+            const double delta = r + (cut ? 0.0 : gamma * vnext) - v;
+            a = delta + (cut ? 0.0 : gamma * lambda * a);
+            adv[t * row + i] = (float)a;
+            vnext = v;
+        }
+    }
+}
+
 extern "C" {
 
 int madrl_wrap_obsnorm(const float *obs_in, double *mean, double *var, float *obs_out, int64_t n_elems, int64_t elems_per_env,
@@ -127,6 +153,15 @@ int madrl_wrap_diagnostics(const float *rew, const uint8_t *done, double *ep_rew
     hipLaunchKernelGGL(diagnostics_kernel, dim3((unsigned)((n_envs + 127) / 128)), dim3(128), 0, (hipStream_t)stream, rew, done,
                        ep_reward, ep_len, disc_ret, disc_pow, n_envs, (int)n_agents, discount, (int)max_traj_len, out_ep_reward,
                        out_disc, out_len, out_finished);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_rollout_gae(const float *rew, const uint8_t *done, const float *values, int64_t T, int64_t n_envs, int32_t n_agents,
+                      double gamma, double lambda, float *returns, float *adv, void *stream) {
+    if (!rew || !done || !returns || T < 1 || n_envs < 1 || n_agents < 1 || (adv && !values)) return fail(MADRL_EINVAL, "gae: bad argument");
+    hipLaunchKernelGGL(gae_kernel, dim3(grid_for(n_envs * n_agents)), dim3(256), 0, (hipStream_t)stream, rew, done, values, T, n_envs,
+                       (int)n_agents, gamma, lambda, returns, adv);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }

@@ -1,0 +1,107 @@
+"""GPU rollout collector: the loop the reference leaves to its external samplers
+(`parallel_sampler` runners/rurllab.py:259, `ParallelSampler`/`SimpleSampler` runners/rurltools.py:170-194;
+in-tree instance of the same loop: heuristics/pursuit.py:71-85) run over a batched env with the policy in
+the loop, producing time-major trajectory tensors [T, N, A, ...] that stay in HBM, plus the
+discounted-return / GAE post-processing those samplers apply (runners/rurllab.py:298-305 `discount`,
+`gae_lambda`; runners/rurltools.py:196-209) as one reverse-scan kernel (madrl_rollout_gae).
+
+The env must be an `auto_reset` batched env (episode boundaries are the done flags; the observation
+returned by a done step already belongs to the next episode) or be shorter-lived than the horizon.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class Trajectory(object):
+    """time-major tensors of one collect() call: actions [T,N,A(,adim)], rewards float32 [T,N,A],
+    dones uint8 [T,N] (bit0 terminal, bit1 time limit), values float32 [T+1,N,A] or None,
+    observations float32 [T,N,A,D] or None, returns / advantages float32 [T,N,A]."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def paths(self, env_ids=None):
+        """The list-of-path-dicts view of the reference's samplers (one dict per finished or cut episode segment
+        and agent: "observations", "actions", "rewards", "returns", "advantages"), built on the host for the
+        chosen env instances (default: all; meant for small N / debugging, the tensors are the product)."""
+        T, N = self.dones.shape
+        ids = range(N) if env_ids is None else env_ids
+        dn = self.dones.cpu().numpy() != 0
+        host = {k: getattr(self, k).cpu().numpy() for k in ("actions", "rewards", "returns") }
+        for k in ("advantages", "observations"):
+            if getattr(self, k) is not None:
+                host[k] = getattr(self, k).cpu().numpy()
+        out = []
+        for n in ids:
+            cuts = [t + 1 for t in range(T) if dn[t, n]]
+            if not cuts or cuts[-1] != T:
+                cuts.append(T)
+            s = 0
+            for e in cuts:
+                for a in range(self.rewards.shape[2]):
+                    d = {k: v[s:e, n, a] for k, v in host.items()}
+                    d["env_id"], d["agent_id"], d["terminated"] = n, a, bool(dn[e - 1, n])
+                    out.append(d)
+                s = e
+        return out
+
+
+class RolloutCollector(object):
+    """collector = RolloutCollector(env, policy, horizon); traj = collector.collect()
+
+    policy(obs [N,A,D]) -> actions [N,A(,adim)] or (actions, values [N,A]); it runs on the env's device.
+    State (the current observation) carries over between collect() calls, like a sampler that keeps its
+    env copies alive between iterations."""
+
+    def __init__(self, env, policy, horizon, discount=0.99, gae_lambda=1.0, store_observations=False):
+        self.env, self.policy, self.T = env, policy, int(horizon)
+        self.discount, self.gae_lambda, self.store_observations = float(discount), float(gae_lambda), store_observations
+        self._obs = None
+        self._buf = None
+
+    def _alloc(self, obs, act, val):
+        T, dev = self.T, obs.device
+        b = dict(actions=torch.empty((T,) + tuple(act.shape), dtype=act.dtype, device=dev),
+                 rewards=torch.empty((T,) + tuple(obs.shape[:2]), dtype=torch.float32, device=dev),
+                 dones=torch.empty((T, obs.shape[0]), dtype=torch.uint8, device=dev),
+                 returns=torch.empty((T,) + tuple(obs.shape[:2]), dtype=torch.float32, device=dev))
+        b["values"] = torch.empty((T + 1,) + tuple(obs.shape[:2]), dtype=torch.float32, device=dev) if val is not None else None
+        b["advantages"] = torch.empty_like(b["returns"]) if val is not None else None
+        b["observations"] = torch.empty((T,) + tuple(obs.shape), dtype=torch.float32, device=dev) if self.store_observations else None
+        return b
+
+    def _act(self, obs):
+        out = self.policy(obs)
+        return out if isinstance(out, tuple) else (out, None)
+
+    def collect(self):
+        env = self.env
+        if self._obs is None:
+            self._obs = env.reset()
+        obs = self._obs
+        for t in range(self.T):
+            act, val = self._act(obs)
+            if self._buf is None:
+                self._buf = self._alloc(obs, act, val)
+            b = self._buf
+            if b["observations"] is not None:
+                b["observations"][t].copy_(obs)
+            b["actions"][t].copy_(act)
+            if val is not None:
+                b["values"][t].copy_(val)
+            obs, rew, done, info = env.step(act)
+            b["rewards"][t].copy_(rew)
+            b["dones"][t].copy_(info["done_bits"] if isinstance(info, dict) and "done_bits" in info else done.to(torch.uint8))
+        self._obs = obs
+        b = self._buf
+        if b["values"] is not None:
+            b["values"][self.T].copy_(self._act(obs)[1])  # bootstrap of the unfinished tail
+        N, A = b["rewards"].shape[1:]
+        _lib.check(_lib.lib().madrl_rollout_gae(_lib.ptr(b["rewards"]), _lib.ptr(b["dones"]),
+                                                _lib.ptr(b["values"]) if b["values"] is not None else None, self.T, N, A,
+                                                self.discount, self.gae_lambda, _lib.ptr(b["returns"]),
+                                                _lib.ptr(b["advantages"]) if b["advantages"] is not None else None,
+                                                _lib.current_stream(obs.device)))
+        return Trajectory(**b)
