@@ -131,6 +131,41 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Register-pressure control.  The compiler hoists every loop-invariant lane compare (lane < P, lane == k, ...)
+// out of the env loop as an SGPR-pair mask and, with ~100 uniform values already live there, spills them to
+// VGPR lanes: each use then costs two v_readlane_b32 (VALU issue slots, the resource this kernel is bound by).
+// fresh(lane) hides the invariance, so a predicate is one v_cmp at its use site and dies there.
+__device__ __forceinline__ int fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t fresh_s(uint32_t v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// w[lane LN] = v for a wave-uniform v: one v_writelane_b32, no lane mask, no compare
+template <int LN>
+__device__ __forceinline__ void put_lane(uint32_t &w, uint32_t v) {
+    const uint32_t sv = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(w) : "s"(sv), "n"(LN));
+}
+template <int LN, int END>
+__device__ __forceinline__ void put_zero_from(uint32_t &w) {
+    if constexpr (LN < END) {
+        put_lane<LN>(w, 0u);
+        put_zero_from<LN + 1, END>(w);
+    }
+}
+
+// Profiling aid (scripts/variants.sh builds one library per value, never the shipped one):
+//   1 no observation stores   2 store stale cells too (all float4 full, nt)   4 no Philox
+//   8 no observation pass at all   16 no record / reward stores
+//   64 no record prefetch (timing only, wrong results)
+#ifndef MADRL_ABLATE
+#define MADRL_ABLATE 0
+#endif
+
 // MODE 0: reset(mask)      MODE 1: step (+ fused auto-reset)
 // INJECT (step only): evader actions come from io.inj_eact (parity harness) instead of Philox.
 // It is a template parameter because a conditional global load in the hot loop makes the
@@ -186,11 +221,14 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
     // The whole packed state record (S::REC_DW dwords) is fetched by ONE coalesced load, lane k
     // holding dword k, together with the pursuer action of the same env; both are issued one
     // env ahead so their HBM latency hides behind the current env's work.
+    auto isP = [&]() { return fresh(lane) < P; };
+    auto isE = [&]() { return (unsigned)(fresh(lane) - P) < (unsigned)E; };
+    auto isAgent = [&]() { return fresh(lane) < A; };
     auto fetch_rec = [&](int64_t env) -> uint32_t {
-        return (lane < S::REC_DW) ? reinterpret_cast<const uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] : 0u;
+        return (fresh(lane) < S::REC_DW) ? reinterpret_cast<const uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] : 0u;
     };
     auto fetch_act = [&](int64_t env) -> int {
-        if constexpr (MODE == 1) return is_p ? io.actions[env * P + lane] : 4;
+        if constexpr (MODE == 1) return isP() ? io.actions[env * P + lane] : 4;
         else return 4;
     };
     uint32_t cur_rec = 0;
@@ -206,10 +244,15 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
         const int64_t nenv = env + gridDim.x;
         uint32_t nxt_rec = 0;
         int nxt_act = 4;
+#if MADRL_ABLATE & 64
+        nxt_rec = cur_rec ^ (uint32_t)(fresh(lane) == 0);  // no loads in the loop: is the in-order vmcnt drain what serialises a wave?
+        nxt_act = cur_act;
+#else
         if (nenv < d.n_envs) {
             nxt_rec = fetch_rec(nenv);
             nxt_act = fetch_act(nenv);
         }
+#endif
         bool skip = false;
         if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
         if (!skip) {
@@ -225,11 +268,12 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
             uint64_t term = __builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4);
             if constexpr (S::NTW > 1) term |= (uint64_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4 + 1) << 32;
             const uint32_t gid = d.gid_base + (uint32_t)env;
+            const uint32_t k0 = fresh_s(d.k0), k1 = fresh_s(d.k1);  // round keys recomputed on the SALU, not kept live
             bool do_reset = (MODE == 0);
             uint32_t done_bits = 0;
             float rew_out = 0.0f;
             int n_removed = 0;
-            bool alive = is_p || (is_e && !((gone >> eslot) & 1ull));
+            bool alive = isP() || (isE() && !((gone >> eslot) & 1ull));
             int cell = (x + PAD) * GW + y + PAD;
 
             auto load_map = [&](int mid) {
@@ -243,12 +287,12 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
             load_map(map_id);
 
             if constexpr (MODE == 1) {
-                const bool e_alive = is_e && alive;
+                const bool e_alive = alive && !isP();
                 // ---------------------------------------------------- pre-move reward (:359-381)
                 if (e_alive) atomicAdd(&layer[cell], 1u);
                 wave_sync();
                 int kpre = 0;
-                if (is_p) {  // np.clip keeps a border pursuer on its own cell (:374-380)
+                if (isP()) {  // np.clip keeps a border pursuer on its own cell (:374-380)
                     const int dxm = (x > 0) ? GW : 0, dxp = (x < S::XS - 1) ? GW : 0;
                     const int dym = (y > 0) ? 1 : 0, dyp = (y < S::YS - 1) ? 1 : 0;
                     const uint32_t *ec = &L[2 * GSZ];
@@ -263,8 +307,12 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                 if constexpr (INJECT) {
                     if (e_alive) act = io.inj_eact[env * E + kidx];
                 } else {
-                    const u32x4 r = philox4x32_10(gid, tick, (uint32_t)kidx, TAG_EVADER_ACT, d.k0, d.k1);
-                    if (!is_p) act = (int)__umulhi(r.x, 5u);  // RandomPolicy.act, Controllers.py:15-16
+#if MADRL_ABLATE & 4
+                    u32x4 r; r.x = (gid * 2654435761u + tick * 40503u + (uint32_t)kidx * 2246822519u) ^ k0 ^ k1;
+#else
+                    const u32x4 r = philox4x32_10(gid, tick, (uint32_t)kidx, TAG_EVADER_ACT, k0, k1);
+#endif
+                    if (!isP()) act = (int)__umulhi(r.x, 5u);  // RandomPolicy.act, Controllers.py:15-16
                 }
                 // DiscreteAgent.step, DiscreteAgent.py:69-97
                 const int dcell = (act == 0 ? -GW : 0) + (act == 1 ? GW : 0) + (act == 2 ? 1 : 0) + (act == 3 ? -1 : 0);
@@ -299,7 +347,7 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                 wave_sync();
                 // ---------------------------------------------------- rewards (:254-262)
                 double r = 0.0;
-                if (is_p) {
+                if (isP()) {
                     const uint32_t *ec = &L[2 * GSZ];
                     bool sur;
                     if (d.surround) {  // a caught evader on one of my four neighbour cells (:489-495)
@@ -336,14 +384,6 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
             // vmcnt(0) would also wait for this env's observation stores to reach HBM.
             asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act));
 
-            if constexpr (MODE == 1) {
-                if (is_p) io.rew[env * P + lane] = rew_out;
-                if (lane == 0) {
-                    io.done[env] = (uint8_t)done_bits;
-                    io.removed[env] = n_removed;
-                }
-            }
-
             // One observation pass normally.  On auto-reset two: the reference sequence is step()
             // then reset(), both write the persistent observation buffer and the cells the second
             // write skips keep the first one's values.  `alive` is the PRE-catch set in the first
@@ -363,22 +403,22 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                     if (inj_map) {
                         map_id = __builtin_amdgcn_readfirstlane(io.inj_map[env]);
                     } else if (d.sample_maps) {  // :182-183
-                        const u32x4 rm = philox4x32_10(gid, tick, 0u, TAG_RESET_ENV, d.k0, d.k1);
+                        const u32x4 rm = philox4x32_10(gid, tick, 0u, TAG_RESET_ENV, k0, k1);
                         map_id = (int)__umulhi(rm.x, (uint32_t)d.n_maps);
                     }
                     load_map(map_id);
-                    const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, d.k0, d.k1);
+                    const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, k0, k1);
                     const double sx = u53(rw.x, rw.y) * (1.0 - d.cw);  // :185-191, float64
                     const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
                     const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + d.cw));
                     const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + d.cw));
-                    if (is_agent) {  // create_agents / feasible_position, agent_utils.py:12-47
+                    if (isAgent()) {  // create_agents / feasible_position, agent_utils.py:12-47
                         if (inj_pos) {
                             x = io.inj_pos[(env * A + lane) * 2];
                             y = io.inj_pos[(env * A + lane) * 2 + 1];
                         } else {
                             for (uint32_t att = 0; att < 1024u; ++att) {
-                                const u32x4 rp = philox4x32_10(gid, tick, (uint32_t)lane, TAG_RESET_POS | (att << 8), d.k0, d.k1);
+                                const u32x4 rp = philox4x32_10(gid, tick, (uint32_t)lane, TAG_RESET_POS | (att << 8), k0, k1);
                                 x = xlb + (int)__umulhi(rp.x, (uint32_t)(xub - xlb));
                                 y = ylb + (int)__umulhi(rp.y, (uint32_t)(yub - ylb));
                                 // building cells hold fl32(1/norm) != 0; window cells are inside the map
@@ -388,7 +428,7 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                         cell = (x + PAD) * GW + y + PAD;
                         atomicAdd(&layer[cell], 1u);  // :201-203
                     }
-                    alive = is_agent;
+                    alive = isAgent();
                     tick += 1;
                     tstep = 0;
                     wave_sync();
@@ -401,8 +441,11 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                 wave_sync();
                 if (alive) layer[cell] = L[S::X_VTAB + cnt];
                 wave_sync();
+#if MADRL_ABLATE & 8
+                if (d.n_envs < 0)
+#endif
                 {
-                    const int origin = is_p ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
+                    const int origin = isP() ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f *orow = reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D));
 #pragma unroll
@@ -413,8 +456,15 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                         const uint32_t v1 = L[base + s_cst[s][1]];
                         const uint32_t v2 = L[base + s_cst[s][2]];
                         const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
-                        if (q < S::NQ) {
+#if MADRL_ABLATE & 1
+                        if (d.n_envs < 0)
+#endif
+                        if ((64 * (s + 1) <= S::NQ) ? true : (fresh(lane) + 64 * s < S::NQ)) {
+#if MADRL_ABLATE & 2
+                            if (true) {
+#else
                             if ((v0 != SENT) & (v1 != SENT) & (v2 != SENT) & (v3 != SENT)) {
+#endif
                                 const v4f val = {__uint_as_float(v0), __uint_as_float(v1), __uint_as_float(v2),
                                                  __uint_as_float(v3)};
                                 __builtin_nontemporal_store(val, &orow[q]);
@@ -434,6 +484,16 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                 if (alive) layer[cell] = 0u;  // restore the count layers for the next pass / env
                 wave_sync();
             }
+#if MADRL_ABLATE & 16
+            if (d.n_envs < 0)
+#endif
+            if constexpr (MODE == 1) {
+                if (isP()) io.rew[env * P + lane] = rew_out;
+                if (fresh(lane) == 0) {
+                    io.done[env] = (uint8_t)done_bits;
+                    io.removed[env] = n_removed;
+                }
+            }
             // ---------------------------------------------------------- registers -> state record
             // one coalesced dword store: lane k writes dword k of the record
             {
@@ -441,16 +501,20 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(rec_src0, myxy);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(rec_src1, myxy);
                 uint32_t w = (lo & 0xFFFFu) | (hi << 16);
-                if (lane == 0) w = tick;
-                if (lane == 1) w = (uint32_t)tstep;
-                if (lane == 2) w = (uint32_t)map_id;
-                if (lane == 3) w = 0u;
-                if (lane == S::OFF_GONE / 4) w = (uint32_t)gone;
-                if (S::NGW > 1 && lane == S::OFF_GONE / 4 + 1) w = (uint32_t)(gone >> 32);
-                if (lane == S::OFF_TERM / 4) w = (uint32_t)term;
-                if (S::NTW > 1 && lane == S::OFF_TERM / 4 + 1) w = (uint32_t)(term >> 32);
-                if (lane > S::OFF_TERM / 4 + S::NTW - 1) w = 0u;  // padding dwords
-                if (lane < S::REC_DW)
+                // the uniform header / bit-set dwords go in with v_writelane (one VALU op each, no lane mask)
+                put_lane<0>(w, tick);
+                put_lane<1>(w, (uint32_t)tstep);
+                put_lane<2>(w, (uint32_t)map_id);
+                put_lane<3>(w, 0u);
+                put_lane<S::OFF_GONE / 4>(w, (uint32_t)gone);
+                if constexpr (S::NGW > 1) put_lane<S::OFF_GONE / 4 + 1>(w, (uint32_t)(gone >> 32));
+                put_lane<S::OFF_TERM / 4>(w, (uint32_t)term);
+                if constexpr (S::NTW > 1) put_lane<S::OFF_TERM / 4 + 1>(w, (uint32_t)(term >> 32));
+                put_zero_from<S::OFF_TERM / 4 + S::NTW, S::REC_DW>(w);  // padding dwords
+#if MADRL_ABLATE & 16
+                if (d.n_envs < 0)
+#endif
+                if (fresh(lane) < S::REC_DW)
                     reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] = w;
             }
         }
