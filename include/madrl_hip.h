@@ -277,6 +277,25 @@ int madrl_wrap_diagnostics(const float *rew, const uint8_t *done, double *ep_rew
 int madrl_rollout_gae(const float *rew, const uint8_t *done, const float *values, int64_t T, int64_t n_envs,
                       int32_t n_agents, double gamma, double lambda, float *returns, float *adv, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Hand-written policies (reference: heuristics/pursuit.py:13-56, heuristics/waterworld.py:6-62,
+ * heuristics/multi_walker.py:10-86): one action per observation row, n_rows = n_envs * n_agents.
+ * ---------------------------------------------------------------------------------------- */
+/* PursuitHeuristicPolicy.sample_actions: element (i, j) of the evader channel of row r is
+ * obs[r * row_stride + ch_offset + (i * obs_range + j) * cell_stride]  (flatten rows: ch_offset = 2*R*R,
+ * cell_stride = 1; (R,R,4) windows: ch_offset = 2, cell_stride = 4).  table_dev uint8 [R*R]: the action for
+ * "nearest evader at window cell k" (255 = sample); empty window / 255 -> Philox(seed; row_id_base + r, tick).
+ * actions int32 [n_rows] */
+int madrl_heuristic_pursuit(const float *obs, int64_t n_rows, int32_t obs_range, int64_t row_stride, int32_t cell_stride,
+                            int32_t ch_offset, const uint8_t *table_dev, uint64_t seed, int64_t row_id_base,
+                            uint32_t tick, int32_t *actions, void *stream);
+/* WaterworldHeuristicPolicy.sample_actions, every row normalised on its own; cos_sin_dev float64 [K][2] with
+ * K = obs_dim / 7 (np.linspace(0, 2 pi, K + 1)[:-1]); actions float32 [n_rows][2] */
+int madrl_heuristic_waterworld(const float *obs, int64_t n_rows, int32_t obs_dim, const double *cos_sin_dev,
+                               float *actions, void *stream);
+/* MultiWalkerHeuristicPolicy.sample_actions; actions float32 [n_rows][4] */
+int madrl_heuristic_multiwalker(const float *obs, int64_t n_rows, int32_t obs_dim, float *actions, void *stream);
+
 /* Philox4x32-10 on the host, exported so tests can pin the generator the kernels use
  * against the published known-answer vectors. */
 void madrl_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

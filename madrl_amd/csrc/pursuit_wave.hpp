@@ -176,8 +176,6 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int lane = threadIdx.x;
     const bool is_p = lane < P;
-    const bool is_agent = lane < A;
-    const bool is_e = is_agent && !is_p;
     const int eslot = lane - P;
 
     // ---------------------------------------------------------------- once per workgroup
