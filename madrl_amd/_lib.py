@@ -97,7 +97,7 @@ SIGNATURES = {
     "madrl_wrap_rewnorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, C.c_double, C.c_double, C.c_double, C.c_int32, _vp]),
     "madrl_wrap_obsbuffer": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "madrl_wrap_diagnostics": (C.c_int, [_vp] * 6 + [C.c_int64, C.c_int32, C.c_double, C.c_int32] + [_vp] * 5),
-    "madrl_heuristic_pursuit": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_uint64, C.c_int64, C.c_uint32, _vp, _vp]),
+    "madrl_heuristic_pursuit": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_uint64, C.c_int64, C.c_uint32, _vp, _vp, _vp]),
     "madrl_heuristic_waterworld": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "madrl_heuristic_multiwalker": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
     "madrl_rollout_gae": (C.c_int, [_vp] * 3 + [C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double] + [_vp] * 3),

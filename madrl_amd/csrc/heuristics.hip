@@ -16,7 +16,7 @@ enum : uint32_t { TAG_HEURISTIC_ACT = 3 };
 __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__restrict__ obs, int64_t n_rows, int R, int64_t row_stride,
                                                              int cell_stride, int ch_offset, const uint8_t *__restrict__ table,
                                                              uint32_t k0, uint32_t k1, int64_t row_id_base, uint32_t tick,
-                                                             int32_t *__restrict__ actions) {
+                                                             const uint32_t *__restrict__ tick_dev, int32_t *__restrict__ actions) {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const int sub = threadIdx.x & 7;
     const int c = R / 2;  // :23 (Python 2 integer division)
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__rest
         if (key != 0xFFFFFFFFu) act = table[key & 0xFFFFu];
         if (act == 255) {
             const uint64_t id = (uint64_t)(row_id_base + row);
-            const u32x4 r = philox4x32_10((uint32_t)id, tick, (uint32_t)(id >> 32), TAG_HEURISTIC_ACT, k0, k1);
+            const uint32_t tk = tick + (tick_dev ? *tick_dev : 0u);  // device counter: survives hipGraph replay
+            const u32x4 r = philox4x32_10((uint32_t)id, tk, (uint32_t)(id >> 32), TAG_HEURISTIC_ACT, k0, k1);
             act = (int)__umulhi(r.x, 5u);
         }
         actions[row] = act;
@@ -129,12 +130,12 @@ extern "C" {
 
 int madrl_heuristic_pursuit(const float *obs, int64_t n_rows, int32_t obs_range, int64_t row_stride, int32_t cell_stride,
                             int32_t ch_offset, const uint8_t *table_dev, uint64_t seed, int64_t row_id_base, uint32_t tick,
-                            int32_t *actions, void *stream) {
+                            const uint32_t *tick_dev, int32_t *actions, void *stream) {
     if (!obs || !table_dev || !actions || n_rows < 1 || obs_range < 1 || obs_range > 255) return fail(MADRL_EINVAL, "heuristic_pursuit: bad argument");
     const int64_t threads = n_rows * 8;
     hipLaunchKernelGGL(pursuit_policy_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, n_rows,
                        (int)obs_range, row_stride, (int)cell_stride, (int)ch_offset, table_dev, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       row_id_base, tick, actions);
+                       row_id_base, tick, tick_dev, actions);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }

@@ -55,11 +55,16 @@ class RolloutCollector(object):
     State (the current observation) carries over between collect() calls, like a sampler that keeps its
     env copies alive between iterations."""
 
-    def __init__(self, env, policy, horizon, discount=0.99, gae_lambda=1.0, store_observations=False):
+    def __init__(self, env, policy, horizon, discount=0.99, gae_lambda=1.0, store_observations=False, graph=False):
+        """graph=True: from the second collect() on, the whole horizon (policy launches, step kernels, buffer copies, the
+        return scan) is one captured hipGraph that is replayed -- for small batches the per-launch overhead of ~4 launches
+        per step otherwise dominates.  The policy must be capturable (no host-side state that changes per call, no syncs);
+        the device policies of madrl_amd.heuristics are."""
         self.env, self.policy, self.T = env, policy, int(horizon)
         self.discount, self.gae_lambda, self.store_observations = float(discount), float(gae_lambda), store_observations
         self._obs = None
         self._buf = None
+        self._use_graph, self._graph, self._calls = bool(graph), None, 0
 
     def _alloc(self, obs, act, val):
         T, dev = self.T, obs.device
@@ -77,6 +82,20 @@ class RolloutCollector(object):
         return out if isinstance(out, tuple) else (out, None)
 
     def collect(self):
+        self._calls += 1
+        if not self._use_graph or self._calls == 1:  # the first call also warms up every allocation
+            return self._collect_eager()
+        if self._graph is None:
+            torch.cuda.synchronize(self._obs.device)
+            self._graph = torch.cuda.CUDAGraph()
+            self._obs_in = self._obs
+            with torch.cuda.graph(self._graph):  # records, does not execute
+                self._collect_eager()
+                self._obs_in.copy_(self._obs)    # the env returns the same persistent tensor; keep it explicit
+        self._graph.replay()
+        return Trajectory(**self._buf)
+
+    def _collect_eager(self):
         env = self.env
         if self._obs is None:
             self._obs = env.reset()
