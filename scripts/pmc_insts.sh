@@ -3,9 +3,9 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_insts
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --output-format csv -d $OUT/a -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/a.log 2>&1
+timeout 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --output-format csv -d $OUT/a -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/a.log 2>&1
 echo "rc=$?"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/b.log 2>&1
+timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/b.log 2>&1
 echo "rc=$?"
 python - <<'PY'
 import csv, glob, collections

@@ -11,7 +11,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ
            "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum GRBM_GUI_ACTIVE" \
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_WRITE_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/s$i -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/s$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d $OUT/s$i -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/s$i.log 2>&1
   echo "set $i rc=$?"
 done
 python - <<'PY'

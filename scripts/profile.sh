@@ -5,11 +5,11 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--steps 200 --warmup 20 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o pursuit -- python bench.py $ARGS > $OUT/trace.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o pursuit -- python bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pursuit -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pursuit -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 echo "pmc fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pursuit -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pursuit -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 echo "pmc write rc=$?"
 find $OUT -type f | head -40
 for f in $(find $OUT/trace -name "*stats*csv"); do echo "== $f"; head -20 $f; done
