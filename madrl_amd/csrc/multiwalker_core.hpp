@@ -32,8 +32,16 @@
 
 namespace mw {
 
+// World::Step parameters of the env (multi_walker.py:365).  Overridable ONLY for oracle/box2d_kat.cpp, which replays
+// the published Box2D HelloWorld scene (1/60 s, 6 velocity / 2 position iterations) through this same solver.
+#ifndef MW_FPS
+#define MW_FPS 50.0f
+#define MW_VEL_ITERS (6 * 30)
+#define MW_POS_ITERS (2 * 30)
+#endif
+
 // ---------------------------------------------------------------- env constants (:17-47)
-constexpr float FPS = 50.0f, SCALE = 30.0f;
+constexpr float FPS = MW_FPS, SCALE = 30.0f;
 constexpr float MOTORS_TORQUE = 80.0f, SPEED_HIP = 4.0f, SPEED_KNEE = 6.0f;
 constexpr float LIDAR_RANGE = 160.0f / SCALE, INITIAL_RANDOM = 5.0f;
 constexpr float LEG_DOWN = -8.0f / SCALE, LEG_W = 8.0f / SCALE, LEG_H = 34.0f / SCALE;
@@ -50,7 +58,7 @@ constexpr float LINEAR_SLOP = 0.005f, ANGULAR_SLOP = 2.0f / 180.0f * B2_PI, POLY
 constexpr float MAX_LINEAR_CORRECTION = 0.2f, MAX_ANGULAR_CORRECTION = 8.0f / 180.0f * B2_PI;
 constexpr float MAX_TRANSLATION = 2.0f, MAX_ROTATION = 0.5f * B2_PI, BAUMGARTE = 0.2f;
 constexpr float GRAVITY_Y = -10.0f;  // b2World() default in pybox2d: gravity=(0,-10)
-constexpr int VEL_ITERS = 6 * 30, POS_ITERS = 2 * 30;
+constexpr int VEL_ITERS = MW_VEL_ITERS, POS_ITERS = MW_POS_ITERS;
 
 constexpr int MAX_WALKERS = 4;
 constexpr int MAXB = 5 * MAX_WALKERS + 1;        // package + 5 bodies per walker
@@ -954,6 +962,7 @@ MW_HD void world_step(const Model &M, World &Wd, Scratch &S, Par par) {
         float fx = 0.0f;
         if (bi >= 1 && (bi - 1) % 5 == 0) { const int w = (bi - 1) / 5; fx = Wd.push_x[w]; }
         const float im = S.bim[bi];
+        if (im == 0.0f) continue;  // static body (b2Island::Solve integrates dynamic bodies only); the env has none
         b.v.x += h * (im * fx);
         b.v.y += h * (GRAVITY_Y + im * 0.0f);
         // linear/angular damping are 0: v *= 1/(1 + h*0)

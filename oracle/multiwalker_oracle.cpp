@@ -3,7 +3,8 @@
  *
  * TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: the reference's arithmetic for this env lives in
  * third-party Box2D (pybox2d), which cannot be imported or built in this image and for which the
- * reference holds no golden vectors.  Unlike the Pursuit / Waterworld oracles this
+ * reference holds no golden vectors; the only published anchor, Box2D's HelloWorld output,
+ * is checked by box2d_kat.cpp.  Unlike the Pursuit / Waterworld oracles this
  * file is therefore NOT an independent restatement pinned to the reference: it compiles the same
  * solver source the HIP kernel uses (madrl_amd/csrc/multiwalker_core.hpp, host/device code) with
  * g++ for the CPU.  What it checks is the GPU *port* (LDS staging, lane mapping, device math

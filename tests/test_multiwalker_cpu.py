@@ -152,3 +152,28 @@ def test_observation_noise_has_the_requested_scale():
     assert np.abs(d.mean(0)).max() < 3e-3
     assert np.allclose(d.std(0), 1e-2, rtol=0.2)
     assert np.array_equal(on[..., :24], oq[..., :24])
+
+
+def test_box2d_helloworld_known_answer():
+    """The one published numeric output of the absent dependency: Box2D v2.3 manual, "Hello Box2D" (a 2x2 box dropped from
+    y = 4 onto static ground, 60 steps of 1/60 s, 6/2 iterations, printed "%4.2f %4.2f %4.2f"):
+        0.00 4.00 0.00 / 0.00 3.99 0.00 / 0.00 3.98 0.00 / ... / 0.00 1.25 0.00 / 0.00 1.13 0.00 / 0.00 1.01 0.00
+    replayed through the env's own world_step (oracle/box2d_kat.cpp).  Steps 44-46 are the three tail lines: the box
+    would reach y = 0.997 at step 46; Box2D's continuous (TOI) pass stops it at the surface (1.01).  This solver has no
+    TOI pass: it penetrates for one step (prints 1.00) and is at the published 1.01 from step 48 on."""
+    import ctypes
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libmadrl_b2kat.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.dirname(os.path.dirname(so))])
+    L = ctypes.CDLL(so)
+    out = np.zeros((60, 3), np.float32)
+    assert L.b2kat_falling_box(out.ctypes.data_as(ctypes.c_void_p), 60) == 0
+    line = lambda i: ("%4.2f %4.2f %4.2f" % tuple(out[i - 1])).replace("-0.00", "0.00")
+    assert [line(1), line(2), line(3)] == ["0.00 4.00 0.00", "0.00 3.99 0.00", "0.00 3.98 0.00"]
+    assert [line(44), line(45)] == ["0.00 1.25 0.00", "0.00 1.13 0.00"]
+    assert line(46) in ("0.00 1.00 0.00", "0.00 1.01 0.00")          # no-TOI deviation, one step
+    assert all(line(i) == "0.00 1.01 0.00" for i in range(48, 61))   # the published resting line
+    # the resting height approaches polygonRadius * 2 - linearSlop = 0.015 above the surface from below, like Box2D's solver
+    assert 1.0135 < out[59, 1] < 1.015 and abs(out[59, 2]) < 1e-3
