@@ -32,8 +32,9 @@
 
 namespace mw {
 
-// World::Step parameters of the env (multi_walker.py:365).  Overridable ONLY for oracle/box2d_kat.cpp, which replays
-// the published Box2D HelloWorld scene (1/60 s, 6 velocity / 2 position iterations) through this same solver.
+// World::Step parameters of the env (multi_walker.py:365).  Overridable ONLY by the known-answer harness of the test
+// infrastructure, which replays the published Box2D HelloWorld scene (1/60 s, 6 velocity / 2 position iterations)
+// through this same solver.
 #ifndef MW_FPS
 #define MW_FPS 50.0f
 #define MW_VEL_ITERS (6 * 30)
