@@ -69,6 +69,11 @@ __device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) 
     return sqrtf(dx * dx + dy * dy);  // scipy cdist 'euclidean'
 }
 
+// Profiling aid (scripts/variants.sh, never the shipped library): 1 no sensing loop, 2 no observation store, 4 no collisions
+#ifndef MADRL_WW_ABLATE
+#define MADRL_WW_ABLATE 0
+#endif
+
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 template <int MODE>
 __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwIO io) {
@@ -207,6 +212,9 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 }
                 wave_sync();
                 // phase B: collisions (:272-293)
+#if MADRL_WW_ABLATE & 4
+                if (d.n_envs < 0)
+#endif
                 for (int idx = lane; idx < Np * (Ne + Npo); idx += 64) {
                     const bool is_ev = idx < Np * Ne;
                     const int r = is_ev ? idx : idx - Np * Ne;
@@ -240,46 +248,79 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 wave_sync();
                 // phase C: sensing (:295-353).  lane = (pursuer i, sensor k)
                 const float srange = d.sensor_range, rad2 = d.r_pu * d.r_pu;  // W3
-                for (int idx = lane; idx < Np * K; idx += 64) {
-                    const int i = idx / K, k = idx - i * K;
-                    const float sx = SEN[2 * k], sy = SEN[2 * k + 1];
-                    const float px = X[2 * i], py = X[2 * i + 1], pvx = V[2 * i], pvy = V[2 * i + 1];
-                    float *o = O + i * D;
-                    float feat_d[4];
-                    int arg[4];
+                // The (pursuer, sensor) pairs are spread over the lanes, PCH passes of 64 at a time; the objects they are tested
+                // against are wave-uniform, so each object's position is broadcast ONCE from the register of the lane that
+                // owns the particle (v_readlane -> SGPR operand) and reused by all passes: the inner loop is pure VALU, no
+                // LDS round trip per (pair, object).  Arithmetic and comparison order per pair are those of the reference loop.
+                constexpr int PCH = 3;
+                const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
+#if MADRL_WW_ABLATE & 1
+                if (d.n_envs < 0)
+#endif
+                for (int base = 0; base < Np * K; base += 64 * PCH) {
+                    int ii[PCH], kk[PCH];
+                    bool ok[PCH];
+                    float sx[PCH], sy[PCH], px[PCH], py[PCH];
+                    float feat_d[4][PCH];
+                    int arg[4][PCH];
+#pragma unroll
+                    for (int q = 0; q < PCH; ++q) {
+                        const int idx = base + 64 * q + lane;
+                        ok[q] = idx < Np * K;
+                        ii[q] = ok[q] ? idx / K : 0;
+                        kk[q] = ok[q] ? idx - ii[q] * K : 0;
+                        sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
+                        px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
+                    }
 #pragma unroll
                     for (int cls = 0; cls < 4; ++cls) {
                         const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
                         const int cnt = cls == 0 ? 1 : (cls == 1 ? Ne : (cls == 2 ? Npo : Np));
-                        float b = INFINITY;
-                        int bi = 0;
-                        for (int m = 0; m < cnt; ++m) {
-                            const float qx = cls == 0 ? ox : X[2 * (lo + m)], qy = cls == 0 ? oy : X[2 * (lo + m) + 1];
-                            const float rx = qx - px, ry = qy - py;
-                            float sv = sx * rx + sy * ry;
-                            const float d2 = rx * rx + ry * ry;
-                            if ((sv < 0.f) || (sv > srange) || (d2 - sv * sv > rad2)) sv = INFINITY;
-                            if (cls == 3 && m == i) sv = INFINITY;
-                            if (sv < b) { b = sv; bi = m; }
-                        }
-                        feat_d[cls] = b;
-                        arg[cls] = bi;
-                    }
-                    const float f_ob = (feat_d[0] < INFINITY) ? feat_d[0] : 0.f;  // W4: raw distance or 0
-                    float fd[3], fs[3];
+                        float b[PCH];
+                        int bi[PCH];
 #pragma unroll
-                    for (int cls = 1; cls < 4; ++cls) {
-                        const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
-                        const bool fin = feat_d[cls] < INFINITY;
-                        fd[cls - 1] = fin ? feat_d[cls] : 0.f;
-                        const int j = lo + arg[cls];
-                        fs[cls - 1] = fin ? (sx * (V[2 * j] - pvx) + sy * (V[2 * j + 1] - pvy)) : 0.f;  // W5
+                        for (int q = 0; q < PCH; ++q) { b[q] = INFINITY; bi[q] = 0; }
+                        for (int m = 0; m < cnt; ++m) {
+                            const float qx = cls == 0 ? ox : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), lo + m));
+                            const float qy = cls == 0 ? oy : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), lo + m));
+#pragma unroll
+                            for (int q = 0; q < PCH; ++q) {
+                                const float rx = qx - px[q], ry = qy - py[q];
+                                float sv = sx[q] * rx + sy[q] * ry;
+                                const float d2 = rx * rx + ry * ry;
+                                // branch-free (bitwise |, selects): no exec-mask round trips in the inner loop
+                                const bool out = (sv < 0.f) | (sv > srange) | (d2 - sv * sv > rad2) | ((cls == 3) & (m == ii[q]));
+                                sv = out ? INFINITY : sv;
+                                const bool better = sv < b[q];
+                                b[q] = better ? sv : b[q];
+                                bi[q] = better ? m : bi[q];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < PCH; ++q) { feat_d[cls][q] = b[q]; arg[cls][q] = bi[q]; }
                     }
-                    if (d.speed_features) {
-                        o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fs[0]; o[3 * K + k] = fd[1];
-                        o[4 * K + k] = fs[1]; o[5 * K + k] = fd[2]; o[6 * K + k] = fs[2];
-                    } else {
-                        o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fd[1]; o[3 * K + k] = fd[2];
+#pragma unroll
+                    for (int q = 0; q < PCH; ++q) {
+                        if (!ok[q]) continue;
+                        const int i = ii[q], k = kk[q];
+                        const float pvx = V[2 * i], pvy = V[2 * i + 1];
+                        float *o = O + i * D;
+                        const float f_ob = (feat_d[0][q] < INFINITY) ? feat_d[0][q] : 0.f;  // W4: raw distance or 0
+                        float fd[3], fs[3];
+#pragma unroll
+                        for (int cls = 1; cls < 4; ++cls) {
+                            const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
+                            const bool fin = feat_d[cls][q] < INFINITY;
+                            fd[cls - 1] = fin ? feat_d[cls][q] : 0.f;
+                            const int j = lo + arg[cls][q];
+                            fs[cls - 1] = fin ? (sx[q] * (V[2 * j] - pvx) + sy[q] * (V[2 * j + 1] - pvy)) : 0.f;  // W5
+                        }
+                        if (d.speed_features) {
+                            o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fs[0]; o[3 * K + k] = fd[1];
+                            o[4 * K + k] = fs[1]; o[5 * K + k] = fd[2]; o[6 * K + k] = fs[2];
+                        } else {
+                            o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fd[1]; o[3 * K + k] = fd[2];
+                        }
                     }
                 }
                 // pursuer lanes: collision flags, id, who-caught tests for the local rewards
@@ -368,6 +409,9 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 }
                 if (pass == npass - 1) {
                     float *orow = io.obs + env * (int64_t)(Np * D);
+#if MADRL_WW_ABLATE & 2
+                    if (d.n_envs < 0)
+#endif
                     for (int e = lane; e < Np * D; e += 64) orow[e] = O[e];
                 }
                 wave_sync();
@@ -448,7 +492,7 @@ size_t ww_lds_bytes(const WwDev &d) {
 }
 
 int ww_launch(const madrl_waterworld *h, const WwIO &io, int mode, void *stream) {
-    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 16;
+    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 64;
     if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0)
