@@ -198,6 +198,51 @@ int madrl_waterworld_set_state(madrl_waterworld *h, const float *pos, const floa
                                const int32_t *t, const uint32_t *tick, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ContinuousHostageWorld (reference: madrl_environments/hostage.py).  One wavefront per env, float32.
+ * ---------------------------------------------------------------------------------------- */
+/* Constructor arguments of ContinuousHostageWorld.__init__ (hostage.py:76-81). */
+typedef struct madrl_hostage_config {
+    int32_t struct_size;     /* = sizeof(madrl_hostage_config) */
+    int32_t n_good, n_hostages, n_bad, n_coop_save, n_coop_avoid, n_sensors;
+    int32_t addid;
+    int32_t reward_global;   /* reward_mech == 'global' (the reference's default here) */
+    int32_t key_fixed;       /* 1: key at key_loc; 0: key_loc=None, sampled by the first reset of an env's life (:143-146) */
+    int32_t max_steps;       /* 0 = the reference's timestep_limit of 1000 (:118-120) */
+    int32_t auto_reset;      /* 1: an env whose step ends with done is reset in the same launch */
+    double radius, bad_speed, sensor_range, action_scale;
+    double save_reward, hit_reward, encounter_reward, not_saved_reward, bomb_reward, bomb_radius, key_radius, control_penalty;
+    double key_loc[2];
+    uint64_t seed;
+    int64_t env_id_base;
+} madrl_hostage_config;
+
+typedef struct madrl_hostage madrl_hostage; /* opaque */
+
+/* n_sensors * 5 + 5 + (1 if addid)  (CircAgent.__init__, hostage.py:17-23) */
+int madrl_hostage_obs_dim(const madrl_hostage_config *cfg, int32_t *out_dim);
+/* packed state per env: float32 pos[NP][2] vel[NP][2] key[2] bomb[2], uint32 saved_lo, saved_hi, flags (bit0 gate open,
+ * bit1 bombed, bit2 key sampled), int32 t, uint32 tick  (NP = rescuers + hostages + criminals, in that order) */
+int madrl_hostage_state_bytes(const madrl_hostage_config *cfg, int64_t n_envs, uint64_t *out_bytes);
+/* sensors_host: float64 [n_sensors][2] unit vectors (CircAgent.__init__ :27-29), rounded to float32 once by the library */
+int madrl_hostage_create(const madrl_hostage_config *cfg, const double *sensors_host, int64_t n_envs, int32_t device,
+                         void *state_dev, madrl_hostage **out);
+void madrl_hostage_destroy(madrl_hostage *h);
+int madrl_hostage_set_launch(madrl_hostage *h, int64_t max_blocks);
+/* ContinuousHostageWorld.reset (:137-177) incl. its trailing zero-action step; obs float32 [N][n_good][obs_dim] */
+int madrl_hostage_reset(madrl_hostage *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
+/* ContinuousHostageWorld.step (:228-430).  actions float32 [N][n_good][2]; inj_respawn_dev float32 [N][n_bad][4] or NULL:
+ * the four uniforms (x, y, u_vx, u_vy) of a criminal respawned in this step (parity hook replacing np_random, :371-374);
+ * rew float32 [N][n_good]; done uint8 [N] (:179-182); info int32 [N][2] = ho_saved, cr_encs */
+int madrl_hostage_step(madrl_hostage *h, const float *actions_dev, const float *inj_respawn_dev, float *obs_dev,
+                       float *rew_dev, uint8_t *done_dev, int32_t *info_dev, void *stream);
+/* teacher-forcing / checkpoint hook; any pointer may be NULL */
+int madrl_hostage_get_state(madrl_hostage *h, float *pos, float *vel, float *key, float *bomb, uint64_t *saved,
+                            uint8_t *flags, int32_t *t, uint32_t *tick, void *stream);
+int madrl_hostage_set_state(madrl_hostage *h, const float *pos, const float *vel, const float *key, const float *bomb,
+                            const uint64_t *saved, const uint8_t *flags, const int32_t *t, const uint32_t *tick,
+                            void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * MultiWalkerEnv  (reference: madrl_environments/walker/multi_walker.py), float32.
  * The rigid-body dynamics the reference delegates to Box2D (`world.Step(1/50, 180, 60)`,
  * multi_walker.py:365) are restated from scratch; parity with Box2D itself is UNPINNED

@@ -47,6 +47,16 @@ class WaterworldConfig(C.Structure):
                     ("obstacle_loc", C.c_double * 2), ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 
 
+class HostageConfig(C.Structure):
+    """mirror of madrl_hostage_config (include/madrl_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "n_good", "n_hostages", "n_bad", "n_coop_save", "n_coop_avoid", "n_sensors", "addid", "reward_global",
+        "key_fixed", "max_steps", "auto_reset")] + [(n, C.c_double) for n in (
+            "radius", "bad_speed", "sensor_range", "action_scale", "save_reward", "hit_reward", "encounter_reward", "not_saved_reward",
+            "bomb_reward", "bomb_radius", "key_radius", "control_penalty")] + [
+                ("key_loc", C.c_double * 2), ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+
+
 class MultiWalkerConfig(C.Structure):
     """mirror of madrl_multiwalker_config (include/madrl_hip.h)"""
     _fields_ = [(n, C.c_int32) for n in (
@@ -84,6 +94,15 @@ SIGNATURES = {
     "madrl_waterworld_step": (C.c_int, [_vp] * 8),
     "madrl_waterworld_get_state": (C.c_int, [_vp] * 7),
     "madrl_waterworld_set_state": (C.c_int, [_vp] * 7),
+    "madrl_hostage_obs_dim": (C.c_int, [_vp, _vp]),
+    "madrl_hostage_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
+    "madrl_hostage_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
+    "madrl_hostage_destroy": (None, [_vp]),
+    "madrl_hostage_set_launch": (C.c_int, [_vp, C.c_int64]),
+    "madrl_hostage_reset": (C.c_int, [_vp] * 4),
+    "madrl_hostage_step": (C.c_int, [_vp] * 8),
+    "madrl_hostage_get_state": (C.c_int, [_vp] * 10),
+    "madrl_hostage_set_state": (C.c_int, [_vp] * 10),
     "madrl_multiwalker_obs_dim": (C.c_int, [_vp, _vp]),
     "madrl_multiwalker_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
     "madrl_multiwalker_create": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),

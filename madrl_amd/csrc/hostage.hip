@@ -1,0 +1,595 @@
+// hostage.hip -- batched ContinuousHostageWorld for MI355X (gfx950 / CDNA4), float32.
+//
+// Same execution model as waterworld.hip: one wavefront owns one env at a time (64-thread persistent workgroups striding
+// over envs); the particles (rescuers | hostages | criminals: position + velocity), key, bomb, flags and the assembled
+// observation rows live in LDS; HBM sees one packed state record in / out, the action row in and observation / reward /
+// done / info rows out.  Lane roles per phase: particle lanes (integration, walls, gate, respawn, motion), (rescuer,
+// object) collision pairs, (rescuer, sensor) sensing pairs -- the objects a sensor is tested against are broadcast once
+// from the owning lane's registers (v_readlane -> SGPR operands) and reused by three passes of pairs held in registers.
+//
+// Reference semantics (file:line under /root/reference/madrl_environments/hostage.py):
+//   sensing ...... CircAgent.sensed :62-71     reset ...... ContinuousHostageWorld.reset :137-177 (ends with a zero-action step)
+//   catch rule ... _caught :184-198             step ....... :228-430
+// Quirks kept (G1..G9) are listed where they occur.  Arithmetic is float32, every expression keeps the statement order of the
+// reference's step() so that a float32 CPU restatement agrees bit for bit.
+#include "common.hpp"
+
+#include <math.h>
+#include <new>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+using namespace madrl;
+
+enum : uint32_t { HW_TAG_RESPAWN = 48, HW_TAG_RESET = 49 };
+
+struct HwDev {
+    int32_t Nr, Nh, Nc, NP, K, D;
+    int32_t n_coop_save, addid, reward_global, key_fixed, max_steps, auto_reset;
+    int32_t rec_dw;  // dwords per packed state record: pos[NP][2] vel[NP][2] key[2] bomb[2] saved_lo saved_hi flags t tick
+    uint32_t k0, k1, gid_base;
+    float radius, r_ho, bad_speed, sensor_range, action_scale, gate_lo;
+    float save_reward, hit_reward, encounter_reward, not_saved_reward, bomb_reward, bomb_radius, key_radius, control_penalty;
+    float key_x, key_y;
+    int64_t n_envs;
+    const float *sensors;  // [K][2]
+    float *state;
+};
+
+struct HwIO {
+    const uint8_t *mask;    // reset mode
+    const float *actions;   // [N][Nr][2]
+    const float *inj_resp;  // [N][Nc][4] or NULL
+    float *obs;             // [N][Nr][D]
+    float *rew;             // [N][Nr]
+    uint8_t *done;          // [N]
+    int32_t *info;          // [N][2]  ho_saved, cr_encs
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float u24(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) {
+    const float dx = ax - bx, dy = ay - by;
+    return sqrtf(dx * dx + dy * dy);  // scipy cdist 'euclidean'
+}
+__device__ __forceinline__ float clipf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+
+// MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
+template <int MODE>
+__global__ __launch_bounds__(64) void hostage_kernel(const HwDev d, const HwIO io) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int Nr = d.Nr, Nh = d.Nh, Nc = d.Nc, NP = d.NP, K = d.K, D = d.D;
+    float *S = smem;                                   // packed record
+    float *X = S, *V = S + 2 * NP;
+    uint32_t *SU = reinterpret_cast<uint32_t *>(S);
+    const int OFF_KEY = 4 * NP, OFF_BOMB = 4 * NP + 2, OFF_SAVED = 4 * NP + 4, OFF_FLAGS = 4 * NP + 6, OFF_T = 4 * NP + 7, OFF_TICK = 4 * NP + 8;
+    float *O = S + ((d.rec_dw + 3) & ~3);              // observation staging [Nr][D]
+    float *SEN = O + ((Nr * D + 3) & ~3);              // sensor unit vectors [K][2]
+    uint8_t *COLH = reinterpret_cast<uint8_t *>(SEN + ((2 * K + 3) & ~3));  // [Nr][Nh]
+    uint8_t *COLC = COLH + Nr * Nh;                    // [Nr][Nc]
+    uint8_t *FLG = COLC + Nr * Nc;                     // ho_caught[Nh] | ho_enc[Nh] | cr_caught[Nc]
+
+    for (int k = lane; k < 2 * K; k += 64) SEN[k] = d.sensors[k];
+    const int rec_dw = d.rec_dw;
+    const int nreg = (rec_dw + 63) >> 6;  // <= 4
+
+    uint32_t cur[4] = {0, 0, 0, 0};
+    float cur_act = 0.0f;
+    auto fetch = [&](int64_t env, uint32_t (&r)[4], float &a) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(d.state) + env * (int64_t)rec_dw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lane + 64 * q;
+            r[q] = (q < nreg && k < rec_dw) ? src[k] : 0u;
+        }
+        if constexpr (MODE == 1) a = (lane < 2 * Nr) ? io.actions[env * 2 * Nr + lane] : 0.0f;
+        else a = 0.0f;
+    };
+    if ((int64_t)blockIdx.x < d.n_envs) fetch(blockIdx.x, cur, cur_act);
+    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur_act));
+    wave_sync();
+
+    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
+        const int64_t nenv = env + gridDim.x;
+        uint32_t nxt[4] = {0, 0, 0, 0};
+        float nxt_act = 0.0f;
+        if (nenv < d.n_envs) fetch(nenv, nxt, nxt_act);
+        bool skip = false;
+        if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
+        if (!skip) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = lane + 64 * q;
+                if (q < nreg && k < rec_dw) SU[k] = cur[q];
+            }
+            wave_sync();
+            int32_t tstep = (int32_t)SU[OFF_T];
+            uint32_t tick = SU[OFF_TICK];
+            uint32_t flags = SU[OFF_FLAGS];  // bit0 gate_open, bit1 bombed, bit2 key sampled
+            uint64_t saved = (uint64_t)SU[OFF_SAVED] | ((uint64_t)SU[OFF_SAVED + 1] << 32);
+            const uint32_t gid = d.gid_base + (uint32_t)env;
+            float act_lane = cur_act;
+
+            bool do_init = (MODE == 0);
+            int npass = 1;
+            for (int pass = 0; pass < npass; ++pass) {
+                if (do_init) {
+                    // ------------------------------------------------ reset (:137-177); draw index: key 0, particle j -> 1 + j, bomb 1 + NP
+                    tstep = 0;
+                    if (lane < NP + 2) {
+                        const uint32_t di = lane < NP ? 1u + (uint32_t)lane : (lane == NP ? 0u : 1u + (uint32_t)NP);
+                        const u32x4 r = philox4x32_10(gid, tick, di, HW_TAG_RESET, d.k0, d.k1);
+                        const float u0 = u24(r.x), u1 = u24(r.y), u2 = u24(r.z), u3 = u24(r.w);
+                        if (lane < Nr) {  // :149-153
+                            X[2 * lane] = u0; X[2 * lane + 1] = clipf(u1, 0.55f, 0.95f);
+                            V[2 * lane] = 0.f; V[2 * lane + 1] = 0.f;
+                        } else if (lane < Nr + Nh) {  // :156-160
+                            X[2 * lane] = u0; X[2 * lane + 1] = clipf(u1, 0.f, 0.35f + u2 * 0.01f);
+                            V[2 * lane] = 0.f; V[2 * lane + 1] = 0.f;
+                        } else if (lane < NP) {  // :165-168 (velocity not centred here)
+                            X[2 * lane] = u0; X[2 * lane + 1] = u1;
+                            V[2 * lane] = u2 * d.bad_speed; V[2 * lane + 1] = u3 * d.bad_speed;
+                        } else if (lane == NP) {  // key: the first reset of the env's life only (G2, :143-146)
+                            if (!(flags & 4u)) {
+                                S[OFF_KEY] = d.key_fixed ? d.key_x : 1.f - u0 * 0.1f;
+                                S[OFF_KEY + 1] = d.key_fixed ? d.key_y : 1.f - u1 * 0.1f;
+                            }
+                        } else {  // bomb :171
+                            S[OFF_BOMB] = clipf(u0, 0.f, 0.25f); S[OFF_BOMB + 1] = clipf(u1, 0.f, 0.25f);
+                        }
+                    }
+                    saved = 0ull;
+                    flags = 4u;
+                    tick += 1;
+                    act_lane = 0.0f;  // reset ends with step(zeros) (:173)
+                    wave_sync();
+                }
+                // ---------------------------------------------------- step (:228-430)
+                const float kx = S[OFF_KEY], ky = S[OFF_KEY + 1], bx = S[OFF_BOMB], by = S[OFF_BOMB + 1];
+                const bool gate0 = flags & 1u;  // gate state before this step's key processing (G5)
+                float reward = 0.0f;
+                bool col_bo = false, col_ke = false;
+                {   // phase A: rescuers (:231-260)
+                    const float a_raw0 = __shfl(act_lane, 2 * (lane < Nr ? lane : 0));
+                    const float a_raw1 = __shfl(act_lane, 2 * (lane < Nr ? lane : 0) + 1);
+                    const float a0 = a_raw0 * d.action_scale, a1 = a_raw1 * d.action_scale;
+                    float pen = d.control_penalty * (a0 * a0 + a1 * a1);
+                    if (d.reward_global) {  // (actions**2).sum(), row-major (:241-242)
+                        float s = 0.0f;
+                        for (int i = 0; i < Nr; ++i) {
+                            const float b0 = __shfl(a0, i), b1 = __shfl(a1, i);
+                            s += b0 * b0;
+                            s += b1 * b1;
+                        }
+                        pen = d.control_penalty * s;
+                    }
+                    if (lane < Nr) {
+                        float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
+                        vx = vx + a0; vy = vy + a1;
+                        x = x + vx; y = y + vy;
+                        reward = 0.0f + pen;
+                        float cx = clipf(x, 0.f, 1.f), cy = clipf(y, 0.f, 1.f);  // walls :247-252
+                        if (x != cx) vx = 0.f;
+                        if (y != cy) vy = 0.f;
+                        x = cx; y = cy;
+                        if (!gate0) {  // G3: both coordinates, velocity component flipped (:255-260)
+                            cx = clipf(x, d.gate_lo, 1.f); cy = clipf(y, d.gate_lo, 1.f);
+                            if (x != cx) vx *= -1.f;
+                            if (y != cy) vy *= -1.f;
+                            x = cx; y = cy;
+                        }
+                        X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
+                        col_bo = dist2d(x, y, bx, by) <= d.radius + d.bomb_radius;  // :281-291
+                        col_ke = dist2d(x, y, kx, ky) <= d.radius + d.key_radius;
+                    }
+                }
+                wave_sync();
+                // phase B: collisions (:263-279), no saved mask here (G4)
+                for (int idx = lane; idx < Nr * (Nh + Nc); idx += 64) {
+                    const bool is_ho = idx < Nr * Nh;
+                    const int r = is_ho ? idx : idx - Nr * Nh;
+                    const int n2 = is_ho ? Nh : Nc;
+                    const int i = r / n2, m = r % n2;
+                    const int j = (is_ho ? Nr : Nr + Nh) + m;
+                    const float thr = d.radius + (is_ho ? d.r_ho : d.radius);
+                    (is_ho ? COLH : COLC)[r] = dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= thr;
+                }
+                wave_sync();
+                bool my_caught = false, my_enc = false;  // hostage / criminal lanes count their column (_caught :184-198)
+                if (lane >= Nr && lane < NP) {
+                    const bool is_ho = lane < Nr + Nh;
+                    const int m = is_ho ? lane - Nr : lane - Nr - Nh;
+                    const uint8_t *col = is_ho ? COLH : COLC;
+                    const int n2 = is_ho ? Nh : Nc;
+                    int s = 0;
+                    for (int i = 0; i < Nr; ++i) s += col[i * n2 + m];
+                    my_caught = s >= (is_ho ? d.n_coop_save : 1);
+                    my_enc = is_ho && s >= 1;
+                    if (is_ho) { FLG[m] = my_caught; FLG[Nh + m] = my_enc; }
+                    else FLG[2 * Nh + m] = my_caught;
+                }
+                const uint64_t ho_lanes = ((Nh >= 64) ? ~0ull : ((1ull << Nh) - 1ull)) << Nr;
+                const uint64_t caught_mask = __ballot(my_caught);
+                const int n_ho_caught = __popcll(caught_mask & ho_lanes);
+                const int n_cr_caught = __popcll(caught_mask & ~ho_lanes);
+                const int n_ho_enc = __popcll(__ballot(my_enc));
+                const bool bo_caught = __ballot(col_bo) != 0ull, ke_caught = __ballot(col_ke) != 0ull;
+                wave_sync();
+                // phase C: sensing (:295-362).  Rows: [criminal dist | criminal speed | hostage dist | key dist | bomb dist] (:398-400)
+                {
+                    constexpr int PCH = 3;
+                    const float srange = d.sensor_range, rad2 = d.radius * d.radius;  // G1
+                    const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
+                    for (int base = 0; base < Nr * K; base += 64 * PCH) {
+                        int ii[PCH], kk[PCH];
+                        bool ok[PCH];
+                        float sx[PCH], sy[PCH], px[PCH], py[PCH];
+                        float b_cr[PCH], b_ho[PCH], b_ke[PCH], b_bo[PCH];
+                        int a_cr[PCH];
+#pragma unroll
+                        for (int q = 0; q < PCH; ++q) {
+                            const int idx = base + 64 * q + lane;
+                            ok[q] = idx < Nr * K;
+                            ii[q] = ok[q] ? idx / K : 0;
+                            kk[q] = ok[q] ? idx - ii[q] * K : 0;
+                            sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
+                            px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
+                            b_cr[q] = INFINITY; b_ho[q] = INFINITY; a_cr[q] = 0;
+                        }
+                        auto sense = [&](int q, float qx, float qy) -> float {
+                            const float rx = qx - px[q], ry = qy - py[q];
+                            const float sv = sx[q] * rx + sy[q] * ry;
+                            const float d2 = rx * rx + ry * ry;
+                            const bool out = (sv < 0.f) | (sv > srange) | (d2 - sv * sv > rad2);
+                            return out ? INFINITY : sv;
+                        };
+                        for (int m = 0; m < Nc; ++m) {
+                            const float qx = bcast(part_x, Nr + Nh + m), qy = bcast(part_y, Nr + Nh + m);
+#pragma unroll
+                            for (int q = 0; q < PCH; ++q) {
+                                const float sv = sense(q, qx, qy);
+                                const bool better = sv < b_cr[q];
+                                b_cr[q] = better ? sv : b_cr[q];
+                                a_cr[q] = better ? m : a_cr[q];
+                            }
+                        }
+                        for (int m = 0; m < Nh; ++m) {
+                            const float qx = bcast(part_x, Nr + m), qy = bcast(part_y, Nr + m);
+                            const bool was_saved = (saved >> m) & 1ull;  // mask from before this step's processing (G5, :296)
+#pragma unroll
+                            for (int q = 0; q < PCH; ++q) {
+                                float sv = sense(q, qx, qy);
+                                sv = was_saved ? INFINITY : sv;
+                                b_ho[q] = sv < b_ho[q] ? sv : b_ho[q];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < PCH; ++q) { b_ke[q] = sense(q, kx, ky); b_bo[q] = sense(q, bx, by); }
+#pragma unroll
+                        for (int q = 0; q < PCH; ++q) {
+                            if (!ok[q]) continue;
+                            const int i = ii[q], k = kk[q];
+                            float *o = O + i * D;
+                            const bool fin = b_cr[q] < INFINITY;
+                            const int j = Nr + Nh + a_cr[q];
+                            o[k] = fin ? b_cr[q] : 0.f;
+                            o[K + k] = fin ? (sx[q] * (V[2 * j] - V[2 * i]) + sy[q] * (V[2 * j + 1] - V[2 * i + 1])) : 0.f;  // :204-226
+                            o[2 * K + k] = (gate0 && b_ho[q] < INFINITY) ? b_ho[q] : 0.f;   // :320-322
+                            o[3 * K + k] = (!gate0 && b_ke[q] < INFINITY) ? b_ke[q] : 0.f;  // :338-340
+                            o[4 * K + k] = (b_bo[q] < INFINITY) ? b_bo[q] : 0.f;
+                        }
+                    }
+                }
+                // rescuer lanes: contact flags and who-caught tests for the local rewards (G9)
+                bool w_ho = false, w_enc = false, w_cr = false, t_ho = false, t_cr = false;
+                if (lane < Nr) {
+                    for (int j = 0; j < Nh; ++j) {
+                        const bool c = COLH[lane * Nh + j];
+                        t_ho |= c;
+                        w_ho |= c && FLG[j];
+                        w_enc |= c && FLG[Nh + j];
+                    }
+                    for (int j = 0; j < Nc; ++j) {
+                        const bool c = COLC[lane * Nc + j];
+                        t_cr |= c;
+                        w_cr |= c && FLG[2 * Nh + j];
+                    }
+                }
+                wave_sync();
+                // phase D: process collisions (:365-383)
+                saved |= (caught_mask & ho_lanes) >> Nr;
+                if (lane >= Nr + Nh && lane < NP && my_caught) {
+                    const int m = lane - Nr - Nh;
+                    float x, y, u0, u1;
+                    if (MODE == 1 && io.inj_resp != nullptr && !do_init) {
+                        const float *r = io.inj_resp + (env * Nc + m) * 4;
+                        x = r[0]; y = r[1]; u0 = r[2]; u1 = r[3];
+                    } else {
+                        const u32x4 r = philox4x32_10(gid, tick, (uint32_t)m, HW_TAG_RESPAWN, d.k0, d.k1);
+                        x = u24(r.x); y = u24(r.y); u0 = u24(r.z); u1 = u24(r.w);
+                    }
+                    X[2 * lane] = x; X[2 * lane + 1] = y;
+                    V[2 * lane] = (u0 - 0.5f) * d.bad_speed; V[2 * lane + 1] = (u1 - 0.5f) * d.bad_speed;
+                }
+                tick += 1;
+                if (bo_caught) flags |= 2u;
+                if (ke_caught) flags |= 1u;
+                const float gate1 = (flags & 1u) ? 1.f : 0.f, bombed1 = (flags & 2u) ? 1.f : 0.f;  // states after processing (G6)
+                // phase E: rewards (:385-396)
+                if (lane < Nr) {
+                    if (d.reward_global) {
+                        reward += ((((float)n_ho_enc * d.encounter_reward) * gate1 + (float)n_ho_caught * d.save_reward) +
+                                   (float)n_cr_caught * d.hit_reward) + bombed1 * d.bomb_reward;
+                    } else {
+                        if (w_ho) reward += d.save_reward;
+                        if (w_enc) reward += d.encounter_reward * gate1;
+                        if (w_cr) reward += d.hit_reward;
+                        if (col_bo) reward += bombed1 * d.bomb_reward;
+                    }
+                }
+                wave_sync();
+                // phase F: criminals move; velocity flips only if BOTH coordinates left [0,1], no clipping (G7, :402-408)
+                if (lane >= Nr + Nh && lane < NP) {
+                    float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
+                    x = x + vx; y = y + vy;
+                    const bool outx = !(x >= 0.f && x <= 1.f), outy = !(y >= 0.f && y <= 1.f);
+                    if (outx && outy) { vx = -1.0f * vx; vy = -1.0f * vy; }
+                    X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
+                }
+                if (lane < Nr) {  // tail of the observation row (:410-425)
+                    float *o = O + lane * D + 5 * K;
+                    o[0] = t_ho ? 1.f : 0.f; o[1] = t_cr ? 1.f : 0.f; o[2] = col_ke ? 1.f : 0.f; o[3] = col_bo ? 1.f : 0.f;
+                    o[4] = gate1;
+                    if (d.addid) o[5] = (float)(lane + 1);
+                }
+                tstep += 1;  // :427
+                const uint64_t all_h = (Nh >= 64) ? ~0ull : ((1ull << Nh) - 1ull);
+                const int limit = d.max_steps > 0 ? d.max_steps : 1000;  // timestep_limit :118-120
+                const bool is_done = (flags & 2u) || ((saved & all_h) == all_h) || tstep >= limit;  // :179-182
+                if (is_done && lane < Nr) reward += (float)(Nh - __popcll(saved & all_h)) * d.not_saved_reward;  // :429-430
+                wave_sync();
+
+                if (pass == 0) asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_act));  // pipeline hinge
+                // ---------------------------------------------------- outputs
+                if (MODE == 1 && !do_init) {
+                    if (lane < Nr) io.rew[env * Nr + lane] = reward;
+                    if (lane == 0) {
+                        io.done[env] = (uint8_t)is_done;
+                        io.info[2 * env] = n_ho_caught;
+                        io.info[2 * env + 1] = n_cr_caught;
+                    }
+                    if (is_done && d.auto_reset) {  // wave-uniform: run the reset pass next
+                        npass = 2;
+                        do_init = true;
+                    }
+                }
+                if (pass == npass - 1) {
+                    float *orow = io.obs + env * (int64_t)(Nr * D);
+                    for (int e = lane; e < Nr * D; e += 64) orow[e] = O[e];
+                }
+                wave_sync();
+            }
+            // ---------------------------------------------------------- LDS -> record
+            if (lane == 0) {
+                SU[OFF_SAVED] = (uint32_t)saved; SU[OFF_SAVED + 1] = (uint32_t)(saved >> 32);
+                SU[OFF_FLAGS] = flags;
+                SU[OFF_T] = (uint32_t)tstep;
+                SU[OFF_TICK] = tick;
+            }
+            wave_sync();
+            {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(d.state) + env * (int64_t)rec_dw;
+                for (int k = lane; k < rec_dw; k += 64) dst[k] = SU[k];
+            }
+            wave_sync();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        cur_act = nxt_act;
+    }
+}
+
+}  // namespace
+
+// =================================================================== host side / C ABI
+struct madrl_hostage {
+    madrl_hostage_config cfg;
+    HwDev dev;
+    int device;
+    int64_t max_blocks;
+    size_t lds_bytes;
+    void *tables;
+};
+
+namespace {
+
+int hw_validate(const madrl_hostage_config *c) {
+    if (!c) return fail(MADRL_EINVAL, "config is NULL");
+    if (c->struct_size != (int32_t)sizeof(madrl_hostage_config))
+        return fail(MADRL_EINVAL, "madrl_hostage_config.struct_size=%d, library expects %d", c->struct_size, (int)sizeof(madrl_hostage_config));
+    if (c->n_good < 1 || c->n_hostages < 1 || c->n_bad < 1) return fail(MADRL_EINVAL, "n_good, n_hostages, n_bad must be >= 1");
+    if (c->n_good + c->n_hostages + c->n_bad > 62) return fail(MADRL_EINVAL, "at most 62 particles per env (one wavefront per env)");
+    if (2 * c->n_good > 64) return fail(MADRL_EINVAL, "n_good must be <= 32");
+    if (c->n_sensors < 1 || c->n_sensors > 256) return fail(MADRL_EINVAL, "n_sensors must be in 1..256");
+    if (c->n_coop_save < 1) return fail(MADRL_EINVAL, "n_coop_save must be >= 1");
+    return MADRL_OK;
+}
+
+int hw_obs_dim_of(const madrl_hostage_config *c) { return c->n_sensors * 5 + 5 + (c->addid ? 1 : 0); }  // CircAgent.__init__ :19-23
+
+void hw_layout(const madrl_hostage_config *c, HwDev *d) {
+    memset(d, 0, sizeof(*d));
+    d->Nr = c->n_good; d->Nh = c->n_hostages; d->Nc = c->n_bad; d->NP = d->Nr + d->Nh + d->Nc;
+    d->K = c->n_sensors; d->D = hw_obs_dim_of(c);
+    d->n_coop_save = c->n_coop_save; d->addid = c->addid; d->reward_global = c->reward_global; d->key_fixed = c->key_fixed;
+    d->max_steps = c->max_steps; d->auto_reset = c->auto_reset;
+    d->rec_dw = (int)align_up((size_t)4 * d->NP + 9, 4);
+    d->k0 = (uint32_t)c->seed; d->k1 = (uint32_t)(c->seed >> 32); d->gid_base = (uint32_t)c->env_id_base;
+    d->radius = (float)c->radius; d->r_ho = (float)(c->radius * 2); d->gate_lo = (float)(0.5 + c->radius);  // evaluated in float64 like the reference
+    d->bad_speed = (float)c->bad_speed; d->sensor_range = (float)c->sensor_range; d->action_scale = (float)c->action_scale;
+    d->save_reward = (float)c->save_reward; d->hit_reward = (float)c->hit_reward; d->encounter_reward = (float)c->encounter_reward;
+    d->not_saved_reward = (float)c->not_saved_reward; d->bomb_reward = (float)c->bomb_reward; d->bomb_radius = (float)c->bomb_radius;
+    d->key_radius = (float)c->key_radius; d->control_penalty = (float)c->control_penalty;
+    d->key_x = (float)c->key_loc[0]; d->key_y = (float)c->key_loc[1];
+}
+
+size_t hw_lds_bytes(const HwDev &d) {
+    size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)d.Nr * d.D, 4) + align_up((size_t)2 * d.K, 4);
+    size_t b = f * 4 + (size_t)d.Nr * (d.Nh + d.Nc) + 2 * (size_t)d.Nh + d.Nc;
+    return align_up(b, 16);
+}
+
+int hw_launch(const madrl_hostage *h, const HwIO &io, int mode, void *stream) {
+    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 64;
+    if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(hostage_kernel<0>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    else hipLaunchKernelGGL(hostage_kernel<1>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+__global__ void hw_state_copy_kernel(const HwDev d, float *pos, float *vel, float *key, float *bomb, uint64_t *saved, uint8_t *flags, int32_t *t,
+                                     uint32_t *tick, const int to_state) {
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    float *rec = d.state + env * (int64_t)d.rec_dw;
+    uint32_t *ru = reinterpret_cast<uint32_t *>(rec);
+    const int NP = d.NP;
+    for (int k = 0; k < 2 * NP; ++k) {
+        if (pos) { if (to_state) rec[k] = pos[env * 2 * NP + k]; else pos[env * 2 * NP + k] = rec[k]; }
+        if (vel) { if (to_state) rec[2 * NP + k] = vel[env * 2 * NP + k]; else vel[env * 2 * NP + k] = rec[2 * NP + k]; }
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (key) { if (to_state) rec[4 * NP + k] = key[env * 2 + k]; else key[env * 2 + k] = rec[4 * NP + k]; }
+        if (bomb) { if (to_state) rec[4 * NP + 2 + k] = bomb[env * 2 + k]; else bomb[env * 2 + k] = rec[4 * NP + 2 + k]; }
+    }
+    if (saved) {
+        if (to_state) { ru[4 * NP + 4] = (uint32_t)saved[env]; ru[4 * NP + 5] = (uint32_t)(saved[env] >> 32); }
+        else saved[env] = (uint64_t)ru[4 * NP + 4] | ((uint64_t)ru[4 * NP + 5] << 32);
+    }
+    if (flags) { if (to_state) ru[4 * NP + 6] = flags[env]; else flags[env] = (uint8_t)ru[4 * NP + 6]; }
+    if (t) { if (to_state) ru[4 * NP + 7] = (uint32_t)t[env]; else t[env] = (int32_t)ru[4 * NP + 7]; }
+    if (tick) { if (to_state) ru[4 * NP + 8] = tick[env]; else tick[env] = ru[4 * NP + 8]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int madrl_hostage_obs_dim(const madrl_hostage_config *cfg, int32_t *out_dim) {
+    int rc = hw_validate(cfg);
+    if (rc) return rc;
+    if (!out_dim) return fail(MADRL_EINVAL, "out_dim is NULL");
+    *out_dim = hw_obs_dim_of(cfg);
+    return MADRL_OK;
+}
+
+int madrl_hostage_state_bytes(const madrl_hostage_config *cfg, int64_t n_envs, uint64_t *out_bytes) {
+    int rc = hw_validate(cfg);
+    if (rc) return rc;
+    if (n_envs < 1 || !out_bytes) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_bytes non-NULL");
+    HwDev d;
+    hw_layout(cfg, &d);
+    *out_bytes = (uint64_t)d.rec_dw * 4u * (uint64_t)n_envs;
+    return MADRL_OK;
+}
+
+int madrl_hostage_create(const madrl_hostage_config *cfg, const double *sensors_host, int64_t n_envs, int32_t device, void *state_dev,
+                         madrl_hostage **out) {
+    int rc = hw_validate(cfg);
+    if (rc) return rc;
+    if (!sensors_host || !state_dev || !out || n_envs < 1) return fail(MADRL_EINVAL, "create: NULL argument or n_envs < 1");
+    if (n_envs + cfg->env_id_base > 0xFFFFFFFFll) return fail(MADRL_EINVAL, "global env index must fit 32 bits");
+    MADRL_HIP_TRY(hipSetDevice(device));
+    madrl_hostage *h = new (std::nothrow) madrl_hostage();
+    if (!h) return fail(MADRL_ENOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    hw_layout(cfg, &h->dev);
+    h->dev.n_envs = n_envs;
+    h->dev.state = (float *)state_dev;
+    h->lds_bytes = hw_lds_bytes(h->dev);
+    h->max_blocks = 0;
+    if (h->lds_bytes > 64 * 1024) {
+        const size_t need = h->lds_bytes;
+        delete h;
+        return fail(MADRL_EINVAL, "configuration needs %zu B of LDS (> 64 KiB)", need);
+    }
+    std::vector<float> sens(2 * (size_t)cfg->n_sensors);
+    for (size_t k = 0; k < sens.size(); ++k) sens[k] = (float)sensors_host[k];  // float64 cos/sin rounded once
+    hipError_t e = hipMalloc(&h->tables, sens.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->tables, sens.data(), sens.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->tables) (void)hipFree(h->tables);
+        delete h;
+        return fail(MADRL_EHIP, "sensor table upload failed: %s", hipGetErrorString(e));
+    }
+    h->dev.sensors = (const float *)h->tables;
+    *out = h;
+    return MADRL_OK;
+}
+
+void madrl_hostage_destroy(madrl_hostage *h) {
+    if (!h) return;
+    if (h->tables) (void)hipFree(h->tables);
+    delete h;
+}
+
+int madrl_hostage_set_launch(madrl_hostage *h, int64_t max_blocks) {
+    if (!h || max_blocks < 0) return fail(MADRL_EINVAL, "set_launch: bad argument");
+    h->max_blocks = max_blocks;
+    return MADRL_OK;
+}
+
+int madrl_hostage_reset(madrl_hostage *h, const uint8_t *mask_dev, float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(MADRL_EINVAL, "reset: handle/obs is NULL");
+    HwIO io;
+    memset(&io, 0, sizeof(io));
+    io.mask = mask_dev;
+    io.obs = obs_dev;
+    return hw_launch(h, io, 0, stream);
+}
+
+int madrl_hostage_step(madrl_hostage *h, const float *actions_dev, const float *inj_respawn_dev, float *obs_dev, float *rew_dev,
+                       uint8_t *done_dev, int32_t *info_dev, void *stream) {
+    if (!h || !actions_dev || !obs_dev || !rew_dev || !done_dev || !info_dev) return fail(MADRL_EINVAL, "step: NULL argument");
+    HwIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = actions_dev;
+    io.inj_resp = inj_respawn_dev;
+    io.obs = obs_dev;
+    io.rew = rew_dev;
+    io.done = done_dev;
+    io.info = info_dev;
+    return hw_launch(h, io, 1, stream);
+}
+
+int madrl_hostage_get_state(madrl_hostage *h, float *pos, float *vel, float *key, float *bomb, uint64_t *saved, uint8_t *flags, int32_t *t,
+                            uint32_t *tick, void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 127) / 128);
+    hipLaunchKernelGGL(hw_state_copy_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, pos, vel, key, bomb, saved, flags, t, tick, 0);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_hostage_set_state(madrl_hostage *h, const float *pos, const float *vel, const float *key, const float *bomb, const uint64_t *saved,
+                            const uint8_t *flags, const int32_t *t, const uint32_t *tick, void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 127) / 128);
+    hipLaunchKernelGGL(hw_state_copy_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, (float *)pos, (float *)vel, (float *)key,
+                       (float *)bomb, (uint64_t *)saved, (uint8_t *)flags, (int32_t *)t, (uint32_t *)tick, 1);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""GPU tests (-m gpu): hostage.hip through the C ABI against (1) golden records of the unmodified reference (teacher-forced,
+1e-5), (2) the float32 oracle free-running with the same Philox draws (bit-identical), plus API / sharding checks."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "hostage_*.npz")))
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[8:-4] for f in FILES])
+def test_hip_matches_reference_golden_teacher_forced(path):
+    """all T records of a file are loaded as T independent envs: set_state(pre) + step(action, respawns) == post"""
+    from madrl_amd.hostage import BatchedContinuousHostageWorld
+    from oracle import hostage as ho
+    g = np.load(path)
+    T = len(g["pre_t"])
+    kw = ho.kwargs_from_golden(g)
+    env = BatchedContinuousHostageWorld(n_envs=T, device=DEV, **kw)
+    Nh = env.n_hostages
+    saved = np.array([sum(int(b) << j for j, b in enumerate(g["pre_saved"][t])) for t in range(T)], np.int64)
+    flags = (g["pre_gate"].astype(np.uint8) | (g["pre_bombed"].astype(np.uint8) << 1) | 4).astype(np.uint8)
+    env.set_state(pos=g["pre_pos"], vel=g["pre_vel"], key=g["key"], bomb=g["bomb"], saved=saved, flags=flags, t=g["pre_t"].astype(np.int32),
+                  tick=np.arange(T, dtype=np.int32))
+    resp = np.where(g["resp"] >= 0, g["resp"], 0.0)
+    obs, rew, done, info = env.step(g["act"], respawn=resp)
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    assert np.abs(st["pos"] - g["post_pos"]).max() < 1e-6 and np.abs(st["vel"] - g["post_vel"]).max() < 1e-6
+    post_saved = np.array([sum(int(b) << j for j, b in enumerate(g["post_saved"][t])) for t in range(T)], np.int64)
+    assert np.array_equal(st["saved"], post_saved)
+    assert np.array_equal(st["flags"] & 3, g["post_gate"] | (g["post_bombed"] << 1))
+    assert np.array_equal(st["t"], g["post_t"])
+    assert np.abs(obs.cpu().numpy() - g["obs"]).max() < 1e-5
+    real = g["is_reset_step"] == 0
+    assert np.abs(rew.cpu().numpy()[real] - g["rew"][real]).max() < 1e-5
+    assert np.array_equal(done.cpu().numpy()[real], g["done"][real] == 1)
+    assert np.array_equal(torch.stack([info["ho_saved"], info["cr_encs"]], 1).cpu().numpy()[real], g["info"][real])
+
+
+@pytest.mark.parametrize("mech", ["global", "local"])
+def test_hip_matches_f32_oracle_free_running(mech):
+    from madrl_amd.hostage import BatchedContinuousHostageWorld
+    from oracle import hostage as ho
+    N, kw = 384, dict(reward_mech=mech, action_scale=0.03, max_steps=60, bad_speed=0.03)
+    env = BatchedContinuousHostageWorld(3, 6, 5, 2, 2, n_envs=N, device=DEV, seed=11, auto_reset=False, **kw)
+    orc = ho.HostageOracle(3, 6, 5, 2, 2, n_envs=N, seed=11, dtype=np.float32, **kw)
+    obs = env.reset(); oobs = orc.reset()
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    rng = np.random.RandomState(0)
+    n_done = n_resp = 0
+    for t in range(150):
+        a = rng.uniform(-1, 1, (N, 3, 2)).astype(np.float32)
+        obs, rew, done, info = env.step(a)
+        oobs, orew, odone, oinfo = orc.step(a)
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        assert np.array_equal(rew.cpu().numpy(), orew), t
+        assert np.array_equal(done.cpu().numpy(), odone != 0), t
+        assert np.array_equal(info["cr_encs"].cpu().numpy(), oinfo[:, 1])
+        n_resp += int(oinfo[:, 1].sum())
+        d = odone != 0
+        if d.any():  # the reference's caller resets finished envs
+            n_done += int(d.sum())
+            obs = env.reset(mask=d); oobs = orc.reset(mask=d.astype(np.uint8))
+            assert np.array_equal(obs.cpu().numpy()[d], oobs[d]), t
+    st, ost = env.get_state(), orc.get_state()
+    assert np.array_equal(st["pos"].cpu().numpy(), ost["pos"]) and np.array_equal(st["saved"].cpu().numpy(), ost["saved"].astype(np.int64))
+    assert n_done > N and n_resp > 50
+
+
+def test_auto_reset_sharding_and_dropin_api():
+    from madrl_amd.hostage import BatchedContinuousHostageWorld, ContinuousHostageWorld
+    N = 256
+    mk = lambda n, base: BatchedContinuousHostageWorld(3, 10, 5, 2, 2, n_envs=n, device=DEV, seed=5, env_id_base=base, auto_reset=True,
+                                                       max_steps=25, action_scale=0.03)
+    full, lo, hi = mk(N, 0), mk(N // 2, 0), mk(N // 2, N // 2)
+    o = full.reset(); assert torch.equal(o[:N // 2], lo.reset()) and torch.equal(o[N // 2:], hi.reset())
+    g = torch.Generator(device="cpu").manual_seed(1)
+    dones = 0
+    for t in range(60):
+        a = (torch.rand((N, 3, 2), generator=g) * 2 - 1).to(DEV)
+        o, r, d, _ = full.step(a)
+        o1, r1, d1, _ = lo.step(a[:N // 2]); o2, r2, d2, _ = hi.step(a[N // 2:])
+        assert torch.equal(o, torch.cat([o1, o2])) and torch.equal(r, torch.cat([r1, r2])) and torch.equal(d, torch.cat([d1, d2]))
+        dones += int(d.sum())
+    assert dones >= 2 * N and int(full.get_state()["t"].max()) <= 25
+    env = ContinuousHostageWorld(3, 10, 5, 2, 2, device=DEV)
+    obs = env.reset()
+    assert len(obs) == 3 and obs[0].shape == (156,) and obs[0].dtype == np.float64 and env.agents[0].observation_space.shape == (156,)
+    obs, rew, done, info = env.step(np.zeros(6))
+    assert rew.shape == (3,) and isinstance(done, bool) and set(info) == {"ho_saved", "cr_encs"} and env.is_gate_open in (False, True)
