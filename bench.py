@@ -105,6 +105,33 @@ def bench_other(args, rank, local_rank, world, dev):
             from oracle import pursuit as po
             return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
                         sample="float32 C oracle (oracle/waterworld_oracle.c, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
+    elif args.workload == "hostage":
+        from madrl_amd.hostage import BatchedContinuousHostageWorld
+        N = args.envs or 32768
+        env = BatchedContinuousHostageWorld(3, 10, 5, 2, 2, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
+                                            max_blocks=args.max_blocks)
+        acts = [(torch.rand((N, 3, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)]
+        outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
+        step = lambda i: _lib.check(L.madrl_hostage_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
+        bytes_per = 24 + 4 * 3 * env.obs_dim + 12 + 1 + 8 + 2 * (env._state.numel() // N)
+        kernel, binding = "hostage_kernel<1>", "VALU issue (about 1 500 ray tests per env-step) and the serial chain of small LDS phases, not HBM"
+        workload = "ContinuousHostageWorld(3, 10, 5, 2, 2) (hostage.py:483), 30 sensors, %d envs per GPU, timestep_limit 1000" % N
+
+        def cpu():
+            from oracle import hostage as ho
+            from oracle import pursuit as po
+            n = 4096
+            o = ho.HostageOracle(3, 10, 5, 2, 2, n_envs=n, seed=0, dtype=np.float32)
+            o.reset()
+            a = np.random.RandomState(0).uniform(-1, 1, (n, 3, 2)).astype(np.float32)
+            t0 = time.time(); k = 0
+            while time.time() - t0 < 10:
+                _, _, dn, _ = o.step(a); k += 1
+                if dn.any():
+                    o.reset(mask=dn)
+            dt = time.time() - t0
+            return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
+                        sample="float32 C oracle (oracle/hostage_oracle.c, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
     else:
         from madrl_amd.multiwalker import BatchedMultiWalkerEnv
         N = args.envs or 16384
@@ -181,7 +208,7 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=0, help="env instances per GPU (0 = the BASELINE config's batch)")
-    ap.add_argument("--workload", default="pursuit", choices=["pursuit", "waterworld", "multiwalker"],
+    ap.add_argument("--workload", default="pursuit", choices=["pursuit", "waterworld", "multiwalker", "hostage"],
                     help="pursuit = BASELINE.json's metric (default); the other two are the remaining north_star envs")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
