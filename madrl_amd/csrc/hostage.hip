@@ -62,11 +62,13 @@ __device__ __forceinline__ float clipf(float v, float lo, float hi) { return v <
 __device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
-template <int MODE>
+// TNr..TK > 0: the particle / sensor counts are compile-time constants (small loops unroll, the index divisions fold); 0: generic.
+template <int MODE, int TNr, int TNh, int TNc, int TK>
 __global__ __launch_bounds__(64) void hostage_kernel(const HwDev d, const HwIO io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const int Nr = d.Nr, Nh = d.Nh, Nc = d.Nc, NP = d.NP, K = d.K, D = d.D;
+    const int Nr = TNr > 0 ? TNr : d.Nr, Nh = TNr > 0 ? TNh : d.Nh, Nc = TNr > 0 ? TNc : d.Nc, K = TNr > 0 ? TK : d.K;
+    const int NP = Nr + Nh + Nc, D = d.D;
     float *S = smem;                                   // packed record
     float *X = S, *V = S + 2 * NP;
     uint32_t *SU = reinterpret_cast<uint32_t *>(S);
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(64) void hostage_kernel(const HwDev d, const HwIO i
                             const bool out = (sv < 0.f) | (sv > srange) | (d2 - sv * sv > rad2);
                             return out ? INFINITY : sv;
                         };
+#pragma nounroll
                         for (int m = 0; m < Nc; ++m) {
                             const float qx = bcast(part_x, Nr + Nh + m), qy = bcast(part_y, Nr + Nh + m);
 #pragma unroll
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(64) void hostage_kernel(const HwDev d, const HwIO i
                                 a_cr[q] = better ? m : a_cr[q];
                             }
                         }
+#pragma nounroll
                         for (int m = 0; m < Nh; ++m) {
                             const float qx = bcast(part_x, Nr + m), qy = bcast(part_y, Nr + m);
                             const bool was_saved = (saved >> m) & 1ull;  // mask from before this step's processing (G5, :296)
@@ -451,8 +455,15 @@ int hw_launch(const madrl_hostage *h, const HwIO &io, int mode, void *stream) {
     int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 64;
     if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL(hostage_kernel<0>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
-    else hipLaunchKernelGGL(hostage_kernel<1>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    const HwDev &d = h->dev;
+    const bool ex = d.Nr == 3 && d.Nh == 10 && d.Nc == 5 && d.K == 30;  // the module's own configuration (hostage.py:483), 30 sensors
+    if (mode == 0) {
+        if (ex) hipLaunchKernelGGL((hostage_kernel<0, 3, 10, 5, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+        else hipLaunchKernelGGL((hostage_kernel<0, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    } else {
+        if (ex) hipLaunchKernelGGL((hostage_kernel<1, 3, 10, 5, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+        else hipLaunchKernelGGL((hostage_kernel<1, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    }
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }

@@ -75,11 +75,13 @@ __device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) 
 #endif
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
-template <int MODE>
+// TNp..TK > 0: the particle / sensor counts are compile-time constants (loops unroll, the index divisions fold); 0: generic.
+template <int MODE, int TNp, int TNe, int TNpo, int TK>
 __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwIO io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const int Np = d.Np, Ne = d.Ne, Npo = d.Npo, NP = d.NP, K = d.K, D = d.D;
+    const int Np = TNp > 0 ? TNp : d.Np, Ne = TNp > 0 ? TNe : d.Ne, Npo = TNp > 0 ? TNpo : d.Npo, K = TNp > 0 ? TK : d.K;
+    const int NP = Np + Ne + Npo, D = d.D;
     // ---- LDS carve
     float *S = smem;                                    // packed record: X[NP][2] | V[NP][2] | obst[2] | t | tick
     float *X = S, *V = S + 2 * NP;
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                         int bi[PCH];
 #pragma unroll
                         for (int q = 0; q < PCH; ++q) { b[q] = INFINITY; bi[q] = 0; }
+#pragma nounroll
                         for (int m = 0; m < cnt; ++m) {
                             const float qx = cls == 0 ? ox : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), lo + m));
                             const float qy = cls == 0 ? oy : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), lo + m));
@@ -495,10 +498,15 @@ int ww_launch(const madrl_waterworld *h, const WwIO &io, int mode, void *stream)
     int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 64;
     if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
-    if (mode == 0)
-        hipLaunchKernelGGL(waterworld_kernel<0>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
-    else
-        hipLaunchKernelGGL(waterworld_kernel<1>, dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    const WwDev &d = h->dev;
+    const bool c3 = d.Np == 5 && d.Ne == 10 && d.Npo == 10 && d.K == 30;  // BASELINE configs[2]: MAWaterWorld(5, 10), 30 sensors
+    if (mode == 0) {
+        if (c3) hipLaunchKernelGGL((waterworld_kernel<0, 5, 10, 10, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+        else hipLaunchKernelGGL((waterworld_kernel<0, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    } else {
+        if (c3) hipLaunchKernelGGL((waterworld_kernel<1, 5, 10, 10, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+        else hipLaunchKernelGGL((waterworld_kernel<1, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+    }
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }
