@@ -42,13 +42,13 @@ def test_hip_matches_reference_golden_teacher_forced(path):
     assert np.array_equal(torch.stack([info["ho_saved"], info["cr_encs"]], 1).cpu().numpy()[real], g["info"][real])
 
 
-@pytest.mark.parametrize("mech", ["global", "local"])
-def test_hip_matches_f32_oracle_free_running(mech):
+@pytest.mark.parametrize("mech,nh", [("global", 6), ("local", 6), ("global", 10)], ids=["global-generic", "local-generic", "global-specialised"])
+def test_hip_matches_f32_oracle_free_running(mech, nh):
     from madrl_amd.hostage import BatchedContinuousHostageWorld
     from oracle import hostage as ho
     N, kw = 384, dict(reward_mech=mech, action_scale=0.03, max_steps=60, bad_speed=0.03)
-    env = BatchedContinuousHostageWorld(3, 6, 5, 2, 2, n_envs=N, device=DEV, seed=11, auto_reset=False, **kw)
-    orc = ho.HostageOracle(3, 6, 5, 2, 2, n_envs=N, seed=11, dtype=np.float32, **kw)
+    env = BatchedContinuousHostageWorld(3, nh, 5, 2, 2, n_envs=N, device=DEV, seed=11, auto_reset=False, **kw)
+    orc = ho.HostageOracle(3, nh, 5, 2, 2, n_envs=N, seed=11, dtype=np.float32, **kw)
     obs = env.reset(); oobs = orc.reset()
     assert np.array_equal(obs.cpu().numpy(), oobs)
     rng = np.random.RandomState(0)
