@@ -227,11 +227,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with WORLD_SIZE=%d (got %d)" % (args.gpus, args.gpus, world))
+    backend = os.environ.get("MADRL_BENCH_BACKEND", "nccl")  # "gloo": exercise the N > 1 path with all ranks on one GPU (tests only)
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload != "pursuit":
         return bench_other(args, rank, local_rank, world, dev)
@@ -260,14 +266,16 @@ def main():
     obs_p, rew_p, done_p, rem_p = (_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._removed))
     act_p = [_lib.ptr(a) for a in actions]
 
+    # N > 1: the step kernel writes rewards / dones straight into their slot of the trajectory chunk (the C ABI takes any
+    # device pointer), only the action row is copied (int32 -> uint8)
+    slot_p = [(_lib.ptr(traj[c]["rewards"][j]), _lib.ptr(traj[c]["dones"][j])) for c in range(n_chunks) for j in range(chunk_len[c])] if world > 1 else []
+
     def one_step(i, record):
-        _lib.check(L.madrl_pursuit_step(h, act_p[i % n_act], None, obs_p, rew_p, done_p, rem_p,
-                                        _lib.current_stream(dev)))
+        rp, dp = slot_p[i] if (record and world > 1) else (rew_p, done_p)
+        _lib.check(L.madrl_pursuit_step(h, act_p[i % n_act], None, obs_p, rp, dp, rem_p, _lib.current_stream(dev)))
         if record and world > 1:
             c, j = divmod(i, CH)
             traj[c]["actions"][j].copy_(actions[i % n_act])
-            traj[c]["rewards"][j].copy_(env._rew)
-            traj[c]["dones"][j].copy_(env._done)
 
     env.reset()
     for i in range(W):
