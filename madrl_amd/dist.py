@@ -55,6 +55,21 @@ class ChunkedTrajectoryGather(object):
         self.group = group
         self.pending = []   # (name, buffer, work)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._reserved = {}  # id(local tensor) -> receive buffer
+
+    def reserve(self, chunks):
+        """Allocate the receive buffers of the given chunks (list of dicts name -> tensor) ahead of the rollout and run one
+        tiny collective, so that neither hipMalloc nor RCCL's lazy channel setup lands between two step launches."""
+        if self.world == 1:
+            return
+        for local in chunks:
+            for k in sorted(local):
+                v = local[k]
+                self._reserved[id(v)] = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+        v = next(iter(chunks[0].values()))
+        warm_in = torch.zeros(64, dtype=torch.uint8, device=v.device)
+        warm_out = torch.empty(64 * self.world, dtype=torch.uint8, device=v.device)
+        dist.all_gather_into_tensor(warm_out, warm_in, group=self.group)
 
     def submit(self, local):
         """local: dict name -> tensor (a finished chunk; must not be written again)."""
@@ -65,7 +80,9 @@ class ChunkedTrajectoryGather(object):
                 out[k] = v.unsqueeze(0)
                 self.pending.append((k, out[k], None))
                 continue
-            buf = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+            buf = self._reserved.pop(id(local[k]), None)
+            if buf is None:
+                buf = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
             work = dist.all_gather_into_tensor(buf.view(-1), v.view(-1), group=self.group, async_op=True)
             self.pending.append((k, buf, work))
             out[k] = buf
