@@ -64,7 +64,7 @@ __device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 // TNr..TK > 0: the particle / sensor counts are compile-time constants (small loops unroll, the index divisions fold); 0: generic.
 template <int MODE, int TNr, int TNh, int TNc, int TK>
-__global__ __launch_bounds__(64) void hostage_kernel(const HwDev d, const HwIO io) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void hostage_kernel(const HwDev d, const HwIO io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int Nr = TNr > 0 ? TNr : d.Nr, Nh = TNr > 0 ? TNh : d.Nh, Nc = TNr > 0 ? TNc : d.Nc, K = TNr > 0 ? TK : d.K;
