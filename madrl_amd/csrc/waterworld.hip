@@ -88,7 +88,8 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
     float *OB = S + 4 * NP;
     float *O = S + ((d.rec_dw + 3) & ~3);               // observation staging [Np][D]
     float *SEN = O + ((Np * D + 3) & ~3);               // sensor unit vectors [K][2]
-    uint8_t *COL = reinterpret_cast<uint8_t *>(SEN + ((2 * K + 3) & ~3));  // col_ev[Np][Ne] | col_po[Np][Npo]
+    uint64_t *NEAR = reinterpret_cast<uint64_t *>(SEN + ((2 * K + 3) & ~3));  // per pursuer: particles (bit j) / obstacle (bit NP) in sensing reach
+    uint8_t *COL = reinterpret_cast<uint8_t *>(NEAR + Np);  // col_ev[Np][Ne] | col_po[Np][Npo]
     uint8_t *COLP = COL + Np * Ne;
     uint8_t *FLG = COLP + Np * Npo;                     // caught_ev[Ne] | enc_ev[Ne] | caught_po[Npo]
 
@@ -256,6 +257,20 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 // LDS round trip per (pair, object).  Arithmetic and comparison order per pair are those of the reference loop.
                 constexpr int PCH = 3;
                 const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
+                // Conservative cull: a sensor of pursuer i can only return a finite value for an object with
+                // d2 <= rad2 + sv^2 <= rad2 + range^2; NEAR[i] marks the objects within that reach plus a 1e-4 relative margin
+                // (d2 is computed exactly as in the test below), everything else would yield INFINITY and is skipped per pass.
+                {
+                    const float thr2 = (rad2 + srange * srange) * 1.0001f + 1e-9f;
+                    const float mx = lane == NP ? ox : part_x, my = lane == NP ? oy : part_y;
+                    for (int i = 0; i < Np; ++i) {
+                        const float rx = mx - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), i));
+                        const float ry = my - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), i));
+                        const uint64_t mk = __ballot((lane <= NP) && (rx * rx + ry * ry <= thr2));
+                        if (lane == 0) NEAR[i] = mk;
+                    }
+                    wave_sync();
+                }
 #if MADRL_WW_ABLATE & 1
                 if (d.n_envs < 0)
 #endif
@@ -265,6 +280,7 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                     float sx[PCH], sy[PCH], px[PCH], py[PCH];
                     float feat_d[4][PCH];
                     int arg[4][PCH];
+                    uint64_t reach[PCH];  // wave-uniform: objects in reach of any pursuer of pass q
 #pragma unroll
                     for (int q = 0; q < PCH; ++q) {
                         const int idx = base + 64 * q + lane;
@@ -273,7 +289,16 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                         kk[q] = ok[q] ? idx - ii[q] * K : 0;
                         sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
                         px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
+                        uint64_t u = 0ull;
+                        const int first = base + 64 * q, last = min(first + 63, Np * K - 1);
+                        if (first < Np * K)
+                            for (int i = first / K; i <= last / K; ++i) u |= NEAR[i];
+                        reach[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
+                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
                     }
+                    uint64_t reach_any = 0ull;
+#pragma unroll
+                    for (int q = 0; q < PCH; ++q) reach_any |= reach[q];
 #pragma unroll
                     for (int cls = 0; cls < 4; ++cls) {
                         const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
@@ -284,10 +309,13 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                         for (int q = 0; q < PCH; ++q) { b[q] = INFINITY; bi[q] = 0; }
 #pragma nounroll
                         for (int m = 0; m < cnt; ++m) {
+                            const int bit = cls == 0 ? NP : lo + m;
+                            if (!((reach_any >> bit) & 1ull)) continue;
                             const float qx = cls == 0 ? ox : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), lo + m));
                             const float qy = cls == 0 ? oy : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), lo + m));
 #pragma unroll
                             for (int q = 0; q < PCH; ++q) {
+                                if (!((reach[q] >> bit) & 1ull)) continue;
                                 const float rx = qx - px[q], ry = qy - py[q];
                                 float sv = sx[q] * rx + sy[q] * ry;
                                 const float d2 = rx * rx + ry * ry;
@@ -490,7 +518,7 @@ void ww_layout(const madrl_waterworld_config *c, WwDev *d) {
 
 size_t ww_lds_bytes(const WwDev &d) {
     size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)d.Np * d.D, 4) + align_up((size_t)2 * d.K, 4);
-    size_t b = f * 4 + (size_t)d.Np * (d.Ne + d.Npo) + 2 * (size_t)d.Ne + d.Npo;
+    size_t b = f * 4 + 8 * (size_t)d.Np + (size_t)d.Np * (d.Ne + d.Npo) + 2 * (size_t)d.Ne + d.Npo;
     return align_up(b, 16);
 }
 
