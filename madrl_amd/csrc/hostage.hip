@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const int OFF_KEY = 4 * NP, OFF_BOMB = 4 * NP + 2, OFF_SAVED = 4 * NP + 4, OFF_FLAGS = 4 * NP + 6, OFF_T = 4 * NP + 7, OFF_TICK = 4 * NP + 8;
     float *O = S + ((d.rec_dw + 3) & ~3);              // observation staging [Nr][D]
     float *SEN = O + ((Nr * D + 3) & ~3);              // sensor unit vectors [K][2]
-    uint8_t *COLH = reinterpret_cast<uint8_t *>(SEN + ((2 * K + 3) & ~3));  // [Nr][Nh]
+    uint64_t *NEAR = reinterpret_cast<uint64_t *>(SEN + ((2 * K + 3) & ~3));  // per rescuer: particles (bit j), key (bit NP), bomb (bit NP + 1) in sensing reach
+    uint8_t *COLH = reinterpret_cast<uint8_t *>(NEAR + Nr);  // [Nr][Nh]
     uint8_t *COLC = COLH + Nr * Nh;                    // [Nr][Nc]
     uint8_t *FLG = COLC + Nr * Nc;                     // ho_caught[Nh] | ho_enc[Nh] | cr_caught[Nc]
 
@@ -230,12 +231,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     constexpr int PCH = 3;
                     const float srange = d.sensor_range, rad2 = d.radius * d.radius;  // G1
                     const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
+                    // Conservative cull (as in waterworld.hip): NEAR[i] = objects with d2 <= (rad2 + range^2) * (1 + 1e-4); all others
+                    // would yield INFINITY for every sensor of rescuer i and are skipped per pass.
+                    {
+                        const float thr2 = (rad2 + srange * srange) * 1.0001f + 1e-9f;
+                        const float mx = lane == NP ? kx : (lane == NP + 1 ? bx : part_x), my = lane == NP ? ky : (lane == NP + 1 ? by : part_y);
+                        for (int i = 0; i < Nr; ++i) {
+                            const float rx = mx - bcast(part_x, i), ry = my - bcast(part_y, i);
+                            const uint64_t mk = __ballot((lane <= NP + 1) && (rx * rx + ry * ry <= thr2));
+                            if (lane == 0) NEAR[i] = mk;
+                        }
+                        wave_sync();
+                    }
                     for (int base = 0; base < Nr * K; base += 64 * PCH) {
                         int ii[PCH], kk[PCH];
                         bool ok[PCH];
                         float sx[PCH], sy[PCH], px[PCH], py[PCH];
                         float b_cr[PCH], b_ho[PCH], b_ke[PCH], b_bo[PCH];
                         int a_cr[PCH];
+                        uint64_t reach[PCH];  // wave-uniform: objects in reach of any rescuer of pass q
 #pragma unroll
                         for (int q = 0; q < PCH; ++q) {
                             const int idx = base + 64 * q + lane;
@@ -245,7 +259,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                             sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
                             px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
                             b_cr[q] = INFINITY; b_ho[q] = INFINITY; a_cr[q] = 0;
+                            uint64_t u = 0ull;
+                            const int first = base + 64 * q, last = min(first + 63, Nr * K - 1);
+                            if (first < Nr * K)
+                                for (int i = first / K; i <= last / K; ++i) u |= NEAR[i];
+                            reach[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
+                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
                         }
+                        uint64_t reach_any = 0ull;
+#pragma unroll
+                        for (int q = 0; q < PCH; ++q) reach_any |= reach[q];
                         auto sense = [&](int q, float qx, float qy) -> float {
                             const float rx = qx - px[q], ry = qy - py[q];
                             const float sv = sx[q] * rx + sy[q] * ry;
@@ -255,9 +278,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                         };
 #pragma nounroll
                         for (int m = 0; m < Nc; ++m) {
+                            const int bit = Nr + Nh + m;
+                            if (!((reach_any >> bit) & 1ull)) continue;
                             const float qx = bcast(part_x, Nr + Nh + m), qy = bcast(part_y, Nr + Nh + m);
 #pragma unroll
                             for (int q = 0; q < PCH; ++q) {
+                                if (!((reach[q] >> bit) & 1ull)) continue;
                                 const float sv = sense(q, qx, qy);
                                 const bool better = sv < b_cr[q];
                                 b_cr[q] = better ? sv : b_cr[q];
@@ -266,17 +292,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                         }
 #pragma nounroll
                         for (int m = 0; m < Nh; ++m) {
-                            const float qx = bcast(part_x, Nr + m), qy = bcast(part_y, Nr + m);
+                            const int bit = Nr + m;
                             const bool was_saved = (saved >> m) & 1ull;  // mask from before this step's processing (G5, :296)
+                            if (was_saved || !((reach_any >> bit) & 1ull)) continue;
+                            const float qx = bcast(part_x, Nr + m), qy = bcast(part_y, Nr + m);
 #pragma unroll
                             for (int q = 0; q < PCH; ++q) {
+                                if (!((reach[q] >> bit) & 1ull)) continue;
                                 float sv = sense(q, qx, qy);
                                 sv = was_saved ? INFINITY : sv;
                                 b_ho[q] = sv < b_ho[q] ? sv : b_ho[q];
                             }
                         }
 #pragma unroll
-                        for (int q = 0; q < PCH; ++q) { b_ke[q] = sense(q, kx, ky); b_bo[q] = sense(q, bx, by); }
+                        for (int q = 0; q < PCH; ++q) {
+                            b_ke[q] = ((reach[q] >> NP) & 1ull) ? sense(q, kx, ky) : INFINITY;
+                            b_bo[q] = ((reach[q] >> (NP + 1)) & 1ull) ? sense(q, bx, by) : INFINITY;
+                        }
 #pragma unroll
                         for (int q = 0; q < PCH; ++q) {
                             if (!ok[q]) continue;
@@ -447,7 +479,7 @@ void hw_layout(const madrl_hostage_config *c, HwDev *d) {
 
 size_t hw_lds_bytes(const HwDev &d) {
     size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)d.Nr * d.D, 4) + align_up((size_t)2 * d.K, 4);
-    size_t b = f * 4 + (size_t)d.Nr * (d.Nh + d.Nc) + 2 * (size_t)d.Nh + d.Nc;
+    size_t b = f * 4 + 8 * (size_t)d.Nr + (size_t)d.Nr * (d.Nh + d.Nc) + 2 * (size_t)d.Nh + d.Nc;
     return align_up(b, 16);
 }
 
