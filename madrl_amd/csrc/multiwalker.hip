@@ -59,19 +59,13 @@ struct WavePar {
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 template <int MODE>
 __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const MwIO io) {
-    __shared__ mw::Model M;
+    const mw::Model &M = *d.model;
     __shared__ mw::World Wd;
     __shared__ mw::Scratch S;
-    __shared__ float s_obs[mw::MAX_WALKERS * mw::OBS_DIM], s_rew[mw::MAX_WALKERS], s_act[4 * mw::MAX_WALKERS];
+    __shared__ float s_rew[mw::MAX_WALKERS], s_act[4 * mw::MAX_WALKERS];
     __shared__ uint8_t s_done;
     const int lane = threadIdx.x;
     const WavePar par{lane};
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(d.model);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&M);
-        for (int k = lane; k < (int)(sizeof(mw::Model) / 4); k += 64) dst[k] = src[k];
-    }
-    lds_sync();
     const int W = M.W;
     for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
         if (MODE == 0 && io.mask != nullptr && io.mask[env] == 0) continue;
@@ -84,6 +78,7 @@ __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const Mw
         }
         lds_sync();
         const uint32_t gid = d.gid_base + (uint32_t)env;
+        float *s_obs = io.obs + env * W * mw::OBS_DIM;  // observation rows go straight to HBM (no LDS staging: 512 B less per workgroup)
         if (MODE == 1) {
             mw::env_step(M, d.cfg, Wd, S, par, gid, s_act, s_obs, s_rew, &s_done);   // all lanes cooperate
             if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) s_done |= 2;
@@ -98,7 +93,6 @@ __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const Mw
             if (lane == 0) Wd.t = 0;
             lds_sync();
         }
-        for (int k = lane; k < W * mw::OBS_DIM; k += 64) io.obs[env * W * mw::OBS_DIM + k] = s_obs[k];
         if (MODE == 1) {
             if (lane < W) io.rew[env * W + lane] = s_rew[lane];
             if (lane == 0) io.done[env] = (uint8_t)dn;

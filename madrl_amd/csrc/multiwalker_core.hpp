@@ -67,7 +67,7 @@ constexpr int MAXJ = 4 * MAX_WALKERS;
 constexpr int MAXT = TERRAIN_LENGTH * MAX_WALKERS / 8;  // terrain points (:301)
 constexpr int EDGE_SLOTS_SMALL = 6, EDGE_SLOTS_PKG = 36;
 constexpr int MAXSLOT = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
-constexpr int MAXM = 48;  // active manifolds per step (pool)
+constexpr int MAXM = 36;  // active manifolds per step (pool); observed maxima over long random / collapsed rollouts: 18, 25, 34 for 2, 3, 4 walkers
 
 struct V2 { float x, y; };
 MW_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }

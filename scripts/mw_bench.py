@@ -8,8 +8,9 @@ dev = torch.device("cuda:0"); N, W = 16384, 3
 env = BatchedMultiWalkerEnv(n_walkers=W, n_envs=N, device=dev, seed=0, auto_reset=True, max_steps=500)
 acts = [(torch.rand((N, W, 4), device=dev) * 2 - 1).contiguous() for _ in range(4)]
 env.reset()
-for blocks in (1024, 2048, 2560, 4096, 16384):
+for blocks in [int(a) for a in sys.argv[1:] if a.isdigit()] or (512, 1024, 2048, 4096):
     env.set_launch(blocks)
+    env.reset()   # same simulation phase for every launch shape (the work per step grows as walkers fall)
     for i in range(3): env.step(acts[i % 4])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
