@@ -452,7 +452,8 @@ int hw_validate(const madrl_hostage_config *c) {
     if (c->struct_size != (int32_t)sizeof(madrl_hostage_config))
         return fail(MADRL_EINVAL, "madrl_hostage_config.struct_size=%d, library expects %d", c->struct_size, (int)sizeof(madrl_hostage_config));
     if (c->n_good < 1 || c->n_hostages < 1 || c->n_bad < 1) return fail(MADRL_EINVAL, "n_good, n_hostages, n_bad must be >= 1");
-    if (c->n_good + c->n_hostages + c->n_bad > 62) return fail(MADRL_EINVAL, "at most 62 particles per env (one wavefront per env)");
+    // one wavefront per env; the packed record (4 * NP + 9 dwords) is prefetched as 4 dwords per lane
+    if (c->n_good + c->n_hostages + c->n_bad > 61) return fail(MADRL_EINVAL, "at most 61 particles per env (one wavefront per env)");
     if (2 * c->n_good > 64) return fail(MADRL_EINVAL, "n_good must be <= 32");
     if (c->n_sensors < 1 || c->n_sensors > 256) return fail(MADRL_EINVAL, "n_sensors must be in 1..256");
     if (c->n_coop_save < 1) return fail(MADRL_EINVAL, "n_coop_save must be >= 1");

@@ -1,0 +1,76 @@
+"""GPU tests (-m gpu): edge cases of the particle envs -- maximum particle counts (62 per env: one wavefront), many sensors,
+tiny and ragged batches, configurations the library must refuse -- against the float32 oracles."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run_ww(kw, N, T, seed):
+    from madrl_amd.waterworld import BatchedMAWaterWorld
+    from oracle import waterworld as ww
+    env = BatchedMAWaterWorld(n_envs=N, device=DEV, seed=seed, max_steps=15, auto_reset=False, **kw)
+    orc = ww.WaterworldOracle(n_envs=N, seed=seed, max_steps=15, dtype=np.float32, **kw)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    rng = np.random.RandomState(seed)
+    Np = kw["n_pursuers"]
+    for t in range(T):
+        a = rng.uniform(-1, 1, (N, Np, 2)).astype(np.float32)
+        o, r, d, info = env.step(a)
+        oo, orr, od, oi = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), orr), t
+        assert np.array_equal(d.cpu().numpy(), od != 0) and np.array_equal(info["evcatches"].cpu().numpy(), oi[:, 0])
+        if od.any():
+            m = od != 0
+            assert np.array_equal(env.reset(mask=m).cpu().numpy()[m], orc.reset(mask=m.astype(np.uint8))[m])
+
+
+def test_waterworld_maximum_particles_and_ragged_batches():
+    big = dict(n_pursuers=12, n_evaders=25, n_poison=25, n_coop=3, n_sensors=16, radius=0.03, ev_speed=0.03, action_scale=0.03)  # 62 particles
+    _run_ww(big, N=65, T=40, seed=1)           # 65 envs: one more than a wavefront's worth of workgroups per pass
+    _run_ww(dict(n_pursuers=1, n_evaders=1, n_poison=1, n_coop=1, n_sensors=1), N=1, T=40, seed=2)   # the smallest env there is
+    _run_ww(dict(n_pursuers=2, n_evaders=3, n_poison=2, n_coop=2, n_sensors=200, sensor_range=0.5), N=3, T=30, seed=3)  # many sensors: 7 chunks of pairs
+
+
+def test_hostage_maximum_particles_and_tiny_batch():
+    from madrl_amd.hostage import BatchedContinuousHostageWorld
+    from oracle import hostage as ho
+    for (args, N, kw) in (((10, 30, 21, 3, 2), 33, dict(n_sensors=8, action_scale=0.03, bad_speed=0.03, radius=0.03)),
+                          ((1, 1, 1, 1, 1), 1, dict(n_sensors=2))):
+        env = BatchedContinuousHostageWorld(*args, n_envs=N, device=DEV, seed=4, max_steps=20, **kw)
+        orc = ho.HostageOracle(*args, n_envs=N, seed=4, max_steps=20, dtype=np.float32, **kw)
+        assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+        rng = np.random.RandomState(0)
+        for t in range(45):
+            a = rng.uniform(-1, 1, (N, args[0], 2)).astype(np.float32)
+            o, r, d, info = env.step(a)
+            oo, orr, od, oi = orc.step(a)
+            assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), orr), t
+            assert np.array_equal(d.cpu().numpy(), od != 0)
+            if od.any():
+                m = od != 0
+                assert np.array_equal(env.reset(mask=m).cpu().numpy()[m], orc.reset(mask=m.astype(np.uint8))[m])
+
+
+def test_configurations_the_library_refuses():
+    from madrl_amd import _lib
+    from madrl_amd.waterworld import BatchedMAWaterWorld
+    from madrl_amd.hostage import BatchedContinuousHostageWorld
+    from madrl_amd.multiwalker import BatchedMultiWalkerEnv
+    with pytest.raises(_lib.MadrlError, match="62 particles"):
+        BatchedMAWaterWorld(13, 25, n_poison=25, n_envs=4, device=DEV)
+    with pytest.raises(_lib.MadrlError, match="LDS"):
+        BatchedMAWaterWorld(12, 25, n_poison=25, n_sensors=256, n_envs=4, device=DEV)   # 12 x 1795 floats of observation staging
+    with pytest.raises(_lib.MadrlError, match="n_sensors"):
+        BatchedMAWaterWorld(2, 2, n_sensors=300, n_envs=4, device=DEV)
+    with pytest.raises(_lib.MadrlError, match="61 particles"):
+        BatchedContinuousHostageWorld(10, 30, 22, 2, 2, n_envs=4, device=DEV)
+    with pytest.raises(_lib.MadrlError, match="n_walkers"):
+        BatchedMultiWalkerEnv(n_walkers=5, n_envs=4, device=DEV)
+    with pytest.raises(_lib.MadrlError, match="no CPU path"):
+        BatchedMAWaterWorld(2, 2, n_envs=4, device="cpu")
+    env = BatchedMAWaterWorld(2, 2, n_envs=4, device=DEV)
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros(4, 3, 2, device=DEV))      # wrong action shape (waterworld.py:227)
