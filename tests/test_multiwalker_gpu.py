@@ -21,7 +21,7 @@ def _mk(n_envs, **kw):
     return BatchedMultiWalkerEnv(n_envs=n_envs, device=DEV, **kw)
 
 
-@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local")])
+@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local")])
 def test_hip_matches_cpu_build_step_by_step(n_walkers, reward_mech):
     from oracle import multiwalker as mwo
     N, T = 96, 70
