@@ -122,9 +122,12 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
     uint32_t *s_misc = s_term + ((d.ntw + 3) & ~3);                    // [0..3] header, [4] removed
     int32_t *s_kpre = reinterpret_cast<int32_t *>(s_misc + 8);         // P ints (pre-move counts)
     double *s_rew = reinterpret_cast<double *>(s_kpre + ((d.P + 3) & ~3));  // P doubles
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_rew + ((d.P + 1) & ~1));  // D slot codes (float4 observation path)
 
     // ---- once per workgroup: value table and this thread's observation slot codes
     for (int k = tid; k < 256; k += nthr) s_vtab[k] = d.vtab[k];
+    const bool vec4 = (d.D & 3) == 0;  // rows are whole float4s (always for odd obs_range)
+    if (vec4) for (int k = tid; k < d.D; k += nthr) s_code[k] = d.codes[k];
     uint32_t code[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -165,7 +168,57 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
         // window origin) feeds it.  Stores are lane-contiguous dwords; cells of the count
         // layers outside the map read 0xFF and are NOT stored (reference leaves them stale).
         auto write_obs = [&]() {
+#if defined(MADRL_ABLATE) && (MADRL_ABLATE & 8)
+            if (d.n_envs >= 0) return;
+#endif
             float *orow = io.obs + env * (int64_t)d.P * d.D;
+            if (vec4) {
+                // float4 path (same scheme as the wave kernel): the P*D/4 float4 slots of the env are spread over the threads;
+                // a slot without stale cells is ONE non-temporal 16-byte store, a slot with stale cells falls back to masked
+                // dword stores (plain, merged in L2).  One float4 instruction touches each 64-byte chunk once, where the
+                // per-pursuer dword rows re-touch the row tails (scripts/ubench/vmem_issue.hip).
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const int DV = d.D >> 2, NQ = d.P * DV;
+                int p = tid / DV, f = tid - p * DV;
+                const int dp = nthr / DV, df = nthr - dp * DV;
+                for (int q = tid; q < NQ; q += nthr) {
+                    const int base = (s_ax[p] - obs_off + pad) * GW + (s_ay[p] - obs_off + pad);
+                    float val[4];
+                    bool keep[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t c = s_code[4 * f + k];
+                        const uint32_t kind = c >> 24;
+                        keep[k] = true;
+                        val[k] = 0.0f;
+                        if (kind == K_GRID) {
+                            const uint32_t v = g_map[base + (int)(c & 0xFFFFFFu)];
+                            keep[k] = v != PAD_CNT;
+                            val[k] = s_vtab[v];
+                        } else if (kind == K_ID) {
+                            val[k] = (float)((double)p / (double)d.P);  // :440-445
+                        } else if (kind == K_FILL) {
+                            val[k] = d.fill32;  // even obs_range: never-copied channel-0 cells
+                        } else {
+                            keep[k] = false;
+                        }
+                    }
+                    float *o = orow + 4 * (int64_t)q;
+                    if (keep[0] & keep[1] & keep[2] & keep[3]) {
+                        const v4f v = {val[0], val[1], val[2], val[3]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(o));
+                    } else {
+                        if (keep[0]) o[0] = val[0];
+                        if (keep[1]) o[1] = val[1];
+                        if (keep[2]) o[2] = val[2];
+                        if (keep[3]) o[3] = val[3];
+                    }
+                    f += df; p += dp;
+                    if (f >= DV) { f -= DV; ++p; }
+                }
+                return;
+            }
+            // dword path (rows that are not whole float4s: even obs_range with flatten)
             for (int p = 0; p < d.P; ++p) {
                 const int base = (s_ax[p] - obs_off + pad) * GW + (s_ay[p] - obs_off + pad);
 #pragma unroll
@@ -609,7 +662,8 @@ size_t lds_bytes_for(const PursuitDev &d) {
     b += 4 * align_up((size_t)d.ngw, 4) + 4 * align_up((size_t)d.ntw, 4) + 32;
     b += 4 * align_up((size_t)d.P, 4);
     b = align_up(b, 8);
-    b += 8 * (size_t)d.P;
+    b += 8 * align_up((size_t)d.P, 2);
+    b += 4 * align_up((size_t)d.D, 4);  // slot codes
     return align_up(b, 16);
 }
 

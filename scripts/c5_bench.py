@@ -14,7 +14,7 @@ L = _lib.lib(); h = env._handle
 ptrs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._removed)]
 env.reset()
 B = 4 * P + 4 * P * 148 + 4 * P + 5 + 2 * (env._state.numel() // N)
-for threads, blocks in ((64, 0), (128, 0), (128, 8192), (192, 0), (256, 0)):
+for threads, blocks in ((64, 0), (64, 8192), (128, 0)):
     env.set_launch(threads, blocks)
     for i in range(10): _lib.check(L.madrl_pursuit_step(h, _lib.ptr(acts[i % 8]), None, *ptrs, _lib.current_stream(dev)))
     torch.cuda.synchronize()
