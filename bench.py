@@ -194,7 +194,7 @@ def bench_other(args, rank, local_rank, world, dev):
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                             "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per,
                             "binding_resource": binding}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
             out["cpu_baseline"] = cpu()
         print(json.dumps(out))
     if world > 1:
@@ -343,7 +343,7 @@ def main():
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": bytes_per},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
             out["cpu_baseline"] = cpu_baseline(maps, kw)
         print(json.dumps(out))
     if world > 1:
