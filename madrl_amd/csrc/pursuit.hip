@@ -539,6 +539,7 @@ struct madrl_pursuit {
     // one-wavefront-per-env fast path (pursuit_wave.hpp), when a specialisation matches
     const WaveEntry *wave;
     madrl::pw::WaveDev wdev;
+    uint64_t step_count = 0;
     void *wtables;
     int kernel_kind;  // MADRL_KERNEL_AUTO / _GENERIC / _WAVE (requested)
 };
@@ -687,7 +688,18 @@ int launch(const madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) 
         w.inj_eact = io.inj_eact; w.obs = io.obs; w.rew = io.rew; w.done = io.done; w.removed = io.removed;
         int64_t blocks = h->max_blocks > 0 ? h->max_blocks : WAVE_DEFAULT_BLOCKS;
         if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
-        h->wave->launch(h->wdev, w, mode, blocks, s);
+        // Large batches: successive step launches walk the env range in opposite directions, so the rows written last by
+        // one step are the first ones touched by the next while they are still in the 256 MB memory-side cache.  Measured
+        // (scripts/sweep_wave.py, C2 shape): forward-only holds 7.2e8 env-steps/s up to 73 728 envs and collapses beyond
+        // (98 304: 4.7e8, 131 072: 4.5e8); alternating holds 6.4-6.7e8 from 81 920 to 131 072 but costs 6 % below.  Hence
+        // the switch at ~375 MB of rows + records per launch.  Env results do not depend on the processing order.
+        pw::WaveDev wd = h->wdev;
+        if (mode == 1) {
+            bool alternate = (double)h->dev.n_envs * (4.0 * h->dev.P * h->dev.D + 2.0 * h->dev.rec_bytes) > 375e6;
+            if (const char *e = getenv("MADRL_PURSUIT_WALK")) alternate = (e[0] == 'a');  // "alternate" / "forward": experiments, tests
+            if (alternate) wd.reverse = (int32_t)(const_cast<madrl_pursuit *>(h)->step_count++ & 1);
+        }
+        h->wave->launch(wd, w, mode, blocks, s);
         MADRL_HIP_TRY(hipGetLastError());
         return MADRL_OK;
     }

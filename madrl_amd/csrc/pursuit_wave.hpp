@@ -38,6 +38,7 @@ constexpr uint32_t CAUGHT = 0x10000u;    // added to an evader-count cell by a c
 struct WaveDev {
     int32_t n_catch, surround, reward_global, sample_maps, n_maps, max_steps, auto_reset;
     int32_t fmap_stride;  // dwords per map entry in fmaps
+    int32_t reverse;      // 1: walk the envs from the last to the first (see launch() in pursuit.hip)
     uint32_t k0, k1, gid_base;
     double catchr, term_pursuit, urgency, cw;
     int64_t n_envs;
@@ -231,22 +232,25 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
     };
     uint32_t cur_rec = 0;
     int cur_act = 4;
+    auto phys = [&](int64_t e) -> int64_t { return d.reverse ? d.n_envs - 1 - e : e; };
     if ((int64_t)blockIdx.x < d.n_envs) {
-        cur_rec = fetch_rec(blockIdx.x);
-        cur_act = fetch_act(blockIdx.x);
+        cur_rec = fetch_rec(phys(blockIdx.x));
+        cur_act = fetch_act(phys(blockIdx.x));
     }
     asm volatile("" : "+v"(cur_rec), "+v"(cur_act));  // loads complete before the loop (see hinge below)
     wave_sync();
 
-    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
-        const int64_t nenv = env + gridDim.x;
+    for (int64_t e = blockIdx.x; e < d.n_envs; e += gridDim.x) {
+        const int64_t env = phys(e);
+        const bool has_next = e + gridDim.x < d.n_envs;
+        const int64_t nenv = phys(has_next ? e + gridDim.x : e);
         uint32_t nxt_rec = 0;
         int nxt_act = 4;
 #if MADRL_ABLATE & 64
         nxt_rec = cur_rec ^ (uint32_t)(fresh(lane) == 0);  // no loads in the loop: is the in-order vmcnt drain what serialises a wave?
         nxt_act = cur_act;
 #else
-        if (nenv < d.n_envs) {
+        if (has_next) {
             nxt_rec = fetch_rec(nenv);
             nxt_act = fetch_act(nenv);
         }

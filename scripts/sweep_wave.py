@@ -6,7 +6,7 @@ from madrl_amd.maps import rectangle_map
 from madrl_amd.pursuit import BatchedPursuitEvade
 from madrl_amd import _lib
 dev = torch.device("cuda:0")
-N, P = 65536, 8
+N, P = int(os.environ.get("MADRL_N", "65536")), 8
 env = BatchedPursuitEvade([rectangle_map(16, 16)], n_envs=N, device=dev, seed=0, max_steps=500, auto_reset=True,
                           n_pursuers=P, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local")
 acts = [torch.randint(0, 5, (N, P), device=dev, dtype=torch.int32) for _ in range(8)]

@@ -162,6 +162,27 @@ def test_launch_shape_does_not_change_results():
             assert torch.equal(o[2][k], outs[0][2][k]), k
 
 
+def test_walk_direction_does_not_change_results(monkeypatch):
+    """large batches alternate the direction in which a launch walks the envs (memory-side cache reuse); results are the same"""
+    outs = []
+    for walk in ("forward", "alternate"):
+        monkeypatch.setenv("MADRL_PURSUIT_WALK", walk)
+        from madrl_amd.maps import rectangle_map
+        env = _mk([rectangle_map(16, 16)], 4099, seed=21, max_steps=30, auto_reset=True, n_pursuers=8, n_evaders=30, obs_range=7,
+                  n_catch=2, surround=True, flatten=True)
+        assert env.kernel_kind == "wave"
+        env.reset()
+        g = torch.Generator(device="cpu").manual_seed(0)
+        acc = []
+        for t in range(45):
+            a = torch.randint(0, 5, (4099, 8), generator=g, dtype=torch.int32).to(DEV)
+            o, r, d, info = env.step(a)
+            acc.append((o.clone(), r.clone(), d.clone(), info["removed"].clone()))
+        outs.append(acc)
+    for (o1, r1, d1, m1), (o2, r2, d2, m2) in zip(*outs):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(m1, m2)
+
+
 def test_sharding_is_invisible_env_id_base():
     """Env n of a shard with env_id_base=b behaves exactly like env b+n of one big batch
     (this is what makes multi-GPU sharding need no communication)."""
