@@ -61,7 +61,8 @@ typedef struct madrl_pursuit_config {
                               (the sampler's max_path_length, runners/__init__.py:88) */
     int32_t auto_reset;    /* 1: an env whose step ends with done != 0 is reset inside the
                               same launch and its obs row holds the new episode's first obs */
-    int32_t reserved0;
+    int32_t max_opponents; /* 0: fixed n_evaders; > 0: random_opponents with train_pursuit (:177-181): every reset creates
+                              randint(1, max_opponents) evaders (at most n_evaders), the other slots count as gone */
     double catchr;            /* :92 */
     double term_pursuit;      /* :95 */
     double urgency_reward;    /* :98 */
@@ -106,7 +107,8 @@ int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_bloc
 /* Replaces PursuitEvade.reset (pursuit_evade.py:173-207) for every env with mask[n] != 0
  * (mask_dev NULL = all).
  *   inj_pos_dev  int32 [n_envs][P+E][2] or NULL: positions used instead of the rejection
- *                sampler (agent_utils.py:31-47) -- parity harness hook, pursuers first;
+ *                sampler (agent_utils.py:31-47) -- parity harness hook, pursuers first; an evader
+ *                entry with x < 0 is not created (random_opponents);
  *   inj_map_dev  int32 [n_envs] or NULL: map index used instead of the sample_maps draw;
  *   obs_dev      float32 [n_envs][P][obs_dim], IN/OUT: this buffer is the reference's
  *                persistent `local_obs` (pursuit_evade.py:119-120).  Cells of channels 1-2

@@ -31,7 +31,7 @@ class PursuitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "xs", "ys", "n_pursuers", "n_evaders", "obs_range", "n_catch", "surround",
         "flatten", "include_id", "reward_global", "sample_maps", "n_maps", "max_steps",
-        "auto_reset", "reserved0")] + [(n, C.c_double) for n in (
+        "auto_reset", "max_opponents")] + [(n, C.c_double) for n in (
             "catchr", "term_pursuit", "urgency_reward", "layer_norm", "constraint_window")] + [
                 ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 

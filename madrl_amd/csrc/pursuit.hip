@@ -40,6 +40,7 @@ struct PursuitDev {
     int32_t xs, ys, P, E, A, R, D;
     int32_t pad, GW, GSZ;  // padded grid: width (y extent), bytes per layer (multiple of 16)
     int32_t n_catch, surround, reward_global, sample_maps, n_maps, max_steps, auto_reset;
+    int32_t max_opponents;  // > 0: random_opponents (pursuit_evade.py:177-181)
     int32_t rec_bytes, off_gone, off_term, ngw, ntw;  // state record layout (byte offsets)
     int32_t map_stride;                               // bytes per map entry in `maps`
     uint32_t k0, k1, gid_base;
@@ -408,9 +409,23 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
             const int xlb = (int)(d.xs * sx), xub = (int)(d.xs * (sx + d.cw));
             const int ylb = (int)(d.ys * sy), yub = (int)(d.ys * (sy + d.cw));
+            // random_opponents (train_pursuit, :177-181): this episode has n_create <= E evaders; the slots above are not
+            // created and count as gone.  An injected position with x < 0 marks a slot that is not created.
+            const bool inj = io.inj_pos != nullptr && mode == 0;
+            int n_create = d.E;
+            if (d.max_opponents > 0 && !inj) {
+                const u32x4 r3 = philox4x32_10(gid, tick, 2u, TAG_RESET_ENV, d.k0, d.k1);
+                n_create = min(1 + (int)__umulhi(r3.x, (uint32_t)(d.max_opponents - 1)), d.E);
+            }
             __syncthreads();
             for (int a = tid; a < d.A; a += nthr) {  // create_agents, agent_utils.py:12-28
                 int x = 0, y = 0;
+                if (a >= d.P && (a - d.P >= n_create || (inj && io.inj_pos[(env * d.A + a) * 2] < 0))) {
+                    atomicOr(&s_gone[(a - d.P) >> 5], 1u << ((a - d.P) & 31));
+                    s_ax[a] = 0;
+                    s_ay[a] = 0;
+                    continue;
+                }
                 if (io.inj_pos != nullptr && mode == 0) {
                     x = io.inj_pos[(env * d.A + a) * 2];
                     y = io.inj_pos[(env * d.A + a) * 2 + 1];
@@ -611,6 +626,7 @@ int validate(const madrl_pursuit_config *c) {
     if (!(c->layer_norm > 0.0)) return fail(MADRL_EINVAL, "layer_norm must be > 0");
     if (!(c->constraint_window > 0.0 && c->constraint_window <= 1.0))
         return fail(MADRL_EINVAL, "constraint_window must be in (0,1]");
+    if (c->max_opponents != 0 && c->max_opponents < 2) return fail(MADRL_EINVAL, "max_opponents=%d: random_opponents draws randint(1, max_opponents)", c->max_opponents);
     return MADRL_OK;
 }
 
@@ -630,6 +646,7 @@ void layout(const madrl_pursuit_config *c, PursuitDev *d) {
     d->n_catch = c->n_catch; d->surround = c->surround; d->reward_global = c->reward_global;
     d->sample_maps = c->sample_maps; d->n_maps = c->n_maps; d->max_steps = c->max_steps;
     d->auto_reset = c->auto_reset;
+    d->max_opponents = c->max_opponents;
     d->ngw = (d->E + 31) / 32; if (d->ngw < 1) d->ngw = 1;
     d->ntw = (d->A + 31) / 32;
     d->off_gone = (int)align_up(HDR_BYTES + 2 * (size_t)d->A, 4);
@@ -901,6 +918,7 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             memset(&w, 0, sizeof(w));
             w.n_catch = d.n_catch; w.surround = d.surround; w.reward_global = d.reward_global;
             w.sample_maps = d.sample_maps; w.n_maps = d.n_maps; w.max_steps = d.max_steps; w.auto_reset = d.auto_reset;
+            w.max_opponents = d.max_opponents;
             w.fmap_stride = fstride;
             w.k0 = d.k0; w.k1 = d.k1; w.gid_base = d.gid_base;
             w.catchr = d.catchr; w.term_pursuit = d.term_pursuit; w.urgency = d.urgency; w.cw = d.cw;

@@ -38,6 +38,7 @@ constexpr uint32_t CAUGHT = 0x10000u;    // added to an evader-count cell by a c
 struct WaveDev {
     int32_t n_catch, surround, reward_global, sample_maps, n_maps, max_steps, auto_reset;
     int32_t fmap_stride;  // dwords per map entry in fmaps
+    int32_t max_opponents;  // > 0: random_opponents (pursuit_evade.py:177-181)
     int32_t reverse;      // 1: walk the envs from the last to the first (see launch() in pursuit.hip)
     uint32_t k0, k1, gid_base;
     double catchr, term_pursuit, urgency, cw;
@@ -414,10 +415,20 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                     const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
                     const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + d.cw));
                     const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + d.cw));
+                    // random_opponents (train_pursuit, :177-181): n_create <= E evaders this episode, the slots above are not
+                    // created and count as gone; an injected position with x < 0 marks a slot that is not created
+                    int n_create = E;
+                    if (d.max_opponents > 0 && !inj_pos) {
+                        const u32x4 r3 = philox4x32_10(gid, tick, 2u, TAG_RESET_ENV, k0, k1);
+                        n_create = min(1 + (int)__umulhi(r3.x, (uint32_t)(d.max_opponents - 1)), E);
+                    }
+                    bool exists = false;
                     if (isAgent()) {  // create_agents / feasible_position, agent_utils.py:12-47
+                        exists = isP() || eslot < n_create;
                         if (inj_pos) {
                             x = io.inj_pos[(env * A + lane) * 2];
                             y = io.inj_pos[(env * A + lane) * 2 + 1];
+                            if (!isP() && x < 0) exists = false;
                         } else {
                             for (uint32_t att = 0; att < 1024u; ++att) {
                                 const u32x4 rp = philox4x32_10(gid, tick, (uint32_t)lane, TAG_RESET_POS | (att << 8), k0, k1);
@@ -427,10 +438,16 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                                 if (L[(x + PAD) * GW + y + PAD] == 0u) break;
                             }
                         }
-                        cell = (x + PAD) * GW + y + PAD;
-                        atomicAdd(&layer[cell], 1u);  // :201-203
+                        if (exists) {
+                            cell = (x + PAD) * GW + y + PAD;
+                            atomicAdd(&layer[cell], 1u);  // :201-203
+                        } else {
+                            x = 0;
+                            y = 0;
+                        }
                     }
-                    alive = isAgent();
+                    gone = __ballot(isE() && !exists) >> P;
+                    alive = exists;
                     tick += 1;
                     tstep = 0;
                     wave_sync();

@@ -67,8 +67,8 @@ class BatchedPursuitEvade(AbstractMAEnv):
             if k not in kw:
                 raise TypeError("unknown PursuitEvade kwarg %r" % k)
             kw[k] = kwargs[k]
-        if kw["random_opponents"]:
-            raise NotImplementedError("random_opponents (pursuit_evade.py:177-181) is not supported")
+        if kw["random_opponents"] and int(kw["max_opponents"]) < 2:
+            raise ValueError("random_opponents draws randint(1, max_opponents): max_opponents must be >= 2")  # :179
         if not kw["train_pursuit"]:
             raise NotImplementedError("train_pursuit=False (controlling the evaders) is not supported")
         for k, v in kw.items():
@@ -101,6 +101,8 @@ class BatchedPursuitEvade(AbstractMAEnv):
         c.reward_global = int(self._reward_mech == "global")
         c.sample_maps, c.n_maps = int(bool(self.sample_maps)), int(self.map_pool.shape[0])
         c.max_steps, c.auto_reset = self.max_steps, int(self.auto_reset)
+        # :177-181 (train_pursuit): every reset creates randint(1, max_opponents) evaders, at most the n_evaders slots
+        c.max_opponents = int(self.max_opponents) if self.random_opponents else 0
         c.catchr, c.term_pursuit = float(self.catchr), float(self.term_pursuit)
         c.urgency_reward, c.layer_norm = float(self.urgency_reward), float(self.layer_norm)
         c.constraint_window = float(self.constraint_window)

@@ -53,6 +53,8 @@ def free_cells(m):
 
 def run_scenario(R, name, maps, cfg, episodes, steps_per_episode, seed, in_building=False,
                  chase=0.5, extra_after_done=3):
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:
+        return   # `make_golden_pursuit.py <name> ...` regenerates only the named scenarios
     PursuitEvade = R["PursuitEvade"]
     from madrl_environments.pursuit.utils import agent_utils
 
@@ -62,6 +64,8 @@ def run_scenario(R, name, maps, cfg, episodes, steps_per_episode, seed, in_build
     kwargs = dict(cfg)
     kwargs["evader_controller"] = ctrl
     env = PursuitEvade(maps, **kwargs)
+    if kwargs.get("random_opponents"):
+        env.seed(seed)   # the evader count comes from the env's own generator
     P, E = env.n_pursuers, env.n_evaders
     xs, ys = env.xs, env.ys
     flatten = kwargs.get("flatten", True)
@@ -81,12 +85,15 @@ def run_scenario(R, name, maps, cfg, episodes, steps_per_episode, seed, in_build
         pp = np.array([env.pursuer_layer.get_position(i).copy() for i in range(P)], dtype=np.int32)
         pe = -np.ones((E, 2), dtype=np.int32)
         k = 0
+        gone = env.evaders_gone.astype(np.uint8).copy()
         for i in range(E):
-            if not env.evaders_gone[i]:
+            if i >= env.n_evaders:      # random_opponents: this episode has fewer evaders; absent slots count as gone
+                gone[i] = 1
+            elif not env.evaders_gone[i]:
                 pe[i] = env.evader_layer.get_position(k)
                 k += 1
         assert k == env.evader_layer.n_agents()
-        return pp, pe, env.evaders_gone.astype(np.uint8).copy()
+        return pp, pe, gone
 
     def obs_array(obslist):
         if flatten:
@@ -113,8 +120,17 @@ def run_scenario(R, name, maps, cfg, episodes, steps_per_episode, seed, in_build
                 # cluster pursuers near evaders so that catches happen
                 ie = cells[rng.randint(min(len(cells), 6), size=E)]
                 ip = cells[rng.randint(min(len(cells), 8), size=P)]
-            pos_queue[:] = [tuple(int(v) for v in p) for p in ip] + [tuple(int(v) for v in p) for p in ie]
+            n_ev = E
+            if getattr(env, "random_opponents", False):
+                # peek the evader count reset() will draw from the env's own generator (pursuit_evade.py:177-181)
+                st2 = env.np_random.get_state()
+                n_ev = int(env.np_random.randint(1, env.max_opponents))
+                env.np_random.set_state(st2)
+                assert n_ev <= E
+                ie = ie.copy(); ie[n_ev:] = -1      # slots that are not created this episode
+            pos_queue[:] = [tuple(int(v) for v in p) for p in ip] + [tuple(int(v) for v in p) for p in ie[:n_ev]]
             obs = env.reset()
+            assert env.n_evaders == n_ev
             assert not pos_queue
             assert env.map_matrix is maps[mid]
             pp, pe, ge = snapshot()
@@ -129,7 +145,7 @@ def run_scenario(R, name, maps, cfg, episodes, steps_per_episode, seed, in_build
             for t in range(steps_per_episode):
                 # pursuer actions: random, biased to chase the nearest remaining evader
                 ap = rng.randint(5, size=P).astype(np.int32)
-                alive = [i for i in range(E) if not env.evaders_gone[i]]
+                alive = [i for i in range(env.n_evaders) if not env.evaders_gone[i]]
                 if alive:
                     for j in range(P):
                         if rng.rand() < chase:
@@ -176,6 +192,7 @@ def run_scenario(R, name, maps, cfg, episodes, steps_per_episode, seed, in_build
     out["rew_f64"] = out.pop("rew")
     out["maps"] = np.stack(maps).astype(np.int8)
     scalars = dict(xs=xs, ys=ys, n_pursuers=P, n_evaders=E, obs_range=env.obs_range,
+                   random_opponents=int(getattr(env, "random_opponents", False)), max_opponents=int(getattr(env, "max_opponents", 10)),
                    n_catch=env.n_catch, surround=int(env.surround), flatten=int(flatten),
                    include_id=int(env.include_id), reward_global=int(env.reward_mech == "global"),
                    sample_maps=int(env.sample_maps))
@@ -251,6 +268,12 @@ def main():
                  dict(n_evaders=90, n_pursuers=70, obs_range=9, n_catch=3, surround=True,
                       flatten=True, reward_mech="global"), episodes=2, steps_per_episode=25,
                  seed=11)
+    # L: random_opponents (train_pursuit): the number of evaders is redrawn by every reset (pursuit_evade.py:177-181);
+    #    n_evaders >= max_opponents - 1, otherwise the reference indexes past evaders_gone (:138, :467)
+    run_scenario(R, "random_opponents", [rect16],
+                 dict(n_evaders=9, n_pursuers=5, obs_range=5, n_catch=2, surround=True, flatten=True,
+                      reward_mech="local", random_opponents=True, max_opponents=10), episodes=10,
+                 steps_per_episode=30, seed=12, chase=0.8)
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ def lib():
 class PoConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "xs", "ys", "n_pursuers", "n_evaders", "obs_range", "n_catch", "surround", "flatten",
-        "include_id", "reward_global", "sample_maps", "n_maps")] + [(n, C.c_double) for n in (
+        "include_id", "reward_global", "sample_maps", "n_maps", "max_opponents", "pad_")] + [(n, C.c_double) for n in (
             "catchr", "term_pursuit", "urgency_reward", "layer_norm", "constraint_window")]
 
 
@@ -63,6 +63,8 @@ class PursuitOracle(object):
         maps = np.ascontiguousarray(np.stack([np.asarray(m) for m in map_pool]).astype(np.int8))
         self.maps = maps
         n_maps, xs, ys = maps.shape
+        random_opp, mo = bool(kw.pop("random_opponents", False)), int(kw.pop("max_opponents", 10))
+        max_opp = mo if random_opp else 0   # pursuit_evade.py:177-181 (train_pursuit)
         self.cfg = PoConfig(
             xs=xs, ys=ys, n_pursuers=kw.pop("n_pursuers", 1), n_evaders=kw.pop("n_evaders", 1),
             obs_range=kw.pop("obs_range", 3), n_catch=kw.pop("n_catch", 2),
@@ -70,6 +72,7 @@ class PursuitOracle(object):
             include_id=int(kw.pop("include_id", True)),
             reward_global=int(kw.pop("reward_mech", "global") == "global"),
             sample_maps=int(kw.pop("sample_maps", False)), n_maps=n_maps,
+            max_opponents=max_opp,
             catchr=kw.pop("catchr", 0.01), term_pursuit=kw.pop("term_pursuit", 5.0),
             urgency_reward=kw.pop("urgency_reward", 0.0), layer_norm=kw.pop("layer_norm", 10),
             constraint_window=kw.pop("constraint_window", 1.0))
@@ -137,4 +140,6 @@ def config_from_golden(g):
                 reward_mech="global" if int(g["cfg_reward_global"]) else "local",
                 sample_maps=bool(g["cfg_sample_maps"]), catchr=float(g["cfg_catchr"]),
                 term_pursuit=float(g["cfg_term_pursuit"]),
-                urgency_reward=float(g["cfg_urgency_reward"]), layer_norm=float(g["cfg_layer_norm"]))
+                urgency_reward=float(g["cfg_urgency_reward"]), layer_norm=float(g["cfg_layer_norm"]),
+                **(dict(random_opponents=True, max_opponents=int(g["cfg_max_opponents"]))
+                   if "cfg_random_opponents" in g and int(g["cfg_random_opponents"]) else {}))

@@ -45,6 +45,9 @@ def test_golden_covers_the_quirks():
     assert files["pursuit_c1_colocate_hwc"]["removed"].sum() > 5
     g = files["pursuit_pool16_sample_maps"]
     assert len(np.unique(g["map_id"])) > 3
+    g = files["pursuit_random_opponents"]      # :177-181: the evader count is redrawn by every reset
+    created = [(g["init_e"][t][:, 0] >= 0).sum() for t in np.where(g["op"] == 0)[0]]
+    assert len(set(created)) >= 4 and min(created) >= 1 and max(created) < int(g["cfg_max_opponents"])
     # Q2: some out-of-map cell of channel 1/2 holds a non-zero (stale) value in a golden obs
     g = files["pursuit_c1_surround_local"]
     R = int(g["cfg_obs_range"])

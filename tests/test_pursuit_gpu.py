@@ -29,7 +29,7 @@ def _cmp_state(st_gpu, st_ref, msg=""):
 
 WAVE_GOLDEN = {"pursuit_c1_surround_local", "pursuit_c1_surround_global", "pursuit_c1_colocate_hwc",
                "pursuit_pool16_sample_maps", "pursuit_tiny5_dense", "pursuit_in_building",
-               "pursuit_nonsquare_12x20", "pursuit_window_gt_map"}
+               "pursuit_nonsquare_12x20", "pursuit_window_gt_map", "pursuit_random_opponents"}
 
 
 @pytest.mark.parametrize("path", pursuit_golden_files(), ids=golden_id)
@@ -80,6 +80,8 @@ CASES = {
     "pool16": dict(maps="pool16", n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True,
                    reward_mech="local", sample_maps=True),
     "c5_32x32": dict(maps="rect32", n_pursuers=16, n_evaders=60, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local"),
+    "c2_random_opponents": dict(maps="rect16", n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True,
+                                reward_mech="local", random_opponents=True, max_opponents=25),
     "tiny_window": dict(maps="open6", n_pursuers=5, n_evaders=4, obs_range=5, n_catch=2, surround=True, flatten=True,
                         reward_mech="global", constraint_window=0.5),
 }
