@@ -257,7 +257,7 @@ typedef struct madrl_multiwalker_config {
     int32_t n_walkers;        /* 1..4 */
     int32_t reward_global;    /* reward_mech != 'local' (:426-428) */
     int32_t terminate_on_fall;
-    int32_t one_hot;          /* must be 0 */
+    int32_t one_hot;          /* 1: the id is np.eye(MAX_AGENTS = 40)[i] instead of i / n_walkers (:397-400): obs_dim 71 */
     int32_t max_steps;        /* 0 = none; else done bit1 when the episode reaches it */
     int32_t auto_reset;
     int32_t reserved0;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const Mw
         }
         lds_sync();
         const uint32_t gid = d.gid_base + (uint32_t)env;
-        float *s_obs = io.obs + env * W * mw::OBS_DIM;  // observation rows go straight to HBM (no LDS staging: 512 B less per workgroup)
+        float *s_obs = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM (no LDS staging: 512 B less per workgroup)
         if (MODE == 1) {
             mw::env_step(M, d.cfg, Wd, S, par, gid, s_act, s_obs, s_rew, &s_done);   // all lanes cooperate
             if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) s_done |= 2;
@@ -143,7 +143,6 @@ int mw_validate(const madrl_multiwalker_config *c) {
                     (int)sizeof(madrl_multiwalker_config));
     if (c->n_walkers < 1 || c->n_walkers > mw::MAX_WALKERS)
         return fail(MADRL_EINVAL, "n_walkers=%d unsupported (1..%d)", c->n_walkers, mw::MAX_WALKERS);
-    if (c->one_hot) return fail(MADRL_EINVAL, "one_hot ids (multi_walker.py:397-398) are not supported");
     return MADRL_OK;
 }
 
@@ -166,7 +165,7 @@ int madrl_multiwalker_obs_dim(const madrl_multiwalker_config *cfg, int32_t *out_
     int rc = mw_validate(cfg);
     if (rc) return rc;
     if (!out_dim) return fail(MADRL_EINVAL, "out_dim is NULL");
-    *out_dim = mw::OBS_DIM;
+    *out_dim = mw::OBS_DIM - 1 + (cfg->one_hot ? mw::MAX_AGENTS_ID : 1);
     return MADRL_OK;
 }
 
@@ -204,7 +203,7 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     MwDev &d = h->dev;
     memset(&d, 0, sizeof(d));
     d.cfg.n_walkers = cfg->n_walkers; d.cfg.reward_global = cfg->reward_global; d.cfg.terminate_on_fall = cfg->terminate_on_fall;
-    d.cfg.one_hot = 0; d.cfg.max_steps = cfg->max_steps; d.cfg.auto_reset = cfg->auto_reset;
+    d.cfg.one_hot = cfg->one_hot ? 1 : 0; d.cfg.max_steps = cfg->max_steps; d.cfg.auto_reset = cfg->auto_reset;
     d.cfg.position_noise = (float)cfg->position_noise; d.cfg.angle_noise = (float)cfg->angle_noise;
     d.cfg.forward_reward = (float)cfg->forward_reward; d.cfg.fall_reward = (float)cfg->fall_reward;
     d.cfg.drop_reward = (float)cfg->drop_reward;

@@ -1087,7 +1087,9 @@ struct EnvCfg {
     float position_noise, angle_noise, forward_reward, fall_reward, drop_reward;
     uint32_t k0, k1;
 };
-constexpr int OBS_DIM = 24 + 4 + 3 + 1;  // :243 (one_hot unsupported)
+constexpr int OBS_DIM = 24 + 4 + 3 + 1;  // :243
+constexpr int MAX_AGENTS_ID = 40;      // MAX_AGENTS (:17): width of the one-hot id (:397-398)
+MW_HD int obs_dim_of(const EnvCfg &C) { return OBS_DIM - 1 + (C.one_hot ? MAX_AGENTS_ID : 1); }  // :241-243
 
 MW_HD void philox10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
     for (int r = 0; r < 10; ++r) {
@@ -1199,7 +1201,7 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid,
     for (int w = 0; w < M.W; ++w) {
         const Body &hull = Wd.b[hull_of(w)];
         const V2 pos = hull_pos[w];
-        float *o = obs + w * OBS_DIM;
+        float *o = obs + w * obs_dim_of(C);
         // get_observation (:205-237)
         o[0] = hull.a;
         o[1] = 2.0f * hull.w / FPS;
@@ -1247,7 +1249,8 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid,
         o[n++] = xd + C.position_noise * nz[4];
         o[n++] = yd + C.position_noise * nz[5];
         o[n++] = pkg.a + C.angle_noise * nz[6];
-        o[n++] = (float)w / (float)M.W;  // :400
+        if (C.one_hot) { for (int k = 0; k < MAX_AGENTS_ID; ++k) o[n++] = (k == w) ? 1.0f : 0.0f; }  // np.eye(MAX_AGENTS)[i] :397-398
+        else o[n++] = (float)w / (float)M.W;  // :400
         // shaping (:403-407)
         const float shaping = 0.0f - 5.0f * fabsf(o[0]);
         rewards[w] = shaping - Wd.prev_shaping[w];

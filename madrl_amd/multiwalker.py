@@ -22,9 +22,12 @@ from .spaces import Box
 class BipedalWalker(Agent):
     """multi_walker.py:87-247 (spaces only)."""
 
+    def __init__(self, obs_dim=24 + 4 + 3 + 1):
+        self._obs_dim = obs_dim
+
     @property
     def observation_space(self):
-        return Box(low=-np.inf, high=np.inf, shape=(24 + 4 + 3 + 1,))  # :243
+        return Box(low=-np.inf, high=np.inf, shape=(self._obs_dim,))  # :241-243: 24 + 4 + 3 + (MAX_AGENTS if one_hot else 1)
 
     @property
     def action_space(self):
@@ -38,8 +41,6 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
                  n_envs=1, device="cuda:0", seed=0, env_id_base=0, max_steps=0, auto_reset=False, max_blocks=0):
         self._ctor = dict(locals())
         self._ctor.pop("self"); self._ctor.pop("__class__", None)
-        if one_hot:
-            raise NotImplementedError("one_hot ids (multi_walker.py:397-398) are not supported")
         self.n_walkers, self.position_noise, self.angle_noise = n_walkers, position_noise, angle_noise
         self._reward_mech, self.forward_reward, self.fall_reward = reward_mech, forward_reward, fall_reward
         self.drop_reward, self.terminate_on_fall, self.one_hot = drop_reward, terminate_on_fall, one_hot
@@ -53,7 +54,7 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         c = _lib.MultiWalkerConfig()
         c.struct_size = C.sizeof(_lib.MultiWalkerConfig)
         c.n_walkers, c.reward_global = int(self.n_walkers), int(self._reward_mech != "local")
-        c.terminate_on_fall, c.one_hot = int(bool(self.terminate_on_fall)), 0
+        c.terminate_on_fall, c.one_hot = int(bool(self.terminate_on_fall)), int(bool(self.one_hot))
         c.max_steps, c.auto_reset = self.max_steps, int(self.auto_reset)
         c.position_noise, c.angle_noise = float(self.position_noise), float(self.angle_noise)
         c.forward_reward, c.fall_reward, c.drop_reward = float(self.forward_reward), float(self.fall_reward), float(self.drop_reward)
@@ -69,12 +70,15 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         nbytes = C.c_uint64()
         _lib.check(L.madrl_multiwalker_state_bytes(C.byref(cfg), self.n_envs, C.byref(nbytes)))
         N, W, dev = self.n_envs, int(self.n_walkers), self.device
-        if getattr(self, "_shape_key", None) != (N, W, nbytes.value):
+        dim = C.c_int32()
+        _lib.check(L.madrl_multiwalker_obs_dim(C.byref(cfg), C.byref(dim)))
+        self.obs_dim = dim.value
+        if getattr(self, "_shape_key", None) != (N, W, nbytes.value, dim.value):
             self._state = torch.zeros(nbytes.value, dtype=torch.uint8, device=dev)
-            self._obs = torch.zeros((N, W, 32), dtype=torch.float32, device=dev)
+            self._obs = torch.zeros((N, W, dim.value), dtype=torch.float32, device=dev)
             self._rew = torch.zeros((N, W), dtype=torch.float32, device=dev)
             self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
-            self._shape_key = (N, W, nbytes.value)
+            self._shape_key = (N, W, nbytes.value, dim.value)
         self._destroy()
         h = C.c_void_p()
         dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -86,7 +90,7 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         _lib.check(L.madrl_multiwalker_dims(h, C.byref(nb), C.byref(nt)))
         self.n_bodies, self.n_terrain = nb.value, nt.value
         self.world_bytes = nbytes.value // N
-        self.walkers = [BipedalWalker() for _ in range(W)]
+        self.walkers = [BipedalWalker(self.obs_dim) for _ in range(W)]
         self.package_scale = W / 1.75
         self.package_length = 240 / 30.0 * self.package_scale
         self.total_agents = W

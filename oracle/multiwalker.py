@@ -15,7 +15,6 @@ class MultiWalkerOracle(object):
     def __init__(self, n_walkers=2, position_noise=1e-3, angle_noise=1e-3, reward_mech="local", forward_reward=1.0,
                  fall_reward=-100.0, drop_reward=-100.0, terminate_on_fall=True, one_hot=False, n_envs=1, seed=0,
                  env_id_base=0):
-        assert not one_hot
         L = _po.lib()
         self.L = L
         L.mwo_create.restype = C.c_void_p
@@ -23,12 +22,14 @@ class MultiWalkerOracle(object):
                                  C.c_int64, C.c_uint64, C.c_int64]
         for name, n in (("mwo_destroy", 1), ("mwo_reset", 3), ("mwo_step", 5), ("mwo_get_worlds", 2), ("mwo_set_worlds", 2),
                         ("mwo_get_bodies", 3), ("mwo_get_terrain", 2), ("mwo_num_terrain", 1), ("mwo_num_bodies", 1),
-                        ("mwo_model_masses", 2)):
+                        ("mwo_model_masses", 2), ("mwo_obs_dim", 1)):
             getattr(L, name).argtypes = [C.c_void_p] * n
         self.N, self.W = int(n_envs), n_walkers
         self.h = L.mwo_create(n_walkers, int(reward_mech == "global"), int(terminate_on_fall), position_noise, angle_noise,
                               forward_reward, fall_reward, drop_reward, self.N, int(seed), int(env_id_base))
-        self.D = L.mwo_obs_dim()
+        L.mwo_set_one_hot.argtypes = [C.c_void_p, C.c_int]
+        L.mwo_set_one_hot(self.h, int(bool(one_hot)))
+        self.D = L.mwo_obs_dim(self.h)
         self.NB, self.NT = L.mwo_num_bodies(self.h), L.mwo_num_terrain(self.h)
         self.world_bytes = L.mwo_world_bytes()
         self.obs = np.zeros((self.N, self.W, self.D), np.float32)

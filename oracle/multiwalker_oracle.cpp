@@ -25,7 +25,8 @@ struct MwOracle {
 
 extern "C" {
 
-int mwo_obs_dim(void) { return mw::OBS_DIM; }
+int mwo_obs_dim(const MwOracle *o) { return mw::obs_dim_of(o->C); }
+void mwo_set_one_hot(MwOracle *o, int one_hot) { o->C.one_hot = one_hot ? 1 : 0; }
 int mwo_world_bytes(void) { return (int)sizeof(mw::World); }
 
 MwOracle *mwo_create(int n_walkers, int reward_global, int terminate_on_fall, float position_noise, float angle_noise,
@@ -54,7 +55,7 @@ void mwo_reset(MwOracle *o, const uint8_t *mask, float *obs) {
         float zero[4 * mw::MAX_WALKERS] = {0};
         const uint32_t gid = (uint32_t)(o->env_id_base + n);
         mw::env_reset_world(o->M, o->C, o->worlds[n], gid);
-        mw::env_step(o->M, o->C, o->worlds[n], S, mw::SerialPar(), gid, zero, obs + n * W * mw::OBS_DIM, nullptr, nullptr);
+        mw::env_step(o->M, o->C, o->worlds[n], S, mw::SerialPar(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
         o->worlds[n].t = 0;
     }
 }
@@ -65,7 +66,7 @@ void mwo_step(MwOracle *o, const float *actions, float *obs, float *rew, uint8_t
     for (int64_t n = 0; n < o->n_envs; ++n) {
         mw::Scratch S;
         mw::env_step(o->M, o->C, o->worlds[n], S, mw::SerialPar(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
-                     obs + n * W * mw::OBS_DIM, rew + n * W, done + n);
+                     obs + n * W * mw::obs_dim_of(o->C), rew + n * W, done + n);
     }
 }
 

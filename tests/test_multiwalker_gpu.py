@@ -21,13 +21,17 @@ def _mk(n_envs, **kw):
     return BatchedMultiWalkerEnv(n_envs=n_envs, device=DEV, **kw)
 
 
-@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local")])
+@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local"), (3, "one_hot")])
 def test_hip_matches_cpu_build_step_by_step(n_walkers, reward_mech):
     from oracle import multiwalker as mwo
     N, T = 96, 70
-    env = _mk(N, n_walkers=n_walkers, reward_mech=reward_mech, seed=11, env_id_base=7)
+    one_hot = reward_mech == "one_hot"   # ids as np.eye(MAX_AGENTS)[i] (multi_walker.py:397-398): 71-wide rows
+    reward_mech = "local" if one_hot else reward_mech
+    env = _mk(N, n_walkers=n_walkers, reward_mech=reward_mech, seed=11, env_id_base=7, one_hot=one_hot)
     orc = mwo.MultiWalkerOracle(n_walkers=n_walkers, position_noise=0.0, angle_noise=0.0, reward_mech=reward_mech,
-                                n_envs=N, seed=11, env_id_base=7)
+                                n_envs=N, seed=11, env_id_base=7, one_hot=one_hot)
+    if one_hot:
+        assert env.obs_dim == 71 and env.agents[0].observation_space.shape == (71,)
     assert env.world_bytes >= orc.world_bytes and env.world_bytes - orc.world_bytes < 16
     obs = env.reset()
     oobs = orc.reset()
