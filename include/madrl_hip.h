@@ -276,7 +276,7 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
 void madrl_multiwalker_destroy(madrl_multiwalker *h);
 int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks);
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain);
-/* MultiWalkerEnv.reset (:330-357) incl. its trailing zero-action step; obs float32 [N][W][32] */
+/* MultiWalkerEnv.reset (:330-357) incl. its trailing zero-action step; obs float32 [N][W][obs_dim] (32, or 71 with one_hot) */
 int madrl_multiwalker_reset(madrl_multiwalker *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
 /* MultiWalkerEnv.step (:359-428): actions float32 [N][W][4]; rew float32 [N][W]; done uint8 [N]
  * (bit0 = the reference's done, bit1 = max_steps reached) */

@@ -2,7 +2,7 @@
 `madrl_environments.walker.multi_walker.MultiWalkerEnv` (multi_walker.py:250-641).
 
 Same constructor arguments / defaults (:256-258), `agents`, `reward_mech`, `reset()`, `step()`:
-    reset()        -> obs float32 [N, W, 32]
+    reset()        -> obs float32 [N, W, 32]  (71 with one_hot ids)
     step(actions)  -> obs, rew float32 [N, W], done bool [N], {}      actions float [N, W, 4]
 `MultiWalkerEnv(...)` is the N == 1 drop-in with the reference's return types.
 
