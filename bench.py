@@ -34,7 +34,7 @@ def algorithmic_bytes_per_env_step(P, E, D, rec_bytes):
     return 4 * P + 4 * P * D + 4 * P + 1 + 4 + 2 * rec_bytes
 
 
-def measured_traffic(n_envs):
+def measured_traffic(n_envs, workload="pursuit"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/pmc_traffic.json,
     FETCH_SIZE + WRITE_SIZE collected in separate runs by scripts/profile.sh); None if absent or
     taken at another batch size.  bench.py cannot collect PMC counters on itself."""
@@ -45,7 +45,7 @@ def measured_traffic(n_envs):
             j = json.load(open(f))
         except Exception:
             continue
-        if int(j.get("envs", -1)) == int(n_envs):
+        if int(j.get("envs", -1)) == int(n_envs) and j.get("workload", "pursuit") == workload:
             best = (float(j["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT))
     return best
 
@@ -192,7 +192,8 @@ def bench_other(args, rank, local_rank, world, dev):
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform random actions resident in HBM, in-kernel Philox, fused auto-reset)",
                "config": {"workload": workload, "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                            "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per,
+                            "traffic": (measured_traffic(N, args.workload) or (None, None))[0],
+                            "traffic_source": (measured_traffic(N, args.workload) or (None, None))[1], "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per,
                             "binding_resource": binding}}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
             out["cpu_baseline"] = cpu()
