@@ -23,7 +23,7 @@ def sources():
 
 def _deps():
     inc = os.path.join(os.path.dirname(HERE), "include")
-    out = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    out = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".def"))]
     out += [os.path.join(inc, f) for f in os.listdir(inc)]
     return out
 
