@@ -74,3 +74,28 @@ def test_configurations_the_library_refuses():
     env = BatchedMAWaterWorld(2, 2, n_envs=4, device=DEV)
     with pytest.raises(AssertionError):
         env.step(torch.zeros(4, 3, 2, device=DEV))      # wrong action shape (waterworld.py:227)
+
+
+def test_step_runs_on_the_callers_stream():
+    """all launches go to torch's current stream: a rollout on a side stream equals the one on the default stream, and a
+    consumer on the same stream sees finished outputs without any explicit synchronisation"""
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    mk = lambda: BatchedPursuitEvade([rectangle_map(16, 16)], n_envs=3000, device=DEV, seed=8, max_steps=20, auto_reset=True,
+                                     n_pursuers=8, n_evaders=30, obs_range=7)
+    a, b = mk(), mk()
+    acts = [torch.randint(0, 5, (3000, 8), device=DEV, dtype=torch.int32) for _ in range(30)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=DEV)
+    sums_a, sums_b = [], []
+    a.reset()
+    for t in range(30):
+        o, r, d, _ = a.step(acts[t]); sums_a.append((o.sum(), r.sum(), d.sum()))
+    with torch.cuda.stream(side):
+        b.reset()
+        for t in range(30):
+            o, r, d, _ = b.step(acts[t]); sums_b.append((o.sum(), r.sum(), d.sum()))   # consumers enqueued right behind the step
+    side.synchronize(); torch.cuda.synchronize()
+    for (x1, y1, z1), (x2, y2, z2) in zip(sums_a, sums_b):
+        assert float(x1) == float(x2) and float(y1) == float(y2) and int(z1) == int(z2)
+    assert torch.equal(a.obs_buffer, b.obs_buffer)
