@@ -9,10 +9,12 @@
 //   particle phases   lane j < NP owns particle j (integration, walls, obstacle rebound,
 //                     respawn, evader/poison motion);
 //   collision phase   lane = (pursuer, evader) / (pursuer, poison) pair;
-//   sensing phase     lane = (pursuer, sensor) pair, looping over the <= ~26 objects whose
-//                     coordinates are LDS broadcasts -- the only O(Np*K*N) part (~4k ray tests).
+//   sensing phase     lane = (pursuer, sensor) pair, three passes of 64 pairs held in registers; the objects are
+//                     broadcast once each from the owning lane's registers (v_readlane -> SGPR operands) and a
+//                     conservative reach mask skips, per pass, the objects none of its pursuers can sense --
+//                     the only O(Np*K*N) part (~4k ray tests before the cull).
 // No dense contraction -> no MFMA.  ~40 kFLOP and 5.2 KB of HBM traffic per env-step: the
-// kernel is VALU/LDS-issue bound, not HBM bound.
+// kernel is VALU-issue bound, not HBM bound.
 //
 // Reference semantics (file:line under /root/reference/madrl_environments/pursuit/waterworld.py):
 //   step phases ........ MAWaterWorld.step :220-436      sensing ...... Archea.sensed :64-72
