@@ -1,0 +1,21 @@
+"""Policy-in-the-loop rollout throughput: Pursuit C2 (65 536 envs) with the device chase policy through RolloutCollector,
+eager launches vs one hipGraph per horizon; plus a small batch where launch overhead dominates."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from madrl_amd.maps import rectangle_map
+from madrl_amd.pursuit import BatchedPursuitEvade
+from madrl_amd.heuristics import PursuitHeuristicPolicy
+from madrl_amd.rollout import RolloutCollector
+dev = "cuda:0"
+for N, T in ((65536, 50), (1024, 50)):
+    for graph in (False, True):
+        env = BatchedPursuitEvade([rectangle_map(16, 16)], n_envs=N, device=dev, seed=0, max_steps=500, auto_reset=True, n_pursuers=8,
+                                  n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local")
+        col = RolloutCollector(env, PursuitHeuristicPolicy(7, flatten=True, seed=1), T, discount=0.99, graph=graph)
+        for _ in range(3): col.collect()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        K = 6
+        for _ in range(K): col.collect()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+        print("N=%6d T=%d graph=%-5s  %.2f ms per horizon  %.1f us per step  %.3e env-steps/s" % (N, T, graph, dt * 1e3, dt / T * 1e6, N * T / dt), flush=True)
