@@ -229,18 +229,23 @@ class BatchedPursuitEvade(AbstractMAEnv):
                                                   _lib.ptr(self._obs), self._stream()))
         return self._obs_view()
 
-    def step(self, actions, evader_actions=None):
+    def step(self, actions, evader_actions=None, rew_out=None, done_out=None):
         """pursuit_evade.py:209-262.  actions: int [N, P] (0..4).  evader_actions: optional int
-        [N, E], entry k drives the k-th remaining evader (scripted evader_controller)."""
+        [N, E], entry k drives the k-th remaining evader (scripted evader_controller).
+        rew_out float32 [N, P] / done_out uint8 [N]: optional contiguous destinations (e.g. a slot of a trajectory tensor) the
+        kernel writes instead of the env's own buffers -- the C ABI takes any device pointer, no copy afterwards."""
         N, P, E = self.n_envs, int(self.n_pursuers), int(self.n_evaders)
         act = self._i32(actions, (N, P), "actions")
         eact = self._i32(evader_actions, (N, E), "evader_actions")
+        rew = self._rew if rew_out is None else rew_out
+        dn = self._done if done_out is None else done_out
+        assert rew.dtype == torch.float32 and rew.numel() == N * P and dn.dtype == torch.uint8 and dn.numel() == N
         _lib.check(_lib.lib().madrl_pursuit_step(self._handle, _lib.ptr(act), _lib.ptr(eact), _lib.ptr(self._obs),
-                                                 _lib.ptr(self._rew), _lib.ptr(self._done), _lib.ptr(self._removed),
+                                                 _lib.ptr(rew), _lib.ptr(dn), _lib.ptr(self._removed),
                                                  self._stream()))
-        done = (self._done & 1).bool()
-        info = {"removed": self._removed, "truncated": (self._done & 2).bool(), "done_bits": self._done}
-        return self._obs_view(), self._rew, done, info
+        done = (dn & 1).bool()
+        info = {"removed": self._removed, "truncated": (dn & 2).bool(), "done_bits": dn}
+        return self._obs_view(), rew, done, info
 
     @property
     def is_terminal(self):

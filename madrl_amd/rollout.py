@@ -65,6 +65,8 @@ class RolloutCollector(object):
         self._obs = None
         self._buf = None
         self._use_graph, self._graph, self._calls = bool(graph), None, 0
+        import inspect
+        self._direct = "rew_out" in inspect.signature(env.step).parameters   # envs whose step() can write into caller buffers
 
     def _alloc(self, obs, act, val):
         T, dev = self.T, obs.device
@@ -110,9 +112,12 @@ class RolloutCollector(object):
             b["actions"][t].copy_(act)
             if val is not None:
                 b["values"][t].copy_(val)
-            obs, rew, done, info = env.step(act)
-            b["rewards"][t].copy_(rew)
-            b["dones"][t].copy_(info["done_bits"] if isinstance(info, dict) and "done_bits" in info else done.to(torch.uint8))
+            if self._direct:   # the step kernel writes rewards / done bits straight into their trajectory slot
+                obs, rew, done, info = env.step(act, rew_out=b["rewards"][t], done_out=b["dones"][t])
+            else:
+                obs, rew, done, info = env.step(act)
+                b["rewards"][t].copy_(rew)
+                b["dones"][t].copy_(info["done_bits"] if isinstance(info, dict) and "done_bits" in info else done.to(torch.uint8))
         self._obs = obs
         b = self._buf
         if b["values"] is not None:
