@@ -228,7 +228,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 wave_sync();
                 // phase C: sensing (:295-362).  Rows: [criminal dist | criminal speed | hostage dist | key dist | bomb dist] (:398-400)
                 {
-                    constexpr int PCH = 3;
+                    // passes of 64 (rescuer, sensor) pairs held in registers at a time: no more than the specialised shape needs
+                    constexpr int PCH = (TNr > 0 && (TNr * TK + 63) / 64 < 3) ? (TNr * TK + 63) / 64 : 3;
                     const float srange = d.sensor_range, rad2 = d.radius * d.radius;  // G1
                     const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
                     // Conservative cull (as in waterworld.hip): NEAR[i] = objects with d2 <= (rad2 + range^2) * (1 + 1e-4); all others

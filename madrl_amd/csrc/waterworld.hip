@@ -257,7 +257,8 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 // against are wave-uniform, so each object's position is broadcast ONCE from the register of the lane that
                 // owns the particle (v_readlane -> SGPR operand) and reused by all passes: the inner loop is pure VALU, no
                 // LDS round trip per (pair, object).  Arithmetic and comparison order per pair are those of the reference loop.
-                constexpr int PCH = 3;
+                // passes of 64 (pursuer, sensor) pairs held in registers at a time: no more than the specialised shape needs
+                constexpr int PCH = (TNp > 0 && (TNp * TK + 63) / 64 < 3) ? (TNp * TK + 63) / 64 : 3;
                 const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
                 // Conservative cull: a sensor of pursuer i can only return a finite value for an object with
                 // d2 <= rad2 + sv^2 <= rad2 + range^2; NEAR[i] marks the objects within that reach plus a 1e-4 relative margin
