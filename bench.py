@@ -12,8 +12,9 @@ in-kernel (Philox).  N > 1: launched by torch.distributed.run, one rank per GPU,
 index ranges sharded by rank (weak scaling), the compact trajectory (actions, rewards,
 dones) of the timed region is all-gathered over RCCL at the end, inside the timed region.
 
-Rank 0 prints ONE JSON line (contract in the task description) with `roofline` and
-`cpu_baseline` objects.
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline`, `cpu_baseline`
+(the unmodified reference's NumPy path, quoted from profiles/*_cpu_reference/record.json with its
+host) and `cpu_baseline_port` (the C restatement timed live on this box's host cores).
 """
 import argparse
 import json
@@ -50,7 +51,27 @@ def measured_traffic(n_envs, workload="pursuit"):
     return best
 
 
-def cpu_baseline(maps, kw, budget_s=12.0):
+def cpu_reference_record(key):
+    """The UNMODIFIED reference's NumPy path, timed by scripts/cpu_reference_bench.py in the build container (the reference
+    tree cannot travel to the GPU box, so bench.py quotes the committed record and labels its host).  `key` selects the
+    workload inside the record.  None when no record is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_reference", "record.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            r = j[key]
+        except Exception:
+            continue
+        return dict(value=r["all_core_steps_per_s"], unit="env-steps/s", cores=r["processes"], kind="reference-numpy",
+                    one_process_value=r["one_process_steps_per_s"],
+                    host="%s, %d logical cores (%s)" % (j["host"]["cpu_model"], j["host"]["logical_cores"], j["host"]["where"]),
+                    source=os.path.relpath(f, ROOT),
+                    sample="%s; one env per process x %d processes x %d steps, OMP_NUM_THREADS=1; recorded, not re-timed by this run"
+                           % (r["config"], r["processes"], r["steps_per_process"]))
+    return None
+
+
+def cpu_baseline_port(maps, kw, budget_s=12.0):
     """The C oracle (a port of the reference's algorithm) on the host cores, OpenMP over envs.
     Bounded sample of the same workload: 4096 envs, free-running, ~budget_s seconds."""
     import numpy as np
@@ -196,7 +217,14 @@ def bench_other(args, rank, local_rank, world, dev):
                             "traffic_source": (measured_traffic(N, args.workload) or (None, None))[1], "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per,
                             "binding_resource": binding}}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
-            out["cpu_baseline"] = cpu()
+            # cpu_baseline = the reference's own NumPy path where a record of it exists (Waterworld), else the port;
+            # cpu_baseline_port = the C restatement timed live on this box's host cores
+            ref = cpu_reference_record("waterworld_c3_single_env") if args.workload == "waterworld" else None
+            port = cpu()
+            if ref is not None:
+                out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
+            else:
+                out["cpu_baseline"] = port
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -345,7 +373,14 @@ def main():
                          "algorithmic_bytes_per_env_step": bytes_per},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
-            out["cpu_baseline"] = cpu_baseline(maps, kw)
+            # cpu_baseline: the unmodified reference NumPy path (configs[0]; committed record, host labelled);
+            # cpu_baseline_port: the C restatement of the same algorithm timed live on this box's host cores
+            ref = cpu_reference_record("pursuit_c1")
+            port = cpu_baseline_port(maps, kw)
+            if ref is not None:
+                out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
+            else:
+                out["cpu_baseline"] = port
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

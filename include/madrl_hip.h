@@ -100,7 +100,7 @@ int madrl_pursuit_set_kernel(madrl_pursuit *h, int32_t kind);
 int madrl_pursuit_kernel_kind(const madrl_pursuit *h, int32_t *out_kind);
 
 /* Launch shape: threads per workgroup (GENERIC kernel only; multiple of 64, 0 = heuristic)
- * and the maximum number of workgroups (0 = default: one per env for GENERIC, 6144 persistent
+ * and the maximum number of workgroups (0 = default: one per env for GENERIC, 4096 persistent
  * workgroups for WAVE); workgroups stride over envs. */
 int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_blocks);
 
@@ -299,9 +299,11 @@ int madrl_wrap_obsnorm(const float *obs_in, double *mean, double *var, float *ob
 /* StandardizedEnv.standardize_rew + scale_reward (:251-271, :290): mean/var float64 [n] (init 0 / 1) */
 int madrl_wrap_rewnorm(const float *rew_in, double *mean, double *var, float *rew_out, int64_t n, int64_t per_env,
                        const uint8_t *mask, double alpha, double eps, double scale, int32_t enable_norm, void *stream);
-/* ObservationBuffer (:176-195): buf float32 [n_elems][k]; envs flagged in reset_mask fill all k slots */
+/* ObservationBuffer (:176-195): buf float32 [n_elems][k]; envs flagged in reset_mask fill all k slots (reset,
+ * :190-192), the others shift their history and push (step, :179-181).  active_mask (uint8 [N] or NULL = all):
+ * envs with a 0 are left untouched -- a partial reset(mask) passes the same mask twice. */
 int madrl_wrap_obsbuffer(const float *obs, float *buf, int64_t n_elems, int64_t elems_per_env, int32_t k,
-                         const uint8_t *reset_mask, void *stream);
+                         const uint8_t *reset_mask, const uint8_t *active_mask, void *stream);
 /* DiagnosticsWrapper.step (:335-369): per-env accumulators ep_reward float64 [N][A], ep_len int32 [N],
  * disc_ret / disc_pow float64 [N] (all init 0); on episode end (any done bit or max_traj_len) the out_* rows
  * receive episode_reward_agent*, episode_disc_return, episode_length and out_finished = 1 */

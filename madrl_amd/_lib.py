@@ -114,7 +114,7 @@ SIGNATURES = {
     "madrl_multiwalker_get_bodies": (C.c_int, [_vp] * 5),
     "madrl_wrap_obsnorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, C.c_double, C.c_double, _vp]),
     "madrl_wrap_rewnorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, C.c_double, C.c_double, C.c_double, C.c_int32, _vp]),
-    "madrl_wrap_obsbuffer": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
+    "madrl_wrap_obsbuffer": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "madrl_wrap_diagnostics": (C.c_int, [_vp] * 6 + [C.c_int64, C.c_int32, C.c_double, C.c_int32] + [_vp] * 5),
     "madrl_heuristic_pursuit": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_uint64, C.c_int64, C.c_uint32, _vp, _vp, _vp]),
     "madrl_heuristic_waterworld": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]),

@@ -55,3 +55,28 @@ class AbstractMAEnv(object):
 
     def __str__(self):
         return "<{} instance>".format(type(self).__name__)
+
+
+class SingleEnvDelegate(object):
+    """Mixin of the N == 1 drop-in classes: attributes the reference's callers read off the env object
+    (n_pursuers, catchr, map_matrix, ...) come from the one-env batched engine held in `_env`.
+
+    pickle / copy.deepcopy probe `__setstate__`, `__reduce_ex__`, ... on an instance whose __dict__ is still empty
+    (the reference samplers hand pickled env copies to their workers, rltools.util.EzPickle): those lookups must end
+    in AttributeError, not in a KeyError from the delegation."""
+
+    def __getattr__(self, name):
+        env = self.__dict__.get("_env")
+        if env is None or (name.startswith("__") and name.endswith("__")):
+            raise AttributeError(name)
+        return getattr(env, name)
+
+    def __getstate__(self):
+        return {"_env": self.__dict__["_env"]}  # the batched engine pickles by constructor arguments (EzPickle-style)
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._after_unpickle()
+
+    def _after_unpickle(self):
+        """EzPickle re-runs the reference constructor; classes whose constructor ends in reset() redo it here."""

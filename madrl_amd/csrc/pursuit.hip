@@ -554,7 +554,8 @@ struct madrl_pursuit {
     // one-wavefront-per-env fast path (pursuit_wave.hpp), when a specialisation matches
     const WaveEntry *wave;
     madrl::pw::WaveDev wdev;
-    uint64_t step_count = 0;
+    uint64_t step_count = 0;  // step launches so far (parity of the walk direction, see launch())
+    int walk_mode = 0;        // 0 auto (alternate above ~375 MB per launch), 1 always alternate, 2 always forward; fixed at create
     void *wtables;
     int kernel_kind;  // MADRL_KERNEL_AUTO / _GENERIC / _WAVE (requested)
 };
@@ -697,7 +698,7 @@ bool use_wave(const madrl_pursuit *h) {
     return h->wave != nullptr && h->kernel_kind != MADRL_KERNEL_GENERIC;
 }
 
-int launch(const madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
+int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (use_wave(h)) {
         pw::WaveIO w;
@@ -713,8 +714,8 @@ int launch(const madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) 
         pw::WaveDev wd = h->wdev;
         if (mode == 1) {
             bool alternate = (double)h->dev.n_envs * (4.0 * h->dev.P * h->dev.D + 2.0 * h->dev.rec_bytes) > 375e6;
-            if (const char *e = getenv("MADRL_PURSUIT_WALK")) alternate = (e[0] == 'a');  // "alternate" / "forward": experiments, tests
-            if (alternate) wd.reverse = (int32_t)(const_cast<madrl_pursuit *>(h)->step_count++ & 1);
+            if (h->walk_mode != 0) alternate = h->walk_mode == 1;
+            if (alternate) wd.reverse = (int32_t)(h->step_count++ & 1);
         }
         h->wave->launch(wd, w, mode, blocks, s);
         MADRL_HIP_TRY(hipGetLastError());
@@ -932,6 +933,8 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         }
     }
 
+    if (const char *e = getenv("MADRL_PURSUIT_WALK"))  // "alternate" / "forward": experiments and tests; read once, here
+        h->walk_mode = (e[0] == 'a') ? 1 : (e[0] == 'f') ? 2 : 0;
     h->max_blocks = 0;
     rc = madrl_pursuit_set_launch(h, 0, 0);
     if (rc) {

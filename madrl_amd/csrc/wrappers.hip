@@ -43,8 +43,10 @@ __global__ void rewnorm_kernel(const float *rew_in, double *mean, double *var, f
     }
 }
 
-__global__ void obsbuffer_kernel(const float *obs, float *buf, int64_t n, int64_t per_env, int k, const uint8_t *reset_mask) {
+__global__ void obsbuffer_kernel(const float *obs, float *buf, int64_t n, int64_t per_env, int k, const uint8_t *reset_mask,
+                                 const uint8_t *active_mask) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (active_mask != nullptr && active_mask[i / per_env] == 0) continue;  // partial reset: the other envs keep their history
         float *b = buf + i * k;
         const float x = obs[i];
         if (reset_mask != nullptr && reset_mask[i / per_env] != 0) {
@@ -136,10 +138,10 @@ int madrl_wrap_rewnorm(const float *rew_in, double *mean, double *var, float *re
 }
 
 int madrl_wrap_obsbuffer(const float *obs, float *buf, int64_t n_elems, int64_t elems_per_env, int32_t k, const uint8_t *reset_mask,
-                         void *stream) {
+                         const uint8_t *active_mask, void *stream) {
     if (!obs || !buf || n_elems < 1 || elems_per_env < 1 || k < 1) return fail(MADRL_EINVAL, "obsbuffer: bad argument");
     hipLaunchKernelGGL(obsbuffer_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, obs, buf, n_elems,
-                       elems_per_env, (int)k, reset_mask);
+                       elems_per_env, (int)k, reset_mask, active_mask);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }

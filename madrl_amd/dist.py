@@ -24,8 +24,36 @@ def shard_range(n_total, rank=None, world=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def gather_ragged(local, group=None):
+    """local: dict name -> tensor whose LEADING dimension may differ between ranks (uneven env shards from
+    shard_range() when n_total % world != 0, per-rank episode counts); trailing dimensions and dtypes agree.
+    Returns dict name -> list of `world` tensors, entry r = rank r's tensor.  all_gather_into_tensor needs equal
+    shapes, so the leading sizes are exchanged first (one tiny collective for all names), every tensor is padded
+    to the largest and the result trimmed."""
+    names = sorted(local)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {k: [local[k]] for k in names}
+    world = dist.get_world_size(group)
+    dev = local[names[0]].device
+    mine = torch.tensor([int(local[k].shape[0]) for k in names], dtype=torch.int64, device=dev)
+    sizes = torch.empty((world, len(names)), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes.view(-1), mine, group=group)
+    sizes = sizes.cpu()
+    out = {}
+    for j, k in enumerate(names):
+        v = local[k].contiguous()
+        m = int(sizes[:, j].max())
+        pad = torch.zeros((m,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        pad[:v.shape[0]] = v
+        buf = torch.empty((world,) + tuple(pad.shape), dtype=v.dtype, device=v.device)
+        dist.all_gather_into_tensor(buf.view(-1), pad.view(-1), group=group)
+        out[k] = [buf[r, :int(sizes[r, j])] for r in range(world)]
+    return out
+
+
 def gather_trajectories(local, group=None):
-    """local: dict name -> tensor with identical shape/dtype on every rank.
+    """local: dict name -> tensor with IDENTICAL shape/dtype on every rank (equal env shards: n_total % world == 0;
+    use gather_ragged() otherwise -- a shape mismatch here would hang or corrupt the collective, RCCL does not check).
     Returns dict name -> tensor [world, *shape] (every rank gets everything: the learner is
     data-parallel too).  One collective per tensor, issued back to back on the current stream."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -100,5 +128,6 @@ class ChunkedTrajectoryGather(object):
 
 
 def gather_episode_stats(returns, lengths, group=None):
-    """Per-episode returns/lengths (KBs) to every rank: float32 [n_local_episodes, A], int32 [n]."""
-    return gather_trajectories(dict(returns=returns, lengths=lengths), group=group)
+    """Per-episode returns/lengths (KBs) to every rank: float32 [n_local_episodes, A], int32 [n_local_episodes]; the
+    number of finished episodes differs per rank, so the result is dict name -> list of per-rank tensors."""
+    return gather_ragged(dict(returns=returns, lengths=lengths), group=group)

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .base import AbstractMAEnv, Agent
+from .base import AbstractMAEnv, Agent, SingleEnvDelegate
 from .spaces import Box
 from .waterworld import sensor_vectors
 
@@ -207,15 +207,12 @@ class BatchedContinuousHostageWorld(AbstractMAEnv):
         self.__init__(**d)
 
 
-class ContinuousHostageWorld(AbstractMAEnv):
+class ContinuousHostageWorld(SingleEnvDelegate, AbstractMAEnv):
     """N == 1 drop-in with the reference's return types (hostage.py:74)."""
 
     def __init__(self, *args, **kwargs):
         kwargs.pop("n_envs", None)
         self._env = BatchedContinuousHostageWorld(*args, n_envs=1, **kwargs)
-
-    def __getattr__(self, name):
-        return getattr(self.__dict__["_env"], name)
 
     @property
     def agents(self):

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .base import AbstractMAEnv, Agent
+from .base import AbstractMAEnv, Agent, SingleEnvDelegate
 from .spaces import Box
 
 
@@ -135,15 +135,22 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
                                                       _lib.current_stream(self.device)))
         return self._obs
 
-    def step(self, actions):
+    def step(self, actions, rew_out=None, done_out=None):
+        """multi_walker.py:359-428.  done = bit 0 of the kernel's done byte (game over / package dropped, :404-424); bit 1 =
+        the max_steps time limit.  With auto_reset ANY bit starts a new episode, so info carries the raw bits like
+        BatchedPursuitEvade does (the rollout collector and the wrappers cut episodes on info['done_bits']).
+        rew_out float32 [N, W] / done_out uint8 [N]: optional destinations the kernel writes instead of the env's buffers."""
         N, W = self.n_envs, int(self.n_walkers)
         a = torch.as_tensor(actions, device=self.device)
         if a.numel() != N * W * 4:
             raise AssertionError("actions have %d elements, expected %d" % (a.numel(), N * W * 4))  # :360-361
         a = a.reshape(N, W, 4).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().madrl_multiwalker_step(self._handle, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._rew),
-                                                     _lib.ptr(self._done), _lib.current_stream(self.device)))
-        return self._obs, self._rew, (self._done & 1).bool(), {}
+        rew = self._rew if rew_out is None else rew_out
+        dn = self._done if done_out is None else done_out
+        assert rew.dtype == torch.float32 and rew.numel() == N * W and dn.dtype == torch.uint8 and dn.numel() == N
+        _lib.check(_lib.lib().madrl_multiwalker_step(self._handle, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(rew),
+                                                     _lib.ptr(dn), _lib.current_stream(self.device)))
+        return self._obs, rew, (dn & 1).bool(), {"done_bits": dn, "truncated": (dn & 2).bool()}
 
     def bodies(self):
         N, W, dev = self.n_envs, int(self.n_walkers), self.device
@@ -166,7 +173,7 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         self.__init__(**d)
 
 
-class MultiWalkerEnv(AbstractMAEnv):
+class MultiWalkerEnv(SingleEnvDelegate, AbstractMAEnv):
     """N == 1 drop-in with the reference's return types (multi_walker.py:250)."""
 
     def __init__(self, *args, **kwargs):
@@ -174,8 +181,8 @@ class MultiWalkerEnv(AbstractMAEnv):
         self._env = BatchedMultiWalkerEnv(*args, n_envs=1, **kwargs)
         self.reset()  # the reference constructor ends in setup() -> reset() (:271, :303)
 
-    def __getattr__(self, name):
-        return getattr(self.__dict__["_env"], name)
+    def _after_unpickle(self):
+        self.reset()  # EzPickle re-runs the constructor, which ends in reset() (:271, :303)
 
     @property
     def agents(self):

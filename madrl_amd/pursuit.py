@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .base import AbstractMAEnv, Agent
+from .base import AbstractMAEnv, Agent, SingleEnvDelegate
 from .maps import as_map_pool
 from .spaces import Box, Discrete
 
@@ -316,14 +316,11 @@ class BatchedPursuitEvade(AbstractMAEnv):
         self.__init__(d.pop("map_pool"), **d, **kwargs)
 
 
-class PursuitEvade(AbstractMAEnv):
+class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
     """N == 1 drop-in with the reference's return types (pursuit_evade.py:26)."""
 
     def __init__(self, map_pool, device="cuda:0", **kwargs):
         self._env = BatchedPursuitEvade(map_pool, n_envs=1, device=device, **kwargs)
-
-    def __getattr__(self, name):  # n_pursuers, catchr, map_matrix, ...
-        return getattr(self.__dict__["_env"], name)
 
     @property
     def agents(self):

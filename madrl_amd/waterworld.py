@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .base import AbstractMAEnv, Agent
+from .base import AbstractMAEnv, Agent, SingleEnvDelegate
 from .spaces import Box
 
 
@@ -210,15 +210,12 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         self.__init__(**d)
 
 
-class MAWaterWorld(AbstractMAEnv):
+class MAWaterWorld(SingleEnvDelegate, AbstractMAEnv):
     """N == 1 drop-in with the reference's return types (waterworld.py:75)."""
 
     def __init__(self, *args, **kwargs):
         kwargs.pop("n_envs", None)
         self._env = BatchedMAWaterWorld(*args, n_envs=1, **kwargs)
-
-    def __getattr__(self, name):
-        return getattr(self.__dict__["_env"], name)
 
     @property
     def agents(self):

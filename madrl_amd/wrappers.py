@@ -84,20 +84,24 @@ class ObservationBuffer(_Wrapper):
                                            shape=tuple(sp.shape) + (self._buffer_size,))))
         return out
 
-    def _push(self, obs, reset_mask):
+    def _push(self, obs, reset_mask, active_mask=None):
         obs = obs.contiguous()
         if self._buf is None:
             self._buf = torch.zeros(tuple(obs.shape) + (self._buffer_size,), dtype=torch.float32, device=obs.device)  # :150
         n = obs.numel()
         _lib.check(_lib.lib().madrl_wrap_obsbuffer(_lib.ptr(obs), _lib.ptr(self._buf), n, n // self.n_envs, self._buffer_size,
-                                                   _lib.ptr(reset_mask), _stream(self)))
+                                                   _lib.ptr(reset_mask), _lib.ptr(active_mask), _stream(self)))
         return self._buf
 
     def reset(self, mask=None):
-        obs = self._unwrapped.reset() if mask is None else self._unwrapped.reset(mask=mask)
-        m = torch.ones(self.n_envs, dtype=torch.uint8, device=self.device) if mask is None else \
-            torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
-        return self._push(obs, m)
+        if mask is None:
+            return self._push(self._unwrapped.reset(), torch.ones(self.n_envs, dtype=torch.uint8, device=self.device))
+        m = torch.as_tensor(mask, device=self.device).reshape(self.n_envs).to(torch.uint8).contiguous()
+        first = self._buf is None
+        obs = self._unwrapped.reset(mask=m)
+        if first:  # nothing to keep yet: every env starts from its current observation
+            return self._push(obs, torch.ones_like(m))
+        return self._push(obs, m, active_mask=m)  # envs outside the mask keep their history untouched
 
     def step(self, action, **kw):
         obs, rew, done, info = self._unwrapped.step(action, **kw)
@@ -173,7 +177,12 @@ class DiagnosticsWrapper(_Wrapper):
 
     def reset(self, **kw):
         obs = self._unwrapped.reset(**kw)  # :328-333
-        self._ep_reward.zero_(); self._disc_ret.zero_(); self._ep_len.zero_()
+        mask = kw.get("mask")
+        if mask is None:
+            self._ep_reward.zero_(); self._disc_ret.zero_(); self._ep_len.zero_()
+        else:  # partial reset: only the envs that were reset start a new episode
+            m = torch.as_tensor(mask, device=self.device).reshape(self.n_envs).bool()
+            self._ep_reward[m] = 0; self._disc_ret[m] = 0; self._ep_len[m] = 0
         return obs
 
     def step(self, *args, **kw):

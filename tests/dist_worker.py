@@ -52,8 +52,16 @@ def main():
             exp_r = torch.randn((5, N, P), generator=gr)
             exp_d = torch.randint(0, 2, (5, N), generator=gr, dtype=torch.uint8)
             assert torch.equal(got["rewards"][c][r], exp_r) and torch.equal(got["dones"][c][r], exp_d), (c, r)
-    st = gather_episode_stats(torch.full((4, P), float(rank)), torch.full((4,), rank, dtype=torch.int32))
-    assert torch.equal(st["lengths"][:, 0], torch.arange(world, dtype=torch.int32))
+    # ragged: every rank finished a different number of episodes / owns an uneven env shard
+    ne = 4 + 3 * rank
+    st = gather_episode_stats(torch.full((ne, P), float(rank)), torch.full((ne,), rank, dtype=torch.int32))
+    for r in range(world):
+        assert st["returns"][r].shape == (4 + 3 * r, P) and bool((st["returns"][r] == float(r)).all())
+        assert st["lengths"][r].shape == (4 + 3 * r,) and bool((st["lengths"][r] == r).all())
+    from madrl_amd.dist import gather_ragged
+    rg = gather_ragged(dict(rewards=torch.full((hi - lo, 2), float(rank))))  # shards of 1001 envs: 501 + 500
+    assert [t.shape[0] for t in rg["rewards"]] == [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    assert all(bool((rg["rewards"][r] == float(r)).all()) for r in range(world))
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)

@@ -1,0 +1,116 @@
+"""Regression tests for defects found in review of round 1: pickling of the N == 1 drop-ins, partial resets through
+the wrappers, MultiWalker time-limit episode cuts through the rollout collector."""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+DEV = "cuda:0"
+
+
+class _FakeEngine(object):
+    n_pursuers = 8
+
+    def __getstate__(self):
+        return {"k": 1}
+
+    def __setstate__(self, d):
+        self.restored = d
+
+
+from madrl_amd.base import SingleEnvDelegate, AbstractMAEnv  # noqa: E402
+
+
+class DropIn(SingleEnvDelegate, AbstractMAEnv):
+    def __init__(self):
+        self._env = _FakeEngine()
+
+
+def test_delegate_protocol_survives_pickle_and_deepcopy_cpu():
+    """pickle / deepcopy probe dunder attributes on an instance with an empty __dict__ (rltools.util.EzPickle consumers)."""
+    d = DropIn()
+    assert d.n_pursuers == 8
+    with pytest.raises(AttributeError):
+        d.no_such_attribute
+    with pytest.raises(AttributeError):
+        DropIn.__new__(DropIn).anything  # empty __dict__: AttributeError, not KeyError
+    e = pickle.loads(pickle.dumps(d))
+    assert e._env.restored == {"k": 1} and e.n_pursuers == 8
+    f = copy.deepcopy(d)
+    assert f._env is not d._env and f.n_pursuers == 8
+
+
+@pytest.mark.gpu
+def test_dropins_pickle_and_deepcopy_roundtrip():
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import PursuitEvade
+    from madrl_amd.waterworld import MAWaterWorld
+    from madrl_amd.multiwalker import MultiWalkerEnv
+    from madrl_amd.hostage import ContinuousHostageWorld
+    envs = [PursuitEvade([rectangle_map(16, 16)], n_evaders=30, n_pursuers=8, obs_range=7, seed=5),
+            MAWaterWorld(5, 10, seed=5), MultiWalkerEnv(n_walkers=2, seed=5), ContinuousHostageWorld(3, 10, 5, 2, 2, seed=5)]
+    for env in envs:
+        for clone in (pickle.loads(pickle.dumps(env)), copy.deepcopy(env)):
+            assert type(clone) is type(env) and clone._env is not env._env
+            assert len(clone.agents) == len(env.agents)
+            a, b = env.reset(), clone.reset()
+            assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), type(env).__name__  # same ctor args, same seed
+            if isinstance(env, PursuitEvade):
+                act = [1] * 8
+            else:
+                act = np.zeros((len(env.agents), env.agents[0].action_space.shape[0]))
+            o1, r1, d1, _ = env.step(act)
+            o2, r2, d2, _ = clone.step(act)
+            assert all(np.array_equal(x, y) for x, y in zip(o1, o2)) and np.array_equal(np.asarray(r1), np.asarray(r2)) and d1 == d2
+
+
+@pytest.mark.gpu
+def test_observation_buffer_and_diagnostics_partial_reset():
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from madrl_amd.wrappers import ObservationBuffer, DiagnosticsWrapper
+    N, P = 64, 4
+    raw = BatchedPursuitEvade([rectangle_map(8, 8)], n_envs=N, device=DEV, seed=2, n_pursuers=P, n_evaders=6, obs_range=5)
+    env = DiagnosticsWrapper(ObservationBuffer(raw, 3))
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for _ in range(4):
+        obs, rew, _, _ = env.step(torch.randint(0, 5, (N, P), generator=g, dtype=torch.int32).to(DEV))
+    before = obs.clone()
+    ep_len, ep_rew = env._ep_len.clone(), env._ep_reward.clone()
+    assert int(ep_len.min()) == 4
+    mask = torch.zeros(N, dtype=torch.uint8, device=DEV)
+    mask[::3] = 1
+    after = env.reset(mask=mask)
+    m = mask.bool()
+    assert torch.equal(after[~m], before[~m]), "envs outside the mask must keep their frame history untouched"
+    fresh = raw.obs_buffer.view(N, P, -1)
+    assert torch.equal(after[m], fresh[m].unsqueeze(-1).expand(-1, -1, -1, 3)), "reset envs hold buffer_size copies of the new observation"
+    assert torch.equal(env._ep_len[~m], ep_len[~m]) and torch.equal(env._ep_reward[~m], ep_rew[~m])
+    assert int(env._ep_len[m].abs().sum()) == 0 and float(env._ep_reward[m].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_multiwalker_time_limit_cuts_episodes_in_the_collector():
+    from madrl_amd.multiwalker import BatchedMultiWalkerEnv
+    from madrl_amd.rollout import RolloutCollector
+    N, W, H = 32, 2, 6
+    env = BatchedMultiWalkerEnv(n_walkers=W, n_envs=N, device=DEV, seed=1, max_steps=H, auto_reset=True)
+    obs = env.reset()
+    _, _, done, info = env.step(torch.zeros((N, W, 4), device=DEV))
+    assert set(info) >= {"done_bits", "truncated"} and info["done_bits"].dtype == torch.uint8
+    env.reset()
+    policy = lambda o: torch.zeros((o.shape[0], W, 4), device=o.device)  # standing still: nobody falls within 2 * H steps
+    col = RolloutCollector(env, policy, horizon=2 * H, discount=1.0)
+    tr = col.collect()
+    dn = tr.dones.cpu().numpy()
+    assert (dn[H - 1] & 2).all() and (dn[2 * H - 1] & 2).all(), "the time limit must reach the trajectory as bit 1"
+    alive = (dn[:, :] & 1).sum(axis=0) == 0
+    assert alive.any()
+    rew, ret = tr.rewards.cpu().numpy(), tr.returns.cpu().numpy()
+    # undiscounted returns restart at the truncation: returns[H] sums only the second episode
+    n = int(np.nonzero(alive)[0][0])
+    assert np.allclose(ret[H, n], rew[H:, n].sum(axis=0), atol=1e-4)
+    assert np.allclose(ret[0, n], rew[:H, n].sum(axis=0), atol=1e-4)

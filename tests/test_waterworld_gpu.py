@@ -46,10 +46,11 @@ def test_hip_matches_reference_golden_teacher_forced(path):
         assert int(st["t"][t]) == int(g["post_t"][t])
         e = max(errs)
         if e > TOL:
-            flips += 1  # a <= / > test decided differently in float32 (Appendix B.3): must be rare
+            flips += 1  # a <= / > test decided differently in float32 -- none on the committed fixtures
+            print("golden %s step %d: error %.3g beyond %.0e" % (gid(path), t, e, TOL))
         else:
             worst = max(worst, e)
-    assert flips <= max(1, T // 200), "%d of %d steps beyond %.0e" % (flips, T, TOL)
+    assert flips == 0, "%d of %d steps beyond %.0e" % (flips, T, TOL)
     assert worst <= TOL
 
 
