@@ -19,6 +19,7 @@
 //   reset .................... pursuit_evade.py:173-207, utils/agent_utils.py:12-47
 #include "common.hpp"
 #include "pursuit_wave.hpp"
+#include "pursuit_group.hpp"
 
 #include <new>
 #include <stdlib.h>
@@ -567,6 +568,7 @@ struct WaveGeom {
     int xs, ys, P, E, R, flatten;
     int GW, PAD, GSZ, D, X_ID, X_SKIP;
     int rec_bytes, off_gone, off_term;
+    int waves;  // wavefronts per env: 1 = pursuit_wave_kernel, > 1 = pursuit_group_kernel
 };
 }  // namespace
 
@@ -588,16 +590,32 @@ void wave_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t b
 }
 
 template <class S>
-constexpr WaveGeom wave_geom() {
+void group_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t blocks, hipStream_t s) {
+    if (mode == 0)
+        hipLaunchKernelGGL((pw::pursuit_group_kernel<S, 0, false>), dim3((unsigned)blocks), dim3(S::NT), 0, s, d, io);
+    else if (io.inj_eact != nullptr)
+        hipLaunchKernelGGL((pw::pursuit_group_kernel<S, 1, true>), dim3((unsigned)blocks), dim3(S::NT), 0, s, d, io);
+    else
+        hipLaunchKernelGGL((pw::pursuit_group_kernel<S, 1, false>), dim3((unsigned)blocks), dim3(S::NT), 0, s, d, io);
+}
+
+template <class S>
+constexpr WaveGeom wave_geom(int waves = 1) {
     return WaveGeom{S::XS, S::YS, S::P, S::E, S::R, S::FLATTEN, S::GW, S::PAD, S::GSZ, S::D, S::X_ID, S::X_SKIP,
-                    S::REC_BYTES, S::OFF_GONE, S::OFF_TERM};
+                    S::REC_BYTES, S::OFF_GONE, S::OFF_TERM, waves};
 }
 
 #define X(XS, YS, NP, NE, R, FL) {wave_geom<pw::Shape<XS, YS, NP, NE, R, FL>>(), wave_launch<pw::Shape<XS, YS, NP, NE, R, FL>>},
+#define XG(XS, YS, NP, NE, R, FL, NW)
 const WaveEntry WAVE_TABLE[] = {
+#include "pursuit_specializations.def"
+#undef X
+#define X(XS, YS, NP, NE, R, FL)
+#define XG(XS, YS, NP, NE, R, FL, NW) {wave_geom<pw::GShape<XS, YS, NP, NE, R, FL, NW>>(NW), group_launch<pw::GShape<XS, YS, NP, NE, R, FL, NW>>},
 #include "pursuit_specializations.def"
 };
 #undef X
+#undef XG
 
 const WaveEntry *find_wave(const madrl_pursuit_config *c) {
     if (c->flatten && !c->include_id) return nullptr;
@@ -704,7 +722,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         pw::WaveIO w;
         w.mask = io.mask; w.inj_pos = io.inj_pos; w.inj_map = io.inj_map; w.actions = io.actions;
         w.inj_eact = io.inj_eact; w.obs = io.obs; w.rew = io.rew; w.done = io.done; w.removed = io.removed;
-        int64_t blocks = h->max_blocks > 0 ? h->max_blocks : WAVE_DEFAULT_BLOCKS;
+        int64_t blocks = h->max_blocks > 0 ? h->max_blocks : WAVE_DEFAULT_BLOCKS / h->wave->g.waves;
         if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
         // Large batches: successive step launches walk the env range in opposite directions, so the rows written last by
         // one step are the first ones touched by the next while they are still in the 256 MB memory-side cache.  Measured

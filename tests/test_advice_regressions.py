@@ -49,14 +49,17 @@ def test_dropins_pickle_and_deepcopy_roundtrip():
     from madrl_amd.waterworld import MAWaterWorld
     from madrl_amd.multiwalker import MultiWalkerEnv
     from madrl_amd.hostage import ContinuousHostageWorld
-    envs = [PursuitEvade([rectangle_map(16, 16)], n_evaders=30, n_pursuers=8, obs_range=7, seed=5),
-            MAWaterWorld(5, 10, seed=5), MultiWalkerEnv(n_walkers=2, seed=5), ContinuousHostageWorld(3, 10, 5, 2, 2, seed=5)]
-    for env in envs:
-        for clone in (pickle.loads(pickle.dumps(env)), copy.deepcopy(env)):
+    makers = [lambda: PursuitEvade([rectangle_map(16, 16)], n_evaders=30, n_pursuers=8, obs_range=7, seed=5),
+              lambda: MAWaterWorld(5, 10, seed=5), lambda: MultiWalkerEnv(n_walkers=2, seed=5),
+              lambda: ContinuousHostageWorld(3, 10, 5, 2, 2, seed=5)]
+    for make in makers:
+        for cloner in (lambda e: pickle.loads(pickle.dumps(e)), copy.deepcopy):
+            env = make()  # a clone restarts from the constructor arguments (EzPickle): compare with a fresh env
+            clone = cloner(make())
             assert type(clone) is type(env) and clone._env is not env._env
             assert len(clone.agents) == len(env.agents)
             a, b = env.reset(), clone.reset()
-            assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), type(env).__name__  # same ctor args, same seed
+            assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), type(env).__name__
             if isinstance(env, PursuitEvade):
                 act = [1] * 8
             else:
