@@ -237,8 +237,9 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=0, help="env instances per GPU (0 = the BASELINE config's batch)")
-    ap.add_argument("--workload", default="pursuit", choices=["pursuit", "waterworld", "multiwalker", "hostage"],
-                    help="pursuit = BASELINE.json's metric (default); the other two are the remaining north_star envs")
+    ap.add_argument("--workload", default="pursuit", choices=["pursuit", "pursuit_c5", "waterworld", "multiwalker", "hostage"],
+                    help="pursuit = BASELINE.json's metric (default, configs[1]); pursuit_c5 = configs[4]'s per-GPU shard "
+                         "(32x32, 16 v 60, 32 768 envs); the others are the remaining north_star envs")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,10 +269,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.workload != "pursuit":
+    if args.workload not in ("pursuit", "pursuit_c5"):
         return bench_other(args, rank, local_rank, world, dev)
-    N, P, E, R = (args.envs or 65536), 8, 30, 7
-    maps = [rectangle_map(16, 16)]
+    c5 = args.workload == "pursuit_c5"
+    N, P, E, R = (args.envs or (32768 if c5 else 65536)), (16 if c5 else 8), (60 if c5 else 30), 7
+    MS = 32 if c5 else 16
+    maps = [rectangle_map(MS, MS)]
     kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, n_catch=2, surround=True, flatten=True, reward_mech="local")
     env = BatchedPursuitEvade(maps, n_envs=N, device=dev, seed=0, env_id_base=rank * N, max_steps=args.horizon,
                               auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw)
@@ -346,9 +349,9 @@ def main():
     if rank == 0:
         bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
         achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
-        traffic = measured_traffic(N)
+        traffic = measured_traffic(N, args.workload)
         out = {
-            "metric": "env-steps/sec at fixed batch (PursuitEvade 16x16, 8v30)",
+            "metric": "env-steps/sec at fixed batch (PursuitEvade %dx%d, %dv%d)" % (MS, MS, P, E),
             "value": world * N * K / dt,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -360,22 +363,22 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
             "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset)",
-            "config": {"workload": "PursuitEvade 16x16 rectangle_map, 8 pursuers / 30 evaders, obs_range 7, surround, "
-                                   "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (N, args.horizon),
+            "config": {"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, surround, "
+                                   "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (MS, MS, P, E, N, args.horizon),
                        "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
                          "algorithmic_bytes_per_launch": bytes_per * N,
-                         "kernel": "pursuit_wave_kernel<16,16,8,30,7,1>" if env.kernel_kind == "wave" else "pursuit_kernel<3>",
+                         "kernel": ("pursuit_group_kernel<32,32,16,60,7,1,2>" if c5 else "pursuit_wave_kernel<16,16,8,30,7,1>") if env.kernel_kind == "wave" else "pursuit_kernel<NT>",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": bytes_per},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
             # cpu_baseline: the unmodified reference NumPy path (configs[0]; committed record, host labelled);
             # cpu_baseline_port: the C restatement of the same algorithm timed live on this box's host cores
-            ref = cpu_reference_record("pursuit_c1")
+            ref = cpu_reference_record("pursuit_c1") if not c5 else None
             port = cpu_baseline_port(maps, kw)
             if ref is not None:
                 out["cpu_baseline"], out["cpu_baseline_port"] = ref, port

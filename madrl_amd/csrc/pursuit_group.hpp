@@ -180,13 +180,13 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
             const uint32_t xy = (tid & 1) ? (xyw >> 16) : (xyw & 0xFFFFu);
             int x = (int)(xy & 0xFF), y = (int)(xy >> 8);
             if (!isAgent()) x = y = 0;  // threads past the last agent keep a harmless in-map cell
-            uint64_t gone = __builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4);
-            if constexpr (S::NGW > 1) gone |= (uint64_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4 + 1) << 32;
+            uint64_t gone = (uint32_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4);  // (uint32_t): readlane returns int, bit 31 must not sign-extend
+            if constexpr (S::NGW > 1) gone |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4 + 1) << 32;
             // terminal flags of THIS wavefront's lanes (record words 2 wv, 2 wv + 1)
             uint64_t term = 0ull;
             {
                 const uint32_t tw = (uint32_t)__shfl((int)cur_rec, (S::OFF_TERM / 4 + 2 * wv + (lane & 1)) & 63);
-                const uint32_t t0 = __builtin_amdgcn_readlane(tw, 0), t1 = __builtin_amdgcn_readlane(tw, 1);
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane(tw, 0), t1 = (uint32_t)__builtin_amdgcn_readlane(tw, 1);
                 if (2 * wv < S::NTW) term = t0;
                 if (2 * wv + 1 < S::NTW) term |= (uint64_t)t1 << 32;
             }

@@ -266,10 +266,10 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
             const uint32_t xyw = (uint32_t)__shfl((int)cur_rec, 4 + (lane >> 1));
             const uint32_t xy = (lane & 1) ? (xyw >> 16) : (xyw & 0xFFFFu);
             int x = (int)(xy & 0xFF), y = (int)(xy >> 8);
-            uint64_t gone = __builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4);
-            if constexpr (S::NGW > 1) gone |= (uint64_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4 + 1) << 32;
-            uint64_t term = __builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4);
-            if constexpr (S::NTW > 1) term |= (uint64_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4 + 1) << 32;
+            uint64_t gone = (uint32_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4);  // (uint32_t): readlane returns int, bit 31 must not sign-extend
+            if constexpr (S::NGW > 1) gone |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_GONE / 4 + 1) << 32;
+            uint64_t term = (uint32_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4);
+            if constexpr (S::NTW > 1) term |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane(cur_rec, S::OFF_TERM / 4 + 1) << 32;
             const uint32_t gid = d.gid_base + (uint32_t)env;
             const uint32_t k0 = fresh_s(d.k0), k1 = fresh_s(d.k1);  // round keys recomputed on the SALU, not kept live
             bool do_reset = (MODE == 0);

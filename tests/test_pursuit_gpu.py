@@ -29,7 +29,8 @@ def _cmp_state(st_gpu, st_ref, msg=""):
 
 WAVE_GOLDEN = {"pursuit_c1_surround_local", "pursuit_c1_surround_global", "pursuit_c1_colocate_hwc",
                "pursuit_pool16_sample_maps", "pursuit_tiny5_dense", "pursuit_in_building",
-               "pursuit_nonsquare_12x20", "pursuit_window_gt_map", "pursuit_random_opponents"}
+               "pursuit_nonsquare_12x20", "pursuit_window_gt_map", "pursuit_random_opponents",
+               "pursuit_c5_32x32"}  # the last one: two wavefronts per env (pursuit_group.hpp)
 
 
 @pytest.mark.parametrize("path", pursuit_golden_files(), ids=golden_id)
@@ -82,6 +83,10 @@ CASES = {
     "c5_32x32": dict(maps="rect32", n_pursuers=16, n_evaders=60, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local"),
     "c2_random_opponents": dict(maps="rect16", n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True,
                                 reward_mech="local", random_opponents=True, max_opponents=25),
+    "group_20v50_pool": dict(maps="pool16", n_pursuers=20, n_evaders=50, obs_range=5, n_catch=1, surround=False, flatten=True,
+                             reward_mech="global", sample_maps=True, random_opponents=True, max_opponents=45, catchr=0.1),
+    "group_20v50_surround": dict(maps="pool16", n_pursuers=20, n_evaders=50, obs_range=5, n_catch=2, surround=True, flatten=True,
+                                 reward_mech="local", sample_maps=True),
     "tiny_window": dict(maps="open6", n_pursuers=5, n_evaders=4, obs_range=5, n_catch=2, surround=True, flatten=True,
                         reward_mech="global", constraint_window=0.5),
 }
@@ -111,8 +116,8 @@ def test_hip_matches_oracle_free_running(case, kernel):
     maps = _maps(kw.pop("maps"))
     N, T, H = 512, 120, 25
     env = _mk(maps, N, seed=2024, env_id_base=1000, max_steps=H, auto_reset=True, kernel=kernel, **kw)
-    if kernel == "auto" and case != "c5_32x32":
-        assert env.kernel_kind == "wave"
+    if kernel == "auto":
+        assert env.kernel_kind == "wave"  # one wavefront per env, or a wavefront group for more than 64 agents
     orc = po.PursuitOracle(maps, n_envs=N, seed=2024, env_id_base=1000, **kw)
     obs = env.reset()
     oobs = orc.reset().copy()
@@ -142,6 +147,41 @@ def test_hip_matches_oracle_free_running(case, kernel):
             _cmp_state(env.get_state(), orc.get_state(), "step %d" % t)
             assert np.array_equal(env.get_state()["t"].cpu().numpy(), tstep), "episode step counter"
     assert n_removed > 0
+
+
+@pytest.mark.parametrize("shape", ["c2_wave", "c5_group"])
+def test_bit31_of_the_alive_and_terminal_masks(shape):
+    """Evader slot 31 gone / agent 31 terminal: bit 31 of a record word must not leak into the upper half of the
+    64-bit wave masks (v_readlane returns a signed int).  Fast path against the generic kernel from the same state."""
+    from madrl_amd.maps import rectangle_map
+    if shape == "c2_wave":
+        maps, P, E = [rectangle_map(16, 16)], 8, 30
+    else:
+        maps, P, E = [rectangle_map(32, 32)], 16, 60
+    N = 64
+    kw = dict(n_pursuers=P, n_evaders=E, obs_range=7, n_catch=2, surround=True, flatten=True, seed=4)
+    envs = [_mk(maps, N, kernel=k, **kw) for k in ("generic", "wave")]
+    for env in envs:
+        env.reset()
+        st = env.get_state()
+        gone = torch.zeros((N, E), dtype=torch.uint8)
+        term_e = torch.zeros((N, E), dtype=torch.uint8)
+        if E > 31:
+            gone[:, 31] = 1
+        term_e[:, 31 - P] = 1            # agent index 31
+        if P + E > 64:
+            term_e[:, 95 - P if 95 - P < E else E - 1] = 1
+            gone[:, E - 1] = 1
+        env.set_state(dict(gone=gone, term_e=term_e))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for t in range(12):
+        act = torch.randint(0, 5, (N, P), generator=g, dtype=torch.int32).to(DEV)
+        outs = [env.step(act) for env in envs]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "step %d" % t
+        sa, sb = envs[0].get_state(), envs[1].get_state()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), "step %d state[%s]" % (t, k)
+    assert bool(sa["term_e"][:, 31 - P].all()) and (E <= 31 or bool(sa["gone"][:, 31].all()))
 
 
 def test_launch_shape_does_not_change_results():
