@@ -1,4 +1,15 @@
 """Env API mirror of madrl_environments/__init__.py:9-119 (Agent, AbstractMAEnv)."""
+import numpy as np
+
+
+def stack_dict_list(dict_list):
+    """rltools.util.stack_dict_list as used by AbstractMAEnv.animate (:106): list of info dicts -> dict of arrays."""
+    ret = {}
+    if not dict_list:
+        return ret
+    for k in dict_list[0].keys():
+        ret[k] = np.asarray([d[k] for d in dict_list])
+    return ret
 
 
 class Agent(object):
@@ -49,6 +60,29 @@ class AbstractMAEnv(object):
             setattr(self, k, v)
         self.setup()
 
+    def render(self, *args, **kwargs):
+        """:69-70.  Rendering (matplotlib / pyglet on the host) is out of scope; animate() runs without frames."""
+        return None
+
+    def animate(self, act_fn, nsteps, **kwargs):
+        """:72-107 without the video encoder: one policy function per agent (or one for all), reset, then up to nsteps
+        steps or until done; returns (summed rewards per agent, stacked info dicts) like the reference."""
+        if not isinstance(act_fn, list):
+            act_fn = [act_fn for _ in range(len(self.agents))]
+        assert len(act_fn) == len(self.agents)
+        obs = self.reset()
+        rew = np.zeros((len(self.agents)))
+        traj_info_list = []
+        for step in range(nsteps):
+            a = list(map(lambda afn, o: afn(o), act_fn, obs))
+            obs, r, done, info = self.step(a)
+            rew += r
+            if info:
+                traj_info_list.append(info)
+            if done:
+                break
+        return rew, stack_dict_list(traj_info_list)
+
     @property
     def unwrapped(self):
         return self
@@ -72,7 +106,7 @@ class SingleEnvDelegate(object):
         return getattr(env, name)
 
     def __getstate__(self):
-        return {"_env": self.__dict__["_env"]}  # the batched engine pickles by constructor arguments (EzPickle-style)
+        return dict(self.__dict__)  # `_env`, the batched engine, pickles by constructor arguments (EzPickle-style)
 
     def __setstate__(self, state):
         self.__dict__.update(state)

@@ -317,10 +317,37 @@ class BatchedPursuitEvade(AbstractMAEnv):
 
 
 class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
-    """N == 1 drop-in with the reference's return types (pursuit_evade.py:26)."""
+    """N == 1 drop-in with the reference's return types (pursuit_evade.py:26).
+
+    `evader_controller=` (pursuit_evade.py:87): an object with `.act(model_state)`; as in the reference (:238-241) it is
+    asked once per REMAINING evader, in layer order, every step, and sees the model_state of the previous step
+    (float32 [4, xs, ys]: map, pursuer counts, evader counts incl. the evaders caught in that step, zeros).  Its
+    answers travel to the kernel as injected evader actions.  Without it the evaders move by in-kernel Philox draws
+    (the reference's default is an unseeded RandomPolicy, Controllers.py:11)."""
 
     def __init__(self, map_pool, device="cuda:0", **kwargs):
+        self._evader_controller = kwargs.pop("evader_controller", None)
+        self._reset_positions = []   # parity hook: see script_reset_positions()
+        self._alive_at_step_start = None
         self._env = BatchedPursuitEvade(map_pool, n_envs=1, device=device, **kwargs)
+
+    def script_reset_positions(self, positions):
+        """Parity hook (the golden generators replace agent_utils.feasible_position the same way): each following
+        reset() takes its initial positions, int [P+E, 2] pursuers first, from this list instead of sampling."""
+        self._reset_positions = [np.asarray(p, dtype=np.int32) for p in positions]
+
+    @property
+    def model_state(self):
+        """pursuit_evade.py:152, :201-203, :244-246 rebuilt from the packed state (host side, N == 1)."""
+        e = self._env
+        st = {k: v[0].cpu().numpy() for k, v in e.get_state().items()}
+        ms = np.zeros((4, e.xs, e.ys), dtype=np.float32)
+        ms[0] = e.map_pool[int(st["map_id"])]
+        np.add.at(ms[1], (st["pos_p"][:, 0], st["pos_p"][:, 1]), 1)
+        drawn = (st["gone"] == 0) if self._alive_at_step_start is None else self._alive_at_step_start  # Q6
+        pe = st["pos_e"][drawn]
+        np.add.at(ms[2], (pe[:, 0], pe[:, 1]), 1)
+        return ms
 
     @property
     def agents(self):
@@ -344,10 +371,12 @@ class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
         return [o[i] for i in range(o.shape[0])]
 
     def reset(self):
-        return self._obslist(self._env.reset())
+        pos = self._reset_positions.pop(0)[None] if self._reset_positions else None
+        self._alive_at_step_start = None
+        return self._obslist(self._env.reset(positions=pos))
 
     def step(self, actions):
-        P = int(self._env.n_pursuers)
+        P, E = int(self._env.n_pursuers), int(self._env.n_evaders)
         if isinstance(actions, (list, np.ndarray)):  # pursuit_evade.py:227-230
             act = np.asarray(actions).reshape(-1)
             if act.shape[0] != P:
@@ -357,7 +386,15 @@ class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
         if ((act < -5) | (act > 4)).any():
             raise IndexError("list index out of range")  # motion_range[a], DiscreteAgent.py:83
         act = np.where(act < 0, act + 5, act)  # python list wrap-around
-        obs, rew, done, info = self._env.step(torch.as_tensor(act.reshape(1, P)))
+        eact = None
+        if self._evader_controller is not None:  # :238-241
+            ms = self.model_state
+            alive = self._env.get_state()["gone"][0].cpu().numpy() == 0
+            eact = np.full((1, E), 4, dtype=np.int32)
+            for k in range(int(alive.sum())):
+                eact[0, k] = int(self._evader_controller.act(ms))
+            self._alive_at_step_start = alive
+        obs, rew, done, info = self._env.step(torch.as_tensor(act.reshape(1, P)), evader_actions=eact)
         r = rew[0].detach().cpu().numpy().astype(np.float64)
         rewards = [float(r[0])] * P if self._env.reward_mech == "global" else r
         return self._obslist(obs), rewards, bool(done[0].item()), {"removed": int(info["removed"][0].item())}

@@ -1,10 +1,18 @@
 """Minimal Box / Discrete spaces with the attributes the reference's callers read
 (rllabwrapper/__init__.py:16-27, runners/rurltools.py:29-38): .shape, .low, .high, .n.
-`gym` itself is not a dependency of this package."""
+`gym` itself is not a dependency of this package; when it IS importable the two classes derive from gym's, so
+that `isinstance(agent.observation_space, spaces.Box)` in the reference's own wrappers
+(madrl_environments/__init__.py:156, :225) holds for the drop-in envs."""
 import numpy as np
 
+try:  # pragma: no cover - depends on the deployment
+    from gym import spaces as _gym_spaces
+    _BoxBase, _DiscreteBase = _gym_spaces.Box, _gym_spaces.Discrete
+except Exception:
+    _BoxBase = _DiscreteBase = object
 
-class Box(object):
+
+class Box(_BoxBase):
     def __init__(self, low, high, shape=None):
         if shape is None:
             self.low = np.asarray(low, dtype=np.float64)
@@ -31,7 +39,7 @@ class Box(object):
         return "Box%s" % (self.shape,)
 
 
-class Discrete(object):
+class Discrete(_DiscreteBase):
     def __init__(self, n):
         self.n = int(n)
 

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .base import AbstractMAEnv, Agent
+from .base import AbstractMAEnv, Agent, SingleEnvDelegate
 from .spaces import Box
 
 
@@ -34,15 +34,71 @@ class WrappedAgent(Agent):
         return self._unwrapped.action_space
 
 
-class _Wrapper(AbstractMAEnv):
+class _SingleAsBatched(object):
+    """Adapter under a wrapper that was handed an N == 1 drop-in env (reference return types: lists of float64
+    arrays, python bool): presents it as a one-env batched env, so the same epilogue kernels serve both.  The drop-in's
+    own reset()/step() still run (action parsing, evader_controller, scripted positions)."""
+
     def __init__(self, env):
-        self._unwrapped = env
-        self.device = env.device
-        self.n_envs = env.n_envs
+        self.single, self.device, self.n_envs, self.auto_reset = env, env.device, 1, False
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["single"], name)
+
+    def _obs(self, obs):
+        return torch.as_tensor(np.stack([np.asarray(o) for o in obs])[None], dtype=torch.float32, device=self.device)
+
+    def reset(self, **kw):
+        return self._obs(self.single.reset(**kw))
+
+    def step(self, action, **kw):
+        obs, rew, done, info = self.single.step(action, **kw)
+        r = torch.as_tensor(np.asarray(rew, dtype=np.float64)[None], dtype=torch.float32, device=self.device)
+        return self._obs(obs), r, torch.as_tensor([bool(done)], device=self.device), info
+
+
+def _rows(t):
+    o = t[0].detach().cpu().numpy().astype(np.float64)
+    return [o[i] for i in range(o.shape[0])]
+
+
+class _Wrapper(AbstractMAEnv):
+    """Every wrapper computes on the batched (tensor) side: `_reset_b` / `_step_b`.  Around an N == 1 drop-in env
+    (or a wrapper of one) the public reset()/step() hand back the reference's types instead -- lists of per-agent
+    float64 arrays, python bool -- so `StandardizedEnv(PursuitEvade(...))` reads like the reference's."""
+
+    def __init__(self, env):
+        self._single = isinstance(env, SingleEnvDelegate) or bool(getattr(env, "_single", False))
+        self._unwrapped = _SingleAsBatched(env) if isinstance(env, SingleEnvDelegate) else env
+        self.device = self._unwrapped.device
+        self.n_envs = self._unwrapped.n_envs
+
+    def _inner_reset(self, **kw):
+        u = self._unwrapped
+        return u._reset_b(**kw) if isinstance(u, _Wrapper) else u.reset(**kw)
+
+    def _inner_step(self, *args, **kw):
+        u = self._unwrapped
+        return u._step_b(*args, **kw) if isinstance(u, _Wrapper) else u.step(*args, **kw)
+
+    def reset(self, **kw):
+        obs = self._reset_b(**kw)
+        return _rows(obs) if self._single else obs
+
+    def step(self, *args, **kw):
+        obs, rew, done, info = self._step_b(*args, **kw)
+        if not self._single:
+            return obs, rew, done, info
+        r = rew[0].detach().cpu().numpy().astype(np.float64)
+        return _rows(obs), [float(x) for x in r], bool(done[0].item()), self._single_info(info)
+
+    def _single_info(self, info):
+        return info
 
     @property
     def unwrapped(self):
-        return self._unwrapped
+        u = self._unwrapped
+        return u.single if isinstance(u, _SingleAsBatched) else u
 
     @property
     def agents(self):
@@ -93,18 +149,18 @@ class ObservationBuffer(_Wrapper):
                                                    _lib.ptr(reset_mask), _lib.ptr(active_mask), _stream(self)))
         return self._buf
 
-    def reset(self, mask=None):
+    def _reset_b(self, mask=None):
         if mask is None:
-            return self._push(self._unwrapped.reset(), torch.ones(self.n_envs, dtype=torch.uint8, device=self.device))
+            return self._push(self._inner_reset(), torch.ones(self.n_envs, dtype=torch.uint8, device=self.device))
         m = torch.as_tensor(mask, device=self.device).reshape(self.n_envs).to(torch.uint8).contiguous()
         first = self._buf is None
-        obs = self._unwrapped.reset(mask=m)
+        obs = self._inner_reset(mask=m)
         if first:  # nothing to keep yet: every env starts from its current observation
             return self._push(obs, torch.ones_like(m))
         return self._push(obs, m, active_mask=m)  # envs outside the mask keep their history untouched
 
-    def step(self, action, **kw):
-        obs, rew, done, info = self._unwrapped.step(action, **kw)
+    def _step_b(self, action, **kw):
+        obs, rew, done, info = self._inner_step(action, **kw)
         reset_mask = self._done_u8(done, info) if getattr(self._unwrapped, "auto_reset", False) else None
         return self._push(obs, reset_mask), rew, done, info
 
@@ -146,11 +202,11 @@ class StandardizedEnv(_Wrapper):
                                                  float(self._scale_reward), int(bool(self._enable_rewnorm)), _stream(self)))
         return self._rew_out
 
-    def reset(self, **kw):
-        return self._norm_obs(self._unwrapped.reset(**kw))  # :276-281
+    def _reset_b(self, **kw):
+        return self._norm_obs(self._inner_reset(**kw))  # :276-281
 
-    def step(self, *args, **kw):
-        obs, rew, done, info = self._unwrapped.step(*args, **kw)  # :283-291
+    def _step_b(self, *args, **kw):
+        obs, rew, done, info = self._inner_step(*args, **kw)  # :283-291
         return self._norm_obs(obs), self._norm_rew(rew), done, info
 
     def __str__(self):
@@ -175,8 +231,8 @@ class DiagnosticsWrapper(_Wrapper):
         self._out_fin = torch.zeros(N, dtype=torch.uint8, device=dev)
         self._local_t, self._last_time = 0, time.time()
 
-    def reset(self, **kw):
-        obs = self._unwrapped.reset(**kw)  # :328-333
+    def _reset_b(self, **kw):
+        obs = self._inner_reset(**kw)  # :328-333
         mask = kw.get("mask")
         if mask is None:
             self._ep_reward.zero_(); self._disc_ret.zero_(); self._ep_len.zero_()
@@ -185,8 +241,19 @@ class DiagnosticsWrapper(_Wrapper):
             self._ep_reward[m] = 0; self._disc_ret[m] = 0; self._ep_len[m] = 0
         return obs
 
-    def step(self, *args, **kw):
-        obs, rew, done, info = self._unwrapped.step(*args, **kw)
+    def _single_info(self, to_log):
+        """:352-367 -- the reference's to_log dict: scalar entries, present only on the step that ends an episode"""
+        out = {k: v for k, v in to_log.items() if k == "diagnostics/fps"}
+        if bool(to_log["finished"][0]):
+            for a in range(self._A):
+                out["global/episode_reward_agent{}".format(a)] = float(to_log["global/episode_reward_agents"][0, a])
+            out["global/episode_avg_reward"] = float(to_log["global/episode_avg_reward"][0])
+            out["global/episode_disc_return"] = float(to_log["global/episode_disc_return"][0])
+            out["global/episode_length"] = int(to_log["global/episode_length"][0])
+        return out
+
+    def _step_b(self, *args, **kw):
+        obs, rew, done, info = self._inner_step(*args, **kw)
         rew_c = rew.contiguous()
         _lib.check(_lib.lib().madrl_wrap_diagnostics(
             _lib.ptr(rew_c), _lib.ptr(self._done_u8(done, info)), _lib.ptr(self._ep_reward), _lib.ptr(self._ep_len),
