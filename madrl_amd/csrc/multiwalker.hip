@@ -1,24 +1,24 @@
 // multiwalker.hip -- batched MultiWalkerEnv for MI355X (gfx950 / CDNA4), float32.
 //
-// One workgroup (one wavefront) owns one env at a time; the whole rigid-body world of the env
-// (16 bodies, 12 revolute joints, manifold cache, terrain: mw::World, 6 KB) and the per-step
-// solver workspace (mw::Scratch, ~8 KB) live in LDS for the 180 + 60 Gauss-Seidel sweeps of
-// Box2D's `Step(1/50, 180, 60)`; HBM sees the world struct in/out once per step, the action row
-// in and observation / reward / done rows out.
+// FOUR ENVS PER WAVEFRONT: a group of 16 lanes owns one env (multiwalker_core.hpp `Par`: bodies and their terrain
+// contacts by lane, one lane per leg for the revolute joints, the package / hull contacts one at a time), the four groups
+// of a wavefront advance their envs through the same instruction stream.  The step is bound by instruction issue (about
+// 1 MFLOP of dependent FP32 work per env-step in 180 + 60 Gauss-Seidel sweeps against ~12 KB of HBM traffic), so sharing
+// the stream between four envs is worth almost 4x per wavefront.
 //
-// Lane mapping (multiwalker_core.hpp `Par`): collision detection by body, joints by walker,
-// terrain contacts by body, the package/hull contacts on one lane, with wave-local syncs between
-// the phases of each Gauss-Seidel sweep; lanes working concurrently never share a body, so the
-// result equals the serial sweep bit for bit.  The remaining lanes move the world struct and the
-// outputs (coalesced dword copies).
-// The path is bound by dependent FP32 VALU latency inside one wavefront, not by HBM
-// (~3 KB per env-step against ~1 MFLOP of serial work) -- DESIGN.md "MultiWalker".
+// Per env, LDS holds only what the sweeps touch: mw::Hot (bodies, joints, flags: 1 KB) and mw::Scratch (active manifolds
+// + schedule, sized by n_walkers: 5.3 KB at three walkers); the joint constants and accumulated impulses of a leg sit in
+// the registers of the lane that owns it for the whole step.  mw::Cold (manifold cache with the warm-start impulses,
+// terrain) is touched once per step by Collide / StoreImpulses / lidar and is read and written in place in HBM (L2).
+// Lanes of a group that work concurrently never share a body and every pair of constraints that shares a body keeps its
+// serial order, so the result equals the serial sweep of the CPU build bit for bit.
 //
 // PARITY UNPINNED (Box2D is not available to pin against) -- see multiwalker_core.hpp.
 #include "common.hpp"
 #include "multiwalker_core.hpp"
 
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -28,7 +28,9 @@ using namespace madrl;
 struct MwDev {
     mw::EnvCfg cfg;
     uint32_t gid_base;
-    int32_t world_dw;  // dwords per env in the state buffer
+    int32_t world_dw;      // dwords per env in the state buffer
+    int32_t scratch_bytes; // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
+    int32_t env_lds_bytes; // LDS per env: Hot | Scratch | actions, rewards, done
     int64_t n_envs;
     const mw::Model *model;
     uint32_t *state;
@@ -41,66 +43,82 @@ struct MwIO {
     uint8_t *done;         // [N]
 };
 
+constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
+constexpr int IO_BYTES = (4 * mw::MAX_WALKERS + mw::MAX_WALKERS + 4) * 4;  // s_act | s_rew | s_done
+
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the cooperating lanes of multiwalker_core.hpp's `Par` = the 64 lanes of the wavefront
-struct WavePar {
+// the cooperating lanes of multiwalker_core.hpp's `Par` = one group of 64 / EPW lanes of the wavefront
+template <int EPW>
+struct GroupPar {
+    static constexpr int NL = 64 / EPW;
+    static constexpr int LEGS = (2 * mw::MAX_WALKERS + NL - 1) / NL;
     int l;
     __device__ __forceinline__ int lane() const { return l; }
-    __device__ __forceinline__ int n() const { return 64; }
+    __device__ __forceinline__ int n() const { return NL; }
     __device__ __forceinline__ void sync() const { lds_sync(); }
     __device__ __forceinline__ int alloc(int *counter) const { return atomicAdd(counter, 1); }
 };
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
-template <int MODE>
+template <int MODE, int EPW>
 __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const MwIO io) {
     const mw::Model &M = *d.model;
-    __shared__ mw::World Wd;
-    __shared__ mw::Scratch S;
-    __shared__ float s_rew[mw::MAX_WALKERS], s_act[4 * mw::MAX_WALKERS];
-    __shared__ uint8_t s_done;
-    const int lane = threadIdx.x;
-    const WavePar par{lane};
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NL = 64 / EPW;
+    const int g = threadIdx.x / NL, lane = threadIdx.x % NL;
+    const GroupPar<EPW> par{lane};
+    unsigned char *base = smem + g * d.env_lds_bytes;
+    mw::Hot &Wd = *reinterpret_cast<mw::Hot *>(base);
+    mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES);
+    float *s_act = reinterpret_cast<float *>(base + HOT_BYTES + d.scratch_bytes);
+    float *s_rew = s_act + 4 * mw::MAX_WALKERS;
+    uint32_t *s_done = reinterpret_cast<uint32_t *>(s_rew + mw::MAX_WALKERS);
     const int W = M.W;
-    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
-        if (MODE == 0 && io.mask != nullptr && io.mask[env] == 0) continue;
-        uint32_t *rec = d.state + env * (int64_t)d.world_dw;
-        {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
-            for (int k = lane; k < (int)(sizeof(mw::World) / 4); k += 64) dst[k] = rec[k];
-            if (lane < 4 * mw::MAX_WALKERS) s_act[lane] = (MODE == 1 && lane < 4 * W) ? io.actions[env * 4 * W + lane] : 0.0f;
-            if (lane == 0) s_done = 0;
-        }
-        lds_sync();
-        const uint32_t gid = d.gid_base + (uint32_t)env;
-        float *s_obs = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM (no LDS staging: 512 B less per workgroup)
-        if (MODE == 1) {
-            mw::env_step(M, d.cfg, Wd, S, par, gid, s_act, s_obs, s_rew, &s_done);   // all lanes cooperate
-            if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) s_done |= 2;
+    for (int64_t e0 = (int64_t)blockIdx.x * EPW; e0 < d.n_envs; e0 += (int64_t)gridDim.x * EPW) {
+        const int64_t env = e0 + g;
+        bool active = env < d.n_envs;
+        if (MODE == 0 && active && io.mask != nullptr && io.mask[env] == 0) active = false;
+        if (active) {
+            uint32_t *rec = d.state + env * (int64_t)d.world_dw;
+            mw::Cold &Cd = *reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
+            {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
+                for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = rec[k];
+                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (MODE == 1 && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
+                if (lane == 0) *s_done = 0;
+            }
             lds_sync();
+            const uint32_t gid = d.gid_base + (uint32_t)env;
+            float *obs_row = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM
+            if (MODE == 1) {
+                mw::env_step(M, d.cfg, Wd, Cd, S, par, gid, s_act, obs_row, s_rew, reinterpret_cast<uint8_t *>(s_done));
+                if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2;
+                lds_sync();
+            }
+            const uint32_t dn = *s_done;  // uniform over the group
+            if (MODE == 0 || (dn != 0 && d.cfg.auto_reset)) {  // MultiWalkerEnv.reset (:330-357) ends with step(zeros)
+                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = 0.0f;
+                if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, Cd, gid);
+                lds_sync();
+                mw::env_step(M, d.cfg, Wd, Cd, S, par, gid, s_act, obs_row, (float *)nullptr, (uint8_t *)nullptr);
+                if (lane == 0) Wd.t = 0;
+                lds_sync();
+            }
+            if (MODE == 1) {
+                if (lane < W) io.rew[env * W + lane] = s_rew[lane];
+                if (lane == 0) io.done[env] = (uint8_t)dn;
+            }
+            {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
+                for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
+            }
         }
-        const uint32_t dn = s_done;  // wave-uniform
-        if (MODE == 0 || (dn != 0 && d.cfg.auto_reset)) {  // MultiWalkerEnv.reset (:330-357) ends with step(zeros)
-            if (lane < 4 * mw::MAX_WALKERS) s_act[lane] = 0.0f;
-            if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, gid);
-            lds_sync();
-            mw::env_step(M, d.cfg, Wd, S, par, gid, s_act, s_obs, (float *)nullptr, (uint8_t *)nullptr);
-            if (lane == 0) Wd.t = 0;
-            lds_sync();
-        }
-        if (MODE == 1) {
-            if (lane < W) io.rew[env * W + lane] = s_rew[lane];
-            if (lane == 0) io.done[env] = (uint8_t)dn;
-        }
-        {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
-            for (int k = lane; k < (int)(sizeof(mw::World) / 4); k += 64) rec[k] = src[k];
-        }
+        // the next env of this group reuses the LDS block; its Cold part is other memory, nothing to wait for
         lds_sync();
     }
 }
@@ -108,7 +126,8 @@ __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const Mw
 __global__ void mw_get_bodies_kernel(const MwDev d, float *bodies, uint8_t *flags, float *terrain) {
     const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (env >= d.n_envs) return;
-    const mw::World *w = reinterpret_cast<const mw::World *>(d.state + env * (int64_t)d.world_dw);
+    const mw::World *wr = reinterpret_cast<const mw::World *>(d.state + env * (int64_t)d.world_dw);
+    const mw::Hot *w = &wr->h;
     const int NB = d.model->NB, W = d.model->W, NT = d.model->NT;
     if (bodies)
         for (int b = 0; b < NB; ++b) {
@@ -120,7 +139,7 @@ __global__ void mw_get_bodies_kernel(const MwDev d, float *bodies, uint8_t *flag
         f[0] = w->game_over;
         for (int k = 0; k < W; ++k) { f[1 + k] = w->fallen[k]; f[1 + W + 2 * k] = w->ground[k][0]; f[1 + W + 2 * k + 1] = w->ground[k][1]; }
     }
-    if (terrain) for (int i = 0; i < NT; ++i) terrain[env * NT + i] = w->ty[i];
+    if (terrain) for (int i = 0; i < NT; ++i) terrain[env * NT + i] = wr->c.ty[i];
 }
 
 }  // namespace
@@ -129,6 +148,7 @@ struct madrl_multiwalker {
     madrl_multiwalker_config cfg;
     MwDev dev;
     int device;
+    int epw;  // envs per wavefront: 4 (default), 2 or 1 (MADRL_MW_EPW at create: experiments)
     int64_t max_blocks;
     void *model_dev;
     int NB, NT;
@@ -146,13 +166,20 @@ int mw_validate(const madrl_multiwalker_config *c) {
     return MADRL_OK;
 }
 
+template <int EPW>
+void mw_launch_epw(const madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
+    int64_t blocks = (h->dev.n_envs + EPW - 1) / EPW;   // default: every group of EPW envs gets its own wavefront
+    if (h->max_blocks > 0 && blocks > h->max_blocks) blocks = h->max_blocks;
+    const size_t lds = (size_t)EPW * h->dev.env_lds_bytes;
+    if (mode == 0) hipLaunchKernelGGL((multiwalker_kernel<0, EPW>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io);
+    else hipLaunchKernelGGL((multiwalker_kernel<1, EPW>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io);
+}
+
 int mw_launch(const madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
-    // default: one workgroup per env (measured best: the step is latency bound, 17 KB of LDS per env)
-    int64_t blocks = h->max_blocks > 0 ? h->max_blocks : h->dev.n_envs;
-    if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL(multiwalker_kernel<0>, dim3((unsigned)blocks), dim3(64), 0, s, h->dev, io);
-    else hipLaunchKernelGGL(multiwalker_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, s, h->dev, io);
+    if (h->epw == 1) mw_launch_epw<1>(h, io, mode, s);
+    else if (h->epw == 2) mw_launch_epw<2>(h, io, mode, s);
+    else mw_launch_epw<4>(h, io, mode, s);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }
@@ -210,6 +237,10 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     d.cfg.k0 = (uint32_t)cfg->seed; d.cfg.k1 = (uint32_t)(cfg->seed >> 32);
     d.gid_base = (uint32_t)cfg->env_id_base;
     d.world_dw = (int32_t)(align_up(sizeof(mw::World), 16) / 4);
+    d.scratch_bytes = (int32_t)align_up(sizeof(mw::Scratch) - (size_t)(mw::MAXM - M.max_manifolds) * sizeof(mw::Manifold), 16);
+    d.env_lds_bytes = HOT_BYTES + d.scratch_bytes + (int32_t)align_up(IO_BYTES, 16);
+    h->epw = 4;
+    if (const char *e = getenv("MADRL_MW_EPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->epw = v; }
     d.n_envs = n_envs;
     d.model = (const mw::Model *)h->model_dev;
     d.state = (uint32_t *)state_dev;

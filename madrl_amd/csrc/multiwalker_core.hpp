@@ -26,8 +26,10 @@
 
 #if defined(__HIPCC__)
 #define MW_HD __host__ __device__ inline
+#define MW_UNROLL _Pragma("unroll")
 #else
 #define MW_HD inline
+#define MW_UNROLL
 #endif
 
 namespace mw {
@@ -67,7 +69,7 @@ constexpr int MAXJ = 4 * MAX_WALKERS;
 constexpr int MAXT = TERRAIN_LENGTH * MAX_WALKERS / 8;  // terrain points (:301)
 constexpr int EDGE_SLOTS_SMALL = 6, EDGE_SLOTS_PKG = 36;
 constexpr int MAXSLOT = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
-constexpr int MAXM = 36;  // active manifolds per step (pool); observed maxima over long random / collapsed rollouts: 18, 25, 34 for 2, 3, 4 walkers
+constexpr int MAXM = 36;  // largest active-manifold pool (Model::max_manifolds <= MAXM)
 
 struct V2 { float x, y; };
 MW_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
@@ -125,6 +127,7 @@ struct JointDef {  // revoluteJointDef, multi_walker.py:145-179
 };
 struct Model {
     int W, NB, NJ, NT;  // walkers, bodies, joints, terrain points
+    int max_manifolds;  // size of the active-manifold pool of a step (Scratch::m)
     Shape shape[N_SHAPES];
     JointDef jd[MAXJ];
     float package_length, package_scale;
@@ -194,6 +197,8 @@ inline void poly_mass(Shape &s, float density) {
 
 inline void build_model(Model &M, int n_walkers) {
     M.W = n_walkers; M.NB = 5 * n_walkers + 1; M.NJ = 4 * n_walkers;
+    // observed maxima of simultaneously touching pairs over long random / collapsed rollouts: 18, 25, 34 for 2, 3, 4 walkers
+    M.max_manifolds = n_walkers <= 1 ? 16 : (n_walkers == 2 ? 24 : (n_walkers == 3 ? 32 : MAXM));
     M.NT = (int)(TERRAIN_LENGTH * n_walkers * 1 / 8.0);          // :301
     M.package_scale = n_walkers / 1.75f;                          // :293
     M.package_length = PACKAGE_LENGTH / SCALE * M.package_scale;  // :294
@@ -239,17 +244,19 @@ inline void build_model(Model &M, int n_walkers) {
 }
 
 // ---------------------------------------------------------------- dynamic state
+// ---------------------------------------------------------------- dynamic state
 struct Body { V2 c; float a; V2 v; float w; };  // centre of mass, angle, velocities
 struct Joint {
     float ix, iy, iz, motor_impulse;  // accumulated impulses (warm start)
     float motor_speed, max_torque;
     int limit_state;                  // 0 inactive, 1 at lower, 2 at upper, 3 equal
 };
-struct Slot {       // persistent manifold cache of one candidate pair (b2Contact)
+struct Slot {       // persistent manifold cache of one candidate pair (b2Contact); 32 bytes
     int16_t edge;   // terrain edge index, or -1: free slot (dyn pairs: always used)
     uint8_t npts, touching;
     uint32_t id[2];
     float ni[2], ti[2];
+    uint32_t pad_;
 };
 struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositionConstraint
     int16_t bA, bB, slot;  // bA = -1: static terrain
@@ -258,34 +265,45 @@ struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositio
     V2 normal, rA[2], rB[2];
     float friction, nm[2], tm[2], ni[2], ti[2];
     float k11, k12, k22, im11, im12, im22;  // block solver K and K^-1
-    uint8_t block;
+    uint32_t block;
 };
-struct World {
+// The env state is split by how often a step touches it.
+//   Hot:  bodies, joints, flags -- read and written by every one of the 180 + 60 solver sweeps; the HIP kernel keeps
+//         it in LDS for the duration of the step.
+//   Cold: the manifold cache (warm-start impulses of the candidate pairs) and the terrain heights -- touched once per
+//         step by Collide, StoreImpulses and the lidar; the HIP kernel reads and writes it in place in HBM (L2).
+struct Hot {
     Body b[MAXB];
     Joint j[MAXJ];
-    Slot slot[MAXSLOT];
-    float ty[MAXT];               // terrain heights (x = i * TERRAIN_STEP)
     float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
     float prev_shaping[MAX_WALKERS], prev_package_shaping;
     uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, pad_;
     uint32_t tick;
     int32_t t;
 };
+struct Cold {
+    Slot slot[MAXSLOT];
+    float ty[MAXT];               // terrain heights (x = i * TERRAIN_STEP)
+};
+struct World { Hot h; Cold c; };  // the packed per-env record in HBM
+
+constexpr int NDYN = MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
+constexpr int MAXSLOT_TERRAIN = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG;
 struct Scratch {  // per-step workspace (LDS on the GPU)
-    Manifold m[MAXM];
     int nm;
-    float jrAx[MAXJ], jrAy[MAXJ], jrBx[MAXJ], jrBy[MAXJ], jmotor_mass[MAXJ];
-    float jk[MAXJ][9];
+    int8_t n_dyn, max_cnt, merge_ok, all_done;
     // per-body constants gathered once per step (avoid shape lookups in the solver loops)
     float bim[MAXB], bii[MAXB];
     V2 blc[MAXB];
     int8_t node[MAXB];  // island graph node of a body: walker index, or W for the package
-    // solver schedule: manifold indices per body (terrain contacts) and per dynamic pair
-    uint8_t bm_cnt[MAXB], bm_idx[MAXB][EDGE_SLOTS_PKG];
-    int8_t dyn_midx[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
+    // solver schedule: terrain manifolds per body (indexed like the body's slots) and the active dynamic pairs
+    uint8_t bm_cnt[MAXB], bm_idx[MAXSLOT_TERRAIN];
+    int8_t dyn_midx[NDYN];   // manifold of pair p, or -1
+    int8_t dyn_list[NDYN];   // the active pairs, in pair order
     int8_t comp[MAX_WALKERS + 1];
-    uint8_t isl_done[MAX_WALKERS + 1], walker_ok[MAX_WALKERS], all_done;
-    float body_minsep[MAXB], dyn_minsep[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
+    uint8_t isl_done[MAX_WALKERS + 1], walker_ok[MAX_WALKERS];
+    float body_minsep[MAXB], dyn_minsep[NDYN];
+    Manifold m[MAXM];  // LAST member: the HIP kernel allocates only Model::max_manifolds of them
 };
 
 MW_HD Xf body_xf(const Model &M, const Body &b, int bi) {
@@ -503,7 +521,7 @@ MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB,
     mo.npts = n;
 }
 
-MW_HD void body_aabb(const Model &M, const World &Wd, int bi, float &xmin, float &xmax, float &ymin, float &ymax) {
+MW_HD void body_aabb(const Model &M, const Hot &Wd, int bi, float &xmin, float &xmax, float &ymin, float &ymax) {
     const Shape &s = M.shape[shape_of_body(bi)];
     const Xf t = body_xf(M, Wd.b[bi], bi);
     xmin = ymin = 3.0e38f; xmax = ymax = -3.0e38f;
@@ -515,7 +533,7 @@ MW_HD void body_aabb(const Model &M, const World &Wd, int bi, float &xmin, float
 }
 
 // ContactDetector.BeginContact / EndContact (:50-84) for one pair whose touching state changed
-MW_HD void contact_event(const Model &M, World &Wd, int bA, int bB, bool begin) {
+MW_HD void contact_event(const Model &M, Hot &Wd, int bA, int bB, bool begin) {
     // bA == -1: terrain
     for (int w = 0; w < M.W; ++w) {
         const int hull = hull_of(w);
@@ -535,13 +553,16 @@ MW_HD void contact_event(const Model &M, World &Wd, int bA, int bB, bool begin) 
 }
 
 // ---------------------------------------------------------------- lane parallelism
-// The step is written once for a group of cooperating lanes (`Par`): SerialPar (CPU build: one
-// lane, no-op sync) or the wavefront of the HIP kernel.  Work is split so that lanes running
-// concurrently never touch the same body: joints by walker, terrain contacts by body, the
-// package-hull / hull-hull contacts by one lane after a sync.  Constraints that share a body keep
-// their serial Gauss-Seidel order, constraints that do not commute trivially -- so the lane-parallel
-// schedule produces bit-identical results to the serial one.
+// The step is written once for a group of cooperating lanes (`Par`): SerialPar (CPU build: one lane that owns
+// everything, no-op sync) or a 16-lane group of a wavefront in the HIP kernel (four envs per wavefront).  Work is split
+// so that lanes running concurrently never touch the same body -- bodies and their terrain contacts by lane, the two legs
+// of a walker on two lanes, the package / hull contacts one at a time -- and every pair of constraints that shares a
+// body keeps its serial Gauss-Seidel order, so the lane-parallel schedule produces bit-identical results to the serial
+// one (constraints on disjoint bodies commute exactly).
+// LEGS = legs (pairs of revolute joints) a lane may own; their per-step constants and accumulated impulses live in
+// lane-private storage (registers on the GPU) for the whole step.
 struct SerialPar {
+    static constexpr int LEGS = 2 * MAX_WALKERS;
     MW_HD int lane() const { return 0; }
     MW_HD int n() const { return 1; }
     MW_HD void sync() const {}
@@ -550,7 +571,7 @@ struct SerialPar {
 
 // push an active manifold into the solver pool, carrying impulses over from the cached contact
 template <class Par>
-MW_HD int emit_manifold(const Model &M, World &Wd, Scratch &S, Par par, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction) {
+MW_HD int emit_manifold(const Model &M, Hot &Wd, Scratch &S, Par par, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction) {
     float ni[2] = {0, 0}, ti[2] = {0, 0};
     for (int i = 0; i < mo.npts; ++i)  // b2Contact::Update: match ids with the old manifold
         for (int k = 0; k < sl.npts; ++k)
@@ -561,7 +582,7 @@ MW_HD int emit_manifold(const Model &M, World &Wd, Scratch &S, Par par, Slot &sl
     for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
     if (!touching) return -1;
     const int idx = par.alloc(&S.nm);
-    if (idx >= MAXM) return -1;  // pool exhausted: the pair is ignored this step
+    if (idx >= M.max_manifolds) return -1;  // pool exhausted: the pair is ignored this step
     Manifold &m = S.m[idx];
     m.bA = (int16_t)bA; m.bB = (int16_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)mo.type;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
@@ -570,55 +591,56 @@ MW_HD int emit_manifold(const Model &M, World &Wd, Scratch &S, Par par, Slot &sl
     return idx;
 }
 
-// b2ContactManager::Collide for body `bi` against the terrain polyline (edge e spans x in [e, e+1] * TERRAIN_STEP)
+// b2ContactManager::Collide for body `bi` against the terrain polyline (edge e spans x in [e, e+1] * TERRAIN_STEP).
+// The body's cache is direct-mapped: edge e lives in slot e % cap (the candidate range is a run of consecutive edges no
+// longer than the cache; a longer run loses its last edges for this step, like a full cache).
 template <class Par>
-MW_HD void collide_body_terrain(const Model &M, World &Wd, Scratch &S, Par par, int bi) {
+MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int bi) {
     const Shape &s = M.shape[shape_of_body(bi)];
     float xmin, xmax, ymin, ymax;
     body_aabb(M, Wd, bi, xmin, xmax, ymin, ymax);
     int e0 = (int)floorf(xmin / TERRAIN_STEP), e1 = (int)floorf(xmax / TERRAIN_STEP);
     if (e0 < 0) e0 = 0;
     if (e1 > M.NT - 2) e1 = M.NT - 2;
-    Slot *slots = Wd.slot + M.slot_base[bi];
+    Slot *slots = Cd.slot + M.slot_base[bi];
     const int cap = M.slot_cap[bi];
     int cnt = 0;
     // contacts whose edge left the candidate range are destroyed (EndContact if touching)
     for (int k = 0; k < cap; ++k) {
         Slot &sl = slots[k];
-        if (sl.edge >= 0 && (sl.edge < e0 || sl.edge > e1)) {
+        const int ed = sl.edge;
+        if (ed >= 0 && (ed < e0 || ed > e1)) {
             if (sl.touching) contact_event(M, Wd, -1, bi, false);
             sl.edge = -1; sl.npts = 0; sl.touching = 0;
         }
     }
     const Xf xfB = body_xf(M, Wd.b[bi], bi);
     for (int e = e0; e <= e1; ++e) {
-        int k = -1;
-        for (int q = 0; q < cap; ++q) if (slots[q].edge == e) { k = q; break; }
-        if (k < 0) { for (int q = 0; q < cap; ++q) if (slots[q].edge < 0) { k = q; break; } }
-        if (k < 0) continue;  // cache full: pair ignored this step
+        const int k = e % cap;
         Slot &sl = slots[k];
+        if (sl.edge >= 0 && sl.edge != e) continue;  // the run is longer than the cache: pair ignored this step
         if (sl.edge != e) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; }
-        const V2 p1 = v2(e * TERRAIN_STEP, Wd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Wd.ty[e + 1]);
+        const V2 p1 = v2(e * TERRAIN_STEP, Cd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
         ManifoldOut mo; mo.npts = 0;
         const float elo = fminf(p1.y, p2.y) - POLY_RADIUS, ehi = fmaxf(p1.y, p2.y) + POLY_RADIUS;
         if (!(ymin > ehi + 0.2f || ymax < elo - 0.2f)) {
             const bool has0 = e > 0, has3 = e < M.NT - 2;
-            const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Wd.ty[e - 1]) : p1;
-            const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Wd.ty[e + 2]) : p2;
+            const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Cd.ty[e - 1]) : p1;
+            const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Cd.ty[e + 2]) : p2;
             collide_edge_polygon(mo, p1, p2, s, xfB, has0, p0, has3, p3);
         }
         const int idx = emit_manifold(M, Wd, S, par, sl, M.slot_base[bi] + k, mo, -1, bi, sqrtf(FRICTION * s.friction));
-        if (idx >= 0 && cnt < EDGE_SLOTS_PKG) S.bm_idx[bi][cnt++] = (uint8_t)idx;
+        if (idx >= 0 && cnt < cap) S.bm_idx[M.slot_base[bi] + cnt++] = (uint8_t)idx;
     }
     S.bm_cnt[bi] = (uint8_t)cnt;
 }
 
 // package - hull and hull - hull pair p
 template <class Par>
-MW_HD void collide_dyn_pair(const Model &M, World &Wd, Scratch &S, Par par, int p) {
+MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int p) {
     const int bA = M.dyn_a[p], bB = M.dyn_b[p];
     const Shape &sA = M.shape[shape_of_body(bA)], &sB = M.shape[shape_of_body(bB)];
-    Slot &sl = Wd.slot[M.dyn_slot_base + p];
+    Slot &sl = Cd.slot[M.dyn_slot_base + p];
     sl.edge = 0;
     float ax0, ax1, ay0, ay1, bx0, bx1, by0, by1;
     body_aabb(M, Wd, bA, ax0, ax1, ay0, ay1);
@@ -654,7 +676,7 @@ MW_HD void solve22(const float *k, float bx, float by, float &x, float &y) {
 }
 
 // b2ContactSolver::InitializeVelocityConstraints + WarmStart for manifold k
-MW_HD void contact_init_warm(const Model &M, World &Wd, Scratch &S, int k) {
+MW_HD void contact_init_warm(const Model &M, Hot &Wd, Scratch &S, int k) {
     Manifold &m = S.m[k];
     float mA, iA, mB, iB;
     inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
@@ -717,16 +739,34 @@ MW_HD void contact_init_warm(const Model &M, World &Wd, Scratch &S, int k) {
     Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
 }
 
+// One revolute joint for the duration of a step: the constants of b2RevoluteJoint::InitVelocityConstraints and the
+// accumulated impulses, held by the lane that owns the joint (registers on the GPU) and written back once at the end.
+struct JointCache {
+    int bA, bB;
+    float mA, iA, mB, iB;
+    V2 lA, lB;                 // local anchors relative to the local centres
+    float lower, upper;
+    V2 rA, rB;
+    float k[9], motor_mass;
+    float motor_speed, maxi;   // maxi = h * maxMotorTorque
+    int limit_state;
+    float ix, iy, iz, motor_impulse;
+};
+
 // b2RevoluteJoint::InitVelocityConstraints (+ warm start)
-MW_HD void joint_init_warm(const Model &M, World &Wd, Scratch &S, int ji) {
+MW_HD void joint_init_warm(const Model &M, Hot &Wd, Scratch &S, int ji, float h, JointCache &c) {
     const JointDef &jd = M.jd[ji];
-    Joint &j = Wd.j[ji];
+    const Joint &j = Wd.j[ji];
+    c.bA = jd.bA; c.bB = jd.bB;
     Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
     float mA, iA, mB, iB;
     inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
-    const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
-    S.jrAx[ji] = rA.x; S.jrAy[ji] = rA.y; S.jrBx[ji] = rB.x; S.jrBy[ji] = rB.y;
-    float *k = S.jk[ji];
+    c.mA = mA; c.iA = iA; c.mB = mB; c.iB = iB;
+    c.lA = jd.lA - local_center_of(M, jd.bA); c.lB = jd.lB - local_center_of(M, jd.bB);
+    c.lower = jd.lower; c.upper = jd.upper;
+    const V2 rA = mul(rot(A.a), c.lA), rB = mul(rot(B.a), c.lB);
+    c.rA = rA; c.rB = rB;
+    float *k = c.k;
     k[0] = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
     k[3] = -rA.y * rA.x * iA - rB.y * rB.x * iB;
     k[6] = -rA.y * iA - rB.y * iB;
@@ -737,52 +777,51 @@ MW_HD void joint_init_warm(const Model &M, World &Wd, Scratch &S, int ji) {
     k[8] = iA + iB;
     float mm = iA + iB;
     if (mm > 0.0f) mm = 1.0f / mm;
-    S.jmotor_mass[ji] = mm;
+    c.motor_mass = mm;
+    c.motor_speed = j.motor_speed; c.maxi = h * j.max_torque;
+    c.ix = j.ix; c.iy = j.iy; c.iz = j.iz; c.motor_impulse = j.motor_impulse; c.limit_state = j.limit_state;
     const float angle = B.a - A.a;  // referenceAngle = 0 (the def is built from kwargs, not Initialize())
-    if (fabsf(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP) j.limit_state = 3;
-    else if (angle <= jd.lower) { if (j.limit_state != 1) j.iz = 0.0f; j.limit_state = 1; }
-    else if (angle >= jd.upper) { if (j.limit_state != 2) j.iz = 0.0f; j.limit_state = 2; }
-    else { j.limit_state = 0; j.iz = 0.0f; }
-    const V2 P = v2(j.ix, j.iy);  // dtRatio = 1
-    A.v = A.v - mA * P; A.w -= iA * (cross(rA, P) + j.motor_impulse + j.iz);
-    B.v = B.v + mB * P; B.w += iB * (cross(rB, P) + j.motor_impulse + j.iz);
+    if (fabsf(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP) c.limit_state = 3;
+    else if (angle <= jd.lower) { if (c.limit_state != 1) c.iz = 0.0f; c.limit_state = 1; }
+    else if (angle >= jd.upper) { if (c.limit_state != 2) c.iz = 0.0f; c.limit_state = 2; }
+    else { c.limit_state = 0; c.iz = 0.0f; }
+    const V2 P = v2(c.ix, c.iy);  // dtRatio = 1
+    A.v = A.v - mA * P; A.w -= iA * (cross(rA, P) + c.motor_impulse + c.iz);
+    B.v = B.v + mB * P; B.w += iB * (cross(rB, P) + c.motor_impulse + c.iz);
 }
 
 // b2RevoluteJoint::SolveVelocityConstraints
-MW_HD void joint_solve_velocity(const Model &M, World &Wd, Scratch &S, int ji, float h) {
-    const JointDef &jd = M.jd[ji];
-    Joint &j = Wd.j[ji];
-    Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
-    float mA, iA, mB, iB;
-    inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
-    const V2 rA = v2(S.jrAx[ji], S.jrAy[ji]), rB = v2(S.jrBx[ji], S.jrBy[ji]);
+MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
+    Body &A = Wd.b[c.bA], &B = Wd.b[c.bB];
+    const float mA = c.mA, iA = c.iA, mB = c.mB, iB = c.iB;
+    const V2 rA = c.rA, rB = c.rB;
     V2 vA = A.v, vB = B.v; float wA = A.w, wB = B.w;
-    if (j.limit_state != 3) {  // motor (enableMotor is always true)
-        const float Cdot = wB - wA - j.motor_speed;
-        float imp = -S.jmotor_mass[ji] * Cdot;
-        const float old = j.motor_impulse, maxi = h * j.max_torque;
-        j.motor_impulse = clampf(old + imp, -maxi, maxi);
-        imp = j.motor_impulse - old;
+    if (c.limit_state != 3) {  // motor (enableMotor is always true)
+        const float Cdot = wB - wA - c.motor_speed;
+        float imp = -c.motor_mass * Cdot;
+        const float old = c.motor_impulse, maxi = c.maxi;
+        c.motor_impulse = clampf(old + imp, -maxi, maxi);
+        imp = c.motor_impulse - old;
         wA -= iA * imp; wB += iB * imp;
     }
-    if (j.limit_state != 0) {  // limit + point constraint (3x3)
+    if (c.limit_state != 0) {  // limit + point constraint (3x3)
         const V2 Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA);
         const float Cdot2 = wB - wA;
         float ix, iy, iz;
-        solve33(S.jk[ji], Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
+        solve33(c.k, Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
         ix = -ix; iy = -iy; iz = -iz;
         bool reduce = false;
-        if (j.limit_state == 3) { j.ix += ix; j.iy += iy; j.iz += iz; }
-        else if (j.limit_state == 1) { reduce = (j.iz + iz) < 0.0f; }
-        else { reduce = (j.iz + iz) > 0.0f; }
-        if (j.limit_state != 3) {
+        if (c.limit_state == 3) { c.ix += ix; c.iy += iy; c.iz += iz; }
+        else if (c.limit_state == 1) { reduce = (c.iz + iz) < 0.0f; }
+        else { reduce = (c.iz + iz) > 0.0f; }
+        if (c.limit_state != 3) {
             if (reduce) {
-                const float rx = -Cdot1.x + j.iz * S.jk[ji][6], ry = -Cdot1.y + j.iz * S.jk[ji][7];
+                const float rx = -Cdot1.x + c.iz * c.k[6], ry = -Cdot1.y + c.iz * c.k[7];
                 float qx, qy;
-                solve22(S.jk[ji], rx, ry, qx, qy);
-                ix = qx; iy = qy; iz = -j.iz;
-                j.ix += qx; j.iy += qy; j.iz = 0.0f;
-            } else { j.ix += ix; j.iy += iy; j.iz += iz; }
+                solve22(c.k, rx, ry, qx, qy);
+                ix = qx; iy = qy; iz = -c.iz;
+                c.ix += qx; c.iy += qy; c.iz = 0.0f;
+            } else { c.ix += ix; c.iy += iy; c.iz += iz; }
         }
         const V2 P = v2(ix, iy);
         vA = vA - mA * P; wA -= iA * (cross(rA, P) + iz);
@@ -790,8 +829,8 @@ MW_HD void joint_solve_velocity(const Model &M, World &Wd, Scratch &S, int ji, f
     } else {  // point-to-point only
         const V2 Cdot = vB + cross(wB, rB) - vA - cross(wA, rA);
         float ix, iy;
-        solve22(S.jk[ji], -Cdot.x, -Cdot.y, ix, iy);
-        j.ix += ix; j.iy += iy;
+        solve22(c.k, -Cdot.x, -Cdot.y, ix, iy);
+        c.ix += ix; c.iy += iy;
         const V2 P = v2(ix, iy);
         vA = vA - mA * P; wA -= iA * cross(rA, P);
         vB = vB + mB * P; wB += iB * cross(rB, P);
@@ -800,7 +839,7 @@ MW_HD void joint_solve_velocity(const Model &M, World &Wd, Scratch &S, int ji, f
 }
 
 // b2ContactSolver::SolveVelocityConstraints for manifold k
-MW_HD void contact_solve_velocity(const Model &M, World &Wd, Scratch &S, int k) {
+MW_HD void contact_solve_velocity(const Model &M, Hot &Wd, Scratch &S, int k) {
     Manifold &m = S.m[k];
     float mA, iA, mB, iB;
     inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
@@ -857,7 +896,7 @@ MW_HD void contact_solve_velocity(const Model &M, World &Wd, Scratch &S, int k) 
 }
 
 // b2ContactSolver::SolvePositionConstraints for manifold k; returns its minimum separation
-MW_HD float contact_solve_position(const Model &M, World &Wd, Scratch &S, int k) {
+MW_HD float contact_solve_position(const Model &M, Hot &Wd, Scratch &S, int k) {
     const Manifold &m = S.m[k];
     float min_sep = 0.0f;
     float mA, iA, mB, iB;
@@ -894,31 +933,28 @@ MW_HD float contact_solve_position(const Model &M, World &Wd, Scratch &S, int k)
 }
 
 // b2RevoluteJoint::SolvePositionConstraints; returns whether the joint is within tolerance
-MW_HD bool joint_solve_position(const Model &M, World &Wd, Scratch &S, int ji) {
-    const JointDef &jd = M.jd[ji];
-    const Joint &j = Wd.j[ji];
-    Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
-    float mA, iA, mB, iB;
-    inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+MW_HD bool joint_solve_position(Hot &Wd, const JointCache &c) {
+    Body &A = Wd.b[c.bA], &B = Wd.b[c.bB];
+    const float mA = c.mA, iA = c.iA, mB = c.mB, iB = c.iB;
     float ang_err = 0.0f;
-    if (j.limit_state != 0) {
+    if (c.limit_state != 0) {
         const float angle = B.a - A.a;
         float limit_imp = 0.0f;
-        if (j.limit_state == 3) {
-            const float C = clampf(angle - jd.lower, -MAX_ANGULAR_CORRECTION, MAX_ANGULAR_CORRECTION);
-            limit_imp = -S.jmotor_mass[ji] * C; ang_err = fabsf(C);
-        } else if (j.limit_state == 1) {
-            float C = angle - jd.lower; ang_err = -C;
+        if (c.limit_state == 3) {
+            const float C = clampf(angle - c.lower, -MAX_ANGULAR_CORRECTION, MAX_ANGULAR_CORRECTION);
+            limit_imp = -c.motor_mass * C; ang_err = fabsf(C);
+        } else if (c.limit_state == 1) {
+            float C = angle - c.lower; ang_err = -C;
             C = clampf(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION, 0.0f);
-            limit_imp = -S.jmotor_mass[ji] * C;
+            limit_imp = -c.motor_mass * C;
         } else {
-            float C = angle - jd.upper; ang_err = C;
+            float C = angle - c.upper; ang_err = C;
             C = clampf(C - ANGULAR_SLOP, 0.0f, MAX_ANGULAR_CORRECTION);
-            limit_imp = -S.jmotor_mass[ji] * C;
+            limit_imp = -c.motor_mass * C;
         }
         A.a -= iA * limit_imp; B.a += iB * limit_imp;
     }
-    const V2 rA = mul(rot(A.a), jd.lA - local_center_of(M, jd.bA)), rB = mul(rot(B.a), jd.lB - local_center_of(M, jd.bB));
+    const V2 rA = mul(rot(A.a), c.lA), rB = mul(rot(B.a), c.lB);
     const V2 C = B.c + rB - A.c - rA;
     const float pos_err = sqrtf(dot(C, C));
     const float kxx = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y, kxy = -iA * rA.x * rA.y - iB * rB.x * rB.y;
@@ -931,12 +967,23 @@ MW_HD bool joint_solve_position(const Model &M, World &Wd, Scratch &S, int ji) {
     return pos_err <= LINEAR_SLOP && ang_err <= ANGULAR_SLOP;
 }
 
-// b2World::Step(1/50, 180, 60) for the lanes of `par`
+// b2World::Step(1/50, 180, 60) for the lanes of `par`.
+//
+// Schedule of one Gauss-Seidel sweep (Box2D: all joints in creation order, then all contacts):
+//   joints   three slots.  A walker's joints in creation order are hip0, knee0, hip1, knee1; hip0 -> knee0 share the
+//            upper leg, hip0 -> hip1 the hull, hip1 -> knee1 the other upper leg, while knee0 and hip1 share nothing.
+//            One lane per LEG: slot 0 = hip0, slot 1 = knee0 | hip1, slot 2 = knee1.  In each lane register set RA holds
+//            the joint of slots 0 / 2 (hip of leg 0, knee of leg 1), RB the joint of slot 1.
+//   contacts sub-slot i = the i-th terrain manifold of every body (by lane) and, while neither the package nor a hull
+//            touches the terrain (`merge_ok`), the i-th active package-hull / hull-hull pair, solved by the lane that
+//            owns the pair's second body -- leg-terrain and package-hull constraints share no body.  Otherwise the
+//            dynamic pairs follow in sub-slots of their own, exactly the serial order.
 template <class Par>
-MW_HD void world_step(const Model &M, World &Wd, Scratch &S, Par par) {
+MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     const float h = 1.0f / FPS;
     const int L0 = par.lane(), LN = par.n();
     const int NODES = M.W + 1;  // island graph nodes: walkers, then the package
+    const int NLEG = 2 * M.W;
     for (int bi = L0; bi < M.NB; bi += LN) {
         const Shape &sh = M.shape[shape_of_body(bi)];
         S.bim[bi] = sh.inv_mass; S.bii[bi] = sh.inv_I; S.blc[bi] = sh.centroid;
@@ -945,17 +992,27 @@ MW_HD void world_step(const Model &M, World &Wd, Scratch &S, Par par) {
     if (L0 == 0) S.nm = 0;
     par.sync();
     // ---- Collide: terrain candidates by body, then the dynamic pairs
-    for (int bi = L0; bi < M.NB; bi += LN) collide_body_terrain(M, Wd, S, par, bi);
+    for (int bi = L0; bi < M.NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi);
     par.sync();
-    for (int p = L0; p < M.n_dyn_pairs; p += LN) collide_dyn_pair(M, Wd, S, par, p);
+    for (int p = L0; p < M.n_dyn_pairs; p += LN) collide_dyn_pair(M, Wd, Cd, S, par, p);
     par.sync();
-    if (L0 == 0) {  // islands: walkers (+ package) joined by touching hull-hull / hull-package contacts
+    if (L0 == 0) {  // islands: walkers (+ package) joined by touching hull-hull / hull-package contacts; contact schedule
         for (int i = 0; i < NODES; ++i) { S.comp[i] = (int8_t)i; S.isl_done[i] = 0; }
+        int nd = 0;
         for (int p = 0; p < M.n_dyn_pairs; ++p) {
             if (S.dyn_midx[p] < 0) continue;
+            S.dyn_list[nd++] = (int8_t)p;
             const int ca = S.comp[S.node[M.dyn_a[p]]], cb = S.comp[S.node[M.dyn_b[p]]];
             if (ca != cb) for (int i = 0; i < NODES; ++i) if (S.comp[i] == cb) S.comp[i] = (int8_t)ca;
         }
+        S.n_dyn = (int8_t)nd;
+        int mc = 0;
+        bool merge = S.bm_cnt[0] == 0;
+        for (int bi = 0; bi < M.NB; ++bi) {
+            if (S.bm_cnt[bi] > mc) mc = S.bm_cnt[bi];
+            if (bi >= 1 && (bi - 1) % 5 == 0 && S.bm_cnt[bi] != 0) merge = false;
+        }
+        S.max_cnt = (int8_t)mc; S.merge_ok = merge ? 1 : 0;
     }
     // ---- integrate velocities (gravity + the pending initial push)
     for (int bi = L0; bi < M.NB; bi += LN) {
@@ -970,24 +1027,68 @@ MW_HD void world_step(const Model &M, World &Wd, Scratch &S, Par par) {
     }
     par.sync();
     for (int w = L0; w < M.W; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces
-    // ---- contact constraints: init + warm start (terrain contacts by body, then the dynamic pairs)
-    for (int bi = L0; bi < M.NB; bi += LN)
-        for (int q = 0; q < S.bm_cnt[bi]; ++q) contact_init_warm(M, Wd, S, S.bm_idx[bi][q]);
-    par.sync();
-    if (L0 == 0) for (int p = 0; p < M.n_dyn_pairs; ++p) if (S.dyn_midx[p] >= 0) contact_init_warm(M, Wd, S, S.dyn_midx[p]);
-    par.sync();
-    // ---- joints: init + warm start, by walker
-    for (int w = L0; w < M.W; w += LN) for (int q = 0; q < 4; ++q) joint_init_warm(M, Wd, S, 4 * w + q);
-    par.sync();
+    const int nsubA = S.merge_ok ? (S.max_cnt > S.n_dyn ? S.max_cnt : S.n_dyn) : S.max_cnt;
+    const int nsubB = S.merge_ok ? 0 : S.n_dyn;
+    const bool merge_ok = S.merge_ok != 0;
+    // one contact sweep; F(manifold index) is applied in the schedule described above
+#define MW_CONTACT_SWEEP(F_TERRAIN, F_DYN)                                                                   \
+    for (int i = 0; i < nsubA; ++i) {                                                                        \
+        for (int bi = L0; bi < M.NB; bi += LN) {                                                             \
+            if (i < S.bm_cnt[bi]) { const int k_ = S.bm_idx[M.slot_base[bi] + i]; F_TERRAIN; }               \
+            if (merge_ok && i < S.n_dyn) {                                                                   \
+                const int p_ = S.dyn_list[i];                                                                \
+                if (M.dyn_b[p_] == bi) { const int k_ = S.dyn_midx[p_]; F_DYN; }                             \
+            }                                                                                                \
+        }                                                                                                    \
+        par.sync();                                                                                          \
+    }                                                                                                        \
+    for (int i = 0; i < nsubB; ++i) {                                                                        \
+        const int p_ = S.dyn_list[i];                                                                        \
+        for (int bi = L0; bi < M.NB; bi += LN)                                                               \
+            if (M.dyn_b[p_] == bi) { const int k_ = S.dyn_midx[p_]; F_DYN; }                                 \
+        par.sync();                                                                                          \
+    }
+    // ---- contact constraints: init + warm start
+    MW_CONTACT_SWEEP(contact_init_warm(M, Wd, S, k_), contact_init_warm(M, Wd, S, k_))
+    // ---- joints: init + warm start.  Register sets: RA = joint of slots 0 / 2, RB = joint of slot 1
+    JointCache RA[Par::LEGS], RB[Par::LEGS];
+    for (int t = 0; t < 3; ++t) {
+        MW_UNROLL
+        for (int kq = 0; kq < Par::LEGS; ++kq) {
+            const int lg = L0 + kq * LN;
+            if (lg >= NLEG) continue;
+            const int w = lg >> 1, s = lg & 1;
+            if (t == 1) joint_init_warm(M, Wd, S, 4 * w + 2 * s + (s ? 0 : 1), h, RB[kq]);
+            else if ((t == 0) == (s == 0)) joint_init_warm(M, Wd, S, 4 * w + 2 * s + (s ? 1 : 0), h, RA[kq]);
+        }
+        par.sync();
+    }
     // ---- velocity iterations (islands are disjoint, so iterating them together changes nothing)
     for (int it = 0; it < VEL_ITERS; ++it) {
-        for (int w = L0; w < M.W; w += LN) for (int q = 0; q < 4; ++q) joint_solve_velocity(M, Wd, S, 4 * w + q, h);
-        par.sync();
-        for (int bi = L0; bi < M.NB; bi += LN)
-            for (int q = 0; q < S.bm_cnt[bi]; ++q) contact_solve_velocity(M, Wd, S, S.bm_idx[bi][q]);
-        par.sync();
-        if (L0 == 0) for (int p = 0; p < M.n_dyn_pairs; ++p) if (S.dyn_midx[p] >= 0) contact_solve_velocity(M, Wd, S, S.dyn_midx[p]);
-        par.sync();
+        for (int t = 0; t < 3; ++t) {
+            MW_UNROLL
+            for (int kq = 0; kq < Par::LEGS; ++kq) {
+                const int lg = L0 + kq * LN;
+                if (lg >= NLEG) continue;
+                const int s = lg & 1;
+                if (t == 1) joint_solve_velocity(Wd, RB[kq]);
+                else if ((t == 0) == (s == 0)) joint_solve_velocity(Wd, RA[kq]);
+            }
+            par.sync();
+        }
+        MW_CONTACT_SWEEP(contact_solve_velocity(M, Wd, S, k_), contact_solve_velocity(M, Wd, S, k_))
+    }
+    // the accumulated joint impulses and limit states go back to the world (warm start of the next step)
+    {
+        MW_UNROLL
+        for (int kq = 0; kq < Par::LEGS; ++kq) {
+            const int lg = L0 + kq * LN;
+            if (lg >= NLEG) continue;
+            const int w = lg >> 1, s = lg & 1;
+            Joint &ja = Wd.j[4 * w + 2 * s + (s ? 1 : 0)], &jb = Wd.j[4 * w + 2 * s + (s ? 0 : 1)];
+            ja.ix = RA[kq].ix; ja.iy = RA[kq].iy; ja.iz = RA[kq].iz; ja.motor_impulse = RA[kq].motor_impulse; ja.limit_state = RA[kq].limit_state;
+            jb.ix = RB[kq].ix; jb.iy = RB[kq].iy; jb.iz = RB[kq].iz; jb.motor_impulse = RB[kq].motor_impulse; jb.limit_state = RB[kq].limit_state;
+        }
     }
     // ---- integrate positions
     for (int bi = L0; bi < M.NB; bi += LN) {
@@ -1002,27 +1103,28 @@ MW_HD void world_step(const Model &M, World &Wd, Scratch &S, Par par) {
     par.sync();
     // ---- position iterations, each island stops on its own (b2Island::Solve early exit)
     for (int it = 0; it < POS_ITERS; ++it) {
-        for (int bi = L0; bi < M.NB; bi += LN) {
-            float ms = 0.0f;
-            if (!S.isl_done[S.comp[S.node[bi]]])
-                for (int q = 0; q < S.bm_cnt[bi]; ++q) ms = fminf(ms, contact_solve_position(M, Wd, S, S.bm_idx[bi][q]));
-            S.body_minsep[bi] = ms;
-        }
+        for (int bi = L0; bi < M.NB; bi += LN) S.body_minsep[bi] = 0.0f;
+        for (int p = L0; p < NDYN; p += LN) S.dyn_minsep[p] = 0.0f;
         par.sync();
-        if (L0 == 0)
-            for (int p = 0; p < M.n_dyn_pairs; ++p) {
-                float ms = 0.0f;
-                if (S.dyn_midx[p] >= 0 && !S.isl_done[S.comp[S.node[M.dyn_b[p]]]]) ms = contact_solve_position(M, Wd, S, S.dyn_midx[p]);
-                S.dyn_minsep[p] = ms;
+        MW_CONTACT_SWEEP(
+            if (!S.isl_done[S.comp[S.node[bi]]]) S.body_minsep[bi] = fminf(S.body_minsep[bi], contact_solve_position(M, Wd, S, k_)),
+            if (!S.isl_done[S.comp[S.node[bi]]]) S.dyn_minsep[p_] = contact_solve_position(M, Wd, S, k_))
+        for (int w = L0; w < M.W; w += LN) S.walker_ok[w] = 1;
+        par.sync();
+        for (int t = 0; t < 3; ++t) {
+            MW_UNROLL
+            for (int kq = 0; kq < Par::LEGS; ++kq) {
+                const int lg = L0 + kq * LN;
+                if (lg >= NLEG) continue;
+                const int w = lg >> 1, s = lg & 1;
+                if (S.isl_done[S.comp[w]]) continue;
+                bool ok = true;
+                if (t == 1) ok = joint_solve_position(Wd, RB[kq]);
+                else if ((t == 0) == (s == 0)) ok = joint_solve_position(Wd, RA[kq]);
+                if (!ok) S.walker_ok[w] = 0;
             }
-        par.sync();
-        for (int w = L0; w < M.W; w += LN) {
-            bool ok = true;
-            if (!S.isl_done[S.comp[w]])
-                for (int q = 0; q < 4; ++q) ok = joint_solve_position(M, Wd, S, 4 * w + q) && ok;
-            S.walker_ok[w] = ok ? 1 : 0;
+            par.sync();
         }
-        par.sync();
         if (L0 == 0) {
             bool all_done = true;
             for (int c = 0; c < NODES; ++c) {
@@ -1044,26 +1146,27 @@ MW_HD void world_step(const Model &M, World &Wd, Scratch &S, Par par) {
     }
     par.sync();
     // b2ContactSolver::StoreImpulses -> manifold cache (warm start of the next step)
-    const int nm = S.nm < MAXM ? S.nm : MAXM;
+    const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
     for (int k = L0; k < nm; k += LN) {
         const Manifold &m = S.m[k];
-        Slot &sl = Wd.slot[m.slot];
+        Slot &sl = Cd.slot[m.slot];
         for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
     }
     par.sync();
 }
+#undef MW_CONTACT_SWEEP
 #undef inv_mass_of
 #undef local_center_of
 
 // ---------------------------------------------------------------- lidar: b2EdgeShape::RayCast over the terrain
-MW_HD float lidar_fraction(const Model &M, const World &Wd, V2 p1, V2 p2) {
+MW_HD float lidar_fraction(const Model &M, const Cold &Cd, V2 p1, V2 p2) {
     const V2 d = p2 - p1;
     float best = 1.0f;  // LidarCallback.fraction starts at 1.0 (:210)
     int e0 = (int)floorf(fminf(p1.x, p2.x) / TERRAIN_STEP), e1 = (int)floorf(fmaxf(p1.x, p2.x) / TERRAIN_STEP);
     if (e0 < 0) e0 = 0;
     if (e1 > M.NT - 2) e1 = M.NT - 2;
     for (int e = e0; e <= e1; ++e) {
-        const V2 v1 = v2(e * TERRAIN_STEP, Wd.ty[e]), v2e = v2((e + 1) * TERRAIN_STEP, Wd.ty[e + 1]);
+        const V2 v1 = v2(e * TERRAIN_STEP, Cd.ty[e]), v2e = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
         const V2 ee = v2e - v1;
         V2 normal = v2(ee.y, -ee.x);
         { const float len = sqrtf(dot(normal, normal)); normal = (1.0f / len) * normal; }
@@ -1102,14 +1205,14 @@ MW_HD void philox10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
 enum : uint32_t { TAG_MW_TERRAIN = 32, TAG_MW_PUSH = 33, TAG_MW_NOISE = 34 };
 MW_HD float u24f(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 
-MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid, float *obs, float *rew, uint8_t *done);
+MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done);
 
 // MultiWalkerEnv.reset (:330-357) without its trailing step
-MW_HD void env_reset_world(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid) {
+MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, uint32_t gid) {
     const uint32_t tick = Wd.tick;
     Wd.game_over = 0; Wd.prev_package_shaping = 0.0f; Wd.t = 0;
     for (int w = 0; w < M.W; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0f; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
-    for (int k = 0; k < MAXSLOT; ++k) { Wd.slot[k].edge = -1; Wd.slot[k].npts = 0; Wd.slot[k].touching = 0; }
+    for (int k = 0; k < MAXSLOT; ++k) { Cd.slot[k].edge = -1; Cd.slot[k].npts = 0; Cd.slot[k].touching = 0; }
     // _generate_terrain, non-hardcore branch (:516-612)
     {
         float velocity = 0.0f, y = TERRAIN_HEIGHT;
@@ -1125,7 +1228,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, World &Wd, uint32_t 
                 y += velocity;
             }
             oneshot = false;
-            Wd.ty[i] = y;
+            Cd.ty[i] = y;
             counter -= 1;
             if (counter == 0) {
                 counter = TERRAIN_GRASS / 2 + (int)(((uint64_t)r[1] * (uint64_t)(TERRAIN_GRASS - TERRAIN_GRASS / 2)) >> 32);  // randint(5, 10)
@@ -1171,7 +1274,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, World &Wd, uint32_t 
 
 // MultiWalkerEnv.step (:359-428).  obs: [W][32], rew: [W]
 template <class Par>
-MW_HD void env_step(const Model &M, const EnvCfg &C, World &Wd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
+MW_HD void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
                     float *rew, uint8_t *done) {
     for (int w = par.lane(); w < M.W; w += par.n()) {  // apply_action (:194-203)
         for (int k = 0; k < 4; ++k) {
@@ -1183,16 +1286,16 @@ MW_HD void env_step(const Model &M, const EnvCfg &C, World &Wd, Scratch &S, Par 
         }
     }
     par.sync();
-    world_step(M, Wd, S, par);  // :365
+    world_step(M, Wd, Cd, S, par);  // :365
     if (par.lane() == 0) {
-        env_observe(M, C, Wd, gid, obs, rew, done);
+        env_observe(M, C, Wd, Cd, gid, obs, rew, done);
         Wd.t += 1;
         Wd.tick += 1;
     }
     par.sync();
 }
 
-MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
+MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
     const Body &pkg = Wd.b[0];
     const V2 pkg_pos = body_xf(M, pkg, 0).p;
     float rewards[MAX_WALKERS];
@@ -1219,7 +1322,7 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, World &Wd, uint32_t gid,
             float ls, lc;
             sincos_det(1.5f * i / 10.0f, ls, lc);
             const V2 p2 = v2(pos.x + ls * LIDAR_RANGE, pos.y - lc * LIDAR_RANGE);
-            o[14 + i] = lidar_fraction(M, Wd, pos, p2);
+            o[14 + i] = lidar_fraction(M, Cd, pos, p2);
         }
         // neighbours and package (:380-400), gaussian noise via Box-Muller on keyed uniforms
         float nz[7] = {0, 0, 0, 0, 0, 0, 0};

@@ -24,7 +24,7 @@ extern "C" int b2kat_falling_box(float *xya, int steps) {
     static World Wd;
     static Scratch S;
     std::memset(&M, 0, sizeof(M)); std::memset(&Wd, 0, sizeof(Wd)); std::memset(&S, 0, sizeof(S));
-    M.W = 0; M.NB = 2; M.NJ = 0; M.NT = 2;
+    M.W = 0; M.NB = 2; M.NJ = 0; M.NT = 2; M.max_manifolds = MAXM;
     const V2 p[4] = {v2(-1, -1), v2(1, -1), v2(1, 1), v2(-1, 1)};  // SetAsBox(1, 1), density 1, friction 0.3
     poly_set(M.shape[SH_PACKAGE], p, 4);
     poly_mass(M.shape[SH_PACKAGE], 1.0f);
@@ -36,15 +36,15 @@ extern "C" int b2kat_falling_box(float *xya, int steps) {
     M.slot_base[0] = 0; M.slot_cap[0] = EDGE_SLOTS_PKG; M.slot_base[1] = EDGE_SLOTS_PKG; M.slot_cap[1] = EDGE_SLOTS_SMALL;
     M.dyn_slot_base = EDGE_SLOTS_PKG + EDGE_SLOTS_SMALL; M.n_dyn_pairs = 1;
     M.dyn_a[0] = 1; M.dyn_b[0] = 0;  // A = ground (the first proxy), B = box
-    for (int k = 0; k < MAXSLOT; ++k) Wd.slot[k].edge = -1;
-    Wd.ty[0] = Wd.ty[1] = -1000.0f;  // the terrain chain plays no part here
+    for (int k = 0; k < MAXSLOT; ++k) Wd.c.slot[k].edge = -1;
+    Wd.c.ty[0] = Wd.c.ty[1] = -1000.0f;  // the terrain chain plays no part here
     const float x0 = 0.0f;
-    Wd.b[0].c = v2(x0, 4.0f);
-    Wd.b[1].c = v2(0.0f, -10.0f);
+    Wd.h.b[0].c = v2(x0, 4.0f);
+    Wd.h.b[1].c = v2(0.0f, -10.0f);
     SerialPar par;
     for (int i = 0; i < steps; ++i) {
-        world_step(M, Wd, S, par);
-        xya[3 * i] = Wd.b[0].c.x - x0; xya[3 * i + 1] = Wd.b[0].c.y; xya[3 * i + 2] = Wd.b[0].a;
+        world_step(M, Wd.h, Wd.c, S, par);
+        xya[3 * i] = Wd.h.b[0].c.x - x0; xya[3 * i + 1] = Wd.h.b[0].c.y; xya[3 * i + 2] = Wd.h.b[0].a;
     }
     return 0;
 }

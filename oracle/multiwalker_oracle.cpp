@@ -54,9 +54,9 @@ void mwo_reset(MwOracle *o, const uint8_t *mask, float *obs) {
         mw::Scratch S;
         float zero[4 * mw::MAX_WALKERS] = {0};
         const uint32_t gid = (uint32_t)(o->env_id_base + n);
-        mw::env_reset_world(o->M, o->C, o->worlds[n], gid);
-        mw::env_step(o->M, o->C, o->worlds[n], S, mw::SerialPar(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
-        o->worlds[n].t = 0;
+        mw::env_reset_world(o->M, o->C, o->worlds[n].h, o->worlds[n].c, gid);
+        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, mw::SerialPar(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
+        o->worlds[n].h.t = 0;
     }
 }
 
@@ -65,7 +65,7 @@ void mwo_step(MwOracle *o, const float *actions, float *obs, float *rew, uint8_t
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < o->n_envs; ++n) {
         mw::Scratch S;
-        mw::env_step(o->M, o->C, o->worlds[n], S, mw::SerialPar(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
+        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, mw::SerialPar(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
                      obs + n * W * mw::obs_dim_of(o->C), rew + n * W, done + n);
     }
 }
@@ -78,7 +78,7 @@ void mwo_set_worlds(MwOracle *o, const void *in) { memcpy(o->worlds.data(), in, 
 void mwo_get_bodies(const MwOracle *o, float *out, uint8_t *flags) {
     const int NB = o->M.NB, W = o->M.W;
     for (int64_t n = 0; n < o->n_envs; ++n) {
-        const mw::World &w = o->worlds[n];
+        const mw::Hot &w = o->worlds[n].h;
         for (int b = 0; b < NB; ++b) {
             float *p = out + (n * NB + b) * 6;
             p[0] = w.b[b].c.x; p[1] = w.b[b].c.y; p[2] = w.b[b].a; p[3] = w.b[b].v.x; p[4] = w.b[b].v.y; p[5] = w.b[b].w;
@@ -91,7 +91,7 @@ void mwo_get_bodies(const MwOracle *o, float *out, uint8_t *flags) {
     }
 }
 void mwo_get_terrain(const MwOracle *o, float *out) {
-    for (int64_t n = 0; n < o->n_envs; ++n) memcpy(out + n * o->M.NT, o->worlds[n].ty, sizeof(float) * o->M.NT);
+    for (int64_t n = 0; n < o->n_envs; ++n) memcpy(out + n * o->M.NT, o->worlds[n].c.ty, sizeof(float) * o->M.NT);
 }
 int mwo_num_terrain(const MwOracle *o) { return o->M.NT; }
 int mwo_num_bodies(const MwOracle *o) { return o->M.NB; }
