@@ -56,7 +56,8 @@ __device__ __forceinline__ void lds_sync() {
 template <int EPW>
 struct GroupPar {
     static constexpr int NL = 64 / EPW;
-    static constexpr int LEGS = (2 * mw::MAX_WALKERS + NL - 1) / NL;
+    static constexpr int JOINTS = (mw::MAXJ + NL - 1) / NL;
+    static constexpr int BODIES = (mw::MAXB + NL - 1) / NL;
     int l;
     __device__ __forceinline__ int lane() const { return l; }
     __device__ __forceinline__ int n() const { return NL; }

@@ -34,6 +34,15 @@
 
 namespace mw {
 
+// optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
+#ifdef MW_STATS
+struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters; };
+extern Stats g_stats;
+#define MW_STAT(f, v) (g_stats.f += (v))
+#else
+#define MW_STAT(f, v) ((void)0)
+#endif
+
 // World::Step parameters of the env (multi_walker.py:365).  Overridable ONLY by the known-answer harness of the test
 // infrastructure, which replays the published Box2D HelloWorld scene (1/60 s, 6 velocity / 2 position iterations)
 // through this same solver.
@@ -299,7 +308,8 @@ struct Scratch {  // per-step workspace (LDS on the GPU)
     // solver schedule: terrain manifolds per body (indexed like the body's slots) and the active dynamic pairs
     uint8_t bm_cnt[MAXB], bm_idx[MAXSLOT_TERRAIN];
     int8_t dyn_midx[NDYN];   // manifold of pair p, or -1
-    int8_t dyn_list[NDYN];   // the active pairs, in pair order
+    int8_t dyn_list[NDYN];   // the active pairs, in pair order ...
+    int8_t dyn_owner[NDYN], dyn_man[NDYN];  // ... the body whose lane solves them (the pair's second body) and their manifolds
     int8_t comp[MAX_WALKERS + 1];
     uint8_t isl_done[MAX_WALKERS + 1], walker_ok[MAX_WALKERS];
     float body_minsep[MAXB], dyn_minsep[NDYN];
@@ -559,10 +569,11 @@ MW_HD void contact_event(const Model &M, Hot &Wd, int bA, int bB, bool begin) {
 // of a walker on two lanes, the package / hull contacts one at a time -- and every pair of constraints that shares a
 // body keeps its serial Gauss-Seidel order, so the lane-parallel schedule produces bit-identical results to the serial
 // one (constraints on disjoint bodies commute exactly).
-// LEGS = legs (pairs of revolute joints) a lane may own; their per-step constants and accumulated impulses live in
-// lane-private storage (registers on the GPU) for the whole step.
+// JOINTS = revolute joints a lane may own (joint ji belongs to lane ji % n()); their per-step constants and accumulated
+// impulses live in lane-private storage (registers on the GPU) for the whole step.
 struct SerialPar {
-    static constexpr int LEGS = 2 * MAX_WALKERS;
+    static constexpr int JOINTS = MAXJ;   // joints a lane may own
+    static constexpr int BODIES = MAXB;   // bodies a lane may own
     MW_HD int lane() const { return 0; }
     MW_HD int n() const { return 1; }
     MW_HD void sync() const {}
@@ -571,7 +582,7 @@ struct SerialPar {
 
 // push an active manifold into the solver pool, carrying impulses over from the cached contact
 template <class Par>
-MW_HD int emit_manifold(const Model &M, Hot &Wd, Scratch &S, Par par, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction) {
+MW_HD int emit_manifold(const Model &M, Hot &Wd, Scratch &S, Par par, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction, int max_manifolds) {
     float ni[2] = {0, 0}, ti[2] = {0, 0};
     for (int i = 0; i < mo.npts; ++i)  // b2Contact::Update: match ids with the old manifold
         for (int k = 0; k < sl.npts; ++k)
@@ -582,7 +593,7 @@ MW_HD int emit_manifold(const Model &M, Hot &Wd, Scratch &S, Par par, Slot &sl, 
     for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
     if (!touching) return -1;
     const int idx = par.alloc(&S.nm);
-    if (idx >= M.max_manifolds) return -1;  // pool exhausted: the pair is ignored this step
+    if (idx >= max_manifolds) return -1;  // pool exhausted: the pair is ignored this step
     Manifold &m = S.m[idx];
     m.bA = (int16_t)bA; m.bB = (int16_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)mo.type;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
@@ -629,7 +640,7 @@ MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, P
             const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Cd.ty[e + 2]) : p2;
             collide_edge_polygon(mo, p1, p2, s, xfB, has0, p0, has3, p3);
         }
-        const int idx = emit_manifold(M, Wd, S, par, sl, M.slot_base[bi] + k, mo, -1, bi, sqrtf(FRICTION * s.friction));
+        const int idx = emit_manifold(M, Wd, S, par, sl, M.slot_base[bi] + k, mo, -1, bi, sqrtf(FRICTION * s.friction), M.max_manifolds);
         if (idx >= 0 && cnt < cap) S.bm_idx[M.slot_base[bi] + cnt++] = (uint8_t)idx;
     }
     S.bm_cnt[bi] = (uint8_t)cnt;
@@ -648,29 +659,37 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par p
     ManifoldOut mo; mo.npts = 0;
     if (!(ax0 > bx1 + 0.2f || bx0 > ax1 + 0.2f || ay0 > by1 + 0.2f || by0 > ay1 + 0.2f))
         collide_polygons(mo, sA, body_xf(M, Wd.b[bA], bA), sB, body_xf(M, Wd.b[bB], bB));
-    S.dyn_midx[p] = (int8_t)emit_manifold(M, Wd, S, par, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction));
+    S.dyn_midx[p] = (int8_t)emit_manifold(M, Wd, S, par, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction), M.max_manifolds);
 }
 
 // ---------------------------------------------------------------- island solver (b2Island::Solve)
 #define inv_mass_of(M_, b_, im_, ii_) do { const int _b = (b_); if (_b < 0) { im_ = 0.0f; ii_ = 0.0f; } else { im_ = S.bim[_b]; ii_ = S.bii[_b]; } } while (0)
 #define local_center_of(M_, b_) ((b_) < 0 ? v2(0, 0) : S.blc[(b_)])
 
-MW_HD void solve33(const float *k, float bx, float by, float bz, float &x, float &y, float &z) {
-    // k = [ex.x ex.y ex.z ey.x ey.y ey.z ez.x ez.y ez.z]; Cramer's rule as b2Mat33::Solve33
+// k = [ex.x ex.y ex.z ey.x ey.y ey.z ez.x ez.y ez.z]; Cramer's rule as b2Mat33::Solve33, split into the part that only
+// depends on the matrix (constant over the sweeps of a step) and the part that depends on the right-hand side
+MW_HD void solve33_prepare(const float *k, float &cx, float &cy, float &cz, float &det) {
     const float exx = k[0], exy = k[1], exz = k[2], eyx = k[3], eyy = k[4], eyz = k[5], ezx = k[6], ezy = k[7], ezz = k[8];
-    const float cx = eyy * ezz - eyz * ezy, cy = eyz * ezx - eyx * ezz, cz = eyx * ezy - eyy * ezx;  // cross(ey, ez)
-    float det = exx * cx + exy * cy + exz * cz;
+    cx = eyy * ezz - eyz * ezy; cy = eyz * ezx - eyx * ezz; cz = eyx * ezy - eyy * ezx;  // cross(ey, ez)
+    det = exx * cx + exy * cy + exz * cz;
     if (det != 0.0f) det = 1.0f / det;
+}
+MW_HD void solve33(const float *k, float cx, float cy, float cz, float det, float bx, float by, float bz, float &x, float &y, float &z) {
+    const float exx = k[0], exy = k[1], exz = k[2], eyx = k[3], eyy = k[4], eyz = k[5], ezx = k[6], ezy = k[7], ezz = k[8];
     x = det * (bx * cx + by * cy + bz * cz);
     const float dx = by * ezz - bz * ezy, dy = bz * ezx - bx * ezz, dz = bx * ezy - by * ezx;        // cross(b, ez)
     y = det * (exx * dx + exy * dy + exz * dz);
     const float fx = eyy * bz - eyz * by, fy = eyz * bx - eyx * bz, fz = eyx * by - eyy * bx;        // cross(ey, b)
     z = det * (exx * fx + exy * fy + exz * fz);
 }
-MW_HD void solve22(const float *k, float bx, float by, float &x, float &y) {
+MW_HD float solve22_prepare(const float *k) {
     const float a11 = k[0], a12 = k[3], a21 = k[1], a22 = k[4];
     float det = a11 * a22 - a12 * a21;
     if (det != 0.0f) det = 1.0f / det;
+    return det;
+}
+MW_HD void solve22(const float *k, float det, float bx, float by, float &x, float &y) {
+    const float a11 = k[0], a12 = k[3], a21 = k[1], a22 = k[4];
     x = det * (a22 * bx - a12 * by);
     y = det * (a11 * by - a21 * bx);
 }
@@ -748,6 +767,7 @@ struct JointCache {
     float lower, upper;
     V2 rA, rB;
     float k[9], motor_mass;
+    float c33x, c33y, c33z, idet33, idet22;  // the b-independent terms of b2Mat33::Solve33 / Solve22 on k
     float motor_speed, maxi;   // maxi = h * maxMotorTorque
     int limit_state;
     float ix, iy, iz, motor_impulse;
@@ -778,6 +798,8 @@ MW_HD void joint_init_warm(const Model &M, Hot &Wd, Scratch &S, int ji, float h,
     float mm = iA + iB;
     if (mm > 0.0f) mm = 1.0f / mm;
     c.motor_mass = mm;
+    solve33_prepare(k, c.c33x, c.c33y, c.c33z, c.idet33);
+    c.idet22 = solve22_prepare(k);
     c.motor_speed = j.motor_speed; c.maxi = h * j.max_torque;
     c.ix = j.ix; c.iy = j.iy; c.iz = j.iz; c.motor_impulse = j.motor_impulse; c.limit_state = j.limit_state;
     const float angle = B.a - A.a;  // referenceAngle = 0 (the def is built from kwargs, not Initialize())
@@ -808,7 +830,7 @@ MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
         const V2 Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA);
         const float Cdot2 = wB - wA;
         float ix, iy, iz;
-        solve33(c.k, Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
+        solve33(c.k, c.c33x, c.c33y, c.c33z, c.idet33, Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
         ix = -ix; iy = -iy; iz = -iz;
         bool reduce = false;
         if (c.limit_state == 3) { c.ix += ix; c.iy += iy; c.iz += iz; }
@@ -818,7 +840,7 @@ MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
             if (reduce) {
                 const float rx = -Cdot1.x + c.iz * c.k[6], ry = -Cdot1.y + c.iz * c.k[7];
                 float qx, qy;
-                solve22(c.k, rx, ry, qx, qy);
+                solve22(c.k, c.idet22, rx, ry, qx, qy);
                 ix = qx; iy = qy; iz = -c.iz;
                 c.ix += qx; c.iy += qy; c.iz = 0.0f;
             } else { c.ix += ix; c.iy += iy; c.iz += iz; }
@@ -829,7 +851,7 @@ MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
     } else {  // point-to-point only
         const V2 Cdot = vB + cross(wB, rB) - vA - cross(wA, rA);
         float ix, iy;
-        solve22(c.k, -Cdot.x, -Cdot.y, ix, iy);
+        solve22(c.k, c.idet22, -Cdot.x, -Cdot.y, ix, iy);
         c.ix += ix; c.iy += iy;
         const V2 P = v2(ix, iy);
         vA = vA - mA * P; wA -= iA * cross(rA, P);
@@ -972,8 +994,8 @@ MW_HD bool joint_solve_position(Hot &Wd, const JointCache &c) {
 // Schedule of one Gauss-Seidel sweep (Box2D: all joints in creation order, then all contacts):
 //   joints   three slots.  A walker's joints in creation order are hip0, knee0, hip1, knee1; hip0 -> knee0 share the
 //            upper leg, hip0 -> hip1 the hull, hip1 -> knee1 the other upper leg, while knee0 and hip1 share nothing.
-//            One lane per LEG: slot 0 = hip0, slot 1 = knee0 | hip1, slot 2 = knee1.  In each lane register set RA holds
-//            the joint of slots 0 / 2 (hip of leg 0, knee of leg 1), RB the joint of slot 1.
+//            One lane per JOINT: slot 0 = hip0, slot 1 = knee0 | hip1, slot 2 = knee1, i.e. joint 4 w + 2 s + r (leg s,
+//            r = 0 hip / 1 knee) runs in slot s + r; the three slots are one loop over the same lane-private JointCache.
 //   contacts sub-slot i = the i-th terrain manifold of every body (by lane) and, while neither the package nor a hull
 //            touches the terrain (`merge_ok`), the i-th active package-hull / hull-hull pair, solved by the lane that
 //            owns the pair's second body -- leg-terrain and package-hull constraints share no body.  Otherwise the
@@ -982,25 +1004,33 @@ template <class Par>
 MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     const float h = 1.0f / FPS;
     const int L0 = par.lane(), LN = par.n();
-    const int NODES = M.W + 1;  // island graph nodes: walkers, then the package
-    const int NLEG = 2 * M.W;
-    for (int bi = L0; bi < M.NB; bi += LN) {
+    // the model scalars are read once: the solver loops below must not go back to memory for them
+    const int NB = M.NB, NW = M.W, NDP = M.n_dyn_pairs, MAXMAN = M.max_manifolds;
+    const int NODES = NW + 1;  // island graph nodes: walkers, then the package
+    int own_sb[Par::BODIES];   // manifold-list base of the bodies this lane owns (bi = L0 + kb * LN)
+    MW_UNROLL
+    for (int kb = 0; kb < Par::BODIES; ++kb) {
+        const int bi = L0 + kb * LN;
+        own_sb[kb] = 0;
+        if (bi >= NB) continue;
         const Shape &sh = M.shape[shape_of_body(bi)];
         S.bim[bi] = sh.inv_mass; S.bii[bi] = sh.inv_I; S.blc[bi] = sh.centroid;
-        S.node[bi] = (int8_t)(bi == 0 ? M.W : (bi - 1) / 5);
+        S.node[bi] = (int8_t)(bi == 0 ? NW : (bi - 1) / 5);
+        own_sb[kb] = M.slot_base[bi];
     }
     if (L0 == 0) S.nm = 0;
     par.sync();
     // ---- Collide: terrain candidates by body, then the dynamic pairs
-    for (int bi = L0; bi < M.NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi);
+    for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi);
     par.sync();
-    for (int p = L0; p < M.n_dyn_pairs; p += LN) collide_dyn_pair(M, Wd, Cd, S, par, p);
+    for (int p = L0; p < NDP; p += LN) collide_dyn_pair(M, Wd, Cd, S, par, p);
     par.sync();
     if (L0 == 0) {  // islands: walkers (+ package) joined by touching hull-hull / hull-package contacts; contact schedule
         for (int i = 0; i < NODES; ++i) { S.comp[i] = (int8_t)i; S.isl_done[i] = 0; }
         int nd = 0;
-        for (int p = 0; p < M.n_dyn_pairs; ++p) {
+        for (int p = 0; p < NDP; ++p) {
             if (S.dyn_midx[p] < 0) continue;
+            S.dyn_owner[nd] = (int8_t)M.dyn_b[p]; S.dyn_man[nd] = S.dyn_midx[p];
             S.dyn_list[nd++] = (int8_t)p;
             const int ca = S.comp[S.node[M.dyn_a[p]]], cb = S.comp[S.node[M.dyn_b[p]]];
             if (ca != cb) for (int i = 0; i < NODES; ++i) if (S.comp[i] == cb) S.comp[i] = (int8_t)ca;
@@ -1008,14 +1038,14 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
         S.n_dyn = (int8_t)nd;
         int mc = 0;
         bool merge = S.bm_cnt[0] == 0;
-        for (int bi = 0; bi < M.NB; ++bi) {
+        for (int bi = 0; bi < NB; ++bi) {
             if (S.bm_cnt[bi] > mc) mc = S.bm_cnt[bi];
             if (bi >= 1 && (bi - 1) % 5 == 0 && S.bm_cnt[bi] != 0) merge = false;
         }
         S.max_cnt = (int8_t)mc; S.merge_ok = merge ? 1 : 0;
     }
     // ---- integrate velocities (gravity + the pending initial push)
-    for (int bi = L0; bi < M.NB; bi += LN) {
+    for (int bi = L0; bi < NB; bi += LN) {
         Body &b = Wd.b[bi];
         float fx = 0.0f;
         if (bi >= 1 && (bi - 1) % 5 == 0) { const int w = (bi - 1) / 5; fx = Wd.push_x[w]; }
@@ -1026,72 +1056,66 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
         // linear/angular damping are 0: v *= 1/(1 + h*0)
     }
     par.sync();
-    for (int w = L0; w < M.W; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces
-    const int nsubA = S.merge_ok ? (S.max_cnt > S.n_dyn ? S.max_cnt : S.n_dyn) : S.max_cnt;
-    const int nsubB = S.merge_ok ? 0 : S.n_dyn;
+    for (int w = L0; w < NW; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces
+    const int n_dyn = S.n_dyn;
+    const int nsubA = S.merge_ok ? (S.max_cnt > n_dyn ? S.max_cnt : n_dyn) : S.max_cnt;
+    const int nsubB = S.merge_ok ? 0 : n_dyn;
     const bool merge_ok = S.merge_ok != 0;
-    // one contact sweep; F(manifold index) is applied in the schedule described above
+    MW_STAT(steps, 1); MW_STAT(sub_a, nsubA); MW_STAT(sub_b, nsubB); MW_STAT(manifolds, S.nm); MW_STAT(merged, merge_ok ? 1 : 0);
+    // one contact sweep; F_TERRAIN / F_DYN see the body `bi` and the manifold index `k_` (F_DYN also the pair `p_`)
 #define MW_CONTACT_SWEEP(F_TERRAIN, F_DYN)                                                                   \
     for (int i = 0; i < nsubA; ++i) {                                                                        \
-        for (int bi = L0; bi < M.NB; bi += LN) {                                                             \
-            if (i < S.bm_cnt[bi]) { const int k_ = S.bm_idx[M.slot_base[bi] + i]; F_TERRAIN; }               \
-            if (merge_ok && i < S.n_dyn) {                                                                   \
-                const int p_ = S.dyn_list[i];                                                                \
-                if (M.dyn_b[p_] == bi) { const int k_ = S.dyn_midx[p_]; F_DYN; }                             \
-            }                                                                                                \
+        const int dyn_own_ = (merge_ok && i < n_dyn) ? S.dyn_owner[i] : -1;                                  \
+        MW_UNROLL                                                                                            \
+        for (int kb = 0; kb < Par::BODIES; ++kb) {                                                           \
+            const int bi = L0 + kb * LN;                                                                     \
+            if (bi >= NB) continue;                                                                          \
+            if (i < S.bm_cnt[bi]) { const int k_ = S.bm_idx[own_sb[kb] + i]; F_TERRAIN; }                    \
+            if (dyn_own_ == bi) { const int k_ = S.dyn_man[i]; const int p_ = S.dyn_list[i]; (void)p_; F_DYN; } \
         }                                                                                                    \
         par.sync();                                                                                          \
     }                                                                                                        \
     for (int i = 0; i < nsubB; ++i) {                                                                        \
-        const int p_ = S.dyn_list[i];                                                                        \
-        for (int bi = L0; bi < M.NB; bi += LN)                                                               \
-            if (M.dyn_b[p_] == bi) { const int k_ = S.dyn_midx[p_]; F_DYN; }                                 \
+        const int dyn_own_ = S.dyn_owner[i];                                                                 \
+        MW_UNROLL                                                                                            \
+        for (int kb = 0; kb < Par::BODIES; ++kb) {                                                           \
+            const int bi = L0 + kb * LN;                                                                     \
+            if (bi < NB && dyn_own_ == bi) { const int k_ = S.dyn_man[i]; const int p_ = S.dyn_list[i]; (void)p_; F_DYN; } \
+        }                                                                                                    \
         par.sync();                                                                                          \
     }
     // ---- contact constraints: init + warm start
     MW_CONTACT_SWEEP(contact_init_warm(M, Wd, S, k_), contact_init_warm(M, Wd, S, k_))
-    // ---- joints: init + warm start.  Register sets: RA = joint of slots 0 / 2, RB = joint of slot 1
-    JointCache RA[Par::LEGS], RB[Par::LEGS];
+    // ---- joints: init + warm start, in the three-slot order
+    JointCache JC[Par::JOINTS];
+    int jslot[Par::JOINTS];
+    MW_UNROLL
+    for (int kq = 0; kq < Par::JOINTS; ++kq) { const int ji = L0 + kq * LN; jslot[kq] = ji < 4 * NW ? ((ji >> 1) & 1) + (ji & 1) : -1; }
     for (int t = 0; t < 3; ++t) {
         MW_UNROLL
-        for (int kq = 0; kq < Par::LEGS; ++kq) {
-            const int lg = L0 + kq * LN;
-            if (lg >= NLEG) continue;
-            const int w = lg >> 1, s = lg & 1;
-            if (t == 1) joint_init_warm(M, Wd, S, 4 * w + 2 * s + (s ? 0 : 1), h, RB[kq]);
-            else if ((t == 0) == (s == 0)) joint_init_warm(M, Wd, S, 4 * w + 2 * s + (s ? 1 : 0), h, RA[kq]);
-        }
+        for (int kq = 0; kq < Par::JOINTS; ++kq)
+            if (jslot[kq] == t) joint_init_warm(M, Wd, S, L0 + kq * LN, h, JC[kq]);
         par.sync();
     }
     // ---- velocity iterations (islands are disjoint, so iterating them together changes nothing)
     for (int it = 0; it < VEL_ITERS; ++it) {
         for (int t = 0; t < 3; ++t) {
             MW_UNROLL
-            for (int kq = 0; kq < Par::LEGS; ++kq) {
-                const int lg = L0 + kq * LN;
-                if (lg >= NLEG) continue;
-                const int s = lg & 1;
-                if (t == 1) joint_solve_velocity(Wd, RB[kq]);
-                else if ((t == 0) == (s == 0)) joint_solve_velocity(Wd, RA[kq]);
-            }
+            for (int kq = 0; kq < Par::JOINTS; ++kq)
+                if (jslot[kq] == t) joint_solve_velocity(Wd, JC[kq]);
             par.sync();
         }
         MW_CONTACT_SWEEP(contact_solve_velocity(M, Wd, S, k_), contact_solve_velocity(M, Wd, S, k_))
     }
     // the accumulated joint impulses and limit states go back to the world (warm start of the next step)
-    {
-        MW_UNROLL
-        for (int kq = 0; kq < Par::LEGS; ++kq) {
-            const int lg = L0 + kq * LN;
-            if (lg >= NLEG) continue;
-            const int w = lg >> 1, s = lg & 1;
-            Joint &ja = Wd.j[4 * w + 2 * s + (s ? 1 : 0)], &jb = Wd.j[4 * w + 2 * s + (s ? 0 : 1)];
-            ja.ix = RA[kq].ix; ja.iy = RA[kq].iy; ja.iz = RA[kq].iz; ja.motor_impulse = RA[kq].motor_impulse; ja.limit_state = RA[kq].limit_state;
-            jb.ix = RB[kq].ix; jb.iy = RB[kq].iy; jb.iz = RB[kq].iz; jb.motor_impulse = RB[kq].motor_impulse; jb.limit_state = RB[kq].limit_state;
-        }
+    MW_UNROLL
+    for (int kq = 0; kq < Par::JOINTS; ++kq) {
+        if (jslot[kq] < 0) continue;
+        Joint &j = Wd.j[L0 + kq * LN];
+        j.ix = JC[kq].ix; j.iy = JC[kq].iy; j.iz = JC[kq].iz; j.motor_impulse = JC[kq].motor_impulse; j.limit_state = JC[kq].limit_state;
     }
     // ---- integrate positions
-    for (int bi = L0; bi < M.NB; bi += LN) {
+    for (int bi = L0; bi < NB; bi += LN) {
         Body &b = Wd.b[bi];
         V2 tr = h * b.v;
         if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) { const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr)); b.v = ratio * b.v; }
@@ -1103,25 +1127,22 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     par.sync();
     // ---- position iterations, each island stops on its own (b2Island::Solve early exit)
     for (int it = 0; it < POS_ITERS; ++it) {
-        for (int bi = L0; bi < M.NB; bi += LN) S.body_minsep[bi] = 0.0f;
+        MW_STAT(pos_iters, 1);
+        for (int bi = L0; bi < NB; bi += LN) S.body_minsep[bi] = 0.0f;
         for (int p = L0; p < NDYN; p += LN) S.dyn_minsep[p] = 0.0f;
         par.sync();
         MW_CONTACT_SWEEP(
             if (!S.isl_done[S.comp[S.node[bi]]]) S.body_minsep[bi] = fminf(S.body_minsep[bi], contact_solve_position(M, Wd, S, k_)),
             if (!S.isl_done[S.comp[S.node[bi]]]) S.dyn_minsep[p_] = contact_solve_position(M, Wd, S, k_))
-        for (int w = L0; w < M.W; w += LN) S.walker_ok[w] = 1;
+        for (int w = L0; w < NW; w += LN) S.walker_ok[w] = 1;
         par.sync();
         for (int t = 0; t < 3; ++t) {
             MW_UNROLL
-            for (int kq = 0; kq < Par::LEGS; ++kq) {
-                const int lg = L0 + kq * LN;
-                if (lg >= NLEG) continue;
-                const int w = lg >> 1, s = lg & 1;
+            for (int kq = 0; kq < Par::JOINTS; ++kq) {
+                if (jslot[kq] != t) continue;
+                const int w = (L0 + kq * LN) >> 2;
                 if (S.isl_done[S.comp[w]]) continue;
-                bool ok = true;
-                if (t == 1) ok = joint_solve_position(Wd, RB[kq]);
-                else if ((t == 0) == (s == 0)) ok = joint_solve_position(Wd, RA[kq]);
-                if (!ok) S.walker_ok[w] = 0;
+                if (!joint_solve_position(Wd, JC[kq])) S.walker_ok[w] = 0;
             }
             par.sync();
         }
@@ -1133,9 +1154,9 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
                 if (!any || S.isl_done[c]) continue;
                 float ms = 0.0f;
                 bool jok = true;
-                for (int bi = 0; bi < M.NB; ++bi) if (S.comp[S.node[bi]] == c) ms = fminf(ms, S.body_minsep[bi]);
-                for (int p = 0; p < M.n_dyn_pairs; ++p) if (S.comp[S.node[M.dyn_b[p]]] == c) ms = fminf(ms, S.dyn_minsep[p]);
-                for (int w = 0; w < M.W; ++w) if (S.comp[w] == c) jok = jok && S.walker_ok[w];
+                for (int bi = 0; bi < NB; ++bi) if (S.comp[S.node[bi]] == c) ms = fminf(ms, S.body_minsep[bi]);
+                for (int i = 0; i < n_dyn; ++i) if (S.comp[S.node[S.dyn_owner[i]]] == c) ms = fminf(ms, S.dyn_minsep[S.dyn_list[i]]);
+                for (int w = 0; w < NW; ++w) if (S.comp[w] == c) jok = jok && S.walker_ok[w];
                 if (ms >= -3.0f * LINEAR_SLOP && jok) S.isl_done[c] = 1;
                 else all_done = false;
             }
@@ -1146,7 +1167,7 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     }
     par.sync();
     // b2ContactSolver::StoreImpulses -> manifold cache (warm start of the next step)
-    const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
+    const int nm = S.nm < MAXMAN ? S.nm : MAXMAN;
     for (int k = L0; k < nm; k += LN) {
         const Manifold &m = S.m[k];
         Slot &sl = Cd.slot[m.slot];

@@ -1,0 +1,33 @@
+// How much work a MultiWalker step really is (CPU build of the solver source with counters): sub-slots of a contact sweep,
+// position iterations until the early exit, active manifolds.   g++ -O2 -DMW_STATS scripts/mw_stats.cpp -o /tmp/mw_stats && /tmp/mw_stats
+#define MW_STATS
+#include "../madrl_amd/csrc/multiwalker_core.hpp"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+mw::Stats mw::g_stats;
+int main() {
+    using namespace mw;
+    for (int W = 2; W <= 4; ++W) {
+        Model M; memset(&M, 0, sizeof(M)); build_model(M, W);
+        EnvCfg C; memset(&C, 0, sizeof(C)); C.n_walkers = W; C.terminate_on_fall = 1; C.forward_reward = 1; C.fall_reward = -100; C.drop_reward = -100; C.k0 = 1;
+        std::vector<World> worlds(64); memset(worlds.data(), 0, sizeof(World) * 64);
+        std::vector<float> obs(W * 32), rew(W), act(4 * W);
+        memset(&g_stats, 0, sizeof(g_stats));
+        uint32_t lcg = 12345;
+        for (int n = 0; n < 64; ++n) {
+            Scratch S; uint8_t done = 0; float zero[16] = {0};
+            env_reset_world(M, C, worlds[n].h, worlds[n].c, n);
+            env_step(M, C, worlds[n].h, worlds[n].c, S, SerialPar(), n, zero, obs.data(), nullptr, nullptr);
+            memset(&g_stats, 0, 0);
+            for (int t = 0; t < 300; ++t) {
+                for (auto &a : act) { lcg = lcg * 1664525u + 1013904223u; a = (float)(lcg >> 8) / 8388608.0f - 1.0f; }
+                env_step(M, C, worlds[n].h, worlds[n].c, S, SerialPar(), n, act.data(), obs.data(), rew.data(), &done);
+                if (done) { env_reset_world(M, C, worlds[n].h, worlds[n].c, n); env_step(M, C, worlds[n].h, worlds[n].c, S, SerialPar(), n, zero, obs.data(), nullptr, nullptr); }
+            }
+        }
+        const double s = (double)g_stats.steps;
+        printf("W=%d steps=%ld  subslots A %.2f B %.2f  manifolds %.2f  merged %.2f  position iterations %.2f\n", W, g_stats.steps,
+               g_stats.sub_a / s, g_stats.sub_b / s, g_stats.manifolds / s, g_stats.merged / s, g_stats.pos_iters / s);
+    }
+}
