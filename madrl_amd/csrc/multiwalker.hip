@@ -58,6 +58,7 @@ struct GroupPar {
     static constexpr int NL = 64 / EPW;
     static constexpr int JOINTS = (mw::MAXJ + NL - 1) / NL;
     static constexpr int BODIES = (mw::MAXB + NL - 1) / NL;
+    static constexpr bool MCACHE = true;
     int l;
     __device__ __forceinline__ int lane() const { return l; }
     __device__ __forceinline__ int n() const { return NL; }
@@ -67,7 +68,7 @@ struct GroupPar {
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 template <int MODE, int EPW>
-__global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const MwIO io) {
+__global__ __launch_bounds__(64, 2) void multiwalker_kernel(const MwDev d, const MwIO io) {
     const mw::Model &M = *d.model;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NL = 64 / EPW;
@@ -96,18 +97,21 @@ __global__ __launch_bounds__(64) void multiwalker_kernel(const MwDev d, const Mw
             lds_sync();
             const uint32_t gid = d.gid_base + (uint32_t)env;
             float *obs_row = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM
-            if (MODE == 1) {
-                mw::env_step(M, d.cfg, Wd, Cd, S, par, gid, s_act, obs_row, s_rew, reinterpret_cast<uint8_t *>(s_done));
-                if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2;
-                lds_sync();
-            }
-            const uint32_t dn = *s_done;  // uniform over the group
-            if (MODE == 0 || (dn != 0 && d.cfg.auto_reset)) {  // MultiWalkerEnv.reset (:330-357) ends with step(zeros)
-                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = 0.0f;
-                if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, Cd, gid);
-                lds_sync();
-                mw::env_step(M, d.cfg, Wd, Cd, S, par, gid, s_act, obs_row, (float *)nullptr, (uint8_t *)nullptr);
-                if (lane == 0) Wd.t = 0;
+            // pass 0: the step proper (MODE 1); pass 1: MultiWalkerEnv.reset (:330-357), which ends with step(zeros).
+            // One call site, so that env_step is inlined here and keeps LDS addressing for Wd / S.
+            uint32_t dn = 0;
+            for (int pass = (MODE == 1 ? 0 : 1); pass < 2; ++pass) {
+                if (pass == 1) {
+                    dn = *s_done;  // uniform over the group
+                    if (!(MODE == 0 || (dn != 0 && d.cfg.auto_reset))) break;
+                    for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = 0.0f;
+                    if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, Cd, gid);
+                    lds_sync();
+                }
+                mw::env_step(M, d.cfg, Wd, Cd, S, par, gid, s_act, obs_row, pass == 0 ? s_rew : (float *)nullptr,
+                             pass == 0 ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
+                if (pass == 0) { if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2; }
+                else if (lane == 0) Wd.t = 0;
                 lds_sync();
             }
             if (MODE == 1) {
@@ -240,6 +244,7 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     d.world_dw = (int32_t)(align_up(sizeof(mw::World), 16) / 4);
     d.scratch_bytes = (int32_t)align_up(sizeof(mw::Scratch) - (size_t)(mw::MAXM - M.max_manifolds) * sizeof(mw::Manifold), 16);
     d.env_lds_bytes = HOT_BYTES + d.scratch_bytes + (int32_t)align_up(IO_BYTES, 16);
+    // 8 resident wavefronts per CU (two per SIMD) need 4 envs x env_lds_bytes <= 20 KB; three walkers: 5 040 bytes per env
     h->epw = 4;
     if (const char *e = getenv("MADRL_MW_EPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->epw = v; }
     d.n_envs = n_envs;

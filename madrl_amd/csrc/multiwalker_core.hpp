@@ -26,9 +26,11 @@
 
 #if defined(__HIPCC__)
 #define MW_HD __host__ __device__ inline
+#define MW_HD_INLINE __host__ __device__ __attribute__((always_inline)) inline  // must be inlined into the kernel: its World / Scratch references are LDS there, an out-of-line copy would fall back to flat addressing
 #define MW_UNROLL _Pragma("unroll")
 #else
 #define MW_HD inline
+#define MW_HD_INLINE inline
 #define MW_UNROLL
 #endif
 
@@ -147,6 +149,7 @@ struct Model {
 };
 MW_HD int shape_of_body(int b) { return b == 0 ? SH_PACKAGE : (((b - 1) % 5 == 0) ? SH_HULL : (((b - 1) % 5) % 2 == 1 ? SH_UPPER : SH_LOWER)); }
 MW_HD int hull_of(int w) { return 1 + 5 * w; }
+MW_HD int node_of(int b, int n_walkers) { return b == 0 ? n_walkers : (b - 1) / 5; }  // island graph node: walker index, or W for the package
 
 // b2PolygonShape::Set (gift wrapping from the right-most, lowest vertex, CCW) + normals
 inline void poly_set(Shape &s, const V2 *pts, int count) {
@@ -207,7 +210,7 @@ inline void poly_mass(Shape &s, float density) {
 inline void build_model(Model &M, int n_walkers) {
     M.W = n_walkers; M.NB = 5 * n_walkers + 1; M.NJ = 4 * n_walkers;
     // observed maxima of simultaneously touching pairs over long random / collapsed rollouts: 18, 25, 34 for 2, 3, 4 walkers
-    M.max_manifolds = n_walkers <= 1 ? 16 : (n_walkers == 2 ? 24 : (n_walkers == 3 ? 32 : MAXM));
+    M.max_manifolds = n_walkers <= 1 ? 16 : (n_walkers == 2 ? 24 : (n_walkers == 3 ? 28 : MAXM));
     M.NT = (int)(TERRAIN_LENGTH * n_walkers * 1 / 8.0);          // :301
     M.package_scale = n_walkers / 1.75f;                          // :293
     M.package_length = PACKAGE_LENGTH / SCALE * M.package_scale;  // :294
@@ -268,22 +271,23 @@ struct Slot {       // persistent manifold cache of one candidate pair (b2Contac
     uint32_t pad_;
 };
 struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositionConstraint
-    int16_t bA, bB, slot;  // bA = -1: static terrain
-    uint8_t npts, type;    // type 0: faceA, 1: faceB
+    int8_t bA, bB;         // bA = -1: static terrain
+    int16_t slot;
+    uint8_t npts, type, block, pad_;  // type 0: faceA, 1: faceB; block: the 2-point block solver applies
     V2 local_normal, local_point, lp[2];  // b2Manifold (lp in the other body's frame)
     V2 normal, rA[2], rB[2];
     float friction, nm[2], tm[2], ni[2], ti[2];
     float k11, k12, k22, im11, im12, im22;  // block solver K and K^-1
-    uint32_t block;
 };
+static_assert(sizeof(Manifold) == 140, "LDS budget of the HIP kernel: 4 envs x (Hot + Scratch) x 8 wavefronts per CU");
 // The env state is split by how often a step touches it.
-//   Hot:  bodies, joints, flags -- read and written by every one of the 180 + 60 solver sweeps; the HIP kernel keeps
-//         it in LDS for the duration of the step.
-//   Cold: the manifold cache (warm-start impulses of the candidate pairs) and the terrain heights -- touched once per
-//         step by Collide, StoreImpulses and the lidar; the HIP kernel reads and writes it in place in HBM (L2).
+//   Hot:  bodies and flags -- read and written by every one of the 180 + 60 solver sweeps; the HIP kernel keeps it in
+//         LDS for the duration of the step.
+//   Cold: the joints' persistent state, the manifold cache (warm-start impulses of the candidate pairs) and the terrain
+//         heights -- touched once per step (joint init / write-back, Collide, StoreImpulses, lidar); the HIP kernel
+//         reads and writes it in place in HBM (L2).
 struct Hot {
     Body b[MAXB];
-    Joint j[MAXJ];
     float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
     float prev_shaping[MAX_WALKERS], prev_package_shaping;
     uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, pad_;
@@ -291,6 +295,8 @@ struct Hot {
     int32_t t;
 };
 struct Cold {
+    Joint j[MAXJ];                // warm-start impulses, motor targets, limit states: read at the start of a step into the
+                                  // owning lane's JointCache, written back at its end
     Slot slot[MAXSLOT];
     float ty[MAXT];               // terrain heights (x = i * TERRAIN_STEP)
 };
@@ -301,15 +307,14 @@ constexpr int MAXSLOT_TERRAIN = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG;
 struct Scratch {  // per-step workspace (LDS on the GPU)
     int nm;
     int8_t n_dyn, max_cnt, merge_ok, all_done;
-    // per-body constants gathered once per step (avoid shape lookups in the solver loops)
-    float bim[MAXB], bii[MAXB];
-    V2 blc[MAXB];
-    int8_t node[MAXB];  // island graph node of a body: walker index, or W for the package
+    // mass data of the four shapes (package, hull, upper leg, lower leg), copied once per step
+    float sh_im[N_SHAPES], sh_ii[N_SHAPES];
+    V2 sh_lc[N_SHAPES];
     // solver schedule: terrain manifolds per body (indexed like the body's slots) and the active dynamic pairs
     uint8_t bm_cnt[MAXB], bm_idx[MAXSLOT_TERRAIN];
     int8_t dyn_midx[NDYN];   // manifold of pair p, or -1
     int8_t dyn_list[NDYN];   // the active pairs, in pair order ...
-    int8_t dyn_owner[NDYN], dyn_man[NDYN];  // ... the body whose lane solves them (the pair's second body) and their manifolds
+    int8_t dyn_owner[NDYN], dyn_man[NDYN], dyn_a_shape[NDYN];  // ... the body whose lane solves them (the pair's second body), their manifolds, the shape of the first body
     int8_t comp[MAX_WALKERS + 1];
     uint8_t isl_done[MAX_WALKERS + 1], walker_ok[MAX_WALKERS];
     float body_minsep[MAXB], dyn_minsep[NDYN];
@@ -574,6 +579,7 @@ MW_HD void contact_event(const Model &M, Hot &Wd, int bA, int bB, bool begin) {
 struct SerialPar {
     static constexpr int JOINTS = MAXJ;   // joints a lane may own
     static constexpr int BODIES = MAXB;   // bodies a lane may own
+    static constexpr bool MCACHE = false; // no lane-private manifold copy: the one lane owns every manifold
     MW_HD int lane() const { return 0; }
     MW_HD int n() const { return 1; }
     MW_HD void sync() const {}
@@ -595,7 +601,7 @@ MW_HD int emit_manifold(const Model &M, Hot &Wd, Scratch &S, Par par, Slot &sl, 
     const int idx = par.alloc(&S.nm);
     if (idx >= max_manifolds) return -1;  // pool exhausted: the pair is ignored this step
     Manifold &m = S.m[idx];
-    m.bA = (int16_t)bA; m.bB = (int16_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)mo.type;
+    m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)mo.type;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
     for (int i = 0; i < mo.npts; ++i) { m.lp[i] = mo.lp[i]; m.ni[i] = ni[i]; m.ti[i] = ti[i]; }
     m.friction = friction;
@@ -663,8 +669,16 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par p
 }
 
 // ---------------------------------------------------------------- island solver (b2Island::Solve)
-#define inv_mass_of(M_, b_, im_, ii_) do { const int _b = (b_); if (_b < 0) { im_ = 0.0f; ii_ = 0.0f; } else { im_ = S.bim[_b]; ii_ = S.bii[_b]; } } while (0)
-#define local_center_of(M_, b_) ((b_) < 0 ? v2(0, 0) : S.blc[(b_)])
+// inverse mass, inverse inertia and local centre of the two bodies of a constraint; A = static terrain: zeros
+struct MassAB { float mA, iA, mB, iB; V2 lcA, lcB; };
+MW_HD MassAB mass_of_pair(const Scratch &S, int bA, int bB) {
+    MassAB q;
+    if (bA < 0) { q.mA = 0.0f; q.iA = 0.0f; q.lcA = v2(0, 0); }
+    else { const int sa = shape_of_body(bA); q.mA = S.sh_im[sa]; q.iA = S.sh_ii[sa]; q.lcA = S.sh_lc[sa]; }
+    const int sb = shape_of_body(bB);
+    q.mB = S.sh_im[sb]; q.iB = S.sh_ii[sb]; q.lcB = S.sh_lc[sb];
+    return q;
+}
 
 // k = [ex.x ex.y ex.z ey.x ey.y ey.z ez.x ez.y ez.z]; Cramer's rule as b2Mat33::Solve33, split into the part that only
 // depends on the matrix (constant over the sweeps of a step) and the part that depends on the right-hand side
@@ -695,18 +709,17 @@ MW_HD void solve22(const float *k, float det, float bx, float by, float &x, floa
 }
 
 // b2ContactSolver::InitializeVelocityConstraints + WarmStart for manifold k
-MW_HD void contact_init_warm(const Model &M, Hot &Wd, Scratch &S, int k) {
-    Manifold &m = S.m[k];
-    float mA, iA, mB, iB;
-    inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+MW_HD void contact_init_warm(Hot &Wd, Manifold &m, const MassAB &q) {
+    const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
-    Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = body_xf(M, Wd.b[m.bA], m.bA);
-    const Xf xfB = body_xf(M, Wd.b[m.bB], m.bB);
+    Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = xf_from(Wd.b[m.bA].c, Wd.b[m.bA].a, q.lcA);
+    const Xf xfB = xf_from(Wd.b[m.bB].c, Wd.b[m.bB].a, q.lcB);
     V2 normal, pts[2];  // b2WorldManifold::Initialize
     if (m.type == 0) {
         normal = mul(xfA.q, m.local_normal);
         const V2 plane = mul(xfA, m.local_point);
-        for (int i = 0; i < m.npts; ++i) {
+        MW_UNROLL
+        for (int i = 0; i < 2; ++i) if (i < m.npts) {
             const V2 clip = mul(xfB, m.lp[i]);
             const V2 a = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, bb = clip - POLY_RADIUS * normal;
             pts[i] = 0.5f * (a + bb);
@@ -714,7 +727,8 @@ MW_HD void contact_init_warm(const Model &M, Hot &Wd, Scratch &S, int k) {
     } else {
         normal = mul(xfB.q, m.local_normal);
         const V2 plane = mul(xfB, m.local_point);
-        for (int i = 0; i < m.npts; ++i) {
+        MW_UNROLL
+        for (int i = 0; i < 2; ++i) if (i < m.npts) {
             const V2 clip = mul(xfA, m.lp[i]);
             const V2 bb = clip + (POLY_RADIUS - dot(clip - plane, normal)) * normal, a = clip - POLY_RADIUS * normal;
             pts[i] = 0.5f * (a + bb);
@@ -723,7 +737,8 @@ MW_HD void contact_init_warm(const Model &M, Hot &Wd, Scratch &S, int k) {
     }
     m.normal = normal;
     const V2 tangent = cross(normal, 1.0f);
-    for (int i = 0; i < m.npts; ++i) {
+    MW_UNROLL
+        for (int i = 0; i < 2; ++i) if (i < m.npts) {
         m.rA[i] = pts[i] - cA; m.rB[i] = pts[i] - cB;
         const float rnA = cross(m.rA[i], normal), rnB = cross(m.rB[i], normal);
         const float kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
@@ -749,7 +764,8 @@ MW_HD void contact_init_warm(const Model &M, Hot &Wd, Scratch &S, int k) {
     }
     V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
     float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
-    for (int i = 0; i < m.npts; ++i) {  // warm start
+    MW_UNROLL
+        for (int i = 0; i < 2; ++i) if (i < m.npts) {  // warm start
         const V2 P = m.ni[i] * normal + m.ti[i] * tangent;
         wA -= iA * cross(m.rA[i], P); vA = vA - mA * P;
         wB += iB * cross(m.rB[i], P); vB = vB + mB * P;
@@ -774,15 +790,15 @@ struct JointCache {
 };
 
 // b2RevoluteJoint::InitVelocityConstraints (+ warm start)
-MW_HD void joint_init_warm(const Model &M, Hot &Wd, Scratch &S, int ji, float h, JointCache &c) {
+MW_HD void joint_init_warm(const Model &M, Hot &Wd, const Cold &Cd, Scratch &S, int ji, float h, JointCache &c) {
     const JointDef &jd = M.jd[ji];
-    const Joint &j = Wd.j[ji];
+    const Joint &j = Cd.j[ji];
     c.bA = jd.bA; c.bB = jd.bB;
     Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
-    float mA, iA, mB, iB;
-    inv_mass_of(M, jd.bA, mA, iA); inv_mass_of(M, jd.bB, mB, iB);
+    const MassAB q = mass_of_pair(S, jd.bA, jd.bB);
+    const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     c.mA = mA; c.iA = iA; c.mB = mB; c.iB = iB;
-    c.lA = jd.lA - local_center_of(M, jd.bA); c.lB = jd.lB - local_center_of(M, jd.bB);
+    c.lA = jd.lA - q.lcA; c.lB = jd.lB - q.lcB;
     c.lower = jd.lower; c.upper = jd.upper;
     const V2 rA = mul(rot(A.a), c.lA), rB = mul(rot(B.a), c.lB);
     c.rA = rA; c.rB = rB;
@@ -861,14 +877,13 @@ MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
 }
 
 // b2ContactSolver::SolveVelocityConstraints for manifold k
-MW_HD void contact_solve_velocity(const Model &M, Hot &Wd, Scratch &S, int k) {
-    Manifold &m = S.m[k];
-    float mA, iA, mB, iB;
-    inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+MW_HD void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
+    const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
     float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
     const V2 normal = m.normal, tangent = cross(normal, 1.0f);
-    for (int i = 0; i < m.npts; ++i) {  // friction first
+    MW_UNROLL
+    for (int i = 0; i < 2; ++i) if (i < m.npts) {  // friction first
         const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
         const float vt = dot(dv, tangent);
         float lambda = m.tm[i] * (-vt);
@@ -881,7 +896,8 @@ MW_HD void contact_solve_velocity(const Model &M, Hot &Wd, Scratch &S, int k) {
         vB = vB + mB * P; wB += iB * cross(m.rB[i], P);
     }
     if (m.npts == 1 || !m.block) {
-        for (int i = 0; i < m.npts; ++i) {
+        MW_UNROLL
+    for (int i = 0; i < 2; ++i) if (i < m.npts) {
             const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
             const float vn = dot(dv, normal);
             float lambda = -m.nm[i] * (vn - 0.0f);  // restitution 0 -> velocityBias 0
@@ -918,15 +934,14 @@ MW_HD void contact_solve_velocity(const Model &M, Hot &Wd, Scratch &S, int k) {
 }
 
 // b2ContactSolver::SolvePositionConstraints for manifold k; returns its minimum separation
-MW_HD float contact_solve_position(const Model &M, Hot &Wd, Scratch &S, int k) {
-    const Manifold &m = S.m[k];
+MW_HD float contact_solve_position(Hot &Wd, const Manifold &m, const MassAB &q) {
     float min_sep = 0.0f;
-    float mA, iA, mB, iB;
-    inv_mass_of(M, m.bA, mA, iA); inv_mass_of(M, m.bB, mB, iB);
+    const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
     float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a, aB = Wd.b[m.bB].a;
-    const V2 lcA = local_center_of(M, m.bA), lcB = local_center_of(M, m.bB);
-    for (int i = 0; i < m.npts; ++i) {
+    const V2 lcA = q.lcA, lcB = q.lcB;
+    MW_UNROLL
+    for (int i = 0; i < 2; ++i) if (i < m.npts) {
         const Xf xfA = xf_from(cA, aA, lcA), xfB = xf_from(cB, aB, lcB);
         V2 normal, point; float sep;
         if (m.type == 0) {
@@ -1001,23 +1016,27 @@ MW_HD bool joint_solve_position(Hot &Wd, const JointCache &c) {
 //            owns the pair's second body -- leg-terrain and package-hull constraints share no body.  Otherwise the
 //            dynamic pairs follow in sub-slots of their own, exactly the serial order.
 template <class Par>
-MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     const float h = 1.0f / FPS;
     const int L0 = par.lane(), LN = par.n();
     // the model scalars are read once: the solver loops below must not go back to memory for them
     const int NB = M.NB, NW = M.W, NDP = M.n_dyn_pairs, MAXMAN = M.max_manifolds;
     const int NODES = NW + 1;  // island graph nodes: walkers, then the package
-    int own_sb[Par::BODIES];   // manifold-list base of the bodies this lane owns (bi = L0 + kb * LN)
+    // lane-private constants of the bodies this lane owns (bi = L0 + kb * LN): manifold-list base, mass data, island node
+    int own_sb[Par::BODIES], own_node[Par::BODIES];
+    MassAB own_q[Par::BODIES];   // as body B of a terrain contact (A = terrain: zeros)
     MW_UNROLL
     for (int kb = 0; kb < Par::BODIES; ++kb) {
         const int bi = L0 + kb * LN;
-        own_sb[kb] = 0;
+        own_sb[kb] = 0; own_node[kb] = 0;
+        own_q[kb].mA = 0.0f; own_q[kb].iA = 0.0f; own_q[kb].lcA = v2(0, 0); own_q[kb].mB = 0.0f; own_q[kb].iB = 0.0f; own_q[kb].lcB = v2(0, 0);
         if (bi >= NB) continue;
         const Shape &sh = M.shape[shape_of_body(bi)];
-        S.bim[bi] = sh.inv_mass; S.bii[bi] = sh.inv_I; S.blc[bi] = sh.centroid;
-        S.node[bi] = (int8_t)(bi == 0 ? NW : (bi - 1) / 5);
+        own_q[kb].mB = sh.inv_mass; own_q[kb].iB = sh.inv_I; own_q[kb].lcB = sh.centroid;
+        own_node[kb] = node_of(bi, NW);
         own_sb[kb] = M.slot_base[bi];
     }
+    for (int sh = L0; sh < N_SHAPES; sh += LN) { S.sh_im[sh] = M.shape[sh].inv_mass; S.sh_ii[sh] = M.shape[sh].inv_I; S.sh_lc[sh] = M.shape[sh].centroid; }
     if (L0 == 0) S.nm = 0;
     par.sync();
     // ---- Collide: terrain candidates by body, then the dynamic pairs
@@ -1030,9 +1049,9 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
         int nd = 0;
         for (int p = 0; p < NDP; ++p) {
             if (S.dyn_midx[p] < 0) continue;
-            S.dyn_owner[nd] = (int8_t)M.dyn_b[p]; S.dyn_man[nd] = S.dyn_midx[p];
+            S.dyn_owner[nd] = (int8_t)M.dyn_b[p]; S.dyn_man[nd] = S.dyn_midx[p]; S.dyn_a_shape[nd] = (int8_t)shape_of_body(M.dyn_a[p]);
             S.dyn_list[nd++] = (int8_t)p;
-            const int ca = S.comp[S.node[M.dyn_a[p]]], cb = S.comp[S.node[M.dyn_b[p]]];
+            const int ca = S.comp[node_of(M.dyn_a[p], NW)], cb = S.comp[node_of(M.dyn_b[p], NW)];
             if (ca != cb) for (int i = 0; i < NODES; ++i) if (S.comp[i] == cb) S.comp[i] = (int8_t)ca;
         }
         S.n_dyn = (int8_t)nd;
@@ -1045,11 +1064,14 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
         S.max_cnt = (int8_t)mc; S.merge_ok = merge ? 1 : 0;
     }
     // ---- integrate velocities (gravity + the pending initial push)
-    for (int bi = L0; bi < NB; bi += LN) {
+    MW_UNROLL
+    for (int kb = 0; kb < Par::BODIES; ++kb) {
+        const int bi = L0 + kb * LN;
+        if (bi >= NB) continue;
         Body &b = Wd.b[bi];
         float fx = 0.0f;
         if (bi >= 1 && (bi - 1) % 5 == 0) { const int w = (bi - 1) / 5; fx = Wd.push_x[w]; }
-        const float im = S.bim[bi];
+        const float im = own_q[kb].mB;
         if (im == 0.0f) continue;  // static body (b2Island::Solve integrates dynamic bodies only); the env has none
         b.v.x += h * (im * fx);
         b.v.y += h * (GRAVITY_Y + im * 0.0f);
@@ -1062,7 +1084,14 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     const int nsubB = S.merge_ok ? 0 : n_dyn;
     const bool merge_ok = S.merge_ok != 0;
     MW_STAT(steps, 1); MW_STAT(sub_a, nsubA); MW_STAT(sub_b, nsubB); MW_STAT(manifolds, S.nm); MW_STAT(merged, merge_ok ? 1 : 0);
-    // one contact sweep; F_TERRAIN / F_DYN see the body `bi` and the manifold index `k_` (F_DYN also the pair `p_`)
+    // One contact sweep.  F_TERRAIN / F_DYN are statements over the manifold `m_`, the body `bi` (F_DYN also the pair `p_`).
+    // MC: on the GPU every lane keeps ONE manifold of its first body in registers for the whole step -- its first terrain
+    // manifold, or (a hull, while merge_ok) its package / hull pair -- so the common sub-slot needs no LDS look-ups.
+    Manifold MC;
+    int mc_idx = -1;
+#define MW_MANIFOLD_DO(K_, F_) { const int k_ = (K_); if (Par::MCACHE && k_ == mc_idx) { Manifold &m_ = MC; F_; } else { Manifold &m_ = S.m[k_]; F_; } }
+    /* a dynamic pair: B = this lane's body, A = the package (pair package-hull) or another hull */                            \
+#define MW_DYN_MASS MassAB q_ = own_q[kb]; { const int sa_ = S.dyn_a_shape[i]; q_.mA = S.sh_im[sa_]; q_.iA = S.sh_ii[sa_]; q_.lcA = S.sh_lc[sa_]; }
 #define MW_CONTACT_SWEEP(F_TERRAIN, F_DYN)                                                                   \
     for (int i = 0; i < nsubA; ++i) {                                                                        \
         const int dyn_own_ = (merge_ok && i < n_dyn) ? S.dyn_owner[i] : -1;                                  \
@@ -1070,8 +1099,8 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
         for (int kb = 0; kb < Par::BODIES; ++kb) {                                                           \
             const int bi = L0 + kb * LN;                                                                     \
             if (bi >= NB) continue;                                                                          \
-            if (i < S.bm_cnt[bi]) { const int k_ = S.bm_idx[own_sb[kb] + i]; F_TERRAIN; }                    \
-            if (dyn_own_ == bi) { const int k_ = S.dyn_man[i]; const int p_ = S.dyn_list[i]; (void)p_; F_DYN; } \
+            if (i < S.bm_cnt[bi]) { const MassAB &q_ = own_q[kb]; MW_MANIFOLD_DO(S.bm_idx[own_sb[kb] + i], F_TERRAIN) } \
+            if (dyn_own_ == bi) { const int p_ = S.dyn_list[i]; (void)p_; MW_DYN_MASS MW_MANIFOLD_DO(S.dyn_man[i], F_DYN) } \
         }                                                                                                    \
         par.sync();                                                                                          \
     }                                                                                                        \
@@ -1080,12 +1109,17 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
         MW_UNROLL                                                                                            \
         for (int kb = 0; kb < Par::BODIES; ++kb) {                                                           \
             const int bi = L0 + kb * LN;                                                                     \
-            if (bi < NB && dyn_own_ == bi) { const int k_ = S.dyn_man[i]; const int p_ = S.dyn_list[i]; (void)p_; F_DYN; } \
+            if (bi < NB && dyn_own_ == bi) { const int p_ = S.dyn_list[i]; (void)p_; MW_DYN_MASS MW_MANIFOLD_DO(S.dyn_man[i], F_DYN) } \
         }                                                                                                    \
         par.sync();                                                                                          \
     }
     // ---- contact constraints: init + warm start
-    MW_CONTACT_SWEEP(contact_init_warm(M, Wd, S, k_), contact_init_warm(M, Wd, S, k_))
+    MW_CONTACT_SWEEP(contact_init_warm(Wd, m_, q_), contact_init_warm(Wd, m_, q_))
+    if (Par::MCACHE && L0 < NB) {
+        if (S.bm_cnt[L0] > 0) mc_idx = S.bm_idx[own_sb[0]];
+        else if (merge_ok) { for (int i = 0; i < n_dyn; ++i) if (S.dyn_owner[i] == L0) { mc_idx = S.dyn_man[i]; break; } }
+        if (mc_idx >= 0) MC = S.m[mc_idx];
+    }
     // ---- joints: init + warm start, in the three-slot order
     JointCache JC[Par::JOINTS];
     int jslot[Par::JOINTS];
@@ -1094,7 +1128,7 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     for (int t = 0; t < 3; ++t) {
         MW_UNROLL
         for (int kq = 0; kq < Par::JOINTS; ++kq)
-            if (jslot[kq] == t) joint_init_warm(M, Wd, S, L0 + kq * LN, h, JC[kq]);
+            if (jslot[kq] == t) joint_init_warm(M, Wd, Cd, S, L0 + kq * LN, h, JC[kq]);
         par.sync();
     }
     // ---- velocity iterations (islands are disjoint, so iterating them together changes nothing)
@@ -1105,13 +1139,14 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
                 if (jslot[kq] == t) joint_solve_velocity(Wd, JC[kq]);
             par.sync();
         }
-        MW_CONTACT_SWEEP(contact_solve_velocity(M, Wd, S, k_), contact_solve_velocity(M, Wd, S, k_))
+        MW_CONTACT_SWEEP(contact_solve_velocity(Wd, m_, q_), contact_solve_velocity(Wd, m_, q_))
     }
+    if (Par::MCACHE && mc_idx >= 0) { S.m[mc_idx].ni[0] = MC.ni[0]; S.m[mc_idx].ni[1] = MC.ni[1]; S.m[mc_idx].ti[0] = MC.ti[0]; S.m[mc_idx].ti[1] = MC.ti[1]; }
     // the accumulated joint impulses and limit states go back to the world (warm start of the next step)
     MW_UNROLL
     for (int kq = 0; kq < Par::JOINTS; ++kq) {
         if (jslot[kq] < 0) continue;
-        Joint &j = Wd.j[L0 + kq * LN];
+        Joint &j = Cd.j[L0 + kq * LN];
         j.ix = JC[kq].ix; j.iy = JC[kq].iy; j.iz = JC[kq].iz; j.motor_impulse = JC[kq].motor_impulse; j.limit_state = JC[kq].limit_state;
     }
     // ---- integrate positions
@@ -1132,8 +1167,8 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
         for (int p = L0; p < NDYN; p += LN) S.dyn_minsep[p] = 0.0f;
         par.sync();
         MW_CONTACT_SWEEP(
-            if (!S.isl_done[S.comp[S.node[bi]]]) S.body_minsep[bi] = fminf(S.body_minsep[bi], contact_solve_position(M, Wd, S, k_)),
-            if (!S.isl_done[S.comp[S.node[bi]]]) S.dyn_minsep[p_] = contact_solve_position(M, Wd, S, k_))
+            if (!S.isl_done[S.comp[own_node[kb]]]) S.body_minsep[bi] = fminf(S.body_minsep[bi], contact_solve_position(Wd, m_, q_)),
+            if (!S.isl_done[S.comp[own_node[kb]]]) S.dyn_minsep[p_] = contact_solve_position(Wd, m_, q_))
         for (int w = L0; w < NW; w += LN) S.walker_ok[w] = 1;
         par.sync();
         for (int t = 0; t < 3; ++t) {
@@ -1154,8 +1189,8 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
                 if (!any || S.isl_done[c]) continue;
                 float ms = 0.0f;
                 bool jok = true;
-                for (int bi = 0; bi < NB; ++bi) if (S.comp[S.node[bi]] == c) ms = fminf(ms, S.body_minsep[bi]);
-                for (int i = 0; i < n_dyn; ++i) if (S.comp[S.node[S.dyn_owner[i]]] == c) ms = fminf(ms, S.dyn_minsep[S.dyn_list[i]]);
+                for (int bi = 0; bi < NB; ++bi) if (S.comp[node_of(bi, NW)] == c) ms = fminf(ms, S.body_minsep[bi]);
+                for (int i = 0; i < n_dyn; ++i) if (S.comp[node_of(S.dyn_owner[i], NW)] == c) ms = fminf(ms, S.dyn_minsep[S.dyn_list[i]]);
                 for (int w = 0; w < NW; ++w) if (S.comp[w] == c) jok = jok && S.walker_ok[w];
                 if (ms >= -3.0f * LINEAR_SLOP && jok) S.isl_done[c] = 1;
                 else all_done = false;
@@ -1176,8 +1211,8 @@ MW_HD void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     par.sync();
 }
 #undef MW_CONTACT_SWEEP
-#undef inv_mass_of
-#undef local_center_of
+#undef MW_MANIFOLD_DO
+#undef MW_DYN_MASS
 
 // ---------------------------------------------------------------- lidar: b2EdgeShape::RayCast over the terrain
 MW_HD float lidar_fraction(const Model &M, const Cold &Cd, V2 p1, V2 p2) {
@@ -1283,7 +1318,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, u
             up.c = v2(init_x, init_y - LEG_H / 2 - LEG_DOWN) + mul(rot(up.a), M.shape[SH_UPPER].centroid);
             lo.a = sgn * 0.05f; lo.v = v2(0, 0); lo.w = 0.0f;
             lo.c = v2(init_x, init_y - LEG_H * 3 / 2 - LEG_DOWN) + mul(rot(lo.a), M.shape[SH_LOWER].centroid);
-            Joint &hip = Wd.j[4 * w + 2 * side], &knee = Wd.j[4 * w + 2 * side + 1];
+            Joint &hip = Cd.j[4 * w + 2 * side], &knee = Cd.j[4 * w + 2 * side + 1];
             hip.ix = hip.iy = hip.iz = hip.motor_impulse = 0.0f; hip.limit_state = 0;
             hip.motor_speed = sgn; hip.max_torque = MOTORS_TORQUE;
             knee.ix = knee.iy = knee.iz = knee.motor_impulse = 0.0f; knee.limit_state = 0;
@@ -1295,12 +1330,12 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, u
 
 // MultiWalkerEnv.step (:359-428).  obs: [W][32], rew: [W]
 template <class Par>
-MW_HD void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
+MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
                     float *rew, uint8_t *done) {
     for (int w = par.lane(); w < M.W; w += par.n()) {  // apply_action (:194-203)
         for (int k = 0; k < 4; ++k) {
             const float a = actions[4 * w + k];
-            Joint &j = Wd.j[4 * w + k];
+            Joint &j = Cd.j[4 * w + k];
             const float sp = (k % 2 == 0) ? SPEED_HIP : SPEED_KNEE;
             j.motor_speed = sp * (a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f));
             j.max_torque = MOTORS_TORQUE * clampf(fabsf(a), 0.0f, 1.0f);
