@@ -161,8 +161,16 @@ def bench_other(args, rank, local_rank, world, dev):
         acts = [(torch.rand((N, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)]
         outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done)]
         step = lambda i: _lib.check(L.madrl_multiwalker_step(env._handle, _lib.ptr(acts[i % 8]), *outs, _lib.current_stream(dev)))
+        # algorithmic HBM bytes per env-step: actions in, observation / reward / done rows out, the hot record (bodies, flags)
+        # read and written once, the cold record (joints, manifold cache, terrain) touched in place: counted as read + written once
         bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * env.world_bytes
-        kernel, binding = "multiwalker_kernel<1>", "dependent FP32 VALU latency of the serial Gauss-Seidel sweeps in one lane, not HBM"
+        kernel = "multiwalker_kernel<1, 4>"
+        # this path is not HBM-bound -- about 1 MFLOP of dependent FP32 work per env-step (180 velocity + up to 60
+        # position Gauss-Seidel sweeps over 12 joints and the active manifolds) against ~14 KB; the binding resource is VALU
+        # instruction issue of wavefronts in which 12-16 of 64 lanes carry constraints (four envs per wavefront)
+        binding = ("FP32 VALU instruction issue / dependent-op latency of the Gauss-Seidel sweeps (not HBM): ~29 k VALU + 9 k SALU + 4 k LDS "
+                   "wave-instructions per env-step (profiles/r02_multiwalker/pmc_mix.txt)")
+        flop_per_env_step = 1.0e6
         workload = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, parity unpinned)" % N
         K, W = min(K, 20), min(W, 3)
 
@@ -213,6 +221,9 @@ def bench_other(args, rank, local_rank, world, dev):
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform random actions resident in HBM, in-kernel Philox, fused auto-reset)",
                "config": {"workload": workload, "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                            **({"valu_flops_achieved_TFLOPs": flop_per_env_step * N / (kernel_ms * 1e-3) / 1e12, "valu_peak_TFLOPs": 157.3,
+                                "valu_frac": flop_per_env_step * N / (kernel_ms * 1e-3) / 157.3e12,
+                                "flop_per_env_step_estimate": flop_per_env_step} if args.workload == "multiwalker" else {}),
                             "traffic": (measured_traffic(N, args.workload) or (None, None))[0],
                             "traffic_source": (measured_traffic(N, args.workload) or (None, None))[1], "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per,
                             "binding_resource": binding}}

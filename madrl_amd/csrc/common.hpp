@@ -71,4 +71,31 @@ __host__ __device__ inline double u53(uint32_t hi, uint32_t lo) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// XCD-aware walk of the env range by a grid of persistent one-wavefront workgroups.  Workgroups are dealt round-robin to
+// the 8 XCDs (block b runs on XCD b % 8, each with its own L2), so the plain walk env = b + k * gridDim hands NEIGHBOURING
+// envs to DIFFERENT L2s: every cache line shared by two envs' rows / records / reward words is then written back partially
+// by two or more L2s.  Here XCD x owns the contiguous eighth [x * per, (x + 1) * per) of the envs and its workgroups stride
+// through that chunk, so lines shared by neighbours merge in one L2.  (Measured on the hostage world: 4 107 -> 2 3xx bytes
+// written per env-step; speed-only -- env results do not depend on the order in which they are processed.)
+struct EnvWalk {
+    int64_t base, first, stride, lim;  // env = base + li for li = first, first + stride, ... < lim
+};
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ EnvWalk env_walk(int64_t n_envs) {
+    EnvWalk w;
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    if ((G & 7) == 0 && n_envs >= 8 * 8) {
+        const int64_t per = (n_envs + 7) / 8;
+        w.base = (b & 7) * per;
+        w.first = b >> 3;
+        w.stride = G >> 3;
+        w.lim = (w.base + per <= n_envs ? per : n_envs - w.base);
+        if (w.lim < 0) w.lim = 0;
+    } else {
+        w.base = 0; w.first = b; w.stride = G; w.lim = n_envs;
+    }
+    return w;
+}
+#endif
+
 }  // namespace madrl

@@ -19,6 +19,17 @@
 #include <string.h>
 #include <vector>
 
+// Profiling aid (scripts/variants.sh builds one library per value, never the shipped one):
+//   1 no observation store   2 non-temporal observation store   4 no record store   8 no reward / done / info stores
+#ifndef MADRL_HW_ABLATE
+#define MADRL_HW_ABLATE 0
+#endif
+#ifndef MADRL_HW_WAVES
+#define MADRL_HW_WAVES 4   // resident wavefronts per SIMD the register allocation aims at: at 5 (96 VGPRs) the kernel spills 60 B per lane to
+                           // scratch, and those spill stores reach HBM (evicted by the streaming rows): 4 013 instead of 2 229 bytes
+                           // written per env-step at the same 61 us (scripts/variant_traffic.sh)
+#endif
+
 namespace {
 
 using namespace madrl;
@@ -64,7 +75,7 @@ __device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 // TNr..TK > 0: the particle / sensor counts are compile-time constants (small loops unroll, the index divisions fold); 0: generic.
 template <int MODE, int TNr, int TNh, int TNc, int TK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void hostage_kernel(const HwDev d, const HwIO io) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAVES, MADRL_HW_WAVES))) void hostage_kernel(const HwDev d, const HwIO io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int Nr = TNr > 0 ? TNr : d.Nr, Nh = TNr > 0 ? TNh : d.Nh, Nc = TNr > 0 ? TNc : d.Nc, K = TNr > 0 ? TK : d.K;
@@ -96,15 +107,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         if constexpr (MODE == 1) a = (lane < 2 * Nr) ? io.actions[env * 2 * Nr + lane] : 0.0f;
         else a = 0.0f;
     };
-    if ((int64_t)blockIdx.x < d.n_envs) fetch(blockIdx.x, cur, cur_act);
+    const EnvWalk walk = env_walk(d.n_envs);  // XCD-aware: neighbouring envs share an L2 (common.hpp)
+    if (walk.first < walk.lim) fetch(walk.base + walk.first, cur, cur_act);
     asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur_act));
     wave_sync();
 
-    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
-        const int64_t nenv = env + gridDim.x;
+    for (int64_t li = walk.first; li < walk.lim; li += walk.stride) {
+        const int64_t env = walk.base + li;
+        const int64_t nenv = env + walk.stride;
         uint32_t nxt[4] = {0, 0, 0, 0};
         float nxt_act = 0.0f;
-        if (nenv < d.n_envs) fetch(nenv, nxt, nxt_act);
+        if (li + walk.stride < walk.lim) fetch(nenv, nxt, nxt_act);
         bool skip = false;
         if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
         if (!skip) {
@@ -396,6 +409,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
                 if (pass == 0) asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_act));  // pipeline hinge
                 // ---------------------------------------------------- outputs
+#if MADRL_HW_ABLATE & 8
+                if (d.n_envs < 0)
+#endif
                 if (MODE == 1 && !do_init) {
                     if (lane < Nr) io.rew[env * Nr + lane] = reward;
                     if (lane == 0) {
@@ -410,7 +426,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 }
                 if (pass == npass - 1) {
                     float *orow = io.obs + env * (int64_t)(Nr * D);
+#if MADRL_HW_ABLATE & 1
+                    if (d.n_envs < 0)
+#endif
+#if MADRL_HW_ABLATE & 2
+                    for (int e = lane; e < Nr * D; e += 64) __builtin_nontemporal_store(O[e], &orow[e]);
+#else
                     for (int e = lane; e < Nr * D; e += 64) orow[e] = O[e];
+#endif
                 }
                 wave_sync();
             }
@@ -424,6 +447,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             wave_sync();
             {
                 uint32_t *dst = reinterpret_cast<uint32_t *>(d.state) + env * (int64_t)rec_dw;
+#if MADRL_HW_ABLATE & 4
+                if (d.n_envs < 0)
+#endif
                 for (int k = lane; k < rec_dw; k += 64) dst[k] = SU[k];
             }
             wave_sync();

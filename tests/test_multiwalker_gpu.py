@@ -37,8 +37,8 @@ def test_hip_matches_cpu_build_step_by_step(n_walkers, reward_mech):
     oobs = orc.reset()
     assert np.abs(obs.cpu().numpy() - oobs).max() <= TOL, "reset obs"
     rng = np.random.RandomState(3)
-    worst = 0.0
-    flips = 0
+    worst = worst_bodies = 0.0
+    inexact = 0
     for t in range(T):
         # teacher forcing: both sides start the step from the CPU build's world bytes
         w = np.zeros((N, env.world_bytes), np.uint8)
@@ -52,14 +52,17 @@ def test_hip_matches_cpu_build_step_by_step(n_walkers, reward_mech):
         e_obs = np.abs(obs.cpu().numpy() - oobs).reshape(N, -1).max(1)
         e_bod = np.abs(b.cpu().numpy() - ob).reshape(N, -1).max(1)
         e_rew = np.abs(rew.cpu().numpy() - orew).reshape(N, -1).max(1)
-        bad = (e_obs > TOL) | (e_bod > 1e-4) | (e_rew > 1e-3) | (done.cpu().numpy() != odone.astype(bool)) | \
-              (f.cpu().numpy() != of).any(1)
-        flips += int(bad.sum())      # a contact / limit threshold decided differently by an ulp: must be rare
-        worst = max(worst, float(e_obs[~bad].max()) if (~bad).any() else 0.0)
+        # no absorbed disagreements: every flag, every done bit and every value of every env-step is checked
+        assert np.array_equal(done.cpu().numpy(), odone.astype(bool)), "step %d: done flags differ" % t
+        assert np.array_equal(f.cpu().numpy(), of), "step %d: contact flags (game_over / fallen / ground_contact) differ" % t
+        worst, worst_bodies = max(worst, float(e_obs.max())), max(worst_bodies, float(e_bod.max()))
+        assert e_obs.max() <= TOL and e_bod.max() <= TOL and e_rew.max() <= 1e-4, "step %d: obs %.3g bodies %.3g rewards %.3g" % (
+            t, e_obs.max(), e_bod.max(), e_rew.max())
+        inexact += int(((e_obs > 0) | (e_bod > 0)).sum())   # env-steps that are not bit-identical (reported, not tolerated above TOL)
         if odone.any():
             orc.reset(mask=odone)
-    assert flips <= max(2, N * T // 500), "%d env-steps of %d disagree" % (flips, N * T)
-    assert worst <= TOL
+    print("multiwalker GPU vs CPU build, W=%d: %d of %d env-steps not bit-identical, worst obs %.3g bodies %.3g" % (
+        n_walkers, inexact, N * T, worst, worst_bodies))
 
 
 def test_full_batch_invariants_c4():
