@@ -100,7 +100,7 @@ int madrl_pursuit_set_kernel(madrl_pursuit *h, int32_t kind);
 int madrl_pursuit_kernel_kind(const madrl_pursuit *h, int32_t *out_kind);
 
 /* Launch shape: threads per workgroup (GENERIC kernel only; multiple of 64, 0 = heuristic)
- * and the maximum number of workgroups (0 = default: one per env for GENERIC, 4096 persistent
+ * and the maximum number of workgroups (0 = default: one per env for GENERIC, 5120 persistent
  * workgroups for WAVE); workgroups stride over envs. */
 int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_blocks);
 

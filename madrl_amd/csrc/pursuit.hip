@@ -555,6 +555,8 @@ struct madrl_pursuit {
     // one-wavefront-per-env fast path (pursuit_wave.hpp), when a specialisation matches
     const WaveEntry *wave;
     madrl::pw::WaveDev wdev;
+    void *zmask = nullptr;          // stale-zero masks of the fast path, [n_envs][64] dwords (pursuit_wave.hpp)
+    const void *zmask_obs = nullptr; // the observation buffer the masks describe; another buffer (or a generic-kernel launch) resets them
     uint64_t step_count = 0;  // step launches so far (parity of the walk direction, see launch())
     int walk_mode = 0;        // 0 auto (alternate above ~375 MB per launch), 1 always alternate, 2 always forward; fixed at create
     void *wtables;
@@ -569,6 +571,7 @@ struct WaveGeom {
     int GW, PAD, GSZ, D, X_ID, X_SKIP;
     int rec_bytes, off_gone, off_term;
     int waves;  // wavefronts per env: 1 = pursuit_wave_kernel, > 1 = pursuit_group_kernel
+    int occ;    // resident wavefronts per SIMD the kernel's registers are allocated for
 };
 }  // namespace
 
@@ -600,12 +603,12 @@ void group_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t 
 }
 
 template <class S>
-constexpr WaveGeom wave_geom(int waves = 1) {
+constexpr WaveGeom wave_geom(int waves = 1, int occ = 4) {
     return WaveGeom{S::XS, S::YS, S::P, S::E, S::R, S::FLATTEN, S::GW, S::PAD, S::GSZ, S::D, S::X_ID, S::X_SKIP,
-                    S::REC_BYTES, S::OFF_GONE, S::OFF_TERM, waves};
+                    S::REC_BYTES, S::OFF_GONE, S::OFF_TERM, waves, occ};
 }
 
-#define X(XS, YS, NP, NE, R, FL) {wave_geom<pw::Shape<XS, YS, NP, NE, R, FL>>(), wave_launch<pw::Shape<XS, YS, NP, NE, R, FL>>},
+#define X(XS, YS, NP, NE, R, FL) {wave_geom<pw::Shape<XS, YS, NP, NE, R, FL>>(1, pw::Shape<XS, YS, NP, NE, R, FL>::OCC), wave_launch<pw::Shape<XS, YS, NP, NE, R, FL>>},
 #define XG(XS, YS, NP, NE, R, FL, NW)
 const WaveEntry WAVE_TABLE[] = {
 #include "pursuit_specializations.def"
@@ -628,7 +631,6 @@ const WaveEntry *find_wave(const madrl_pursuit_config *c) {
     return nullptr;
 }
 
-constexpr int64_t WAVE_DEFAULT_BLOCKS = 256 * 16;  // persistent workgroups: 16 waves per CU (4 per SIMD at ~98 VGPRs)
 
 int validate(const madrl_pursuit_config *c) {
     if (!c) return fail(MADRL_EINVAL, "config is NULL");
@@ -722,7 +724,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         pw::WaveIO w;
         w.mask = io.mask; w.inj_pos = io.inj_pos; w.inj_map = io.inj_map; w.actions = io.actions;
         w.inj_eact = io.inj_eact; w.obs = io.obs; w.rew = io.rew; w.done = io.done; w.removed = io.removed;
-        int64_t blocks = h->max_blocks > 0 ? h->max_blocks : WAVE_DEFAULT_BLOCKS / h->wave->g.waves;
+        int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 4 * h->wave->g.occ / h->wave->g.waves;  // exactly the resident capacity
         if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
         // Large batches: successive step launches walk the env range in opposite directions, so the rows written last by
         // one step are the first ones touched by the next while they are still in the 256 MB memory-side cache.  Measured
@@ -730,6 +732,10 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         // (98 304: 4.7e8, 131 072: 4.5e8); alternating holds 6.4-6.7e8 from 81 920 to 131 072 but costs 6 % below.  Hence
         // the switch at ~375 MB of rows + records per launch.  Env results do not depend on the processing order.
         pw::WaveDev wd = h->wdev;
+        if (h->zmask_obs != (const void *)io.obs) {  // unknown buffer contents: every cell "not known to be zero"
+            MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0xFF, (size_t)h->dev.n_envs * 256, s));
+            h->zmask_obs = io.obs;
+        }
         if (mode == 1) {
             bool alternate = (double)h->dev.n_envs * (4.0 * h->dev.P * h->dev.D + 2.0 * h->dev.rec_bytes) > 375e6;
             if (h->walk_mode != 0) alternate = h->walk_mode == 1;
@@ -739,6 +745,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         MADRL_HIP_TRY(hipGetLastError());
         return MADRL_OK;
     }
+    h->zmask_obs = nullptr;  // the generic kernel does not maintain the fast path's stale-zero masks
     switch (h->nt) {
         case 1: launch_nt<1>(h, io, mode, s); break;
         case 2: launch_nt<2>(h, io, mode, s); break;
@@ -908,7 +915,12 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         }
         uint32_t *wc = wh.data() + w_codes;
         const int R = d.R;
-        bool eligible = (wall_bits != 0u) && (fill_bits != 0u) && g.rec_bytes == d.rec_bytes &&
+        // the fast path tells 0.0f, observation values and its "outside the map" marker apart by the top byte of the value:
+        // every non-zero observation value must be a positive float >= 2^-63 (top byte 0x20..0x7F)
+        uint32_t unit_bits;
+        { const float unit = (float)1 / (float)cfg->layer_norm; memcpy(&unit_bits, &unit, 4); }
+        bool eligible = (wall_bits != 0u) && (fill_bits != 0u) && (unit_bits >> 24) >= 0x20u && (unit_bits >> 24) < 0x80u &&
+                        (fill_bits >> 24) >= 0x20u && (fill_bits >> 24) < 0x80u && g.rec_bytes == d.rec_bytes &&
                         g.off_gone == d.off_gone && g.off_term == d.off_term && g.D == d.D;
         for (int r = 0; r < d.D; ++r) {
             int c, i, j;
@@ -946,6 +958,13 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             w.vtab = d.vtab;
             w.codes = reinterpret_cast<const uint32_t *>(h->wtables) + w_codes;
             w.state = d.state;
+            e = hipMalloc(&h->zmask, (size_t)d.n_envs * 256);
+            if (e != hipSuccess) {
+                (void)hipFree(h->wtables); (void)hipFree(h->tables);
+                delete h;
+                return fail(MADRL_EHIP, "stale-zero masks: %s", hipGetErrorString(e));
+            }
+            w.zmask = reinterpret_cast<uint32_t *>(h->zmask);
         } else {
             h->wave = nullptr;
         }
@@ -993,6 +1012,7 @@ void madrl_pursuit_destroy(madrl_pursuit *h) {
     if (!h) return;
     if (h->tables) (void)hipFree(h->tables);
     if (h->wtables) (void)hipFree(h->wtables);
+    if (h->zmask) (void)hipFree(h->zmask);
     delete h;
 }
 

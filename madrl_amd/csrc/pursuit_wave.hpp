@@ -32,6 +32,15 @@
 namespace madrl {
 namespace pw {
 
+// Register allocation for this many resident wavefronts per SIMD.  Measured at BASELINE C2 (scripts/sweep_wave.py): 4 waves (105
+// VGPRs, 4 096 persistent workgroups) 87.8 us per launch, 5 waves (96 VGPRs, no scratch; 5 120 workgroups = exactly the resident
+// capacity) 77.0 us, 6 waves (80 VGPRs, 32 B of scratch; 6 144 workgroups) 80.2 us.
+#ifndef MADRL_PW_WAVES
+#define MADRL_PW_WAVES 5
+#endif
+// Shapes with more than 5 float4 slots per lane keep 4 waves (at 96 VGPRs they would spill, and spill stores reach HBM).
+#define MADRL_PW_OCC __attribute__((amdgpu_waves_per_eu(S::OCC, S::OCC)))
+
 constexpr uint32_t SENT = 0xFFFFFFFFu;   // layer 1/2 outside the map: element is not stored
 constexpr uint32_t CAUGHT = 0x10000u;    // added to an evader-count cell by a caught evader
 
@@ -47,6 +56,7 @@ struct WaveDev {
     const float *vtab;       // fl32(k / layer_norm), k = 0..255
     const uint32_t *codes;   // D entries: bit31 = relative to window origin, low bits = dword offset
     uint8_t *state;
+    uint32_t *zmask;         // [n_envs][64]: per lane, which of its observation cells hold a NON-ZERO stale value (see "stale-zero mask")
 };
 
 struct WaveIO {
@@ -73,6 +83,7 @@ struct Shape {
     static constexpr int DV = D / 4;                             // float4 per pursuer row
     static constexpr int NQ = P * DV;                            // float4 slots per env
     static constexpr int NS = (NQ + 63) / 64;                    // slots per lane
+    static constexpr int OCC = NS <= 5 ? MADRL_PW_WAVES : (MADRL_PW_WAVES < 4 ? MADRL_PW_WAVES : 4);  // resident wavefronts per SIMD aimed at
     static constexpr int X_FILL = 3 * GSZ;                       // extras after the layers
     static constexpr int X_SKIP = 3 * GSZ + 1;
     static constexpr int X_ID = 3 * GSZ + 2;                     // P id values
@@ -92,6 +103,7 @@ struct Shape {
     static_assert(R % 2 == 1, "odd obs_range only (even ranges run on the generic kernel)");
     static_assert(D % 4 == 0, "observation row must be a whole number of float4");
     static_assert(LDS_DWORDS * 4 <= 64 * 1024, "LDS budget");
+    static_assert(NS <= 8, "stale-zero mask: one bit per slot in each byte of the lane's mask dword");
 };
 
 __device__ __forceinline__ double pairwise8(const double *r) {
@@ -168,12 +180,22 @@ __device__ __forceinline__ void put_zero_from(uint32_t &w) {
 #define MADRL_ABLATE 0
 #endif
 
+// Stale-zero mask (quirk Q2).  A cell of channel 1 / 2 outside the map is not written: it keeps the value of the last time it
+// was inside.  A float4 slot that mixes written and unwritten cells becomes a partial store, which the memory side turns into
+// a read-modify-write of the sector (about 20 us of the 90 us launch at BASELINE C2).  Most stale values are 0.0 -- counts of
+// mostly empty cells -- and storing 0.0 over a stale 0.0 changes nothing.  So the kernel keeps, per lane, one bit per observation
+// cell it owns (5 slots x 4 cells; dword [env][lane] of `zmask`, prefetched and written back with the state record):
+// "the value this cell holds in the caller's observation buffer is not known to be zero".  A cell inside the map sets its bit to
+// (value != 0), a cell outside keeps it.  A slot is stored as ONE non-temporal float4, zeros in its outside cells, unless an
+// outside cell's bit is set; only those slots (about 3 % instead of 19 %) fall back to masked dword stores.  All bits set =
+// "nothing known" is always correct: the library starts there and returns there whenever the caller hands it another buffer.
+//
 // MODE 0: reset(mask)      MODE 1: step (+ fused auto-reset)
 // INJECT (step only): evader actions come from io.inj_eact (parity harness) instead of Philox.
 // It is a template parameter because a conditional global load in the hot loop makes the
 // compiler's s_waitcnt pass put a vmcnt(0) on the common path (see "pipeline hinge" below).
 template <class S, int MODE, bool INJECT>
-__global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const WaveIO io) {
+__global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const WaveDev d, const WaveIO io) {
     constexpr int P = S::P, E = S::E, A = S::A, GW = S::GW, PAD = S::PAD, GSZ = S::GSZ, NS = S::NS;
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int lane = threadIdx.x;
@@ -231,21 +253,23 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
         if constexpr (MODE == 1) return isP() ? io.actions[env * P + lane] : 4;
         else return 4;
     };
-    uint32_t cur_rec = 0;
+    auto fetch_zm = [&](int64_t env) -> uint32_t { return d.zmask[env * 64 + lane]; };
+    uint32_t cur_rec = 0, cur_zm = 0xFFFFFFFFu;
     int cur_act = 4;
     auto phys = [&](int64_t e) -> int64_t { return d.reverse ? d.n_envs - 1 - e : e; };
     if ((int64_t)blockIdx.x < d.n_envs) {
         cur_rec = fetch_rec(phys(blockIdx.x));
         cur_act = fetch_act(phys(blockIdx.x));
+        cur_zm = fetch_zm(phys(blockIdx.x));
     }
-    asm volatile("" : "+v"(cur_rec), "+v"(cur_act));  // loads complete before the loop (see hinge below)
+    asm volatile("" : "+v"(cur_rec), "+v"(cur_act), "+v"(cur_zm));  // loads complete before the loop (see hinge below)
     wave_sync();
 
     for (int64_t e = blockIdx.x; e < d.n_envs; e += gridDim.x) {
         const int64_t env = phys(e);
         const bool has_next = e + gridDim.x < d.n_envs;
         const int64_t nenv = phys(has_next ? e + gridDim.x : e);
-        uint32_t nxt_rec = 0;
+        uint32_t nxt_rec = 0, nxt_zm = 0xFFFFFFFFu;
         int nxt_act = 4;
 #if MADRL_ABLATE & 64
         nxt_rec = cur_rec ^ (uint32_t)(fresh(lane) == 0);  // no loads in the loop: is the in-order vmcnt drain what serialises a wave?
@@ -254,6 +278,7 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
         if (has_next) {
             nxt_rec = fetch_rec(nenv);
             nxt_act = fetch_act(nenv);
+            nxt_zm = fetch_zm(nenv);
         }
 #endif
         bool skip = false;
@@ -385,7 +410,8 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
             // for the next env's record now -- when only loads and the previous env's long-issued
             // stores are outstanding -- instead of at the loop back-edge, where an in-order
             // vmcnt(0) would also wait for this env's observation stores to reach HBM.
-            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act));
+            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act), "+v"(nxt_zm));
+            uint32_t zm = cur_zm;  // stale-zero mask of this env: byte k, bit (4 - s) = cell k of slot s
 
             // One observation pass normally.  On auto-reset two: the reference sequence is step()
             // then reset(), both write the persistent observation buffer and the cells the second
@@ -467,6 +493,7 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                     const int origin = isP() ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f *orow = reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D));
+                    uint32_t acc = 0u;  // the new mask, slot by slot
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         const int q = lane + 64 * s;
@@ -475,6 +502,14 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                         const uint32_t v1 = L[base + s_cst[s][1]];
                         const uint32_t v2 = L[base + s_cst[s][2]];
                         const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
+                        // flags of the four cells, one per byte (bit 0).  The top byte of a value is 0x00 for +0.0f, 0x3D..0x41 for the
+                        // positive observation values and 0xFF for SENT (outside the map).
+                        const uint32_t top = __builtin_amdgcn_perm(v1, v0, 0x0C0C0703u) | __builtin_amdgcn_perm(v3, v2, 0x07030C0Cu);
+                        const uint32_t out4 = (top >> 7) & 0x01010101u;                    // outside the map: not written
+                        const uint32_t nz4 = ((top >> 5) | (top >> 6)) & 0x01010101u;      // value != 0 (meaningful where inside)
+                        const uint32_t old4 = (zm >> (NS - 1 - s)) & 0x01010101u;          // holds a value not known to be zero
+                        const uint32_t dirty = out4 & old4;                                 // outside AND possibly non-zero: must stay untouched
+                        acc = (acc << 1) | ((out4 & old4) | (~out4 & nz4));
 #if MADRL_ABLATE & 1
                         if (d.n_envs < 0)
 #endif
@@ -482,12 +517,15 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
 #if MADRL_ABLATE & 2
                             if (true) {
 #else
-                            if ((v0 != SENT) & (v1 != SENT) & (v2 != SENT) & (v3 != SENT)) {
+                            if (dirty == 0u) {
 #endif
-                                const v4f val = {__uint_as_float(v0), __uint_as_float(v1), __uint_as_float(v2),
-                                                 __uint_as_float(v3)};
-                                __builtin_nontemporal_store(val, &orow[q]);
-                            } else {  // a count-layer cell outside the map: leave it stale (Q2).
+                                if (out4 != 0x01010101u) {  // all four outside and known zero: nothing changes
+                                    // outside cells (SENT = -1 as an integer) are written as the +0.0f they already hold
+                                    const v4f val = {__uint_as_float((uint32_t)max((int)v0, 0)), __uint_as_float((uint32_t)max((int)v1, 0)),
+                                                     __uint_as_float((uint32_t)max((int)v2, 0)), __uint_as_float((uint32_t)max((int)v3, 0))};
+                                    __builtin_nontemporal_store(val, &orow[q]);
+                                }
+                            } else {  // an outside cell with a non-zero stale value: leave it alone (Q2).
                                 // Plain (L2-cached) stores: partial lines must merge in L2 -- nontemporal
                                 // partial writes cost a read-modify-write at the memory side (3x slower).
                                 float *o = reinterpret_cast<float *>(orow + q);
@@ -498,6 +536,7 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
                             }
                         }
                     }
+                    zm = acc;
                 }
                 wave_sync();
                 if (alive) layer[cell] = 0u;  // restore the count layers for the next pass / env
@@ -535,10 +574,15 @@ __global__ __launch_bounds__(64) void pursuit_wave_kernel(const WaveDev d, const
 #endif
                 if (fresh(lane) < S::REC_DW)
                     reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] = w;
+#if MADRL_ABLATE & 16
+                if (d.n_envs < 0)
+#endif
+                d.zmask[env * 64 + lane] = zm;
             }
         }
         cur_rec = nxt_rec;
         cur_act = nxt_act;
+        cur_zm = nxt_zm;
     }
 }
 
