@@ -733,7 +733,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         // the switch at ~375 MB of rows + records per launch.  Env results do not depend on the processing order.
         pw::WaveDev wd = h->wdev;
         if (h->zmask_obs != (const void *)io.obs) {  // unknown buffer contents: every cell "not known to be zero"
-            MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0xFF, (size_t)h->dev.n_envs * 256, s));
+            MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0xFF, (size_t)h->dev.n_envs * 256 * h->wave->g.waves, s));
             h->zmask_obs = io.obs;
         }
         if (mode == 1) {
@@ -958,7 +958,7 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             w.vtab = d.vtab;
             w.codes = reinterpret_cast<const uint32_t *>(h->wtables) + w_codes;
             w.state = d.state;
-            e = hipMalloc(&h->zmask, (size_t)d.n_envs * 256);
+            e = hipMalloc(&h->zmask, (size_t)d.n_envs * 256 * g.waves);
             if (e != hipSuccess) {
                 (void)hipFree(h->wtables); (void)hipFree(h->tables);
                 delete h;

@@ -59,6 +59,7 @@ struct GShape {
     static_assert(R % 2 == 1, "odd obs_range only");
     static_assert(D % 4 == 0, "observation row must be a whole number of float4");
     static_assert(LDS_DWORDS * 4 <= 64 * 1024, "LDS budget");
+    static_assert(NS <= 8, "stale-zero mask: one bit per slot in each byte of the thread's mask dword");
 };
 
 // LDS-only workgroup barrier: the DS queue of this wavefront is drained, global stores stay in flight.
@@ -149,25 +150,28 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
             return ((uint64_t)hi << 32) | lo;
         }
     };
-    uint32_t cur_rec = 0;
+    auto fetch_zm = [&](int64_t env) -> uint32_t { return d.zmask[env * NT + tid]; };  // stale-zero mask, pursuit_wave.hpp
+    uint32_t cur_rec = 0, cur_zm = 0xFFFFFFFFu;
     int cur_act = 4;
     auto phys = [&](int64_t e) -> int64_t { return d.reverse ? d.n_envs - 1 - e : e; };
     if ((int64_t)blockIdx.x < d.n_envs) {
         cur_rec = fetch_rec(phys(blockIdx.x));
         cur_act = fetch_act(phys(blockIdx.x));
+        cur_zm = fetch_zm(phys(blockIdx.x));
     }
-    asm volatile("" : "+v"(cur_rec), "+v"(cur_act));
+    asm volatile("" : "+v"(cur_rec), "+v"(cur_act), "+v"(cur_zm));
     group_sync();
 
     for (int64_t e = blockIdx.x; e < d.n_envs; e += gridDim.x) {
         const int64_t env = phys(e);
         const bool has_next = e + gridDim.x < d.n_envs;
         const int64_t nenv = phys(has_next ? e + gridDim.x : e);
-        uint32_t nxt_rec = 0;
+        uint32_t nxt_rec = 0, nxt_zm = 0xFFFFFFFFu;
         int nxt_act = 4;
         if (has_next) {
             nxt_rec = fetch_rec(nenv);
             nxt_act = fetch_act(nenv);
+            nxt_zm = fetch_zm(nenv);
         }
         bool skip = false;
         if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
@@ -294,7 +298,8 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                 n_removed = __popcll(caught_mask);
             }
 
-            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act));  // pipeline hinge (pursuit_wave.hpp)
+            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act), "+v"(nxt_zm));  // pipeline hinge (pursuit_wave.hpp)
+            uint32_t zm = cur_zm;
 
             const int npass = (MODE == 1 && do_reset) ? 2 : 1;
             for (int pass = 0; pass < npass; ++pass) {
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                 {
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f *orow = reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D));
+                    uint32_t acc = 0u;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         const int q = tid + NT * s;
@@ -371,12 +377,21 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                         const uint32_t v1 = L[base + s_cst[s][1]];
                         const uint32_t v2 = L[base + s_cst[s][2]];
                         const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
+                        // stale-zero mask: see pursuit_wave.hpp
+                        const uint32_t top = __builtin_amdgcn_perm(v1, v0, 0x0C0C0703u) | __builtin_amdgcn_perm(v3, v2, 0x07030C0Cu);
+                        const uint32_t out4 = (top >> 7) & 0x01010101u;
+                        const uint32_t nz4 = ((top >> 5) | (top >> 6)) & 0x01010101u;
+                        const uint32_t old4 = (zm >> (NS - 1 - s)) & 0x01010101u;
+                        const uint32_t dirty = out4 & old4;
+                        acc = (acc << 1) | (dirty | (~out4 & nz4));
                         if ((NT * (s + 1) <= S::NQ) ? true : (fresh(tid) + NT * s < S::NQ)) {
-                            if ((v0 != SENT) & (v1 != SENT) & (v2 != SENT) & (v3 != SENT)) {
-                                const v4f val = {__uint_as_float(v0), __uint_as_float(v1), __uint_as_float(v2),
-                                                 __uint_as_float(v3)};
-                                __builtin_nontemporal_store(val, &orow[q]);
-                            } else {  // stale cells (Q2): plain stores that merge in L2, see pursuit_wave.hpp
+                            if (dirty == 0u) {
+                                if (out4 != 0x01010101u) {
+                                    const v4f val = {__uint_as_float((uint32_t)max((int)v0, 0)), __uint_as_float((uint32_t)max((int)v1, 0)),
+                                                     __uint_as_float((uint32_t)max((int)v2, 0)), __uint_as_float((uint32_t)max((int)v3, 0))};
+                                    __builtin_nontemporal_store(val, &orow[q]);
+                                }
+                            } else {  // an outside cell with a non-zero stale value (Q2): plain stores that merge in L2
                                 float *o = reinterpret_cast<float *>(orow + q);
                                 if (v0 != SENT) o[0] = __uint_as_float(v0);
                                 if (v1 != SENT) o[1] = __uint_as_float(v1);
@@ -385,6 +400,7 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                             }
                         }
                     }
+                    zm = acc;
                 }
                 group_sync();
                 if (alive) layer[cell] = 0u;
@@ -412,10 +428,12 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                 if (own_term) w = ((lane - S::OFF_TERM / 4) & 1) ? (uint32_t)(term >> 32) : (uint32_t)term;
                 if (lane >= S::OFF_TERM / 4 + S::NTW) w = 0u;  // padding dwords
                 if (own_dw) reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] = w;
+                d.zmask[env * NT + tid] = zm;
             }
         }
         cur_rec = nxt_rec;
         cur_act = nxt_act;
+        cur_zm = nxt_zm;
     }
 }
 
