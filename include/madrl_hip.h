@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MADRL_ABI_VERSION 1
+#define MADRL_ABI_VERSION 2
 
 #define MADRL_OK 0
 #define MADRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -181,6 +181,22 @@ int madrl_waterworld_create(const madrl_waterworld_config *cfg, const double *se
                             int32_t device, void *state_dev, madrl_waterworld **out);
 void madrl_waterworld_destroy(madrl_waterworld *h);
 int madrl_waterworld_set_launch(madrl_waterworld *h, int64_t max_blocks);
+
+/* Fused StandardizedEnv (madrl_environments/__init__.py:204-311): bind the wrapper's state to the env handle and the step /
+ * reset kernels normalise the observation row as it leaves LDS (and the rewards as they are produced) instead of storing it
+ * raw for a second launch (madrl_wrap_obsnorm / _rewnorm) to read back: 36 instead of 44 bytes of HBM traffic per observation
+ * element, one launch instead of three.  Same arithmetic (float64 exponential running mean / variance per env, agent and
+ * element, :242-271).  All pointers are device memory that stays valid while bound; running statistics start at mean 0 /
+ * var 1 (:229-232).  While bound, obs_dev of reset / step may be NULL (the raw row is then not stored).  args NULL unbinds. */
+typedef struct madrl_standardize_args {
+    int32_t struct_size, enable_obsnorm, enable_rewnorm, reserved0;
+    double obs_alpha, rew_alpha, eps, scale_reward;
+    double *obs_mean, *obs_var;   /* [N][A][D] */
+    float *obs_out;               /* [N][A][D] */
+    double *rew_mean, *rew_var;   /* [N][A] */
+    float *rew_out;               /* [N][A] or NULL: rewards are not touched */
+} madrl_standardize_args;
+int madrl_waterworld_set_standardize(madrl_waterworld *h, const madrl_standardize_args *args);
 
 /* MAWaterWorld.reset (:144-172) incl. its trailing zero-action step; obs float32 [N][Np][obs_dim]. */
 int madrl_waterworld_reset(madrl_waterworld *h, const uint8_t *mask_dev, float *obs_dev, void *stream);

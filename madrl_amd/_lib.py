@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MADRL_HIP_LIB") or os.path.join(_HERE, "libmadrl_hip.so")  # override: profiling variants only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
 
@@ -66,6 +66,13 @@ class MultiWalkerConfig(C.Structure):
                 ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 
 
+class StandardizeArgs(C.Structure):
+    """mirror of madrl_standardize_args (include/madrl_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("struct_size", "enable_obsnorm", "enable_rewnorm", "reserved0")] + [
+        (n, C.c_double) for n in ("obs_alpha", "rew_alpha", "eps", "scale_reward")] + [
+        (n, C.c_void_p) for n in ("obs_mean", "obs_var", "obs_out", "rew_mean", "rew_var", "rew_out")]
+
+
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); this table is also what tests use to check that the library
@@ -90,6 +97,7 @@ SIGNATURES = {
     "madrl_waterworld_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),
     "madrl_waterworld_destroy": (None, [_vp]),
     "madrl_waterworld_set_launch": (C.c_int, [_vp, C.c_int64]),
+    "madrl_waterworld_set_standardize": (C.c_int, [_vp, _vp]),
     "madrl_waterworld_reset": (C.c_int, [_vp] * 4),
     "madrl_waterworld_step": (C.c_int, [_vp] * 8),
     "madrl_waterworld_get_state": (C.c_int, [_vp] * 7),

@@ -48,6 +48,19 @@ struct WwDev {
     float *state;
 };
 
+// Fused StandardizedEnv (madrl_environments/__init__.py:204-311): when `obs_out` is set, the observation row is normalised as
+// it leaves LDS -- per env, per agent, per element exponential running mean / variance in float64, exactly the arithmetic of the
+// stand-alone epilogue kernel (wrappers.hip obsnorm_kernel / rewnorm_kernel) -- instead of being stored raw and read back by a
+// second launch: 36 instead of 44 bytes of HBM traffic per observation element.
+struct WwStd {
+    double *obs_mean, *obs_var;   // [N][Np][D]
+    float *obs_out;               // [N][Np][D] normalised observations; NULL = not fused
+    double *rew_mean, *rew_var;   // [N][Np]
+    float *rew_out;               // [N][Np] scale * (reward / (sqrt(var) + eps)); NULL = rewards are not touched
+    double obs_alpha, rew_alpha, eps, scale;
+    int32_t enable_obsnorm, enable_rewnorm;
+};
+
 struct WwIO {
     const uint8_t *mask;    // reset mode
     const float *actions;   // [N][Np][2]
@@ -56,6 +69,7 @@ struct WwIO {
     float *rew;             // [N][Np]
     uint8_t *done;          // [N]
     int32_t *info;          // [N][2]  evcatches, pocatches
+    const WwStd *st;        // device copy of the fused-wrapper arguments, or NULL
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -431,6 +445,20 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 // ---------------------------------------------------- outputs
                 if (MODE == 1 && !do_init) {
                     if (lane < Np) io.rew[env * Np + lane] = reward;
+                    if (io.st != nullptr && io.st->rew_out != nullptr && lane < Np) {  // StandardizedEnv.step :283-291
+                        const WwStd &st = *io.st;
+                        const int64_t i = env * Np + lane;
+                        double r = (double)reward;
+                        if (st.enable_rewnorm) {
+                            const double m = (1.0 - st.rew_alpha) * st.rew_mean[i] + st.rew_alpha * r;      // :253-254
+                            const double dd = r - m;
+                            const double v = (1.0 - st.rew_alpha) * st.rew_var[i] + st.rew_alpha * (dd * dd);  // :255-257
+                            st.rew_mean[i] = m;
+                            st.rew_var[i] = v;
+                            r = r / (sqrt(v) + st.eps);                                                   // :268-271
+                        }
+                        st.rew_out[i] = (float)(st.scale * r);                                           // :290
+                    }
                     if (lane == 0) {
                         io.done[env] = (uint8_t)is_done;
                         io.info[2 * env] = n_evc;
@@ -446,7 +474,44 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
 #if MADRL_WW_ABLATE & 2
                     if (d.n_envs < 0)
 #endif
+                    if (io.obs != nullptr)   // the raw row may be dropped when the fused wrapper output is all the caller reads
                     for (int e = lane; e < Np * D; e += 64) orow[e] = O[e];
+                    if (io.st != nullptr && io.st->obs_out != nullptr) {  // StandardizedEnv.standardize_obs :242-263
+                        const WwStd &st = *io.st;
+                        const int64_t base = env * (int64_t)(Np * D);
+                        if (st.enable_obsnorm) {
+                            // batches of 4 elements per lane: all 8 statistics loads of a batch are in flight before the first
+                            // dependent float64 operation (element by element the loop pays one HBM round trip each: 421 instead
+                            // of 357 us per wrapped step; 16-byte pair accesses on top measured no further gain)
+                            const int n_el = Np * D;
+                            const double *__restrict__ gm = st.obs_mean + base;
+                            const double *__restrict__ gv = st.obs_var + base;
+                            for (int e0 = lane; e0 < n_el; e0 += 256) {
+                                double m[4], v[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int e = e0 + 64 * u;
+                                    m[u] = e < n_el ? __builtin_nontemporal_load(&gm[e]) : 0.0;
+                                    v[u] = e < n_el ? __builtin_nontemporal_load(&gv[e]) : 1.0;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int e = e0 + 64 * u;
+                                    if (e < n_el) {
+                                        const double x = (double)O[e];
+                                        const double mm = (1.0 - st.obs_alpha) * m[u] + st.obs_alpha * x;      // :245-246
+                                        const double dd = x - mm;
+                                        const double vv = (1.0 - st.obs_alpha) * v[u] + st.obs_alpha * (dd * dd);  // :247-249
+                                        __builtin_nontemporal_store(mm, &st.obs_mean[base + e]);
+                                        __builtin_nontemporal_store(vv, &st.obs_var[base + e]);
+                                        __builtin_nontemporal_store((float)((x - mm) / (sqrt(vv) + st.eps)), &st.obs_out[base + e]);  // :262-263
+                                    }
+                                }
+                            }
+                        } else {
+                            for (int e = lane; e < Np * D; e += 64) st.obs_out[base + e] = O[e];
+                        }
+                    }
                 }
                 wave_sync();
             }
@@ -478,6 +543,8 @@ struct madrl_waterworld {
     int64_t max_blocks;
     size_t lds_bytes;
     void *tables;
+    WwStd *std_dev;   // device copy of the bound StandardizedEnv arguments (madrl_waterworld_set_standardize)
+    bool std_bound;
 };
 
 namespace {
@@ -619,7 +686,27 @@ int madrl_waterworld_create(const madrl_waterworld_config *cfg, const double *se
 void madrl_waterworld_destroy(madrl_waterworld *h) {
     if (!h) return;
     if (h->tables) (void)hipFree(h->tables);
+    if (h->std_dev) (void)hipFree(h->std_dev);
     delete h;
+}
+
+int madrl_waterworld_set_standardize(madrl_waterworld *h, const madrl_standardize_args *a) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    if (!a) { h->std_bound = false; return MADRL_OK; }
+    if (a->struct_size != (int32_t)sizeof(madrl_standardize_args))
+        return fail(MADRL_EINVAL, "madrl_standardize_args.struct_size=%d, library expects %d", a->struct_size, (int)sizeof(madrl_standardize_args));
+    if (!a->obs_out || (a->enable_obsnorm && (!a->obs_mean || !a->obs_var)) || (a->rew_out && a->enable_rewnorm && (!a->rew_mean || !a->rew_var)))
+        return fail(MADRL_EINVAL, "set_standardize: obs_out and the running statistics of every enabled normalisation are required");
+    WwStd st;
+    st.obs_mean = a->obs_mean; st.obs_var = a->obs_var; st.obs_out = a->obs_out;
+    st.rew_mean = a->rew_mean; st.rew_var = a->rew_var; st.rew_out = a->rew_out;
+    st.obs_alpha = a->obs_alpha; st.rew_alpha = a->rew_alpha; st.eps = a->eps; st.scale = a->scale_reward;
+    st.enable_obsnorm = a->enable_obsnorm; st.enable_rewnorm = a->enable_rewnorm;
+    MADRL_HIP_TRY(hipSetDevice(h->device));
+    if (!h->std_dev) MADRL_HIP_TRY(hipMalloc((void **)&h->std_dev, sizeof(WwStd)));
+    MADRL_HIP_TRY(hipMemcpy(h->std_dev, &st, sizeof(WwStd), hipMemcpyHostToDevice));
+    h->std_bound = true;
+    return MADRL_OK;
 }
 
 int madrl_waterworld_set_launch(madrl_waterworld *h, int64_t max_blocks) {
@@ -629,22 +716,24 @@ int madrl_waterworld_set_launch(madrl_waterworld *h, int64_t max_blocks) {
 }
 
 int madrl_waterworld_reset(madrl_waterworld *h, const uint8_t *mask_dev, float *obs_dev, void *stream) {
-    if (!h || !obs_dev) return fail(MADRL_EINVAL, "reset: handle/obs is NULL");
+    if (!h || (!obs_dev && !h->std_bound)) return fail(MADRL_EINVAL, "reset: handle/obs is NULL");
     WwIO io;
     memset(&io, 0, sizeof(io));
     io.mask = mask_dev;
     io.obs = obs_dev;
+    io.st = h->std_bound ? h->std_dev : nullptr;
     return ww_launch(h, io, 0, stream);
 }
 
 int madrl_waterworld_step(madrl_waterworld *h, const float *actions_dev, const float *inj_respawn_dev, float *obs_dev,
                           float *rew_dev, uint8_t *done_dev, int32_t *info_dev, void *stream) {
-    if (!h || !actions_dev || !obs_dev || !rew_dev || !done_dev || !info_dev) return fail(MADRL_EINVAL, "step: NULL argument");
+    if (!h || !actions_dev || (!obs_dev && !h->std_bound) || !rew_dev || !done_dev || !info_dev) return fail(MADRL_EINVAL, "step: NULL argument");
     WwIO io;
     memset(&io, 0, sizeof(io));
     io.actions = actions_dev;
     io.inj_resp = inj_respawn_dev;
     io.obs = obs_dev;
+    io.st = h->std_bound ? h->std_dev : nullptr;
     io.rew = rew_dev;
     io.done = done_dev;
     io.info = info_dev;

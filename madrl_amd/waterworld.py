@@ -110,6 +110,7 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         _lib.check(L.madrl_waterworld_create(C.byref(cfg), self._sensors.ctypes.data_as(C.c_void_p), N, dev_index,
                                              _lib.ptr(self._state), C.byref(h)))
         self._handle = h
+        self._std = None  # a fused StandardizedEnv binding belongs to the old handle
         if self._max_blocks:
             _lib.check(L.madrl_waterworld_set_launch(h, self._max_blocks))
         self._pursuers = [Archea(i + 1, D) for i in range(Np)]
@@ -155,9 +156,34 @@ class BatchedMAWaterWorld(AbstractMAEnv):
     def reset(self, mask=None):
         if mask is not None:
             mask = torch.as_tensor(mask, device=self.device).reshape(self.n_envs).to(torch.uint8).contiguous()
-        _lib.check(_lib.lib().madrl_waterworld_reset(self._handle, _lib.ptr(mask), _lib.ptr(self._obs),
+        std = getattr(self, "_std", None)
+        _lib.check(_lib.lib().madrl_waterworld_reset(self._handle, _lib.ptr(mask), None if std else _lib.ptr(self._obs),
                                                      _lib.current_stream(self.device)))
-        return self._obs
+        return std["obs_out"] if std else self._obs
+
+    # ------------------------------------------------------------------ fused StandardizedEnv (include/madrl_hip.h)
+    def bind_standardize(self, scale_reward=1.0, enable_obsnorm=False, enable_rewnorm=False, obs_alpha=0.001, rew_alpha=0.001, eps=1e-8):
+        """The kernels normalise observations / rewards on their way out (madrl_waterworld_set_standardize): reset() and
+        step() then return the standardised tensors and the raw observation row is not stored.  Returns the dict of
+        state tensors (running statistics, outputs) the wrapper owns."""
+        N, Np, D, dev = self.n_envs, self.n_pursuers, self.obs_dim, self.device
+        st = dict(obs_mean=torch.zeros((N, Np, D), dtype=torch.float64, device=dev), obs_var=torch.ones((N, Np, D), dtype=torch.float64, device=dev),
+                  obs_out=torch.zeros((N, Np, D), dtype=torch.float32, device=dev),
+                  rew_mean=torch.zeros((N, Np), dtype=torch.float64, device=dev), rew_var=torch.ones((N, Np), dtype=torch.float64, device=dev),
+                  rew_out=torch.zeros((N, Np), dtype=torch.float32, device=dev))
+        a = _lib.StandardizeArgs()
+        a.struct_size = C.sizeof(_lib.StandardizeArgs)
+        a.enable_obsnorm, a.enable_rewnorm = int(bool(enable_obsnorm)), int(bool(enable_rewnorm))
+        a.obs_alpha, a.rew_alpha, a.eps, a.scale_reward = float(obs_alpha), float(rew_alpha), float(eps), float(scale_reward)
+        for k, v in st.items():
+            setattr(a, k, v.data_ptr())
+        _lib.check(_lib.lib().madrl_waterworld_set_standardize(self._handle, C.byref(a)))
+        self._std = st
+        return st
+
+    def unbind_standardize(self):
+        _lib.check(_lib.lib().madrl_waterworld_set_standardize(self._handle, None))
+        self._std = None
 
     def step(self, action, respawn=None):
         """waterworld.py:220-436.  action: float [N, Np, 2] (or anything that reshapes to it, :221-222).
@@ -170,10 +196,14 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         r = None
         if respawn is not None:
             r = torch.as_tensor(respawn, device=self.device).reshape(N, self.n_particles, 4).to(torch.float32).contiguous()
-        _lib.check(_lib.lib().madrl_waterworld_step(self._handle, _lib.ptr(a), _lib.ptr(r), _lib.ptr(self._obs),
+        std = getattr(self, "_std", None)
+        _lib.check(_lib.lib().madrl_waterworld_step(self._handle, _lib.ptr(a), _lib.ptr(r), None if std else _lib.ptr(self._obs),
                                                     _lib.ptr(self._rew), _lib.ptr(self._done), _lib.ptr(self._info),
                                                     _lib.current_stream(self.device)))
-        return self._obs, self._rew, self._done.bool(), {"evcatches": self._info[:, 0], "pocatches": self._info[:, 1]}
+        info = {"evcatches": self._info[:, 0], "pocatches": self._info[:, 1]}
+        if std:  # fused StandardizedEnv: standardised observations and scaled / normalised rewards straight from the kernel
+            return std["obs_out"], std["rew_out"], self._done.bool(), info
+        return self._obs, self._rew, self._done.bool(), info
 
     @property
     def is_terminal(self):

@@ -170,12 +170,23 @@ class StandardizedEnv(_Wrapper):
     per element) and rewards (per agent), plus reward scaling."""
 
     def __init__(self, env, scale_reward=1., enable_obsnorm=False, enable_rewnorm=False, obs_alpha=0.001, rew_alpha=0.001,
-                 eps=1e-8):
+                 eps=1e-8, fused=None):
+        """fused: None = fuse into the env's step / reset kernels when the env directly below supports it
+        (`bind_standardize`, today the Waterworld engine): the observation row is normalised as it leaves LDS instead of
+        being stored raw and read back by an epilogue launch.  False = always the stand-alone epilogue kernels."""
         super().__init__(env)
         self._scale_reward, self._enable_obsnorm, self._enable_rewnorm = scale_reward, enable_obsnorm, enable_rewnorm
         self._obs_alpha, self._rew_alpha, self._eps = obs_alpha, rew_alpha, eps
         self._obs_mean = self._obs_var = self._rew_mean = self._rew_var = None
         self._obs_out = self._rew_out = None
+        self._fused = False
+        if fused is not False and not self._single and hasattr(self._unwrapped, "bind_standardize"):
+            st = self._unwrapped.bind_standardize(scale_reward=scale_reward, enable_obsnorm=enable_obsnorm, enable_rewnorm=enable_rewnorm,
+                                                  obs_alpha=obs_alpha, rew_alpha=rew_alpha, eps=eps)
+            self._obs_mean, self._obs_var, self._rew_mean, self._rew_var = st["obs_mean"], st["obs_var"], st["rew_mean"], st["rew_var"]
+            self._fused = True
+        elif fused:
+            raise ValueError("fused=True needs an env with bind_standardize() directly below this wrapper")
 
     def _norm_obs(self, obs):
         if not self._enable_obsnorm:
@@ -203,10 +214,14 @@ class StandardizedEnv(_Wrapper):
         return self._rew_out
 
     def _reset_b(self, **kw):
+        if self._fused:
+            return self._inner_reset(**kw)  # already standardised by the env's kernel
         return self._norm_obs(self._inner_reset(**kw))  # :276-281
 
     def _step_b(self, *args, **kw):
         obs, rew, done, info = self._inner_step(*args, **kw)  # :283-291
+        if self._fused:
+            return obs, rew, done, info
         return self._norm_obs(obs), self._norm_rew(rew), done, info
 
     def __str__(self):

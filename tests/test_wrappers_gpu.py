@@ -105,3 +105,32 @@ def test_wrappers_on_live_auto_reset_env_match_numpy_oracle():
             assert np.abs(log["global/episode_disc_return"].cpu().numpy()[fin] - out["disc"][fin]).max() < 1e-3
             assert np.array_equal(log["global/episode_length"].cpu().numpy()[fin], out["length"][fin])
     assert nfin > N
+
+
+def test_fused_standardized_waterworld_matches_unfused_and_oracle():
+    """StandardizedEnv fused into the Waterworld step / reset kernels (madrl_waterworld_set_standardize): same values as the
+    stand-alone epilogue kernels on an identical env, and both within 1e-5 of the NumPy restatement of the reference wrapper."""
+    from madrl_amd.waterworld import BatchedMAWaterWorld
+    from madrl_amd.wrappers import StandardizedEnv
+    from oracle import wrappers_oracle as wo
+    N, H = 256, 12
+    mk = lambda: BatchedMAWaterWorld(5, 10, n_envs=N, device=DEV, seed=9, max_steps=H, auto_reset=True)
+    cfg = dict(scale_reward=0.7, enable_obsnorm=True, enable_rewnorm=True, obs_alpha=0.05, rew_alpha=0.05)
+    fused, plain, raw = StandardizedEnv(mk(), **cfg), StandardizedEnv(mk(), fused=False, **cfg), mk()
+    assert fused._fused and not plain._fused
+    D = raw.obs_dim
+    so = wo.StdOracle((N, 5, D), (N, 5), **cfg)
+    of, op = fused.reset(), plain.reset()
+    ref = so.obs(raw.reset().cpu().numpy())
+    assert torch.equal(of, op) and np.abs(of.cpu().numpy() - ref).max() < 1e-5
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for t in range(30):
+        a = (torch.rand((N, 5, 2), generator=g) * 2 - 1).to(DEV)
+        of, rf, df, _ = fused.step(a)
+        op, rp, dp, _ = plain.step(a)
+        ro, rr, rd, _ = raw.step(a)
+        assert torch.equal(of, op) and torch.equal(rf, rp) and torch.equal(df, dp), "step %d: fused != epilogue kernels" % t
+        assert np.abs(of.cpu().numpy() - so.obs(ro.cpu().numpy())).max() < 1e-5, t
+        want = so.rew(rr.cpu().numpy())
+        assert np.abs(rf.cpu().numpy() - want).max() < 1e-5 * max(1.0, np.abs(want).max()), t
+    assert torch.equal(fused._obs_mean, plain._obs_mean) and torch.equal(fused._rew_var, plain._rew_var)
