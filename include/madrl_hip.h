@@ -276,7 +276,8 @@ typedef struct madrl_multiwalker_config {
     int32_t one_hot;          /* 1: the id is np.eye(MAX_AGENTS = 40)[i] instead of i / n_walkers (:397-400): obs_dim 71 */
     int32_t max_steps;        /* 0 = none; else done bit1 when the episode reaches it */
     int32_t auto_reset;
-    int32_t reserved0;
+    int32_t discrete_only;    /* 0 (default): Box2D's continuous pass (b2World::SolveTOI, continuousPhysics = true, the b2World default
+                                 the reference runs with) follows every discrete solve; 1: b2World.continuousPhysics = False */
     double position_noise, angle_noise, forward_reward, fall_reward, drop_reward;
     uint64_t seed;
     int64_t env_id_base;

@@ -224,6 +224,8 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     mw::Model M;
     memset(&M, 0, sizeof(M));
     mw::build_model(M, cfg->n_walkers);
+    M.continuous = cfg->discrete_only ? 0 : 1;
+    if (const char *e = getenv("MADRL_MW_TOI")) M.continuous = atoi(e);  // experiments: 0 = no continuous pass, 2 = candidates only
     h->NB = M.NB; h->NT = M.NT;
     hipError_t e = hipMalloc(&h->model_dev, sizeof(M));
     if (e == hipSuccess) e = hipMemcpy(h->model_dev, &M, sizeof(M), hipMemcpyHostToDevice);

@@ -38,7 +38,7 @@ namespace mw {
 
 // optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
 #ifdef MW_STATS
-struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters; };
+struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6]; };
 extern Stats g_stats;
 #define MW_STAT(f, v) (g_stats.f += (v))
 #else
@@ -122,6 +122,10 @@ MW_HD V2 mulT(Xf t, V2 v) { return mulT(t.q, v - t.p); }
 MW_HD Rot mulT(Rot q, Rot r) { Rot o; o.s = q.c * r.s - q.s * r.c; o.c = q.c * r.c + q.s * r.s; return o; }
 MW_HD Xf mulT(Xf A, Xf B) { Xf C; C.q = mulT(A.q, B.q); C.p = mulT(A.q, B.p - A.p); return C; }
 
+}  // namespace mw
+#include "multiwalker_toi.hpp"
+namespace mw {
+
 // ---------------------------------------------------------------- static model (per n_walkers)
 enum { SH_PACKAGE = 0, SH_HULL = 1, SH_UPPER = 2, SH_LOWER = 3, N_SHAPES = 4 };
 struct Shape {
@@ -139,6 +143,7 @@ struct JointDef {  // revoluteJointDef, multi_walker.py:145-179
 struct Model {
     int W, NB, NJ, NT;  // walkers, bodies, joints, terrain points
     int max_manifolds;  // size of the active-manifold pool of a step (Scratch::m)
+    int continuous;     // b2World continuousPhysics (Box2D's default: on)
     Shape shape[N_SHAPES];
     JointDef jd[MAXJ];
     float package_length, package_scale;
@@ -210,6 +215,7 @@ inline void poly_mass(Shape &s, float density) {
 inline void build_model(Model &M, int n_walkers) {
     M.W = n_walkers; M.NB = 5 * n_walkers + 1; M.NJ = 4 * n_walkers;
     // observed maxima of simultaneously touching pairs over long random / collapsed rollouts: 18, 25, 34 for 2, 3, 4 walkers
+    M.continuous = 1;
     M.max_manifolds = n_walkers <= 1 ? 16 : (n_walkers == 2 ? 24 : (n_walkers == 3 ? 28 : MAXM));
     M.NT = (int)(TERRAIN_LENGTH * n_walkers * 1 / 8.0);          // :301
     M.package_scale = n_walkers / 1.75f;                          // :293
@@ -268,7 +274,10 @@ struct Slot {       // persistent manifold cache of one candidate pair (b2Contac
     uint8_t npts, touching;
     uint32_t id[2];
     float ni[2], ti[2];
-    uint32_t pad_;
+    // continuous pass (b2Contact e_toiFlag / e_enabledFlag / m_toiCount), valid within one step; m_toi lives in Cold::slot_toi
+    uint8_t toi_flags;           // bit 0: the cached time of impact is valid, bit 1: disabled for the rest of this step
+    uint8_t toi_count;
+    uint16_t pad_;
 };
 struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositionConstraint
     int8_t bA, bB;         // bA = -1: static terrain
@@ -279,6 +288,7 @@ struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositio
     float friction, nm[2], tm[2], ni[2], ti[2];
     float k11, k12, k22, im11, im12, im22;  // block solver K and K^-1
 };
+static_assert(sizeof(Slot) == 32, "HBM record layout");
 static_assert(sizeof(Manifold) == 140, "LDS budget of the HIP kernel: 4 envs x (Hot + Scratch) x 8 wavefronts per CU");
 // The env state is split by how often a step touches it.
 //   Hot:  bodies and flags -- read and written by every one of the 180 + 60 solver sweeps; the HIP kernel keeps it in
@@ -298,6 +308,10 @@ struct Cold {
     Joint j[MAXJ];                // warm-start impulses, motor targets, limit states: read at the start of a step into the
                                   // owning lane's JointCache, written back at its end
     Slot slot[MAXSLOT];
+    float slot_toi[MAXSLOT];      // continuous pass: cached time of impact per slot (valid while Slot::toi_flags bit 0)
+    V2 sweep_c0[MAXB];            // continuous pass: body centres / angles at the start of the step (b2Sweep::c0, a0) and the
+    float sweep_a0[MAXB];         // time up to which a body has already been advanced (b2Sweep::alpha0)
+    float sweep_alpha0[MAXB];
     float ty[MAXT];               // terrain heights (x = i * TERRAIN_STEP)
 };
 struct World { Hot h; Cold c; };  // the packed per-env record in HBM
@@ -877,10 +891,9 @@ MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
 }
 
 // b2ContactSolver::SolveVelocityConstraints for manifold k
-MW_HD void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
+// ... on velocities the caller holds (the continuous pass keeps its one moving body in registers over all sweeps)
+MW_HD void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float &wA, V2 &vB, float &wB) {
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
-    V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
-    float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
     const V2 normal = m.normal, tangent = cross(normal, 1.0f);
     MW_UNROLL
     for (int i = 0; i < 2; ++i) if (i < m.npts) {  // friction first
@@ -929,6 +942,11 @@ MW_HD void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
             m.ni[0] = x1; m.ni[1] = x2;
         }
     }
+}
+MW_HD void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
+    V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
+    float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
+    contact_solve_velocity_on(m, q, vA, wA, vB, wB);
     if (m.bA >= 0) { Wd.b[m.bA].v = vA; Wd.b[m.bA].w = wA; }
     Wd.b[m.bB].v = vB; Wd.b[m.bB].w = wB;
 }
@@ -1002,6 +1020,394 @@ MW_HD bool joint_solve_position(Hot &Wd, const JointCache &c) {
     A.c = A.c - mA * imp; A.a -= iA * cross(rA, imp);
     B.c = B.c + mB * imp; B.a += iB * cross(rB, imp);
     return pos_err <= LINEAR_SLOP && ang_err <= ANGULAR_SLOP;
+}
+
+// ---------------------------------------------------------------- continuous pass (b2World::SolveTOI)
+// After the discrete solve Box2D looks, for every contact between a dynamic body and a static one (here: terrain edges; in
+// the known-answer scene the static ground box), for the first time in this step at which the two shapes come within
+// linearSlop of each other (multiwalker_toi.hpp), takes the earliest such event, moves the body back to that time, solves
+// a sub-step for the remaining time on a mini island (that body and its touching static contacts: 20 TOI position
+// iterations at Baumgarte 0.75, the step's velocity iterations without warm starting, integration) and repeats until no
+// event is left (at most 8 sub-steps per contact).  Joints take no part (b2Island::SolveTOI ignores them).
+MW_HD void poly_aabb_at(const Shape &s, V2 c, float a, float &xmin, float &xmax, float &ymin, float &ymax) {
+    const Xf t = xf_from(c, a, s.centroid);
+    for (int i = 0; i < s.n; ++i) {
+        const V2 p = mul(t, s.v[i]);
+        xmin = fminf(xmin, p.x); xmax = fmaxf(xmax, p.x); ymin = fminf(ymin, p.y); ymax = fmaxf(ymax, p.y);
+    }
+}
+MW_HD void proxy_of_shape(Proxy &p, const Shape &s) {
+    p.n = s.n;
+    MW_UNROLL
+    for (int i = 0; i < TOI_MAX_VERTS; ++i) p.v[i] = i < s.n ? s.v[i] : s.v[0];
+}
+MW_HD Sweep sweep_of_body(const Model &M, const Hot &Wd, const Cold &Cd, int b) {
+    Sweep s;
+    s.lc = M.shape[shape_of_body(b)].centroid;
+    s.c0 = Cd.sweep_c0[b]; s.a0 = Cd.sweep_a0[b]; s.alpha0 = Cd.sweep_alpha0[b];
+    s.c = Wd.b[b].c; s.a = Wd.b[b].a;
+    return s;
+}
+// time of impact of body `bi` (dynamic) with terrain edge e, as b2World::SolveTOI computes it for one contact
+MW_HD float toi_alpha_terrain(const Model &M, const Hot &Wd, const Cold &Cd, int bi, int e, const Sweep &sB, float xmin, float xmax, float ymin, float ymax) {
+    const V2 p1 = v2(e * TERRAIN_STEP, Cd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
+    // conservative cull (never changes a result): the swept vertex box of the body, inflated by what TOI calls touching, misses the edge
+    const float m = 4.0f * LINEAR_SLOP;
+    if (xmin - m > p2.x || xmax + m < p1.x || ymin - m > fmaxf(p1.y, p2.y) || ymax + m < fminf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
+    MW_STAT(toi_full, 1);
+    Proxy pA, pB;
+    pA.n = 2; pA.v[0] = p1; pA.v[1] = p2;
+    MW_UNROLL
+    for (int i = 2; i < TOI_MAX_VERTS; ++i) pA.v[i] = p1;
+    proxy_of_shape(pB, M.shape[shape_of_body(bi)]);
+    Sweep sA;
+    sA.lc = v2(0, 0); sA.c0 = v2(0, 0); sA.c = v2(0, 0); sA.a0 = 0.0f; sA.a = 0.0f; sA.alpha0 = 0.0f;
+    float beta;
+    const int state = time_of_impact(beta, pA, sA, pB, sB);
+    const float alpha0 = sB.alpha0;
+    return state == TOI_TOUCHING ? fminf(alpha0 + (1.0f - alpha0) * beta, 1.0f) : 1.0f;
+}
+// the same for dynamic pair p when one of its bodies is static (known-answer scene)
+MW_HD float toi_alpha_pair(const Model &M, const Hot &Wd, const Cold &Cd, int bA, int bB) {
+    Proxy pA, pB;
+    proxy_of_shape(pA, M.shape[shape_of_body(bA)]); proxy_of_shape(pB, M.shape[shape_of_body(bB)]);
+    Sweep sA = sweep_of_body(M, Wd, Cd, bA), sB = sweep_of_body(M, Wd, Cd, bB);
+    float alpha0 = sA.alpha0;
+    if (sA.alpha0 < sB.alpha0) { alpha0 = sB.alpha0; sweep_advance(sA, alpha0); }
+    else if (sB.alpha0 < sA.alpha0) { alpha0 = sA.alpha0; sweep_advance(sB, alpha0); }
+    float beta;
+    const int state = time_of_impact(beta, pA, sA, pB, sB);
+    return state == TOI_TOUCHING ? fminf(alpha0 + (1.0f - alpha0) * beta, 1.0f) : 1.0f;
+}
+// b2Contact::Update of a cached pair at the bodies' current poses: new manifold, impulses carried over by feature id,
+// Begin / EndContact; returns whether the pair touches.  bA < 0: terrain edge `sl.edge`.
+MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl, int bA, int bB, ManifoldOut &mo) {
+    mo.npts = 0;
+    const Shape &sB = M.shape[shape_of_body(bB)];
+    const Xf xfB = body_xf(M, Wd.b[bB], bB);
+    if (bA < 0) {
+        const int e = sl.edge;
+        const V2 p1 = v2(e * TERRAIN_STEP, Cd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
+        const bool has0 = e > 0, has3 = e < M.NT - 2;
+        const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Cd.ty[e - 1]) : p1;
+        const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Cd.ty[e + 2]) : p2;
+        collide_edge_polygon(mo, p1, p2, sB, xfB, has0, p0, has3, p3);
+    } else {
+        collide_polygons(mo, M.shape[shape_of_body(bA)], body_xf(M, Wd.b[bA], bA), sB, xfB);
+    }
+    float ni[2] = {0, 0}, ti[2] = {0, 0};
+    for (int i = 0; i < mo.npts; ++i)
+        for (int k = 0; k < sl.npts; ++k)
+            if (sl.id[k] == mo.id[i]) { ni[i] = sl.ni[k]; ti[i] = sl.ti[k]; break; }
+    const bool touching = mo.npts > 0;
+    if (touching != (sl.touching != 0)) contact_event(M, Wd, bA, bB, touching);
+    sl.touching = touching; sl.npts = (uint8_t)mo.npts;
+    for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
+    return touching;
+}
+// b2ContactSolver::SolveTOIPositionConstraints for one manifold: only the TOI body (B; A is static) moves
+MW_HD float contact_solve_toi_position(Hot &Wd, const Manifold &m, const MassAB &q) {
+    float min_sep = 0.0f;
+    const float mB = q.mB, iB = q.iB;
+    const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c;
+    const float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a;
+    V2 cB = Wd.b[m.bB].c;
+    float aB = Wd.b[m.bB].a;
+    MW_UNROLL
+    for (int i = 0; i < 2; ++i) if (i < m.npts) {
+        const Xf xfA = xf_from(cA, aA, q.lcA), xfB = xf_from(cB, aB, q.lcB);
+        V2 normal, point; float sep;
+        if (m.type == 0) {
+            normal = mul(xfA.q, m.local_normal);
+            const V2 plane = mul(xfA, m.local_point), clip = mul(xfB, m.lp[i]);
+            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+        } else {
+            normal = mul(xfB.q, m.local_normal);
+            const V2 plane = mul(xfB, m.local_point), clip = mul(xfA, m.lp[i]);
+            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+            normal = -normal;
+        }
+        const V2 rB = point - cB;
+        min_sep = fminf(min_sep, sep);
+        const float C = clampf(0.75f * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);  // b2_toiBaugarte
+        const float rnB = cross(rB, normal);
+        const float K = mB + iB * rnB * rnB;   // the static body contributes nothing
+        const float imp = K > 0.0f ? -C / K : 0.0f;
+        const V2 P = imp * normal;
+        cB = cB + mB * P; aB += iB * cross(rB, P);
+    }
+    Wd.b[m.bB].c = cB; Wd.b[m.bB].a = aB;
+    return min_sep;
+}
+
+constexpr int MAX_TOI_CONTACTS = 32;  // b2_maxTOIContacts
+constexpr int MAX_SUB_STEPS = 8;      // b2_maxSubSteps
+
+// (re)compute the invalidated times of impact of a body's terrain contacts and its earliest remaining event
+MW_HD void toi_refresh_body(const Model &M, const Hot &Wd, Cold &Cd, Scratch &S, int bi) {
+    const int base = M.slot_base[bi], cap = M.slot_cap[bi];
+    const Sweep sB = sweep_of_body(M, Wd, Cd, bi);
+    const Shape &sh = M.shape[shape_of_body(bi)];
+    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+    poly_aabb_at(sh, sB.c0, sB.a0, xmin, xmax, ymin, ymax);
+    poly_aabb_at(sh, sB.c, sB.a, xmin, xmax, ymin, ymax);
+    {
+        float r2 = 0.0f;
+        for (int i = 0; i < sh.n; ++i) { const V2 r = sh.v[i] - sh.centroid; r2 = fmaxf(r2, dot(r, r)); }
+        const float da = sB.a - sB.a0, mrg = sqrtf(r2) * da * da * 0.125f + LINEAR_SLOP;
+        xmin -= mrg; xmax += mrg; ymin -= mrg; ymax += mrg;
+    }
+    float body_min = 1.0f;
+    for (int k = 0; k < cap; ++k) {
+        Slot &sl = Cd.slot[base + k];
+        if (sl.edge < 0 || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS) continue;
+        if (!(sl.toi_flags & 1)) {
+            Cd.slot_toi[base + k] = toi_alpha_terrain(M, Wd, Cd, bi, sl.edge, sB, xmin, xmax, ymin, ymax);
+            sl.toi_flags |= 1;
+        }
+        body_min = fminf(body_min, Cd.slot_toi[base + k]);
+    }
+    S.body_minsep[bi] = body_min;
+}
+
+// b2World::SolveTOI.  `par`: the TOI of every candidate is computed by the lane that owns the body; the event loop itself
+// (rare: a body arriving at the terrain within this step) runs on lane 0 of the env.
+template <class Par>
+MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, float h) {
+    const int L0 = par.lane(), LN = par.n();
+    const int NB = M.NB, NDP = M.n_dyn_pairs;
+    // ---- pass 0 (by body): candidate contacts over the swept box (SynchronizeFixtures + FindNewContacts of the previous
+    // step, done here where the sweep is known), flags reset, first time-of-impact of every contact
+    for (int bi = L0; bi < NB; bi += LN) {
+        const Shape &sh = M.shape[shape_of_body(bi)];
+        S.body_minsep[bi] = 1.0f;
+        if (sh.inv_mass == 0.0f) continue;  // static body
+        const Sweep sB = sweep_of_body(M, Wd, Cd, bi);
+        float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+        poly_aabb_at(sh, sB.c0, sB.a0, xmin, xmax, ymin, ymax);
+        poly_aabb_at(sh, sB.c, sB.a, xmin, xmax, ymin, ymax);
+        {   // a vertex leaves the box of its two end poses by at most |r| (1 - cos(da / 2)) <= |r| da^2 / 8 in between
+            float r2 = 0.0f;
+            for (int i = 0; i < sh.n; ++i) { const V2 r = sh.v[i] - sh.centroid; r2 = fmaxf(r2, dot(r, r)); }
+            const float da = sB.a - sB.a0, mrg = sqrtf(r2) * da * da * 0.125f + LINEAR_SLOP;
+            xmin -= mrg; xmax += mrg; ymin -= mrg; ymax += mrg;
+        }
+        int e0 = (int)floorf((xmin - 0.1f) / TERRAIN_STEP), e1 = (int)floorf((xmax + 0.1f) / TERRAIN_STEP);  // b2_aabbExtension
+        if (e0 < 0) e0 = 0;
+        if (e1 > M.NT - 2) e1 = M.NT - 2;
+        Slot *slots = Cd.slot + M.slot_base[bi];
+        const int cap = M.slot_cap[bi];
+        for (int e = e0; e <= e1; ++e) {  // new candidates (not touching yet)
+            Slot &sl = slots[e % cap];
+            if (sl.edge < 0) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; }
+        }
+        float body_min = 1.0f;
+        for (int k = 0; k < cap; ++k) {
+            Slot &sl = slots[k];
+            sl.toi_flags = 0; sl.toi_count = 0;
+            if (sl.edge < 0) continue;
+            const float alpha = toi_alpha_terrain(M, Wd, Cd, bi, sl.edge, sB, xmin, xmax, ymin, ymax);
+            Cd.slot_toi[M.slot_base[bi] + k] = alpha;
+            sl.toi_flags = 1;
+            body_min = fminf(body_min, alpha);
+        }
+        S.body_minsep[bi] = body_min;  // (the array is free after the position iterations) earliest event of this body
+    }
+    for (int p = L0; p < NDP; p += LN) {
+        Slot &sl = Cd.slot[M.dyn_slot_base + p];
+        sl.toi_flags = 0; sl.toi_count = 0;
+        const int bA = M.dyn_a[p], bB = M.dyn_b[p];
+        const bool stA = M.shape[shape_of_body(bA)].inv_mass == 0.0f, stB = M.shape[shape_of_body(bB)].inv_mass == 0.0f;
+        if (stA == stB) continue;  // two dynamic (non-bullet) bodies: no continuous collision between them; two static: nothing moves
+        Cd.slot_toi[M.dyn_slot_base + p] = toi_alpha_pair(M, Wd, Cd, bA, bB);
+        sl.toi_flags = 1;
+    }
+    par.sync();
+    if (L0 != 0 || M.continuous == 2) { par.sync(); return; }   // continuous == 2: timing experiments only (candidates without events)
+    // ---- event loop (lane 0)
+    for (int guard = 0; guard < 4 * MAX_TOI_CONTACTS; ++guard) {
+        // the earliest event: per-body minima are kept in LDS (pass 0 / the end of the previous sub-step), only the winning
+        // body's slots are looked at in HBM
+        int min_slot = -1, min_bA = 0, min_bB = 0;
+        float min_alpha = 1.0f;
+        int min_body = -1;
+        for (int bi = 0; bi < NB; ++bi) { const float a = S.body_minsep[bi]; if (a < min_alpha) { min_alpha = a; min_body = bi; } }
+        if (min_body >= 0) {
+            const int base = M.slot_base[min_body], cap = M.slot_cap[min_body];
+            float best = 1.0f;
+            for (int k = 0; k < cap; ++k) {
+                const Slot &sl = Cd.slot[base + k];
+                if (sl.edge < 0 || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS || !(sl.toi_flags & 1)) continue;
+                const float alpha = Cd.slot_toi[base + k];
+                if (alpha < best) { best = alpha; min_slot = base + k; min_bA = -1; min_bB = min_body; }
+            }
+            min_alpha = best;
+        }
+        for (int p = 0; p < NDP; ++p) {
+            Slot &sl = Cd.slot[M.dyn_slot_base + p];
+            const int bA = M.dyn_a[p], bB = M.dyn_b[p];
+            const bool stA = M.shape[shape_of_body(bA)].inv_mass == 0.0f, stB = M.shape[shape_of_body(bB)].inv_mass == 0.0f;
+            if (stA == stB || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS) continue;
+            if (!(sl.toi_flags & 1)) { Cd.slot_toi[M.dyn_slot_base + p] = toi_alpha_pair(M, Wd, Cd, bA, bB); sl.toi_flags |= 1; }
+            const float alpha = Cd.slot_toi[M.dyn_slot_base + p];
+            if (alpha < min_alpha) { min_alpha = alpha; min_slot = M.dyn_slot_base + p; min_bA = bA; min_bB = bB; }
+        }
+        if (min_slot < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha) break;
+        // ---- advance the moving body of the event to the time of impact (b2Body::Advance)
+        const int mover = (min_bA >= 0 && M.shape[shape_of_body(min_bB)].inv_mass == 0.0f) ? min_bA : min_bB;  // the dynamic one
+        const V2 bk_c0 = Cd.sweep_c0[mover], bk_c = Wd.b[mover].c;
+        const float bk_a0 = Cd.sweep_a0[mover], bk_a = Wd.b[mover].a, bk_alpha0 = Cd.sweep_alpha0[mover];
+        {
+            Sweep sw = sweep_of_body(M, Wd, Cd, mover);
+            sweep_advance(sw, min_alpha);
+            Cd.sweep_c0[mover] = sw.c0; Cd.sweep_a0[mover] = sw.a0; Cd.sweep_alpha0[mover] = sw.alpha0;
+            Wd.b[mover].c = sw.c0; Wd.b[mover].a = sw.a0;
+        }
+        Slot &ms = Cd.slot[min_slot];
+        ManifoldOut mo;
+        const bool touching = toi_update_contact(M, Wd, Cd, ms, min_bA, min_bB, mo);
+        ms.toi_flags &= (uint8_t)~1u;
+        ms.toi_count = (uint8_t)(ms.toi_count + 1);
+        MW_STAT(toi_events, 1);
+        if (!touching) {  // not solid after all: undo, and leave this contact alone for the rest of the step
+            MW_STAT(toi_undone, 1);
+            ms.toi_flags |= 2;
+            Cd.sweep_c0[mover] = bk_c0; Cd.sweep_a0[mover] = bk_a0; Cd.sweep_alpha0[mover] = bk_alpha0;
+            Wd.b[mover].c = bk_c; Wd.b[mover].a = bk_a;
+            toi_refresh_body(M, Wd, Cd, S, mover);
+            continue;
+        }
+        // ---- mini island: the event's contact and the mover's other touching contacts with static bodies
+        int n_isl = 0;
+        auto add_manifold = [&](const ManifoldOut &o, int bA, int bB, int slot_index, float friction) {
+            if (n_isl >= MAX_TOI_CONTACTS || n_isl >= M.max_manifolds) return;
+            Manifold &m = S.m[n_isl++];
+            m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)o.npts; m.type = (uint8_t)o.type;
+            m.local_normal = o.local_normal; m.local_point = o.local_point;
+            for (int i = 0; i < 2; ++i) { m.lp[i] = i < o.npts ? o.lp[i] : v2(0, 0); m.ni[i] = 0.0f; m.ti[i] = 0.0f; }  // no warm starting
+            m.friction = friction;
+        };
+        const Shape &msh = M.shape[shape_of_body(mover)];
+        if (min_bA < 0) add_manifold(mo, -1, mover, min_slot, sqrtf(FRICTION * msh.friction));
+        else add_manifold(mo, min_bA, min_bB, min_slot, sqrtf(M.shape[shape_of_body(min_bA)].friction * M.shape[shape_of_body(min_bB)].friction));
+        {
+            const int base = M.slot_base[mover], cap = M.slot_cap[mover];
+            float mv_x0 = 3.0e38f, mv_x1 = -3.0e38f, mv_y0 = 3.0e38f, mv_y1 = -3.0e38f;
+            poly_aabb_at(msh, Wd.b[mover].c, Wd.b[mover].a, mv_x0, mv_x1, mv_y0, mv_y1);
+            for (int k = 0; k < cap; ++k) {
+                Slot &sl = Cd.slot[base + k];
+                if (base + k == min_slot || sl.edge < 0) continue;
+                if (!sl.touching) {  // an edge the body's box (at the time of impact) does not reach cannot start touching: nothing to update
+                    const float ex0 = sl.edge * TERRAIN_STEP, ex1 = (sl.edge + 1) * TERRAIN_STEP;
+                    const float ey0 = fminf(Cd.ty[sl.edge], Cd.ty[sl.edge + 1]), ey1 = fmaxf(Cd.ty[sl.edge], Cd.ty[sl.edge + 1]);
+                    const float mg = 4.0f * POLY_RADIUS;
+                    if (mv_x0 - mg > ex1 || mv_x1 + mg < ex0 || mv_y0 - mg > ey1 || mv_y1 + mg < ey0) continue;
+                }
+                ManifoldOut o2;
+                if (toi_update_contact(M, Wd, Cd, sl, -1, mover, o2)) add_manifold(o2, -1, mover, base + k, sqrtf(FRICTION * msh.friction));
+            }
+        }
+        // ---- b2Island::SolveTOI
+        const MassAB qm = mass_of_pair(S, -1, mover);  // the static side carries no mass whichever slot it sits in
+        auto mass_for = [&](const Manifold &m) -> MassAB {
+            MassAB q = mass_of_pair(S, m.bA, m.bB);
+            if (m.bA >= 0 && m.bA != mover) { q.mA = 0.0f; q.iA = 0.0f; }
+            return q;
+        };
+        (void)qm;
+        for (int it = 0; it < 20; ++it) {
+            float ms_min = 0.0f;
+            for (int k = 0; k < n_isl; ++k) {
+                const Manifold &m = S.m[k];
+                if (m.bB == mover) ms_min = fminf(ms_min, contact_solve_toi_position(Wd, m, mass_for(m)));
+            }
+            if (ms_min >= -1.5f * LINEAR_SLOP) break;
+        }
+        Cd.sweep_c0[mover] = Wd.b[mover].c; Cd.sweep_a0[mover] = Wd.b[mover].a;  // "leap of faith to new safe state"
+        for (int k = 0; k < n_isl; ++k) contact_init_warm(Wd, S.m[k], mass_for(S.m[k]));  // impulses are zero: no warm start
+        {
+            // Box2D runs all the step's velocity iterations; once a whole sweep leaves every accumulated impulse and the body's
+            // velocity exactly unchanged, every further sweep is the same no-op, so stopping there changes no bit of the result.
+            // The moving body's velocity stays in registers over the sweeps (the static side never changes).
+            V2 vB = Wd.b[mover].v, vA = v2(0, 0);
+            float wB = Wd.b[mover].w, wA = 0.0f;
+            // The sweep is a deterministic map of (velocity, accumulated impulses).  Besides the exact fixed point it often ends in a
+            // short cycle (impulses flipping in their last bits): once state(i) == state(i - p), p <= 4, the state after the last of
+            // the VEL_ITERS sweeps is known without running them.  History kept for islands of at most two manifolds.
+            constexpr int NST = 3 + 4 * 2;
+            float h1[NST], h2[NST], h3[NST], h4[NST];  // states after sweeps i - 1 .. i - 4
+            for (int q = 0; q < NST; ++q) { h1[q] = 0.0f; h2[q] = 0.0f; h3[q] = 0.0f; h4[q] = 0.0f; }
+            const bool track = n_isl <= 2;
+            auto snapshot = [&](float *st) {
+                st[0] = vB.x; st[1] = vB.y; st[2] = wB;
+                for (int k = 0; k < 2; ++k) {
+                    const bool on = k < n_isl;
+                    st[3 + 4 * k] = on ? S.m[k].ni[0] : 0.0f; st[4 + 4 * k] = on ? S.m[k].ni[1] : 0.0f;
+                    st[5 + 4 * k] = on ? S.m[k].ti[0] : 0.0f; st[6 + 4 * k] = on ? S.m[k].ti[1] : 0.0f;
+                }
+            };
+            auto restore = [&](const float *st) {
+                vB.x = st[0]; vB.y = st[1]; wB = st[2];
+                for (int k = 0; k < 2; ++k) if (k < n_isl) { S.m[k].ni[0] = st[3 + 4 * k]; S.m[k].ni[1] = st[4 + 4 * k]; S.m[k].ti[0] = st[5 + 4 * k]; S.m[k].ti[1] = st[6 + 4 * k]; }
+            };
+            for (int it = 0; it < VEL_ITERS; ++it) {
+                MW_STAT(toi_vel_iters, 1);
+                for (int k = 0; k < n_isl; ++k) {
+                    Manifold &m = S.m[k];
+                    if (m.bB == mover) contact_solve_velocity_on(m, mass_for(m), vA, wA, vB, wB);
+                    else { V2 z = v2(0, 0); float zw = 0.0f; contact_solve_velocity_on(m, mass_for(m), vB, wB, z, zw); }  // the mover is body A (known-answer scene only)
+                }
+                if (!track) { if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1); continue; }
+                float cur[NST];
+                snapshot(cur);
+                bool same1 = it >= 1, same2 = it >= 2, same3 = it >= 3, same4 = it >= 4;
+                for (int q = 0; q < NST; ++q) {
+                    same1 = same1 && cur[q] == h1[q]; same2 = same2 && cur[q] == h2[q]; same3 = same3 && cur[q] == h3[q]; same4 = same4 && cur[q] == h4[q];
+                }
+                if (same1) { MW_STAT(toi_hist[it / 20], 1); break; }   // fixed point: every further sweep is a no-op
+                const int period = same2 ? 2 : (same3 ? 3 : (same4 ? 4 : 0));
+                if (period != 0) {  // state(j + period) = state(j) from here on; `left` sweeps remain: state(last) = state(it - period + left % period)
+                    MW_STAT(toi_hist[8], 1);
+                    const int left = (VEL_ITERS - 1 - it) % period;   // 0: cur
+                    const int back = left == 0 ? 0 : period - left;    // the wanted state lies `back` sweeps before cur
+                    if (back == 1) restore(h1); else if (back == 2) restore(h2); else if (back == 3) restore(h3);
+                    break;
+                }
+                if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1);
+                for (int q = 0; q < NST; ++q) { h4[q] = h3[q]; h3[q] = h2[q]; h2[q] = h1[q]; h1[q] = cur[q]; }
+            }
+            MW_STAT(toi_nisl[n_isl < 5 ? n_isl : 5], 1);
+            Wd.b[mover].v = vB; Wd.b[mover].w = wB;
+        }
+        {   // integrate the rest of the step
+            const float hs = (1.0f - min_alpha) * h;
+            Body &b = Wd.b[mover];
+            const V2 tr = hs * b.v;
+            if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) { const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr)); b.v = ratio * b.v; }
+            const float ro = hs * b.w;
+            if (ro * ro > MAX_ROTATION * MAX_ROTATION) { const float ratio = MAX_ROTATION / fabsf(ro); b.w *= ratio; }
+            b.c = b.c + hs * b.v;
+            b.a += hs * b.w;
+        }
+        // the displaced body's cached times of impact are stale; its candidate set follows its new sweep (FindNewContacts)
+        {
+            const int base = M.slot_base[mover], cap = M.slot_cap[mover];
+            for (int k = 0; k < cap; ++k) Cd.slot[base + k].toi_flags &= (uint8_t)~1u;
+            float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+            poly_aabb_at(msh, Cd.sweep_c0[mover], Cd.sweep_a0[mover], xmin, xmax, ymin, ymax);
+            poly_aabb_at(msh, Wd.b[mover].c, Wd.b[mover].a, xmin, xmax, ymin, ymax);
+            int e0 = (int)floorf((xmin - 0.1f) / TERRAIN_STEP), e1 = (int)floorf((xmax + 0.1f) / TERRAIN_STEP);
+            if (e0 < 0) e0 = 0;
+            if (e1 > M.NT - 2) e1 = M.NT - 2;
+            for (int e = e0; e <= e1; ++e) {
+                Slot &sl = Cd.slot[base + e % cap];
+                if (sl.edge < 0) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.toi_flags = 0; sl.toi_count = 0; }
+            }
+            for (int p = 0; p < NDP; ++p) if (M.dyn_a[p] == mover || M.dyn_b[p] == mover) Cd.slot[M.dyn_slot_base + p].toi_flags &= (uint8_t)~1u;
+            toi_refresh_body(M, Wd, Cd, S, mover);
+        }
+    }
+    par.sync();
 }
 
 // b2World::Step(1/50, 180, 60) for the lanes of `par`.
@@ -1156,6 +1562,7 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
         if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) { const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr)); b.v = ratio * b.v; }
         const float ro = h * b.w;
         if (ro * ro > MAX_ROTATION * MAX_ROTATION) { const float ratio = MAX_ROTATION / fabsf(ro); b.w *= ratio; }
+        Cd.sweep_c0[bi] = b.c; Cd.sweep_a0[bi] = b.a; Cd.sweep_alpha0[bi] = 0.0f;  // b2Island::Solve: sweep.c0 / a0 = the pose at the start of the step
         b.c = b.c + h * b.v;
         b.a += h * b.w;
     }
@@ -1209,6 +1616,8 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
         for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
     }
     par.sync();
+    // ---- continuous pass (b2World::Step: "if (m_continuousPhysics && step.dt > 0) SolveTOI(step)")
+    if (M.continuous) solve_toi(M, Wd, Cd, S, par, h);
 }
 #undef MW_CONTACT_SWEEP
 #undef MW_MANIFOLD_DO

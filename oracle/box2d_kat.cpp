@@ -24,7 +24,7 @@ extern "C" int b2kat_falling_box(float *xya, int steps) {
     static World Wd;
     static Scratch S;
     std::memset(&M, 0, sizeof(M)); std::memset(&Wd, 0, sizeof(Wd)); std::memset(&S, 0, sizeof(S));
-    M.W = 0; M.NB = 2; M.NJ = 0; M.NT = 2; M.max_manifolds = MAXM;
+    M.W = 0; M.NB = 2; M.NJ = 0; M.NT = 2; M.max_manifolds = MAXM; M.continuous = 1;
     const V2 p[4] = {v2(-1, -1), v2(1, -1), v2(1, 1), v2(-1, 1)};  // SetAsBox(1, 1), density 1, friction 0.3
     poly_set(M.shape[SH_PACKAGE], p, 4);
     poly_mass(M.shape[SH_PACKAGE], 1.0f);

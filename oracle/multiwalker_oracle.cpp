@@ -27,6 +27,7 @@ extern "C" {
 
 int mwo_obs_dim(const MwOracle *o) { return mw::obs_dim_of(o->C); }
 void mwo_set_one_hot(MwOracle *o, int one_hot) { o->C.one_hot = one_hot ? 1 : 0; }
+void mwo_set_continuous(MwOracle *o, int on) { o->M.continuous = on ? 1 : 0; }  /* b2World continuousPhysics: experiments only */
 int mwo_world_bytes(void) { return (int)sizeof(mw::World); }
 
 MwOracle *mwo_create(int n_walkers, int reward_global, int terminate_on_fall, float position_noise, float angle_noise,

@@ -27,7 +27,13 @@ int main() {
             }
         }
         const double s = (double)g_stats.steps;
-        printf("W=%d steps=%ld  subslots A %.2f B %.2f  manifolds %.2f  merged %.2f  position iterations %.2f\n", W, g_stats.steps,
-               g_stats.sub_a / s, g_stats.sub_b / s, g_stats.manifolds / s, g_stats.merged / s, g_stats.pos_iters / s);
+        printf("W=%d steps=%ld  subslots A %.2f B %.2f  manifolds %.2f  merged %.2f  position iterations %.2f | TOI per step: full %.2f culled %.2f events %.3f undone %.3f velocity sweeps per event %.1f\n", W, g_stats.steps,
+               g_stats.sub_a / s, g_stats.sub_b / s, g_stats.manifolds / s, g_stats.merged / s, g_stats.pos_iters / s,
+               g_stats.toi_full / s, g_stats.toi_culled / s, g_stats.toi_events / s, g_stats.toi_undone / s, g_stats.toi_events ? (double)g_stats.toi_vel_iters / g_stats.toi_events : 0.0);
+        printf("    sweeps until the fixed point, buckets of 20 (last = never): ");
+        for (int i = 0; i < 10; ++i) printf("%ld ", g_stats.toi_hist[i]);
+        printf(" | island manifolds 0..5+: ");
+        for (int i = 0; i < 6; ++i) printf("%ld ", g_stats.toi_nisl[i]);
+        printf("\n");
     }
 }

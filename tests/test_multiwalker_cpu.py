@@ -68,6 +68,7 @@ def test_constraints_hold_under_random_actions():
     o.reset()
     rng = np.random.RandomState(0)
     max_v = 0.0
+    knee_over, anchor_gaps = [], []
     for t in range(150):
         obs, rew, done = o.step(rng.uniform(-1, 1, (8, 3, 4)))
         b, f = o.bodies()
@@ -78,7 +79,11 @@ def test_constraints_hold_under_random_actions():
         knee = obs[..., [6, 11]] - 1.0
         # limits are enforced from the step AFTER the crossing (b2RevoluteJoint sets its limit state at the start of a step): one step of overshoot is legal
         assert (hip > -0.8 - 0.4).all() and (hip < 1.1 + 0.4).all(), (hip.min(), hip.max())
-        assert (knee > -1.6 - 0.4).all() and (knee < -0.1 + 0.4).all(), (knee.min(), knee.max())
+        # knees: a lower leg that hits the terrain is moved by the continuous (TOI) sub-step, whose island holds contacts only
+        # -- Box2D solves no joints there (b2Island::SolveTOI) -- so a hard foot strike may leave the knee beyond its limit
+        # until the next step's joint position correction: bounded absolutely, rare beyond 0.4 rad
+        assert (knee > -1.6 - 1.5).all() and (knee < -0.1 + 1.5).all(), (knee.min(), knee.max())
+        knee_over.append(np.maximum(knee - (-0.1), -1.6 - knee).clip(0))
         # hip anchor: hull origin + R(hull) (0, LEG_DOWN)  ==  upper-leg centre + R(leg) (0, LEG_H / 2)
         for w in range(3):
             hull, up = b[:, 1 + 5 * w], b[:, 2 + 5 * w]
@@ -86,10 +91,16 @@ def test_constraints_hold_under_random_actions():
             lo = b[:, 3 + 5 * w]
             a_up = up[:, :2] + np.stack([np.sin(up[:, 2]) * (LEG_H / 2), -np.cos(up[:, 2]) * (LEG_H / 2)], 1)   # bottom of upper leg
             a_lo = lo[:, :2] + np.stack([-np.sin(lo[:, 2]) * (LEG_H / 2), np.cos(lo[:, 2]) * (LEG_H / 2)], 1)  # top of lower leg
-            assert np.abs(a_up - a_lo).max() < 0.03, np.abs(a_up - a_lo).max()
+            # "Continuous collision does not handle joints ... you may see joint stretching on fast moving objects" (Box2D manual):
+            # the TOI sub-step of a foot strike moves the lower leg alone; the joint is pulled together again over the next steps
+            gap = np.abs(a_up - a_lo).max(axis=1)
+            assert gap.max() < 0.6, gap.max()
+            anchor_gaps.append(gap)
         if done.any():
             o.reset(mask=done)
     assert max_v < 30.0
+    assert (np.stack(knee_over) > 0.4).mean() < 0.02
+    assert (np.concatenate(anchor_gaps) > 0.03).mean() < 0.15 and np.median(np.concatenate(anchor_gaps)) < 0.01
     ty = o.terrain()
     b, f = o.bodies()
     # lower legs do not sink below the terrain by more than a few slops
@@ -159,8 +170,8 @@ def test_box2d_helloworld_known_answer():
     y = 4 onto static ground, 60 steps of 1/60 s, 6/2 iterations, printed "%4.2f %4.2f %4.2f"):
         0.00 4.00 0.00 / 0.00 3.99 0.00 / 0.00 3.98 0.00 / ... / 0.00 1.25 0.00 / 0.00 1.13 0.00 / 0.00 1.01 0.00
     replayed through the env's own world_step (oracle/box2d_kat.cpp).  Steps 44-46 are the three tail lines: the box
-    would reach y = 0.997 at step 46; Box2D's continuous (TOI) pass stops it at the surface (1.01).  This solver has no
-    TOI pass: it penetrates for one step (prints 1.00) and is at the published 1.01 from step 48 on."""
+    would reach y = 0.997 at step 46; the continuous (TOI) pass stops it at the surface and its sub-step leaves it at the
+    published 1.01.  All six published lines are asserted."""
     import ctypes
     import os
     so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libmadrl_b2kat.so")
@@ -173,7 +184,7 @@ def test_box2d_helloworld_known_answer():
     line = lambda i: ("%4.2f %4.2f %4.2f" % tuple(out[i - 1])).replace("-0.00", "0.00")
     assert [line(1), line(2), line(3)] == ["0.00 4.00 0.00", "0.00 3.99 0.00", "0.00 3.98 0.00"]
     assert [line(44), line(45)] == ["0.00 1.25 0.00", "0.00 1.13 0.00"]
-    assert line(46) in ("0.00 1.00 0.00", "0.00 1.01 0.00")          # no-TOI deviation, one step
-    assert all(line(i) == "0.00 1.01 0.00" for i in range(48, 61))   # the published resting line
+    assert line(46) == "0.00 1.01 0.00"                              # the sixth published line: needs the continuous pass
+    assert all(line(i) == "0.00 1.01 0.00" for i in range(46, 61))   # ... and the box rests there
     # the resting height approaches polygonRadius * 2 - linearSlop = 0.015 above the surface from below, like Box2D's solver
     assert 1.0135 < out[59, 1] < 1.015 and abs(out[59, 2]) < 1e-3

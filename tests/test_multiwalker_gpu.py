@@ -91,7 +91,8 @@ def test_full_batch_invariants_c4():
     # bounded loosely, the bulk tightly
     assert (hip.abs() < 3.2).all() and (knee.abs() < 3.2).all()
     inside = ((hip > -0.8 - 0.3) & (hip < 1.1 + 0.3)).float().mean(), ((knee > -1.6 - 0.3) & (knee < -0.1 + 0.3)).float().mean()
-    assert inside[0] > 0.999 and inside[1] > 0.999, inside
+    # knees: a hard foot strike is resolved by the continuous (TOI) sub-step, which solves no joints (b2Island::SolveTOI)
+    assert inside[0] > 0.999 and inside[1] > 0.98, inside
     assert n_done > 0                                              # random flailing makes some walkers fall
 
 
