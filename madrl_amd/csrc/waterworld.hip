@@ -92,7 +92,9 @@ __device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) 
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 // TNp..TK > 0: the particle / sensor counts are compile-time constants (loops unroll, the index divisions fold); 0: generic.
-template <int MODE, int TNp, int TNe, int TNpo, int TK>
+// FUSED: the StandardizedEnv epilogue (WwStd) is compiled in; a template parameter because its float64 code would otherwise cost the
+// plain kernel a wavefront per SIMD (132 instead of 119 VGPRs: 96 instead of 78 us per step)
+template <int MODE, int TNp, int TNe, int TNpo, int TK, bool FUSED = false>
 __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwIO io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 // ---------------------------------------------------- outputs
                 if (MODE == 1 && !do_init) {
                     if (lane < Np) io.rew[env * Np + lane] = reward;
-                    if (io.st != nullptr && io.st->rew_out != nullptr && lane < Np) {  // StandardizedEnv.step :283-291
+                    if (FUSED && io.st->rew_out != nullptr && lane < Np) {  // StandardizedEnv.step :283-291
                         const WwStd &st = *io.st;
                         const int64_t i = env * Np + lane;
                         double r = (double)reward;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
 #endif
                     if (io.obs != nullptr)   // the raw row may be dropped when the fused wrapper output is all the caller reads
                     for (int e = lane; e < Np * D; e += 64) orow[e] = O[e];
-                    if (io.st != nullptr && io.st->obs_out != nullptr) {  // StandardizedEnv.standardize_obs :242-263
+                    if (FUSED) {  // StandardizedEnv.standardize_obs :242-263
                         const WwStd &st = *io.st;
                         const int64_t base = env * (int64_t)(Np * D);
                         if (st.enable_obsnorm) {
@@ -598,13 +600,16 @@ int ww_launch(const madrl_waterworld *h, const WwIO &io, int mode, void *stream)
     hipStream_t s = (hipStream_t)stream;
     const WwDev &d = h->dev;
     const bool c3 = d.Np == 5 && d.Ne == 10 && d.Npo == 10 && d.K == 30;  // BASELINE configs[2]: MAWaterWorld(5, 10), 30 sensors
-    if (mode == 0) {
-        if (c3) hipLaunchKernelGGL((waterworld_kernel<0, 5, 10, 10, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
-        else hipLaunchKernelGGL((waterworld_kernel<0, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
-    } else {
-        if (c3) hipLaunchKernelGGL((waterworld_kernel<1, 5, 10, 10, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
-        else hipLaunchKernelGGL((waterworld_kernel<1, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
-    }
+    const dim3 g((unsigned)blocks), b(64);
+    const bool fused = io.st != nullptr;
+#define WW_LAUNCH(MODE_, FUSED_)                                                                                                   \
+    do {                                                                                                                          \
+        if (c3) hipLaunchKernelGGL((waterworld_kernel<MODE_, 5, 10, 10, 30, FUSED_>), g, b, h->lds_bytes, s, h->dev, io);         \
+        else hipLaunchKernelGGL((waterworld_kernel<MODE_, 0, 0, 0, 0, FUSED_>), g, b, h->lds_bytes, s, h->dev, io);               \
+    } while (0)
+    if (mode == 0) { if (fused) WW_LAUNCH(0, true); else WW_LAUNCH(0, false); }
+    else { if (fused) WW_LAUNCH(1, true); else WW_LAUNCH(1, false); }
+#undef WW_LAUNCH
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }
