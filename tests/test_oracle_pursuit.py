@@ -97,3 +97,45 @@ def test_oracle_free_running_is_deterministic_and_seed_sensitive():
         outs.append(o.get_state()["pos_e"].copy())
     assert np.array_equal(outs[0], outs[1])
     assert not np.array_equal(outs[0], outs[2])
+
+
+def test_free_running_reset_samples_the_reference_distribution():
+    """The free-running reset (own Philox draws) against the UNMODIFIED reference's reset() distribution with a constraint window of
+    0.5 and a sampled 10-map pool (tests/golden/pursuit_reset_hist.npz, 40 000 reference resets, oracle/make_golden_reset_hist.py).
+    Agents of one reset share its window, so only ONE position per reset enters each chi-square (agent indices 0, 7, 8, 37, pooled over
+    the maps: independent samples); the map choice is tested the same way; the all-agent histograms are checked for support only.
+    The HIP kernels are bit-identical to this oracle in free-running mode (tests/test_pursuit_gpu.py cases `pool16`, `tiny_window`)."""
+    import os
+    from oracle import pursuit as po
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pursuit_reset_hist.npz"))
+    maps = [m.astype(np.int32) for m in g["maps"]]
+    P, E = int(g["n_pursuers"]), int(g["n_evaders"])
+    N = 40000
+    orc = po.PursuitOracle(maps, n_envs=N, seed=7, n_pursuers=P, n_evaders=E, obs_range=7, constraint_window=float(g["constraint_window"]),
+                           sample_maps=True)
+    orc.reset()
+    st = orc.get_state()
+    pos = np.concatenate([st["pos_p"], st["pos_e"]], axis=1)   # [N, P + E, 2]
+    cell = pos[..., 0].astype(np.int64) * 16 + pos[..., 1]
+    nmap = np.bincount(st["map_id"], minlength=len(maps))
+
+    def two_sample_chi2(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        keep = (a + b) >= 10
+        A, B = a[keep].sum(), b[keep].sum()
+        stat = (((a[keep] * np.sqrt(B / A) - b[keep] * np.sqrt(A / B)) ** 2) / (a[keep] + b[keep])).sum()
+        return stat, int(keep.sum()) - 1
+
+    stat, dof = two_sample_chi2(nmap, g["nmap"])
+    assert abs(stat - dof) < 6 * np.sqrt(2 * dof), ("map choice", stat, dof)
+    for k, agent in enumerate(g["agents"]):
+        mine = np.bincount(cell[:, int(agent)], minlength=256)
+        stat, dof = two_sample_chi2(mine, g["one"][k])
+        assert dof > 150 and abs(stat - dof) < 6 * np.sqrt(2 * dof), ("agent %d" % agent, stat, dof)
+    hist = np.zeros_like(g["hist"])
+    np.add.at(hist, (np.repeat(st["map_id"], cell.shape[1]), cell.ravel()), 1)
+    for m in range(len(maps)):  # same support on every map: nobody inside a building, every free cell reachable
+        assert np.array_equal(hist[m] > 0, g["hist"][m] > 0) and (hist[m][maps[m].ravel() == -1] == 0).all()
+    # the window makes the distribution non-uniform (cells near the middle are covered by more windows): the test has power
+    flat = g["one"].sum(0).astype(np.float64)
+    assert flat.max() > 1.5 * flat[flat > 0].min()
