@@ -897,7 +897,10 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         const int need_words = ((int)cells + 3) / 4;
         const int fstride = g.GSZ + need_words;
         const size_t w_codes = (size_t)fstride * d.n_maps;
-        std::vector<uint32_t> wh(w_codes + d.D, 0u);
+        // after the maps: slot codes [D] | empty count layer [GSZ] | per-thread slot table [NS][6][NT]
+        const int NT = 64 * g.waves, DV = d.D / 4, NQ = d.P * DV, NS = (NQ + NT - 1) / NT;
+        const size_t w_tmpl = w_codes + (size_t)d.D, w_slots = w_tmpl + (size_t)g.GSZ;
+        std::vector<uint32_t> wh(w_slots + (size_t)NS * 6 * NT, 0u);
         const float wallv = (float)1 / (float)cfg->layer_norm;  // |-1| / layer_norm in float32
         uint32_t wall_bits, fill_bits;
         memcpy(&wall_bits, &wallv, 4);
@@ -935,6 +938,23 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         }
         for (int r = 0; r < d.D; ++r)  // the kernel assumes only element 3 of a float4 can be absolute
             if ((r & 3) != 3 && !(wc[r] >> 31)) eligible = false;
+        for (int k = 0; k < g.GSZ; ++k) {
+            const int gx = k / g.GW - g.PAD, gy = k % g.GW - g.PAD;
+            wh[w_tmpl + k] = (gx >= 0 && gx < xs && gy >= 0 && gy < ys) ? 0u : pw::SENT;
+        }
+        for (int sl = 0; sl < NS; ++sl)
+            for (int t = 0; t < NT; ++t) {
+                const int q = t + NT * sl, pidx = q / DV, f = q % DV;
+                uint32_t *row = wh.data() + w_slots + (size_t)sl * 6 * NT + t;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = (q < NQ) ? wc[4 * f + k] : (k == 3 ? (uint32_t)g.X_SKIP : 0u);
+                    uint32_t cst = c & 0x7FFFFFFFu;
+                    if ((int)cst >= g.X_ID && (int)cst < g.X_ID + d.P) cst = (uint32_t)(g.X_ID + pidx);  // this pursuer's id cell
+                    row[(size_t)NT * k] = cst;
+                    if (k == 3) row[(size_t)NT * 4] = c >> 31;
+                }
+                row[(size_t)NT * 5] = (uint32_t)(q < NQ ? pidx : 0);
+            }
         if (eligible) {
             const size_t wbytes = wh.size() * sizeof(uint32_t);
             e = hipMalloc(&h->wtables, wbytes);
@@ -957,6 +977,8 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             w.fmaps = reinterpret_cast<const uint32_t *>(h->wtables);
             w.vtab = d.vtab;
             w.codes = reinterpret_cast<const uint32_t *>(h->wtables) + w_codes;
+            w.cnt_tmpl = reinterpret_cast<const uint32_t *>(h->wtables) + w_tmpl;
+            w.slot_tab = reinterpret_cast<const uint32_t *>(h->wtables) + w_slots;
             w.state = d.state;
             e = hipMalloc(&h->zmask, (size_t)d.n_envs * 256 * g.waves);
             if (e != hipSuccess) {

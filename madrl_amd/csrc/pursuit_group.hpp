@@ -80,10 +80,10 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
     const int eslot = tid - P;
 
     // ---------------------------------------------------------------- once per workgroup
-    for (int k = tid; k < 2 * GSZ; k += NT) {
-        const int c = k % GSZ;
-        const int gx = c / GW - PAD, gy = c % GW - PAD;
-        L[GSZ + k] = (gx >= 0 && gx < S::XS && gy >= 0 && gy < S::YS) ? 0u : SENT;
+    for (int k = tid; k < GSZ; k += NT) {  // count layers: 0 inside the map, SENT outside
+        const uint32_t v = d.cnt_tmpl[k];
+        L[GSZ + k] = v;
+        L[2 * GSZ + k] = v;
     }
     if (tid == 0) {
         L[S::X_FILL] = d.fmaps[0];
@@ -96,17 +96,11 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
     int s_org[NS];    // LDS index of the owning pursuer's window origin
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int q = tid + NT * s;
-        const int pidx = q / S::DV, f = q % S::DV;
-        s_org[s] = S::X_ORG + (q < S::NQ ? pidx : 0);
+        const uint32_t *t = d.slot_tab + s * 6 * NT + tid;  // host-built (pursuit.hip), see WaveDev
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t c = (q < S::NQ) ? d.codes[4 * f + k] : (k == 3 ? (uint32_t)S::X_SKIP : 0u);
-            int cst = (int)(c & 0x7FFFFFFFu);
-            if (cst >= S::X_ID && cst < S::X_ID + P) cst = S::X_ID + pidx;
-            s_cst[s][k] = cst;
-            if (k == 3) s_rel3[s] = (int)(c >> 31);
-        }
+        for (int k = 0; k < 4; ++k) s_cst[s][k] = (int)t[NT * k];
+        s_rel3[s] = (int)t[NT * 4];
+        s_org[s] = S::X_ORG + (int)t[NT * 5];
     }
     int cached_map = -1;
     const uint8_t *need_tab = reinterpret_cast<const uint8_t *>(&L[S::X_NEED]);

@@ -55,6 +55,10 @@ struct WaveDev {
     const uint32_t *fmaps;   // per map: padded float layer [GSZ] then need_to_surround [XS*YS] as u32
     const float *vtab;       // fl32(k / layer_norm), k = 0..255
     const uint32_t *codes;   // D entries: bit31 = relative to window origin, low bits = dword offset
+    // Host-built launch constants, so that the per-workgroup preamble is loads, not index arithmetic (every resident wavefront
+    // runs it at the same moment, 2.8 us of a 78 us launch when it was computed in the kernel):
+    const uint32_t *cnt_tmpl;  // [GSZ] an empty count layer: 0 inside the map, SENT outside
+    const uint32_t *slot_tab;  // [NS][6][NT] per thread and float4 slot: 4 cell offsets, element-3-is-relative flag, owning pursuer
     uint8_t *state;
     uint32_t *zmask;         // [n_envs][64]: per lane, which of its observation cells hold a NON-ZERO stale value (see "stale-zero mask")
 };
@@ -179,6 +183,10 @@ __device__ __forceinline__ void put_zero_from(uint32_t &w) {
 #ifndef MADRL_ABLATE
 #define MADRL_ABLATE 0
 #endif
+// Experiments (same rules): 1 record / mask / reward stores non-temporal   2 first record fetched before the LDS preamble
+#ifndef MADRL_PW_EXP
+#define MADRL_PW_EXP 0
+#endif
 
 // Stale-zero mask (quirk Q2).  A cell of channel 1 / 2 outside the map is not written: it keeps the value of the last time it
 // was inside.  A float4 slot that mixes written and unwritten cells becomes a partial store, which the memory side turns into
@@ -202,11 +210,26 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     const bool is_p = lane < P;
     const int eslot = lane - P;
 
+#if MADRL_PW_EXP & 4
+    if (d.n_envs > 0) return;
+#endif
+#if MADRL_PW_EXP & 2
+    uint32_t pre_rec = 0, pre_zm = 0xFFFFFFFFu;
+    int pre_act = 4;
+    {
+        const int64_t e0 = d.reverse ? d.n_envs - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
+        if ((int64_t)blockIdx.x < d.n_envs) {
+            pre_rec = (lane < S::REC_DW) ? reinterpret_cast<const uint32_t *>(d.state + e0 * (int64_t)S::REC_BYTES)[lane] : 0u;
+            if constexpr (MODE == 1) pre_act = lane < P ? io.actions[e0 * P + lane] : 4;
+            pre_zm = d.zmask[e0 * 64 + lane];
+        }
+    }
+#endif
     // ---------------------------------------------------------------- once per workgroup
-    for (int k = lane; k < 2 * GSZ; k += 64) {  // count layers: 0 inside the map, SENT outside
-        const int c = k % GSZ;
-        const int gx = c / GW - PAD, gy = c % GW - PAD;
-        L[GSZ + k] = (gx >= 0 && gx < S::XS && gy >= 0 && gy < S::YS) ? 0u : SENT;
+    for (int k = lane; k < GSZ; k += 64) {  // count layers: 0 inside the map, SENT outside
+        const uint32_t v = d.cnt_tmpl[k];
+        L[GSZ + k] = v;
+        L[2 * GSZ + k] = v;
     }
     if (lane == 0) {
         L[S::X_FILL] = d.fmaps[0];  // a corner of the padded map layer is always outside the map
@@ -220,18 +243,11 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     int s_src[NS];    // ds_bpermute byte address of the owning pursuer's lane
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int q = lane + 64 * s;
-        const int pidx = q / S::DV, f = q % S::DV;
-        s_src[s] = (q < S::NQ ? pidx : 0) * 4;
+        const uint32_t *t = d.slot_tab + s * 6 * 64 + lane;  // slots past the end of the row read harmless cells and are never stored
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // slots past the end of the row read harmless cells and are never stored
-            const uint32_t c = (q < S::NQ) ? d.codes[4 * f + k] : (k == 3 ? (uint32_t)S::X_SKIP : 0u);
-            int cst = (int)(c & 0x7FFFFFFFu);
-            if (cst >= S::X_ID && cst < S::X_ID + P) cst = S::X_ID + pidx;
-            s_cst[s][k] = cst;
-            if (k == 3) s_rel3[s] = (int)(c >> 31);
-        }
+        for (int k = 0; k < 4; ++k) s_cst[s][k] = (int)t[64 * k];
+        s_rel3[s] = (int)t[64 * 4];
+        s_src[s] = (int)t[64 * 5] * 4;
     }
     int cached_map = -1;
     const uint8_t *need_tab = reinterpret_cast<const uint8_t *>(&L[S::X_NEED]);
@@ -257,13 +273,20 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     uint32_t cur_rec = 0, cur_zm = 0xFFFFFFFFu;
     int cur_act = 4;
     auto phys = [&](int64_t e) -> int64_t { return d.reverse ? d.n_envs - 1 - e : e; };
+#if MADRL_PW_EXP & 2
+    cur_rec = pre_rec; cur_act = pre_act; cur_zm = pre_zm;
+#else
     if ((int64_t)blockIdx.x < d.n_envs) {
         cur_rec = fetch_rec(phys(blockIdx.x));
         cur_act = fetch_act(phys(blockIdx.x));
         cur_zm = fetch_zm(phys(blockIdx.x));
     }
+#endif
     asm volatile("" : "+v"(cur_rec), "+v"(cur_act), "+v"(cur_zm));  // loads complete before the loop (see hinge below)
     wave_sync();
+#if MADRL_PW_EXP & 8
+    if (d.n_envs > 0) { if (s_cst[0][0] + s_cst[NS - 1][3] + s_rel3[0] + s_src[NS - 1] + (int)cur_rec == 0x12345) io.rew[0] = 1.f; return; }
+#endif
 
     for (int64_t e = blockIdx.x; e < d.n_envs; e += gridDim.x) {
         const int64_t env = phys(e);
@@ -546,7 +569,11 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
             if (d.n_envs < 0)
 #endif
             if constexpr (MODE == 1) {
+#if MADRL_PW_EXP & 1
+                if (isP()) __builtin_nontemporal_store(rew_out, &io.rew[env * P + lane]);
+#else
                 if (isP()) io.rew[env * P + lane] = rew_out;
+#endif
                 if (fresh(lane) == 0) {
                     io.done[env] = (uint8_t)done_bits;
                     io.removed[env] = n_removed;
@@ -572,12 +599,21 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
 #if MADRL_ABLATE & 16
                 if (d.n_envs < 0)
 #endif
+#if MADRL_PW_EXP & 1
+                if (fresh(lane) < S::REC_DW)
+                    __builtin_nontemporal_store(w, &reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane]);
+#else
                 if (fresh(lane) < S::REC_DW)
                     reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] = w;
+#endif
 #if MADRL_ABLATE & 16
                 if (d.n_envs < 0)
 #endif
+#if MADRL_PW_EXP & 1
+                __builtin_nontemporal_store(zm, &d.zmask[env * 64 + lane]);
+#else
                 d.zmask[env * 64 + lane] = zm;
+#endif
             }
         }
         cur_rec = nxt_rec;

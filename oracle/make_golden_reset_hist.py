@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Occupancy histogram of the UNMODIFIED reference's reset() (pursuit_evade.py:173-207) with a constraint window and a sampled
 map pool -- the distribution the free-running reset kernels must sample from.  TEST INFRASTRUCTURE ONLY; runs in
-the build container, writes tests/golden/pursuit_reset_hist.npz.
+the build container, writes tests/golden/resetdist_pursuit.npz.
 
     window start  sx, sy ~ U(0, 1 - cw)  -> cells [int(xs sx), int(xs (sx + cw))) x [int(ys sy), int(ys (sy + cw)))
     every agent   uniform over the free cells of the window (rejection sampling, agent_utils.py:31-47)
@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_loader  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "pursuit_reset_hist.npz")
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "resetdist_pursuit.npz")
 CFG = dict(n_evaders=30, n_pursuers=8, obs_range=7, constraint_window=0.5, sample_maps=True)
 N_RESETS_PER_WORKER = 5000
 AGENTS = [0, 7, 8, 37]   # agent indices (pursuers first) whose single positions are histogrammed

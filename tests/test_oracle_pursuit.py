@@ -101,13 +101,13 @@ def test_oracle_free_running_is_deterministic_and_seed_sensitive():
 
 def test_free_running_reset_samples_the_reference_distribution():
     """The free-running reset (own Philox draws) against the UNMODIFIED reference's reset() distribution with a constraint window of
-    0.5 and a sampled 10-map pool (tests/golden/pursuit_reset_hist.npz, 40 000 reference resets, oracle/make_golden_reset_hist.py).
+    0.5 and a sampled 10-map pool (tests/golden/resetdist_pursuit.npz, 40 000 reference resets, oracle/make_golden_reset_hist.py).
     Agents of one reset share its window, so only ONE position per reset enters each chi-square (agent indices 0, 7, 8, 37, pooled over
     the maps: independent samples); the map choice is tested the same way; the all-agent histograms are checked for support only.
     The HIP kernels are bit-identical to this oracle in free-running mode (tests/test_pursuit_gpu.py cases `pool16`, `tiny_window`)."""
     import os
     from oracle import pursuit as po
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pursuit_reset_hist.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resetdist_pursuit.npz"))
     maps = [m.astype(np.int32) for m in g["maps"]]
     P, E = int(g["n_pursuers"]), int(g["n_evaders"])
     N = 40000
