@@ -45,6 +45,9 @@ __host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
 #endif
 }
 
+#ifndef MADRL_PHILOX_VARIANT
+#define MADRL_PHILOX_VARIANT 0
+#endif
 // a ^ b ^ c: one v_bitop3_b32 on gfx950 (truth table 0x96)
 __host__ __device__ inline uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -60,11 +63,21 @@ __host__ __device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
                                                uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+#if MADRL_PHILOX_VARIANT == 1   // separate high / low products
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = xor3(hi1, c1, k0); c1 = lo1; c2 = xor3(hi0, c3, k1); c3 = lo0;
+#elif MADRL_PHILOX_VARIANT == 2  // and two-way XORs (round 1)
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+#else
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         c0 = xor3((uint32_t)(p1 >> 32), c1, k0);
         c1 = (uint32_t)p1;
         c2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c3 = (uint32_t)p0;
+#endif
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }

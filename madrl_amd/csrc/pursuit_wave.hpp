@@ -162,6 +162,18 @@ __device__ __forceinline__ uint32_t fresh_s(uint32_t v) {
     return v;
 }
 
+// A wave-uniform pointer pinned to an SGPR pair at this point of the program.  Per-lane accesses written as
+// uniform_ptr(base + env * stride)[lane] then select the "SGPR base + 32-bit VGPR offset" addressing form; without the pin the
+// compiler reassociates to (base + lane * 4) + env * stride, keeps one 64-bit VGPR pair per array live across the env loop and,
+// at 96 VGPRs, spills them -- and a scratch reload in the loop waits (in-order vmcnt) for the previous env's observation stores.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *uniform_ptr(T *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (__attribute__((address_space(1))) T *)(((uint64_t)hi << 32) | lo);  // global address space: global_*, not flat_*, instructions
+}
+
 // w[lane LN] = v for a wave-uniform v: one v_writelane_b32, no lane mask, no compare
 template <int LN>
 __device__ __forceinline__ void put_lane(uint32_t &w, uint32_t v) {
@@ -183,7 +195,7 @@ __device__ __forceinline__ void put_zero_from(uint32_t &w) {
 #ifndef MADRL_ABLATE
 #define MADRL_ABLATE 0
 #endif
-// Experiments (same rules): 1 record / mask / reward stores non-temporal   2 first record fetched before the LDS preamble
+// Timing aids (same rules): 4 return at once (launch cost)   8 return after the per-workgroup preamble
 #ifndef MADRL_PW_EXP
 #define MADRL_PW_EXP 0
 #endif
@@ -207,23 +219,12 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     constexpr int P = S::P, E = S::E, A = S::A, GW = S::GW, PAD = S::PAD, GSZ = S::GSZ, NS = S::NS;
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int lane = threadIdx.x;
+    const uint32_t ulane = threadIdx.x;  // as an unsigned 32-bit index: zero-extends into the VGPR-offset addressing form
     const bool is_p = lane < P;
     const int eslot = lane - P;
 
 #if MADRL_PW_EXP & 4
     if (d.n_envs > 0) return;
-#endif
-#if MADRL_PW_EXP & 2
-    uint32_t pre_rec = 0, pre_zm = 0xFFFFFFFFu;
-    int pre_act = 4;
-    {
-        const int64_t e0 = d.reverse ? d.n_envs - 1 - (int64_t)blockIdx.x : (int64_t)blockIdx.x;
-        if ((int64_t)blockIdx.x < d.n_envs) {
-            pre_rec = (lane < S::REC_DW) ? reinterpret_cast<const uint32_t *>(d.state + e0 * (int64_t)S::REC_BYTES)[lane] : 0u;
-            if constexpr (MODE == 1) pre_act = lane < P ? io.actions[e0 * P + lane] : 4;
-            pre_zm = d.zmask[e0 * 64 + lane];
-        }
-    }
 #endif
     // ---------------------------------------------------------------- once per workgroup
     for (int k = lane; k < GSZ; k += 64) {  // count layers: 0 inside the map, SENT outside
@@ -263,25 +264,21 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     auto isE = [&]() { return (unsigned)(fresh(lane) - P) < (unsigned)E; };
     auto isAgent = [&]() { return fresh(lane) < A; };
     auto fetch_rec = [&](int64_t env) -> uint32_t {
-        return (fresh(lane) < S::REC_DW) ? reinterpret_cast<const uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] : 0u;
+        return (fresh(lane) < S::REC_DW) ? uniform_ptr(reinterpret_cast<const uint32_t *>(d.state + env * (int64_t)S::REC_BYTES))[ulane] : 0u;
     };
     auto fetch_act = [&](int64_t env) -> int {
-        if constexpr (MODE == 1) return isP() ? io.actions[env * P + lane] : 4;
+        if constexpr (MODE == 1) return isP() ? uniform_ptr(io.actions + env * P)[ulane] : 4;
         else return 4;
     };
-    auto fetch_zm = [&](int64_t env) -> uint32_t { return d.zmask[env * 64 + lane]; };
+    auto fetch_zm = [&](int64_t env) -> uint32_t { return uniform_ptr(d.zmask + env * 64)[ulane]; };
     uint32_t cur_rec = 0, cur_zm = 0xFFFFFFFFu;
     int cur_act = 4;
     auto phys = [&](int64_t e) -> int64_t { return d.reverse ? d.n_envs - 1 - e : e; };
-#if MADRL_PW_EXP & 2
-    cur_rec = pre_rec; cur_act = pre_act; cur_zm = pre_zm;
-#else
     if ((int64_t)blockIdx.x < d.n_envs) {
         cur_rec = fetch_rec(phys(blockIdx.x));
         cur_act = fetch_act(phys(blockIdx.x));
         cur_zm = fetch_zm(phys(blockIdx.x));
     }
-#endif
     asm volatile("" : "+v"(cur_rec), "+v"(cur_act), "+v"(cur_zm));  // loads complete before the loop (see hinge below)
     wave_sync();
 #if MADRL_PW_EXP & 8
@@ -515,11 +512,11 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                 {
                     const int origin = isP() ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
                     typedef float v4f __attribute__((ext_vector_type(4)));
-                    v4f *orow = reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D));
+                    auto orow = uniform_ptr(reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D)));
                     uint32_t acc = 0u;  // the new mask, slot by slot
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        const int q = lane + 64 * s;
+                        const uint32_t q = ulane + 64u * s;
                         const int base = __builtin_amdgcn_ds_bpermute(s_src[s], origin);
                         const uint32_t v0 = L[base + s_cst[s][0]];
                         const uint32_t v1 = L[base + s_cst[s][1]];
@@ -551,7 +548,7 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                             } else {  // an outside cell with a non-zero stale value: leave it alone (Q2).
                                 // Plain (L2-cached) stores: partial lines must merge in L2 -- nontemporal
                                 // partial writes cost a read-modify-write at the memory side (3x slower).
-                                float *o = reinterpret_cast<float *>(orow + q);
+                                auto o = (__attribute__((address_space(1))) float *)(orow + q);
                                 if (v0 != SENT) o[0] = __uint_as_float(v0);
                                 if (v1 != SENT) o[1] = __uint_as_float(v1);
                                 if (v2 != SENT) o[2] = __uint_as_float(v2);
@@ -569,11 +566,7 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
             if (d.n_envs < 0)
 #endif
             if constexpr (MODE == 1) {
-#if MADRL_PW_EXP & 1
-                if (isP()) __builtin_nontemporal_store(rew_out, &io.rew[env * P + lane]);
-#else
-                if (isP()) io.rew[env * P + lane] = rew_out;
-#endif
+                if (isP()) uniform_ptr(io.rew + env * P)[ulane] = rew_out;
                 if (fresh(lane) == 0) {
                     io.done[env] = (uint8_t)done_bits;
                     io.removed[env] = n_removed;
@@ -599,21 +592,12 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
 #if MADRL_ABLATE & 16
                 if (d.n_envs < 0)
 #endif
-#if MADRL_PW_EXP & 1
                 if (fresh(lane) < S::REC_DW)
-                    __builtin_nontemporal_store(w, &reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane]);
-#else
-                if (fresh(lane) < S::REC_DW)
-                    reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] = w;
-#endif
+                    uniform_ptr(reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES))[ulane] = w;
 #if MADRL_ABLATE & 16
                 if (d.n_envs < 0)
 #endif
-#if MADRL_PW_EXP & 1
-                __builtin_nontemporal_store(zm, &d.zmask[env * 64 + lane]);
-#else
-                d.zmask[env * 64 + lane] = zm;
-#endif
+                uniform_ptr(d.zmask + env * 64)[ulane] = zm;
             }
         }
         cur_rec = nxt_rec;
