@@ -924,7 +924,8 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         { const float unit = (float)1 / (float)cfg->layer_norm; memcpy(&unit_bits, &unit, 4); }
         bool eligible = (wall_bits != 0u) && (fill_bits != 0u) && (unit_bits >> 24) >= 0x20u && (unit_bits >> 24) < 0x80u &&
                         (fill_bits >> 24) >= 0x20u && (fill_bits >> 24) < 0x80u && g.rec_bytes == d.rec_bytes &&
-                        g.off_gone == d.off_gone && g.off_term == d.off_term && g.D == d.D;
+                        g.off_gone == d.off_gone && g.off_term == d.off_term && g.D == d.D &&
+                        n_envs < 0x7FF00000ll;  // the fast kernels index envs with 32-bit integers (index + workgroup count < 2^31)
         for (int r = 0; r < d.D; ++r) {
             int c, i, j;
             if (cfg->flatten) {

@@ -75,6 +75,20 @@ struct WaveIO {
     int32_t *removed;
 };
 
+// Launch parameters that only the rare paths read (episode reset, a change of map) are not kept in SGPRs across the env loop: the
+// kernel reads them from its kernel-argument segment (scalar loads) where they are needed.  The loop otherwise runs out of SGPRs
+// and the compiler parks the excess in VGPR lanes -- one v_readlane_b32 (a VALU issue slot) per use.
+struct KArgs {
+    WaveDev d;
+    WaveIO io;
+};
+typedef const __attribute__((address_space(4))) KArgs *KArgsPtr;
+__device__ __forceinline__ KArgsPtr cold_args() {
+    KArgsPtr p = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));  // a fresh pointer at every call: the loads cannot be merged with the ones at kernel entry or hoisted
+    return p;
+}
+
 template <int XS_, int YS_, int P_, int E_, int R_, int FLATTEN_>
 struct Shape {
     static constexpr int XS = XS_, YS = YS_, P = P_, E = E_, A = P_ + E_, R = R_, FLATTEN = FLATTEN_;
@@ -273,8 +287,10 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     auto fetch_zm = [&](int64_t env) -> uint32_t { return uniform_ptr(d.zmask + env * 64)[ulane]; };
     uint32_t cur_rec = 0, cur_zm = 0xFFFFFFFFu;
     int cur_act = 4;
-    auto phys = [&](int64_t e) -> int64_t { return d.reverse ? d.n_envs - 1 - e : e; };
-    if ((int64_t)blockIdx.x < d.n_envs) {
+    // env indices are 32-bit (the C ABI caps n_envs below 2^31); only byte offsets are 64-bit
+    const int n_envs = (int)d.n_envs, stride = (int)gridDim.x;
+    auto phys = [&](int e) -> int64_t { return (int64_t)(d.reverse ? n_envs - 1 - e : e); };
+    if ((int)blockIdx.x < n_envs) {
         cur_rec = fetch_rec(phys(blockIdx.x));
         cur_act = fetch_act(phys(blockIdx.x));
         cur_zm = fetch_zm(phys(blockIdx.x));
@@ -285,10 +301,10 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     if (d.n_envs > 0) { if (s_cst[0][0] + s_cst[NS - 1][3] + s_rel3[0] + s_src[NS - 1] + (int)cur_rec == 0x12345) io.rew[0] = 1.f; return; }
 #endif
 
-    for (int64_t e = blockIdx.x; e < d.n_envs; e += gridDim.x) {
+    for (int e = blockIdx.x; e < n_envs; e += stride) {
         const int64_t env = phys(e);
-        const bool has_next = e + gridDim.x < d.n_envs;
-        const int64_t nenv = phys(has_next ? e + gridDim.x : e);
+        const bool has_next = e + stride < n_envs;  // n_envs + number of workgroups < 2^31
+        const int64_t nenv = phys(has_next ? e + stride : e);
         uint32_t nxt_rec = 0, nxt_zm = 0xFFFFFFFFu;
         int nxt_act = 4;
 #if MADRL_ABLATE & 64
@@ -326,7 +342,8 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
 
             auto load_map = [&](int mid) {
                 if (cached_map == mid) return;
-                const uint32_t *src = d.fmaps + (int64_t)mid * d.fmap_stride;
+                const KArgsPtr ka = cold_args();
+                const uint32_t *src = ka->d.fmaps + (int64_t)mid * ka->d.fmap_stride;
                 for (int k = lane; k < GSZ; k += 64) L[k] = src[k];
                 for (int k = lane; k < (S::XS * S::YS + 3) / 4; k += 64) L[S::X_NEED + k] = src[GSZ + k];
                 cached_map = mid;
@@ -444,6 +461,9 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                     // -------------------------------------------------- reset (:173-207)
                     gone = 0ull;
                     term = 0ull;
+                    const KArgsPtr ka = cold_args();
+                    const double cw = ka->d.cw;
+                    const int max_opponents = ka->d.max_opponents;
                     bool inj_map = false, inj_pos = false;
                     if constexpr (MODE == 0) {
                         inj_map = io.inj_map != nullptr;
@@ -451,22 +471,22 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                     }
                     if (inj_map) {
                         map_id = __builtin_amdgcn_readfirstlane(io.inj_map[env]);
-                    } else if (d.sample_maps) {  // :182-183
+                    } else if (ka->d.sample_maps) {  // :182-183
                         const u32x4 rm = philox4x32_10(gid, tick, 0u, TAG_RESET_ENV, k0, k1);
-                        map_id = (int)__umulhi(rm.x, (uint32_t)d.n_maps);
+                        map_id = (int)__umulhi(rm.x, (uint32_t)ka->d.n_maps);
                     }
                     load_map(map_id);
                     const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, k0, k1);
-                    const double sx = u53(rw.x, rw.y) * (1.0 - d.cw);  // :185-191, float64
-                    const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
-                    const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + d.cw));
-                    const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + d.cw));
+                    const double sx = u53(rw.x, rw.y) * (1.0 - cw);  // :185-191, float64
+                    const double sy = u53(rw.z, rw.w) * (1.0 - cw);
+                    const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + cw));
+                    const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + cw));
                     // random_opponents (train_pursuit, :177-181): n_create <= E evaders this episode, the slots above are not
                     // created and count as gone; an injected position with x < 0 marks a slot that is not created
                     int n_create = E;
-                    if (d.max_opponents > 0 && !inj_pos) {
+                    if (max_opponents > 0 && !inj_pos) {
                         const u32x4 r3 = philox4x32_10(gid, tick, 2u, TAG_RESET_ENV, k0, k1);
-                        n_create = min(1 + (int)__umulhi(r3.x, (uint32_t)(d.max_opponents - 1)), E);
+                        n_create = min(1 + (int)__umulhi(r3.x, (uint32_t)(max_opponents - 1)), E);
                     }
                     bool exists = false;
                     if (isAgent()) {  // create_agents / feasible_position, agent_utils.py:12-47
