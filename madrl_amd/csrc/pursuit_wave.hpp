@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     for (int s = 0; s < NS; ++s) {
         const uint32_t *t = d.slot_tab + s * 6 * 64 + lane;  // slots past the end of the row read harmless cells and are never stored
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_cst[s][k] = (int)t[64 * k];
+        for (int k = 0; k < 4; ++k) s_cst[s][k] = (int)t[64 * k] * 4;  // byte offsets into L
         s_rel3[s] = (int)t[64 * 4];
         s_src[s] = (int)t[64 * 5] * 4;
     }
@@ -530,18 +530,22 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                 if (d.n_envs < 0)
 #endif
                 {
-                    const int origin = isP() ? (x - S::OFF + PAD) * GW + (y - S::OFF + PAD) : 0;
+                    // byte offset of this pursuer's window origin in L; the slot constants are byte offsets too, so a cell address is one add
+                    const int origin = isP() ? ((x - S::OFF + PAD) * GW + (y - S::OFF + PAD)) * 4 : 0;
                     typedef float v4f __attribute__((ext_vector_type(4)));
-                    auto orow = uniform_ptr(reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D)));
+                    typedef __attribute__((address_space(1))) char *gbytes;
+                    // SGPR base + one loop-invariant 32-bit VGPR offset (+ immediate) for every store of the row
+                    const gbytes orow = (gbytes)uniform_ptr(io.obs + env * (int64_t)(P * S::D)) + ulane * 16u;
+                    const char *Lb = reinterpret_cast<const char *>(L);
+                    auto cell_at = [&](int off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(Lb + off); };
                     uint32_t acc = 0u;  // the new mask, slot by slot
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        const uint32_t q = ulane + 64u * s;
                         const int base = __builtin_amdgcn_ds_bpermute(s_src[s], origin);
-                        const uint32_t v0 = L[base + s_cst[s][0]];
-                        const uint32_t v1 = L[base + s_cst[s][1]];
-                        const uint32_t v2 = L[base + s_cst[s][2]];
-                        const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
+                        const uint32_t v0 = cell_at(base + s_cst[s][0]);
+                        const uint32_t v1 = cell_at(base + s_cst[s][1]);
+                        const uint32_t v2 = cell_at(base + s_cst[s][2]);
+                        const uint32_t v3 = cell_at((int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]);
                         // flags of the four cells, one per byte (bit 0).  The top byte of a value is 0x00 for +0.0f, 0x3D..0x41 for the
                         // positive observation values and 0xFF for SENT (outside the map).
                         const uint32_t top = __builtin_amdgcn_perm(v1, v0, 0x0C0C0703u) | __builtin_amdgcn_perm(v3, v2, 0x07030C0Cu);
@@ -563,12 +567,12 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                                     // outside cells (SENT = -1 as an integer) are written as the +0.0f they already hold
                                     const v4f val = {__uint_as_float((uint32_t)max((int)v0, 0)), __uint_as_float((uint32_t)max((int)v1, 0)),
                                                      __uint_as_float((uint32_t)max((int)v2, 0)), __uint_as_float((uint32_t)max((int)v3, 0))};
-                                    __builtin_nontemporal_store(val, &orow[q]);
+                                    __builtin_nontemporal_store(val, (__attribute__((address_space(1))) v4f *)(orow + 1024 * s));
                                 }
                             } else {  // an outside cell with a non-zero stale value: leave it alone (Q2).
                                 // Plain (L2-cached) stores: partial lines must merge in L2 -- nontemporal
                                 // partial writes cost a read-modify-write at the memory side (3x slower).
-                                auto o = (__attribute__((address_space(1))) float *)(orow + q);
+                                auto o = (__attribute__((address_space(1))) float *)(orow + 1024 * s);
                                 if (v0 != SENT) o[0] = __uint_as_float(v0);
                                 if (v1 != SENT) o[1] = __uint_as_float(v1);
                                 if (v2 != SENT) o[2] = __uint_as_float(v2);
