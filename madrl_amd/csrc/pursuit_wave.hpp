@@ -27,6 +27,8 @@
 //     (out-of-map) cell falls back to per-dword conditional stores.
 #pragma once
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace madrl {
@@ -186,6 +188,39 @@ __device__ __forceinline__ __attribute__((address_space(1))) T *uniform_ptr(T *p
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return (__attribute__((address_space(1))) T *)(((uint64_t)hi << 32) | lo);  // global address space: global_*, not flat_*, instructions
+}
+
+// Masked global stores that are ALWAYS issued (exec narrowed inside the asm, no compiler-made skip branch around them): the
+// number of vector-memory instructions per env iteration is then a compile-time constant, which is what lets the record
+// prefetch wait with an exact s_waitcnt vmcnt(N) instead of vmcnt(0) (see "software pipeline").  base: wave-uniform pointer,
+// voff: per-lane byte offset, OFF: immediate byte offset (< 4096).  The trailing s_nop covers the "store of more than 8 bytes,
+// then a VALU write of its data registers" hazard that the compiler cannot see through inline asm.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void store4_nt_masked(const void *base, uint32_t voff, v4f_t val, uint64_t mask) {
+    uint64_t sv;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dwordx4 %2, %3, %4 offset:%5 nt\n\ts_mov_b64 exec, %0\n\ts_nop 0"
+                 : "=&s"(sv) : "s"(mask), "v"(voff), "v"(val), "s"(base), "n"(OFF) : "scc");  // s_and_b64 writes SCC
+}
+// the four elements of one float4 slot, each under its own lane mask, as plain (L2-merged) dword stores
+template <int OFF>
+__device__ __forceinline__ void store1x4_masked(const void *base, uint32_t voff, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3,
+                                                uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+    uint64_t sv;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_and_b64 exec, %0, %1\n\tglobal_store_dword %5, %6, %10 offset:%11\n\t"
+                 "s_and_b64 exec, %0, %2\n\tglobal_store_dword %5, %7, %10 offset:%11+4\n\t"
+                 "s_and_b64 exec, %0, %3\n\tglobal_store_dword %5, %8, %10 offset:%11+8\n\t"
+                 "s_and_b64 exec, %0, %4\n\tglobal_store_dword %5, %9, %10 offset:%11+12\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(voff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "n"(OFF) : "scc");
 }
 
 // w[lane LN] = v for a wave-uniform v: one v_writelane_b32, no lane mask, no compare
@@ -532,15 +567,14 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                 {
                     // byte offset of this pursuer's window origin in L; the slot constants are byte offsets too, so a cell address is one add
                     const int origin = isP() ? ((x - S::OFF + PAD) * GW + (y - S::OFF + PAD)) * 4 : 0;
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    typedef __attribute__((address_space(1))) char *gbytes;
                     // SGPR base + one loop-invariant 32-bit VGPR offset (+ immediate) for every store of the row
-                    const gbytes orow = (gbytes)uniform_ptr(io.obs + env * (int64_t)(P * S::D)) + ulane * 16u;
+                    const char *orow_u = (const char *)uniform_ptr(io.obs + env * (int64_t)(P * S::D));
+                    const uint32_t voff = ulane * 16u;
                     const char *Lb = reinterpret_cast<const char *>(L);
                     auto cell_at = [&](int off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(Lb + off); };
                     uint32_t acc = 0u;  // the new mask, slot by slot
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
+                    static_for<0, NS>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
                         const int base = __builtin_amdgcn_ds_bpermute(s_src[s], origin);
                         const uint32_t v0 = cell_at(base + s_cst[s][0]);
                         const uint32_t v1 = cell_at(base + s_cst[s][1]);
@@ -554,32 +588,30 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                         const uint32_t old4 = (zm >> (NS - 1 - s)) & 0x01010101u;          // holds a value not known to be zero
                         const uint32_t dirty = out4 & old4;                                 // outside AND possibly non-zero: must stay untouched
                         acc = (acc << 1) | ((out4 & old4) | (~out4 & nz4));
+                        bool valid = (64 * (s + 1) <= S::NQ) ? true : (fresh(lane) + 64 * s < S::NQ);
+                        bool clean = dirty == 0u;
 #if MADRL_ABLATE & 1
-                        if (d.n_envs < 0)
+                        valid = d.n_envs < 0;
 #endif
-                        if ((64 * (s + 1) <= S::NQ) ? true : (fresh(lane) + 64 * s < S::NQ)) {
 #if MADRL_ABLATE & 2
-                            if (true) {
-#else
-                            if (dirty == 0u) {
+                        clean = true;
 #endif
-                                if (out4 != 0x01010101u) {  // all four outside and known zero: nothing changes
-                                    // outside cells (SENT = -1 as an integer) are written as the +0.0f they already hold
-                                    const v4f val = {__uint_as_float((uint32_t)max((int)v0, 0)), __uint_as_float((uint32_t)max((int)v1, 0)),
-                                                     __uint_as_float((uint32_t)max((int)v2, 0)), __uint_as_float((uint32_t)max((int)v3, 0))};
-                                    __builtin_nontemporal_store(val, (__attribute__((address_space(1))) v4f *)(orow + 1024 * s));
-                                }
-                            } else {  // an outside cell with a non-zero stale value: leave it alone (Q2).
-                                // Plain (L2-cached) stores: partial lines must merge in L2 -- nontemporal
-                                // partial writes cost a read-modify-write at the memory side (3x slower).
-                                auto o = (__attribute__((address_space(1))) float *)(orow + 1024 * s);
-                                if (v0 != SENT) o[0] = __uint_as_float(v0);
-                                if (v1 != SENT) o[1] = __uint_as_float(v1);
-                                if (v2 != SENT) o[2] = __uint_as_float(v2);
-                                if (v3 != SENT) o[3] = __uint_as_float(v3);
-                            }
-                        }
-                    }
+                        // An outside cell with a non-zero stale value: leave it alone (Q2), store the inside cells one by one.  Plain
+                        // (L2-cached) stores: partial lines must merge in L2 -- nontemporal partial writes cost a read-modify-write
+                        // at the memory side (3x slower).  They are issued BEFORE the non-temporal store of the slot's other lanes: the
+                        // line is then in L2 when the streaming store arrives and leaves as one write (the other order: 175 us, not 77).
+                        const void *sb = orow_u + 4096 * (s / 4);
+                        const uint64_t md = __builtin_amdgcn_ballot_w64(valid && !clean);
+                        store1x4_masked<1024 * (s % 4)>(sb, voff, v0, v1, v2, v3, md & __builtin_amdgcn_ballot_w64(v0 != SENT),
+                                                        md & __builtin_amdgcn_ballot_w64(v1 != SENT), md & __builtin_amdgcn_ballot_w64(v2 != SENT),
+                                                        md & __builtin_amdgcn_ballot_w64(v3 != SENT));
+                        // One non-temporal float4 unless a cell must stay untouched; nothing if all four are outside and known zero.
+                        // Outside cells (SENT = -1 as an integer) are written as the +0.0f they already hold.
+                        const uint64_t m_nt = __builtin_amdgcn_ballot_w64(valid && clean && out4 != 0x01010101u);
+                        const v4f_t val = {__uint_as_float((uint32_t)max((int)v0, 0)), __uint_as_float((uint32_t)max((int)v1, 0)),
+                                           __uint_as_float((uint32_t)max((int)v2, 0)), __uint_as_float((uint32_t)max((int)v3, 0))};
+                        store4_nt_masked<1024 * (s % 4)>(sb, voff, val, m_nt);
+                    });
                     zm = acc;
                 }
                 wave_sync();
