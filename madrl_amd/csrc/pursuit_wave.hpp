@@ -223,6 +223,24 @@ __device__ __forceinline__ void store1x4_masked(const void *base, uint32_t voff,
                  : "=&s"(sv) : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(voff), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "n"(OFF) : "scc");
 }
 
+// Record prefetch with an exact wait (step kernel).  vmcnt counts loads and stores alike and retires them in issue order, and the
+// compiler, which cannot know how many of the masked stores above were issued, would wait for a prefetched record with
+// vmcnt(0): every wavefront then stalls until its previous env's observation stores have been acknowledged, half an iteration
+// after issuing them.  Here the three loads of the next env are issued (inline asm, so the compiler inserts no wait of its own)
+// at the top of an iteration and waited for at its END with s_waitcnt vmcnt(<stores per iteration>): only the stores of the
+// PREVIOUS iteration -- a whole iteration old -- must have retired, this iteration's may all be in flight.
+// Every lane loads (clamped offsets, no exec games); s_nop 4 covers a base pointer that a VALU instruction may have just written.
+__device__ __forceinline__ void prefetch3(uint32_t &r0, uint32_t &r1, uint32_t &r2, const void *b0, uint32_t o0, const void *b1, uint32_t o1,
+                                          const void *b2, uint32_t o2) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %3, %4\n\tglobal_load_dword %1, %5, %6\n\tglobal_load_dword %2, %7, %8"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(o0), "s"(b0), "v"(o1), "s"(b1), "v"(o2), "s"(b2));
+}
+template <int N>
+__device__ __forceinline__ void prefetch_wait(uint32_t &r0, uint32_t &r1, uint32_t &r2) {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
+}
+
 // w[lane LN] = v for a wave-uniform v: one v_writelane_b32, no lane mask, no compare
 template <int LN>
 __device__ __forceinline__ void put_lane(uint32_t &w, uint32_t v) {
@@ -336,22 +354,35 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     if (d.n_envs > 0) { if (s_cst[0][0] + s_cst[NS - 1][3] + s_rel3[0] + s_src[NS - 1] + (int)cur_rec == 0x12345) io.rew[0] = 1.f; return; }
 #endif
 
+    // PIPE: the exact-wait prefetch above (production step kernel); the reset kernel (envs may be skipped) and the parity
+    // harness variant keep compiler-managed loads and the mid-iteration hinge.
+    constexpr bool PIPE = (MODE == 1) && !INJECT && !(MADRL_ABLATE & (1 | 8 | 16 | 64));
+    constexpr int VM_PER_ENV = 5 * NS + 5;  // stores every step iteration issues: NS x (4 dword + 1 float4), reward, done, removed, record, mask
+    static_assert(!PIPE || VM_PER_ENV < 64, "vmcnt range");
+    const uint32_t rec_off = (ulane < (uint32_t)S::REC_DW ? ulane : (uint32_t)S::REC_DW - 1u) * 4u;
+    const uint32_t act_off = (ulane < (uint32_t)P ? ulane : (uint32_t)P - 1u) * 4u;
     for (int e = blockIdx.x; e < n_envs; e += stride) {
         const int64_t env = phys(e);
         const bool has_next = e + stride < n_envs;  // n_envs + number of workgroups < 2^31
         const int64_t nenv = phys(has_next ? e + stride : e);
         uint32_t nxt_rec = 0, nxt_zm = 0xFFFFFFFFu;
         int nxt_act = 4;
+        uint32_t pf_rec, pf_act, pf_zm;
+        if constexpr (PIPE) {
+            prefetch3(pf_rec, pf_act, pf_zm, d.state + nenv * (int64_t)S::REC_BYTES, rec_off, io.actions + nenv * P, act_off,
+                      d.zmask + nenv * 64, ulane * 4u);
+        } else {
 #if MADRL_ABLATE & 64
-        nxt_rec = cur_rec ^ (uint32_t)(fresh(lane) == 0);  // no loads in the loop: is the in-order vmcnt drain what serialises a wave?
-        nxt_act = cur_act;
+            nxt_rec = cur_rec ^ (uint32_t)(fresh(lane) == 0);  // no loads in the loop: is the in-order vmcnt drain what serialises a wave?
+            nxt_act = cur_act;
 #else
-        if (has_next) {
-            nxt_rec = fetch_rec(nenv);
-            nxt_act = fetch_act(nenv);
-            nxt_zm = fetch_zm(nenv);
-        }
+            if (has_next) {
+                nxt_rec = fetch_rec(nenv);
+                nxt_act = fetch_act(nenv);
+                nxt_zm = fetch_zm(nenv);
+            }
 #endif
+        }
         bool skip = false;
         if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
         if (!skip) {
@@ -482,7 +513,7 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
             // for the next env's record now -- when only loads and the previous env's long-issued
             // stores are outstanding -- instead of at the loop back-edge, where an in-order
             // vmcnt(0) would also wait for this env's observation stores to reach HBM.
-            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act), "+v"(nxt_zm));
+            if constexpr (!PIPE) asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act), "+v"(nxt_zm));
             uint32_t zm = cur_zm;  // stale-zero mask of this env: byte k, bit (4 - s) = cell k of slot s
 
             // One observation pass normally.  On auto-reset two: the reference sequence is step()
@@ -655,6 +686,12 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
 #endif
                 uniform_ptr(d.zmask + env * 64)[ulane] = zm;
             }
+        }
+        if constexpr (PIPE) {
+            prefetch_wait<VM_PER_ENV>(pf_rec, pf_act, pf_zm);
+            nxt_rec = (fresh(lane) < S::REC_DW) ? pf_rec : 0u;
+            nxt_act = (int)pf_act;  // lanes that are not pursuers never read it
+            nxt_zm = pf_zm;
         }
         cur_rec = nxt_rec;
         cur_act = nxt_act;
