@@ -72,6 +72,37 @@ struct WwIO {
     const WwStd *st;        // device copy of the fused-wrapper arguments, or NULL
 };
 
+// Launch parameters are read from the kernel-argument segment (scalar loads) at the phase that needs them instead of being held in
+// SGPRs across the whole env loop: the loop's scalar live set (broadcast masks, reach sets, counters) is already at the SGPR limit,
+// and what does not fit is parked in VGPR lanes at two VALU issue slots (v_writelane / v_readlane) per value and use.
+struct WwKArgs {
+    WwDev d;
+    WwIO io;
+};
+typedef const __attribute__((address_space(4))) WwKArgs *WwKArgsPtr;
+__device__ __forceinline__ WwKArgsPtr ww_args() {
+    WwKArgsPtr p = (WwKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));  // a fresh pointer at every call: loads are neither merged with earlier ones nor hoisted out of the loop
+    return p;
+}
+
+// A wave-uniform pointer pinned to an SGPR pair (global address space): per-lane accesses become "SGPR base + 32-bit VGPR offset"
+// instead of a 64-bit VGPR address pair per array kept live across the env loop.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *uniform_ptr(T *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (__attribute__((address_space(1))) T *)(((uint64_t)hi << 32) | lo);
+}
+
+// Hides the loop-invariance of a lane predicate: fresh(lane) < n is one v_cmp where it is used and dies there, instead of an SGPR
+// pair hoisted out of the env loop (and, past the SGPR budget, parked in a VGPR lane).
+__device__ __forceinline__ int fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -90,21 +121,42 @@ __device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) 
 #define MADRL_WW_ABLATE 0
 #endif
 
+// Resident wavefronts per SIMD the registers are allocated for (MADRL_WW_WAVES=0: compiler's choice)
+#ifndef MADRL_WW_WAVES
+#define MADRL_WW_WAVES 5
+#endif
+#if MADRL_WW_WAVES > 0
+#define MADRL_WW_OCC __attribute__((amdgpu_waves_per_eu(MADRL_WW_WAVES, MADRL_WW_WAVES)))
+#else
+#define MADRL_WW_OCC
+#endif
+
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 // TNp..TK > 0: the particle / sensor counts are compile-time constants (loops unroll, the index divisions fold); 0: generic.
 // FUSED: the StandardizedEnv epilogue (WwStd) is compiled in; a template parameter because its float64 code would otherwise cost the
 // plain kernel a wavefront per SIMD (132 instead of 119 VGPRs: 96 instead of 78 us per step)
-template <int MODE, int TNp, int TNe, int TNpo, int TK, bool FUSED = false>
-__global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwIO io) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int MODE, int TNp, int TNe, int TNpo, int TK, bool FUSED = false, int TD = 0>
+__global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev d, const WwIO io) {
+    // The specialised shape has a compile-time LDS layout in a STATIC array (launched with 0 dynamic bytes): every LDS address is
+    // "lane-dependent register + immediate offset".  With the dynamic array the base is a link-time symbol the compiler adds in
+    // registers, hoists out of the env loop per access pattern and -- at 5 waves per SIMD -- spills.
+    constexpr int SPEC_DW = TNp > 0 ? ((4 * (TNp + TNe + TNpo) + 4 + 3) / 4 * 4 + (TNp * (TD > 0 ? TD : 1) + 3) / 4 * 4 + (2 * TK + 3) / 4 * 4) : 0;
+    constexpr int SPEC_BYTES = TNp > 0 ? (SPEC_DW * 4 + 8 * TNp + TNp * (TNe + TNpo) + 2 * TNe + TNpo + 15) / 16 * 16 : 16;
+    static_assert(TNp == 0 || TD > 0, "a specialised shape fixes the observation width too");
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    __shared__ __attribute__((aligned(16))) float smem_static[SPEC_BYTES / 4];
+    float *const smem = TNp > 0 ? smem_static : smem_dyn;
     const int lane = threadIdx.x;
+    const uint32_t ulane = threadIdx.x;
+#define DA (ww_args()->d)
+#define IOA (ww_args()->io)
     const int Np = TNp > 0 ? TNp : d.Np, Ne = TNp > 0 ? TNe : d.Ne, Npo = TNp > 0 ? TNpo : d.Npo, K = TNp > 0 ? TK : d.K;
-    const int NP = Np + Ne + Npo, D = d.D;
+    const int NP = Np + Ne + Npo, D = TD > 0 ? TD : d.D;  // TD: the observation width of the specialised shape (7 K + 3)
     // ---- LDS carve
     float *S = smem;                                    // packed record: X[NP][2] | V[NP][2] | obst[2] | t | tick
     float *X = S, *V = S + 2 * NP;
     float *OB = S + 4 * NP;
-    float *O = S + ((d.rec_dw + 3) & ~3);               // observation staging [Np][D]
+    float *O = S + (((TNp > 0 ? 4 * (TNp + TNe + TNpo) + 4 : d.rec_dw) + 3) & ~3);  // observation staging [Np][D]
     float *SEN = O + ((Np * D + 3) & ~3);               // sensor unit vectors [K][2]
     uint64_t *NEAR = reinterpret_cast<uint64_t *>(SEN + ((2 * K + 3) & ~3));  // per pursuer: particles (bit j) / obstacle (bit NP) in sensing reach
     uint8_t *COL = reinterpret_cast<uint8_t *>(NEAR + Np);  // col_ev[Np][Ne] | col_po[Np][Npo]
@@ -112,33 +164,35 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
     uint8_t *FLG = COLP + Np * Npo;                     // caught_ev[Ne] | enc_ev[Ne] | caught_po[Npo]
 
     for (int k = lane; k < 2 * K; k += 64) SEN[k] = d.sensors[k];
-    const int rec_dw = d.rec_dw;
+    const int rec_dw = TNp > 0 ? (4 * (TNp + TNe + TNpo) + 4 + 3) / 4 * 4 : d.rec_dw;
     const int nreg = (rec_dw + 63) >> 6;  // <= 4 (NP <= 62)
 
     // ---- software pipeline: next env's record + action row are fetched one env ahead
     uint32_t cur[4] = {0, 0, 0, 0};
     float cur_act = 0.0f;
     auto fetch = [&](int64_t env, uint32_t (&r)[4], float &a) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(d.state) + env * (int64_t)rec_dw;
+        const auto src = uniform_ptr(reinterpret_cast<const uint32_t *>(DA.state) + env * (int64_t)rec_dw);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k = lane + 64 * q;
-            r[q] = (q < nreg && k < rec_dw) ? src[k] : 0u;
+            const uint32_t k = ulane + 64u * q;
+            r[q] = (q < nreg && (int)k < rec_dw) ? src[k] : 0u;
         }
-        if constexpr (MODE == 1) a = (lane < 2 * Np) ? io.actions[env * 2 * Np + lane] : 0.0f;
+        if constexpr (MODE == 1) a = (lane < 2 * Np) ? uniform_ptr(IOA.actions + env * 2 * Np)[ulane] : 0.0f;
         else a = 0.0f;
     };
-    if ((int64_t)blockIdx.x < d.n_envs) fetch(blockIdx.x, cur, cur_act);
+    const int n_envs = (int)d.n_envs;
+    if ((int)blockIdx.x < n_envs) fetch(blockIdx.x, cur, cur_act);
     asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur_act));
     wave_sync();
 
-    for (int64_t env = blockIdx.x; env < d.n_envs; env += gridDim.x) {
-        const int64_t nenv = env + gridDim.x;
+    for (int e32 = blockIdx.x; e32 < n_envs; e32 += (int)gridDim.x) {  // env indices are 32-bit (n_envs < 2^31 - grid), byte offsets 64-bit
+        const int64_t env = e32;
+        const int n32 = e32 + (int)gridDim.x;
         uint32_t nxt[4] = {0, 0, 0, 0};
         float nxt_act = 0.0f;
-        if (nenv < d.n_envs) fetch(nenv, nxt, nxt_act);
+        if (n32 < n_envs) fetch(n32, nxt, nxt_act);
         bool skip = false;
-        if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
+        if constexpr (MODE == 0) skip = (IOA.mask != nullptr && IOA.mask[env] == 0);
         if (!skip) {
             // record -> LDS
 #pragma unroll
@@ -149,7 +203,7 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
             wave_sync();
             int32_t tstep = reinterpret_cast<int32_t *>(S)[4 * NP + 2];
             uint32_t tick = reinterpret_cast<uint32_t *>(S)[4 * NP + 3];
-            const uint32_t gid = d.gid_base + (uint32_t)env;
+            const uint32_t gid = DA.gid_base + (uint32_t)env;
             float act_lane = cur_act;  // lane 2i / 2i+1 hold pursuer i's action components
 
             bool do_init = (MODE == 0);
@@ -158,10 +212,10 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 if (do_init) {
                     // ------------------------------------------------ reset (:144-172)
                     tstep = 0;
-                    if (lane == 0) {
-                        float ox = d.obst_x, oy = d.obst_y;
-                        if (!d.obstacle_fixed) {  // :147-148
-                            const u32x4 r = philox4x32_10(gid, tick, 0u, WW_TAG_OBSTACLE, d.k0, d.k1);
+                    if (fresh(lane) == 0) {
+                        float ox = DA.obst_x, oy = DA.obst_y;
+                        if (!DA.obstacle_fixed) {  // :147-148
+                            const u32x4 r = philox4x32_10(gid, tick, 0u, WW_TAG_OBSTACLE, DA.k0, DA.k1);
                             ox = u24(r.x);
                             oy = u24(r.y);
                         }
@@ -169,13 +223,13 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                         OB[1] = oy;
                     }
                     wave_sync();
-                    if (lane < NP) {  // :153-170 each particle: uniform position, redrawn while too close to the obstacle
-                        const float pr = lane < Np ? d.r_pu : (lane < Np + Ne ? d.r_ev : d.r_po);
-                        const float thr = pr * 2.0f + d.obst_r;
+                    if (fresh(lane) < NP) {  // :153-170 each particle: uniform position, redrawn while too close to the obstacle
+                        const float pr = fresh(lane) < Np ? DA.r_pu : (fresh(lane) < Np + Ne ? DA.r_ev : DA.r_po);
+                        const float thr = pr * 2.0f + DA.obst_r;
                         const float ox = OB[0], oy = OB[1];
                         float x = 0.f, y = 0.f, u0 = 0.f, u1 = 0.f;
                         for (uint32_t att = 0; att < 1024u; ++att) {
-                            const u32x4 r = philox4x32_10(gid, tick, (uint32_t)lane, WW_TAG_RESET | (att << 8), d.k0, d.k1);
+                            const u32x4 r = philox4x32_10(gid, tick, (uint32_t)lane, WW_TAG_RESET | (att << 8), DA.k0, DA.k1);
                             x = u24(r.x);
                             y = u24(r.y);
                             if (att == 0) { u0 = u24(r.z); u1 = u24(r.w); }
@@ -183,8 +237,8 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                         }
                         X[2 * lane] = x;
                         X[2 * lane + 1] = y;
-                        V[2 * lane] = lane < Np ? 0.0f : (u0 - 0.5f) * d.ev_speed;      // :164, :170 (W9)
-                        V[2 * lane + 1] = lane < Np ? 0.0f : (u1 - 0.5f) * d.ev_speed;
+                        V[2 * lane] = fresh(lane) < Np ? 0.0f : (u0 - 0.5f) * DA.ev_speed;      // :164, :170 (W9)
+                        V[2 * lane + 1] = fresh(lane) < Np ? 0.0f : (u1 - 0.5f) * DA.ev_speed;
                     }
                     tick += 1;
                     act_lane = 0.0f;  // reset ends with step(zeros) (:172, W11)
@@ -195,23 +249,23 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 // phase A: particles
                 float reward = 0.0f;
                 {
-                    const float a_raw0 = __shfl(act_lane, 2 * (lane < Np ? lane : 0));
-                    const float a_raw1 = __shfl(act_lane, 2 * (lane < Np ? lane : 0) + 1);
-                    const float a0 = a_raw0 * d.action_scale, a1 = a_raw1 * d.action_scale;  // :224
-                    float pen_local = d.control_penalty * (a0 * a0 + a1 * a1);
-                    if (d.reward_global) {  // (actions**2).sum(), row-major (:234-235, W12)
+                    const float a_raw0 = __shfl(act_lane, 2 * (fresh(lane) < Np ? lane : 0));
+                    const float a_raw1 = __shfl(act_lane, 2 * (fresh(lane) < Np ? lane : 0) + 1);
+                    const float a0 = a_raw0 * DA.action_scale, a1 = a_raw1 * DA.action_scale;  // :224
+                    float pen_local = DA.control_penalty * (a0 * a0 + a1 * a1);
+                    if (DA.reward_global) {  // (actions**2).sum(), row-major (:234-235, W12)
                         float s = 0.0f;
                         for (int i = 0; i < Np; ++i) {
                             const float b0 = __shfl(a0, i), b1 = __shfl(a1, i);
                             s += b0 * b0;
                             s += b1 * b1;
                         }
-                        pen_local = d.control_penalty * s;
+                        pen_local = DA.control_penalty * s;
                     }
-                    if (lane < NP) {
+                    if (fresh(lane) < NP) {
                         float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
-                        float pr = d.r_po, f = -1.0f;
-                        if (lane < Np) {
+                        float pr = DA.r_po, f = -1.0f;
+                        if (fresh(lane) < Np) {
                             vx = vx + a0; vy = vy + a1;  // :229-231
                             x = x + vx; y = y + vy;
                             reward = 0.0f + pen_local;   // :233-237
@@ -220,11 +274,11 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                             if (x != cx) vx = 0.f;
                             if (y != cy) vy = 0.f;
                             x = cx; y = cy;
-                            pr = d.r_pu; f = -0.5f;
-                        } else if (lane < Np + Ne) {
-                            pr = d.r_ev; f = -0.5f;
+                            pr = DA.r_pu; f = -0.5f;
+                        } else if (fresh(lane) < Np + Ne) {
+                            pr = DA.r_ev; f = -0.5f;
                         }
-                        if (dist2d(x, y, ox, oy) <= pr + d.obst_r) {  // :247-270 (W1, W2)
+                        if (dist2d(x, y, ox, oy) <= pr + DA.obst_r) {  // :247-270 (W1, W2)
                             vx = f * vx;
                             vy = f * vy;
                         }
@@ -233,8 +287,40 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 }
                 wave_sync();
                 // phase B: collisions (:272-293)
+                // BITROWS (specialised shapes with at most 64 pursuer x evader and pursuer x poison pairs): a collision matrix is ONE
+                // wave-uniform 64-bit mask (bit i * n + m = pursuer i touches particle m) made by a ballot; columns are counted and rows
+                // tested with bit operations.  No byte matrices in LDS, no loop over the other side of the pair.
+                constexpr bool BITROWS = TNp > 0 && TNp * TNe <= 64 && TNp * TNpo <= 64 && TNe < 64 && TNpo < 64;
+                uint64_t col_ev = 0ull, col_po = 0ull;
+                bool my_caught = false, my_enc = false;
+                if constexpr (BITROWS) {
+                    {
+                        const bool in = fresh(lane) < Np * Ne;
+                        const int i = in ? lane / Ne : 0, m = in ? lane - i * Ne : 0, j = Np + m;
+                        col_ev = __ballot(in && dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= DA.r_pu + DA.r_ev);
+                    }
+                    {
+                        const bool in = fresh(lane) < Np * Npo;
+                        const int i = in ? lane / Npo : 0, m = in ? lane - i * Npo : 0, j = Np + Ne + m;
+                        col_po = __ballot(in && dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= DA.r_pu + DA.r_po);
+                    }
 #if MADRL_WW_ABLATE & 4
-                if (d.n_envs < 0)
+                    col_ev = col_po = 0ull;
+#endif
+                    // _caught (:180-193): evader lanes / poison lanes count their column
+                    uint64_t cm_ev = 0ull, cm_po = 0ull;  // bit i * n of every row
+#pragma unroll
+                    for (int i = 0; i < (TNp > 0 ? TNp : 1); ++i) { cm_ev |= 1ull << (i * Ne); cm_po |= 1ull << (i * Npo); }
+                    if (fresh(lane) >= Np && fresh(lane) < NP) {
+                        const bool is_ev = fresh(lane) < Np + Ne;
+                        const int m = is_ev ? lane - Np : lane - Np - Ne;
+                        const int sc = __popcll((is_ev ? col_ev : col_po) & ((is_ev ? cm_ev : cm_po) << m));
+                        my_caught = sc >= (is_ev ? DA.n_coop : 1);
+                        my_enc = is_ev && sc >= 1;
+                    }
+                } else {
+#if MADRL_WW_ABLATE & 4
+                if (DA.n_envs < 0)
 #endif
                 for (int idx = lane; idx < Np * (Ne + Npo); idx += 64) {
                     const bool is_ev = idx < Np * Ne;
@@ -242,23 +328,23 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                     const int n2 = is_ev ? Ne : Npo;
                     const int i = r / n2, m = r % n2;
                     const int j = (is_ev ? Np : Np + Ne) + m;
-                    const float thr = d.r_pu + (is_ev ? d.r_ev : d.r_po);
+                    const float thr = DA.r_pu + (is_ev ? DA.r_ev : DA.r_po);
                     COL[idx] = dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= thr;
                 }
                 wave_sync();
                 // _caught (:180-193): evader lanes / poison lanes count their column
-                bool my_caught = false, my_enc = false;
-                if (lane >= Np && lane < NP) {
-                    const bool is_ev = lane < Np + Ne;
+                if (fresh(lane) >= Np && fresh(lane) < NP) {
+                    const bool is_ev = fresh(lane) < Np + Ne;
                     const int m = is_ev ? lane - Np : lane - Np - Ne;
                     const uint8_t *col = is_ev ? COL : COLP;
                     const int n2 = is_ev ? Ne : Npo;
                     int s = 0;
                     for (int i = 0; i < Np; ++i) s += col[i * n2 + m];
-                    my_caught = s >= (is_ev ? d.n_coop : 1);
+                    my_caught = s >= (is_ev ? DA.n_coop : 1);
                     my_enc = is_ev && s >= 1;
                     if (is_ev) { FLG[m] = my_caught; FLG[Ne + m] = my_enc; }
                     else FLG[2 * Ne + m] = my_caught;
+                }
                 }
                 const uint64_t ev_lanes = ((Ne >= 64) ? ~0ull : ((1ull << Ne) - 1ull)) << Np;
                 const uint64_t caught_mask = __ballot(my_caught);
@@ -268,37 +354,35 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 const int n_enc = __popcll(enc_mask);
                 wave_sync();
                 // phase C: sensing (:295-353).  lane = (pursuer i, sensor k)
-                const float srange = d.sensor_range, rad2 = d.r_pu * d.r_pu;  // W3
+                const float srange = DA.sensor_range, rad2 = DA.r_pu * DA.r_pu;  // W3
                 // The (pursuer, sensor) pairs are spread over the lanes, PCH passes of 64 at a time; the objects they are tested
                 // against are wave-uniform, so each object's position is broadcast ONCE from the register of the lane that
                 // owns the particle (v_readlane -> SGPR operand) and reused by all passes: the inner loop is pure VALU, no
                 // LDS round trip per (pair, object).  Arithmetic and comparison order per pair are those of the reference loop.
                 // passes of 64 (pursuer, sensor) pairs held in registers at a time: no more than the specialised shape needs
                 constexpr int PCH = (TNp > 0 && (TNp * TK + 63) / 64 < 3) ? (TNp * TK + 63) / 64 : 3;
-                const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
+                const float part_x = fresh(lane) < NP ? X[2 * lane] : 0.f, part_y = fresh(lane) < NP ? X[2 * lane + 1] : 0.f;
                 // Conservative cull: a sensor of pursuer i can only return a finite value for an object with
                 // d2 <= rad2 + sv^2 <= rad2 + range^2; NEAR[i] marks the objects within that reach plus a 1e-4 relative margin
                 // (d2 is computed exactly as in the test below), everything else would yield INFINITY and is skipped per pass.
                 {
                     const float thr2 = (rad2 + srange * srange) * 1.0001f + 1e-9f;
-                    const float mx = lane == NP ? ox : part_x, my = lane == NP ? oy : part_y;
+                    const float mx = fresh(lane) == NP ? ox : part_x, my = fresh(lane) == NP ? oy : part_y;
                     for (int i = 0; i < Np; ++i) {
                         const float rx = mx - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), i));
                         const float ry = my - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), i));
-                        const uint64_t mk = __ballot((lane <= NP) && (rx * rx + ry * ry <= thr2));
-                        if (lane == 0) NEAR[i] = mk;
+                        const uint64_t mk = __ballot((fresh(lane) <= NP) && (rx * rx + ry * ry <= thr2));
+                        if (fresh(lane) == 0) NEAR[i] = mk;
                     }
                     wave_sync();
                 }
 #if MADRL_WW_ABLATE & 1
-                if (d.n_envs < 0)
+                if (DA.n_envs < 0)
 #endif
                 for (int base = 0; base < Np * K; base += 64 * PCH) {
                     int ii[PCH], kk[PCH];
                     bool ok[PCH];
                     float sx[PCH], sy[PCH], px[PCH], py[PCH];
-                    float feat_d[4][PCH];
-                    int arg[4][PCH];
                     uint64_t reach[PCH];  // wave-uniform: objects in reach of any pursuer of pass q
 #pragma unroll
                     for (int q = 0; q < PCH; ++q) {
@@ -346,37 +430,40 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                                 bi[q] = better ? m : bi[q];
                             }
                         }
+                        // the class's features go to the staging row now (not after all four classes): nothing but the running
+                        // minimum of ONE class is held in registers across the object loop
+                        const bool speed = DA.speed_features;
 #pragma unroll
-                        for (int q = 0; q < PCH; ++q) { feat_d[cls][q] = b[q]; arg[cls][q] = bi[q]; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < PCH; ++q) {
-                        if (!ok[q]) continue;
-                        const int i = ii[q], k = kk[q];
-                        const float pvx = V[2 * i], pvy = V[2 * i + 1];
-                        float *o = O + i * D;
-                        const float f_ob = (feat_d[0][q] < INFINITY) ? feat_d[0][q] : 0.f;  // W4: raw distance or 0
-                        float fd[3], fs[3];
-#pragma unroll
-                        for (int cls = 1; cls < 4; ++cls) {
-                            const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
-                            const bool fin = feat_d[cls][q] < INFINITY;
-                            fd[cls - 1] = fin ? feat_d[cls][q] : 0.f;
-                            const int j = lo + arg[cls][q];
-                            fs[cls - 1] = fin ? (sx[q] * (V[2 * j] - pvx) + sy[q] * (V[2 * j + 1] - pvy)) : 0.f;  // W5
-                        }
-                        if (d.speed_features) {
-                            o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fs[0]; o[3 * K + k] = fd[1];
-                            o[4 * K + k] = fs[1]; o[5 * K + k] = fd[2]; o[6 * K + k] = fs[2];
-                        } else {
-                            o[k] = f_ob; o[K + k] = fd[0]; o[2 * K + k] = fd[1]; o[3 * K + k] = fd[2];
+                        for (int q = 0; q < PCH; ++q) {
+                            if (!ok[q]) continue;
+                            const int i = ii[q], k = kk[q];
+                            float *o = O + i * D;
+                            const bool fin = b[q] < INFINITY;
+                            const float fd = fin ? b[q] : 0.f;  // W4: raw distance or 0
+                            if (cls == 0) {
+                                o[k] = fd;
+                            } else {
+                                const int j = lo + bi[q];
+                                const float fs = fin ? (sx[q] * (V[2 * j] - V[2 * i]) + sy[q] * (V[2 * j + 1] - V[2 * i + 1])) : 0.f;  // W5
+                                if (speed) { o[(2 * cls - 1) * K + k] = fd; o[2 * cls * K + k] = fs; }
+                                else o[cls * K + k] = fd;
+                            }
                         }
                     }
                 }
                 // pursuer lanes: collision flags, id, who-caught tests for the local rewards
                 bool wc = false, wp = false, we = false;
-                if (lane < Np) {
+                if (fresh(lane) < Np) {
                     bool tev = false, tpo = false;
+                    if constexpr (BITROWS) {
+                        const uint64_t row_ev = (col_ev >> (lane * Ne)) & ((1ull << Ne) - 1ull);
+                        const uint64_t row_po = (col_po >> (lane * Npo)) & ((1ull << Npo) - 1ull);
+                        tev = row_ev != 0ull;
+                        tpo = row_po != 0ull;
+                        wc = (row_ev & (caught_mask >> Np)) != 0ull;           // touches a caught evader
+                        we = (row_ev & (enc_mask >> Np)) != 0ull;              // touches an encountered evader
+                        wp = (row_po & (caught_mask >> (Np + Ne))) != 0ull;    // touches a caught poison
+                    } else {
                     for (int e = 0; e < Ne; ++e) {
                         const bool c = COL[lane * Ne + e];
                         tev |= c;
@@ -388,50 +475,51 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                         tpo |= c;
                         wp |= c && FLG[2 * Ne + p];
                     }
-                    float *o = O + lane * D + d.nfeat * K;  // :411-428
+                    }
+                    float *o = O + lane * D + DA.nfeat * K;  // :411-428
                     o[0] = tev ? 1.f : 0.f;
                     o[1] = tpo ? 1.f : 0.f;
-                    if (d.addid) o[2] = (float)(lane + 1);  // W10
+                    if (DA.addid) o[2] = (float)(lane + 1);  // W10
                 }
                 wave_sync();
                 // phase E: respawn caught evaders / poisons (:355-374)
-                if (lane >= Np && lane < NP && my_caught) {
-                    const bool is_ev = lane < Np + Ne;
+                if (fresh(lane) >= Np && fresh(lane) < NP && my_caught) {
+                    const bool is_ev = fresh(lane) < Np + Ne;
                     float x, y, u0, u1;
-                    if (MODE == 1 && io.inj_resp != nullptr && !do_init) {
-                        const float *r = io.inj_resp + (env * NP + lane) * 4;
+                    if (MODE == 1 && IOA.inj_resp != nullptr && !do_init) {
+                        const float *r = IOA.inj_resp + (env * NP + lane) * 4;
                         x = r[0]; y = r[1]; u0 = r[2]; u1 = r[3];
                     } else {
-                        const float thr = (is_ev ? d.r_ev : d.r_po) * 2.0f + d.obst_r;
+                        const float thr = (is_ev ? DA.r_ev : DA.r_po) * 2.0f + DA.obst_r;
                         x = y = u0 = u1 = 0.f;
                         for (uint32_t att = 0; att < 1024u; ++att) {
-                            const u32x4 r = philox4x32_10(gid, tick, (uint32_t)lane, WW_TAG_RESPAWN | (att << 8), d.k0, d.k1);
+                            const u32x4 r = philox4x32_10(gid, tick, (uint32_t)lane, WW_TAG_RESPAWN | (att << 8), DA.k0, DA.k1);
                             x = u24(r.x);
                             y = u24(r.y);
                             if (att == 0) { u0 = u24(r.z); u1 = u24(r.w); }
                             if (!(dist2d(x, y, ox, oy) <= thr)) break;
                         }
                     }
-                    const float sp = is_ev ? d.ev_speed : d.poison_speed;  // W9
+                    const float sp = is_ev ? DA.ev_speed : DA.poison_speed;  // W9
                     X[2 * lane] = x; X[2 * lane + 1] = y;
                     V[2 * lane] = (u0 - 0.5f) * sp;
                     V[2 * lane + 1] = (u1 - 0.5f) * sp;
                 }
                 tick += 1;
                 // phase F: rewards (:376-385)
-                if (lane < Np) {
-                    if (d.reward_global) {
-                        reward += ((float)n_evc * d.food_reward) + ((float)n_poc * d.poison_reward) +
-                                  ((float)n_enc * d.encounter_reward);
+                if (fresh(lane) < Np) {
+                    if (DA.reward_global) {
+                        reward += ((float)n_evc * DA.food_reward) + ((float)n_poc * DA.poison_reward) +
+                                  ((float)n_enc * DA.encounter_reward);
                     } else {  // fancy-index += pays a pursuer once per kind (W7)
-                        if (wc) reward += d.food_reward;
-                        if (wp) reward += d.poison_reward;
-                        if (we) reward += d.encounter_reward;
+                        if (wc) reward += DA.food_reward;
+                        if (wp) reward += DA.poison_reward;
+                        if (we) reward += DA.encounter_reward;
                     }
                 }
                 wave_sync();
                 // phase G: evaders / poisons move; velocity flips only if BOTH coordinates left [0,1] (W6)
-                if (lane >= Np && lane < NP) {
+                if (fresh(lane) >= Np && fresh(lane) < NP) {
                     float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
                     x = x + vx; y = y + vy;
                     const bool outx = !(x >= 0.f && x <= 1.f), outy = !(y >= 0.f && y <= 1.f);
@@ -439,16 +527,16 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                     X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
                 }
                 tstep += 1;  // :433
-                const int limit = d.max_steps > 0 ? d.max_steps : 1000;  // timestep_limit :124-126
+                const int limit = DA.max_steps > 0 ? DA.max_steps : 1000;  // timestep_limit :124-126
                 const bool is_done = tstep >= limit;                     // :174-178
                 wave_sync();
 
                 if (pass == 0) asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_act));  // pipeline hinge
                 // ---------------------------------------------------- outputs
                 if (MODE == 1 && !do_init) {
-                    if (lane < Np) io.rew[env * Np + lane] = reward;
-                    if (FUSED && io.st->rew_out != nullptr && lane < Np) {  // StandardizedEnv.step :283-291
-                        const WwStd &st = *io.st;
+                    if (fresh(lane) < Np) uniform_ptr(IOA.rew + env * Np)[ulane] = reward;
+                    if (FUSED && IOA.st->rew_out != nullptr && fresh(lane) < Np) {  // StandardizedEnv.step :283-291
+                        const WwStd &st = *IOA.st;
                         const int64_t i = env * Np + lane;
                         double r = (double)reward;
                         if (st.enable_rewnorm) {
@@ -461,25 +549,26 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                         }
                         st.rew_out[i] = (float)(st.scale * r);                                           // :290
                     }
-                    if (lane == 0) {
-                        io.done[env] = (uint8_t)is_done;
-                        io.info[2 * env] = n_evc;
-                        io.info[2 * env + 1] = n_poc;
+                    if (fresh(lane) == 0) {
+                        IOA.done[env] = (uint8_t)is_done;
+                        IOA.info[2 * env] = n_evc;
+                        IOA.info[2 * env + 1] = n_poc;
                     }
-                    if (is_done && d.auto_reset) {  // wave-uniform: run the reset pass next
+                    if (is_done && DA.auto_reset) {  // wave-uniform: run the reset pass next
                         npass = 2;
                         do_init = true;
                     }
                 }
                 if (pass == npass - 1) {
-                    float *orow = io.obs + env * (int64_t)(Np * D);
+                    float *const obs_p = IOA.obs;
+                    const auto orow = uniform_ptr(obs_p + env * (int64_t)(Np * D));
 #if MADRL_WW_ABLATE & 2
-                    if (d.n_envs < 0)
+                    if (DA.n_envs < 0)
 #endif
-                    if (io.obs != nullptr)   // the raw row may be dropped when the fused wrapper output is all the caller reads
-                    for (int e = lane; e < Np * D; e += 64) orow[e] = O[e];
+                    if (obs_p != nullptr)   // the raw row may be dropped when the fused wrapper output is all the caller reads
+                    for (uint32_t e = ulane; e < (uint32_t)(Np * D); e += 64u) orow[e] = O[e];
                     if (FUSED) {  // StandardizedEnv.standardize_obs :242-263
-                        const WwStd &st = *io.st;
+                        const WwStd &st = *IOA.st;
                         const int64_t base = env * (int64_t)(Np * D);
                         if (st.enable_obsnorm) {
                             // batches of 4 elements per lane: all 8 statistics loads of a batch are in flight before the first
@@ -518,14 +607,14 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
                 wave_sync();
             }
             // ---------------------------------------------------------- LDS -> record
-            if (lane == 0) {
+            if (fresh(lane) == 0) {
                 reinterpret_cast<int32_t *>(S)[4 * NP + 2] = tstep;
                 reinterpret_cast<uint32_t *>(S)[4 * NP + 3] = tick;
             }
             wave_sync();
             {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(d.state) + env * (int64_t)rec_dw;
-                for (int k = lane; k < rec_dw; k += 64) dst[k] = reinterpret_cast<const uint32_t *>(S)[k];
+                const auto dst = uniform_ptr(reinterpret_cast<uint32_t *>(DA.state) + env * (int64_t)rec_dw);
+                for (uint32_t k = ulane; k < (uint32_t)rec_dw; k += 64u) dst[k] = reinterpret_cast<const uint32_t *>(S)[k];
             }
             wave_sync();
         }
@@ -534,9 +623,10 @@ __global__ __launch_bounds__(64) void waterworld_kernel(const WwDev d, const WwI
         cur_act = nxt_act;
     }
 }
+#undef DA
+#undef IOA
 
 }  // namespace
-
 // =================================================================== host side / C ABI
 struct madrl_waterworld {
     madrl_waterworld_config cfg;
@@ -599,12 +689,12 @@ int ww_launch(const madrl_waterworld *h, const WwIO &io, int mode, void *stream)
     if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
     const WwDev &d = h->dev;
-    const bool c3 = d.Np == 5 && d.Ne == 10 && d.Npo == 10 && d.K == 30;  // BASELINE configs[2]: MAWaterWorld(5, 10), 30 sensors
+    const bool c3 = d.Np == 5 && d.Ne == 10 && d.Npo == 10 && d.K == 30 && d.D == 213;  // (speed features and agent id: the defaults)  // BASELINE configs[2]: MAWaterWorld(5, 10), 30 sensors
     const dim3 g((unsigned)blocks), b(64);
     const bool fused = io.st != nullptr;
 #define WW_LAUNCH(MODE_, FUSED_)                                                                                                   \
     do {                                                                                                                          \
-        if (c3) hipLaunchKernelGGL((waterworld_kernel<MODE_, 5, 10, 10, 30, FUSED_>), g, b, h->lds_bytes, s, h->dev, io);         \
+        if (c3) hipLaunchKernelGGL((waterworld_kernel<MODE_, 5, 10, 10, 30, FUSED_, 213>), g, b, 0, s, h->dev, io);               \
         else hipLaunchKernelGGL((waterworld_kernel<MODE_, 0, 0, 0, 0, FUSED_>), g, b, h->lds_bytes, s, h->dev, io);               \
     } while (0)
     if (mode == 0) { if (fused) WW_LAUNCH(0, true); else WW_LAUNCH(0, false); }
