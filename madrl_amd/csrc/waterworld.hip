@@ -43,6 +43,10 @@ struct WwDev {
     float r_pu, r_ev, r_po, obst_r, ev_speed, poison_speed, sensor_range, action_scale;
     float poison_reward, food_reward, encounter_reward, control_penalty;
     float obst_x, obst_y;
+    // sq_*: the largest float32 x with sqrtf(x) <= threshold, so that "distance <= threshold" is the single compare "dx*dx + dy*dy <= sq"
+    // with the same truth value for every input (sqrtf is monotonic and correctly rounded); the correctly rounded sqrtf itself is a
+    // 20-instruction sequence.  Thresholds: obstacle rebound per particle kind (:247-270), pursuer-evader / pursuer-poison contact (:272-293).
+    float sq_obst_pu, sq_obst_ev, sq_obst_po, sq_hit_ev, sq_hit_po;
     int64_t n_envs;
     const float *sensors;  // [K][2]
     float *state;
@@ -116,20 +120,26 @@ __device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) 
     return sqrtf(dx * dx + dy * dy);  // scipy cdist 'euclidean'
 }
 
+// dist2d(a, b) <= thr, with sq = sq_threshold(thr) (host side): same truth value, no square root
+__device__ __forceinline__ bool dist2_le(float ax, float ay, float bx, float by, float sq) {
+    const float dx = ax - bx, dy = ay - by;
+    return dx * dx + dy * dy <= sq;
+}
+
 // Profiling aid (scripts/variants.sh, never the shipped library): 1 no sensing loop, 2 no observation store, 4 no collisions
 #ifndef MADRL_WW_ABLATE
 #define MADRL_WW_ABLATE 0
 #endif
 
-// Resident wavefronts per SIMD the registers are allocated for (MADRL_WW_WAVES=0: compiler's choice)
+// Resident wavefronts per SIMD the SPECIALISED kernel's registers are allocated for (the generic one is left to the compiler).
+// Measured at BASELINE C3, 32 768 envs: 4 waves (104 VGPRs) 77 us, 5 waves (86) 60.4 us, 6 waves (80, no scratch) 57.2 us, 7 waves
+// (72 + 32 B of scratch) 57.4 us.
 #ifndef MADRL_WW_WAVES
-#define MADRL_WW_WAVES 5
+#define MADRL_WW_WAVES 6
 #endif
-#if MADRL_WW_WAVES > 0
-#define MADRL_WW_OCC __attribute__((amdgpu_waves_per_eu(MADRL_WW_WAVES, MADRL_WW_WAVES)))
-#else
-#define MADRL_WW_OCC
-#endif
+// (the fused-wrapper variant holds float64 statistics: one wave fewer, or it spills)
+#define MADRL_WW_OCC_N (TNp > 0 ? (FUSED ? MADRL_WW_WAVES - 1 : MADRL_WW_WAVES) : 0)
+#define MADRL_WW_OCC __attribute__((amdgpu_waves_per_eu(MADRL_WW_OCC_N > 0 ? MADRL_WW_OCC_N : 1, MADRL_WW_OCC_N > 0 ? MADRL_WW_OCC_N : 8)))
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 // TNp..TK > 0: the particle / sensor counts are compile-time constants (loops unroll, the index divisions fold); 0: generic.
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                     }
                     if (fresh(lane) < NP) {
                         float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
-                        float pr = DA.r_po, f = -1.0f;
+                        float sq_obst = DA.sq_obst_po, f = -1.0f;
                         if (fresh(lane) < Np) {
                             vx = vx + a0; vy = vy + a1;  // :229-231
                             x = x + vx; y = y + vy;
@@ -274,11 +284,11 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                             if (x != cx) vx = 0.f;
                             if (y != cy) vy = 0.f;
                             x = cx; y = cy;
-                            pr = DA.r_pu; f = -0.5f;
+                            sq_obst = DA.sq_obst_pu; f = -0.5f;
                         } else if (fresh(lane) < Np + Ne) {
-                            pr = DA.r_ev; f = -0.5f;
+                            sq_obst = DA.sq_obst_ev; f = -0.5f;
                         }
-                        if (dist2d(x, y, ox, oy) <= pr + DA.obst_r) {  // :247-270 (W1, W2)
+                        if (dist2_le(x, y, ox, oy, sq_obst)) {  // dist <= pr + obst_r, :247-270 (W1, W2)
                             vx = f * vx;
                             vy = f * vy;
                         }
@@ -297,12 +307,12 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                     {
                         const bool in = fresh(lane) < Np * Ne;
                         const int i = in ? lane / Ne : 0, m = in ? lane - i * Ne : 0, j = Np + m;
-                        col_ev = __ballot(in && dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= DA.r_pu + DA.r_ev);
+                        col_ev = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_ev));
                     }
                     {
                         const bool in = fresh(lane) < Np * Npo;
                         const int i = in ? lane / Npo : 0, m = in ? lane - i * Npo : 0, j = Np + Ne + m;
-                        col_po = __ballot(in && dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= DA.r_pu + DA.r_po);
+                        col_po = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_po));
                     }
 #if MADRL_WW_ABLATE & 4
                     col_ev = col_po = 0ull;
@@ -328,8 +338,7 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                     const int n2 = is_ev ? Ne : Npo;
                     const int i = r / n2, m = r % n2;
                     const int j = (is_ev ? Np : Np + Ne) + m;
-                    const float thr = DA.r_pu + (is_ev ? DA.r_ev : DA.r_po);
-                    COL[idx] = dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= thr;
+                    COL[idx] = dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], is_ev ? DA.sq_hit_ev : DA.sq_hit_po);
                 }
                 wave_sync();
                 // _caught (:180-193): evader lanes / poison lanes count their column
@@ -660,6 +669,18 @@ int ww_obs_dim_of(const madrl_waterworld_config *c) {
     return c->n_sensors * (c->speed_features ? 7 : 4) + 2 + (c->addid ? 1 : 0);  // Archea.__init__ :18-24
 }
 
+// largest float32 x with sqrtf(x) <= thr (thr >= 0 finite); see WwDev::sq_*
+float sq_threshold(float thr) {
+    float x = thr * thr;
+    while (x > 0.0f && sqrtf(x) > thr) x = nextafterf(x, 0.0f);
+    for (;;) {
+        const float up = nextafterf(x, INFINITY);
+        if (!(sqrtf(up) <= thr)) break;
+        x = up;
+    }
+    return x;
+}
+
 void ww_layout(const madrl_waterworld_config *c, WwDev *d) {
     memset(d, 0, sizeof(*d));
     d->Np = c->n_pursuers; d->Ne = c->n_evaders; d->Npo = c->n_poison; d->NP = d->Np + d->Ne + d->Npo;
@@ -676,6 +697,10 @@ void ww_layout(const madrl_waterworld_config *c, WwDev *d) {
     d->poison_reward = (float)c->poison_reward; d->food_reward = (float)c->food_reward;
     d->encounter_reward = (float)c->encounter_reward; d->control_penalty = (float)c->control_penalty;
     d->obst_x = (float)c->obstacle_loc[0]; d->obst_y = (float)c->obstacle_loc[1];
+    // the float32 sums are the ones the kernel used to form before comparing (pr + obst_r, r_pu + r_ev, r_pu + r_po)
+    d->sq_obst_pu = sq_threshold(d->r_pu + d->obst_r); d->sq_obst_ev = sq_threshold(d->r_ev + d->obst_r);
+    d->sq_obst_po = sq_threshold(d->r_po + d->obst_r);
+    d->sq_hit_ev = sq_threshold(d->r_pu + d->r_ev); d->sq_hit_po = sq_threshold(d->r_pu + d->r_po);
 }
 
 size_t ww_lds_bytes(const WwDev &d) {
