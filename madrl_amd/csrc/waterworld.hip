@@ -369,7 +369,14 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 // owns the particle (v_readlane -> SGPR operand) and reused by all passes: the inner loop is pure VALU, no
                 // LDS round trip per (pair, object).  Arithmetic and comparison order per pair are those of the reference loop.
                 // passes of 64 (pursuer, sensor) pairs held in registers at a time: no more than the specialised shape needs
-                constexpr int PCH = (TNp > 0 && (TNp * TK + 63) / 64 < 3) ? (TNp * TK + 63) / 64 : 3;
+                // Lane layout of a pass.  ALIGNED (compile-time K <= 64): a pass holds floor(64 / K) WHOLE pursuers (the last lanes idle), so
+                // the objects a pass must visit are those in reach of 2 pursuers at BASELINE C3 instead of the 2.1-3 a pass of 64
+                // consecutive (pursuer, sensor) pairs straddles: about a quarter fewer (object, pass) visits.  Otherwise: consecutive pairs.
+                constexpr bool ALIGNED = TK > 0 && TK <= 64;
+                constexpr int PPP = ALIGNED ? 64 / (TK > 0 ? TK : 1) : 1;  // pursuers per pass
+                const int n_pass = ALIGNED ? (Np + PPP - 1) / PPP : (Np * K + 63) / 64;
+                constexpr int N_PASS_T = TNp > 0 ? (ALIGNED ? (TNp + PPP - 1) / PPP : (TNp * TK + 63) / 64) : 3;
+                constexpr int PCH = N_PASS_T < 3 ? N_PASS_T : 3;
                 const float part_x = fresh(lane) < NP ? X[2 * lane] : 0.f, part_y = fresh(lane) < NP ? X[2 * lane + 1] : 0.f;
                 // Conservative cull: a sensor of pursuer i can only return a finite value for an object with
                 // d2 <= rad2 + sv^2 <= rad2 + range^2; NEAR[i] marks the objects within that reach plus a 1e-4 relative margin
@@ -388,23 +395,33 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
 #if MADRL_WW_ABLATE & 1
                 if (DA.n_envs < 0)
 #endif
-                for (int base = 0; base < Np * K; base += 64 * PCH) {
+                for (int p0 = 0; p0 < n_pass; p0 += PCH) {
                     int ii[PCH], kk[PCH];
                     bool ok[PCH];
                     float sx[PCH], sy[PCH], px[PCH], py[PCH];
                     uint64_t reach[PCH];  // wave-uniform: objects in reach of any pursuer of pass q
 #pragma unroll
                     for (int q = 0; q < PCH; ++q) {
-                        const int idx = base + 64 * q + lane;
-                        ok[q] = idx < Np * K;
-                        ii[q] = ok[q] ? idx / K : 0;
-                        kk[q] = ok[q] ? idx - ii[q] * K : 0;
+                        const int pass_q = p0 + q;
+                        int i_first, i_last;  // pursuers of this pass
+                        if constexpr (ALIGNED) {
+                            const int li = lane / K;
+                            i_first = pass_q * PPP; i_last = min(i_first + PPP, Np) - 1;
+                            ok[q] = li < PPP && i_first + li <= i_last;
+                            ii[q] = ok[q] ? i_first + li : 0;
+                            kk[q] = ok[q] ? lane - li * K : 0;
+                        } else {
+                            const int idx = 64 * pass_q + lane;
+                            ok[q] = idx < Np * K;
+                            ii[q] = ok[q] ? idx / K : 0;
+                            kk[q] = ok[q] ? idx - ii[q] * K : 0;
+                            i_first = 64 * pass_q / K; i_last = min(64 * pass_q + 63, Np * K - 1) / K;
+                        }
                         sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
                         px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
                         uint64_t u = 0ull;
-                        const int first = base + 64 * q, last = min(first + 63, Np * K - 1);
-                        if (first < Np * K)
-                            for (int i = first / K; i <= last / K; ++i) u |= NEAR[i];
+                        if (pass_q < n_pass)
+                            for (int i = i_first; i <= i_last; ++i) u |= NEAR[i];
                         reach[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
                     }
