@@ -25,9 +25,9 @@
 #define MADRL_HW_ABLATE 0
 #endif
 #ifndef MADRL_HW_WAVES
-#define MADRL_HW_WAVES 4   // resident wavefronts per SIMD the register allocation aims at: at 5 (96 VGPRs) the kernel spills 60 B per lane to
-                           // scratch, and those spill stores reach HBM (evicted by the streaming rows): 4 013 instead of 2 229 bytes
-                           // written per env-step at the same 61 us (scripts/variant_traffic.sh)
+#define MADRL_HW_WAVES 7   // resident wavefronts per SIMD the SPECIALISED kernel's register allocation aims at (generic: compiler's choice).  Round 1 kernel: 117 VGPRs, 4 waves (at 5 it spilled
+                           // 60 B per lane and the spill stores reached HBM).  With the launch parameters out of the SGPR file
+                           // and the static LDS layout: 72 VGPRs, no scratch at 7 waves.  32 768 envs: 4 waves 55.2 us, 5 50.7, 6 48.0, 7 46.9.
 #endif
 
 namespace {
@@ -59,6 +59,32 @@ struct HwIO {
     int32_t *info;          // [N][2]  ho_saved, cr_encs
 };
 
+// Same register discipline as waterworld.hip: launch parameters are read from the kernel-argument segment (scalar loads) where a
+// phase needs them instead of being held in SGPRs across the env loop (what does not fit in SGPRs is parked in VGPR lanes at two
+// VALU issue slots per value and use); per-lane global accesses go through an SGPR base + 32-bit VGPR offset; a lane predicate
+// is recomputed at its use (fresh) instead of being hoisted out of the env loop as an SGPR pair.
+struct HwKArgs {
+    HwDev d;
+    HwIO io;
+};
+typedef const __attribute__((address_space(4))) HwKArgs *HwKArgsPtr;
+__device__ __forceinline__ HwKArgsPtr hw_args() {
+    HwKArgsPtr p = (HwKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *uniform_ptr(T *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (__attribute__((address_space(1))) T *)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -74,17 +100,27 @@ __device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
 // TNr..TK > 0: the particle / sensor counts are compile-time constants (small loops unroll, the index divisions fold); 0: generic.
-template <int MODE, int TNr, int TNh, int TNc, int TK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAVES, MADRL_HW_WAVES))) void hostage_kernel(const HwDev d, const HwIO io) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int MODE, int TNr, int TNh, int TNc, int TK, int TD = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MADRL_HW_WAVES : 1, TNr > 0 ? MADRL_HW_WAVES : 8))) void hostage_kernel(const HwDev d, const HwIO io) {
+    // specialised shape: compile-time LDS layout in a static array, launched with 0 dynamic bytes (see waterworld.hip)
+    constexpr int SPEC_DW = TNr > 0 ? ((4 * (TNr + TNh + TNc) + 9 + 3) / 4 * 4 + (TNr * (TD > 0 ? TD : 1) + 3) / 4 * 4 + (2 * TK + 3) / 4 * 4) : 0;
+    constexpr int SPEC_BYTES = TNr > 0 ? (SPEC_DW * 4 + 8 * TNr + TNr * (TNh + TNc) + 2 * TNh + TNc + 15) / 16 * 16 : 16;
+    static_assert(TNr == 0 || TD > 0, "a specialised shape fixes the observation width too");
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    __shared__ __attribute__((aligned(16))) float smem_static[SPEC_BYTES / 4];
+    float *const smem = TNr > 0 ? smem_static : smem_dyn;
     const int lane = threadIdx.x;
+    const uint32_t ulane = threadIdx.x;
+#define DA (hw_args()->d)
+#define IOA (hw_args()->io)
     const int Nr = TNr > 0 ? TNr : d.Nr, Nh = TNr > 0 ? TNh : d.Nh, Nc = TNr > 0 ? TNc : d.Nc, K = TNr > 0 ? TK : d.K;
-    const int NP = Nr + Nh + Nc, D = d.D;
+    const int NP = Nr + Nh + Nc, D = TD > 0 ? TD : d.D;
     float *S = smem;                                   // packed record
     float *X = S, *V = S + 2 * NP;
     uint32_t *SU = reinterpret_cast<uint32_t *>(S);
     const int OFF_KEY = 4 * NP, OFF_BOMB = 4 * NP + 2, OFF_SAVED = 4 * NP + 4, OFF_FLAGS = 4 * NP + 6, OFF_T = 4 * NP + 7, OFF_TICK = 4 * NP + 8;
-    float *O = S + ((d.rec_dw + 3) & ~3);              // observation staging [Nr][D]
+    const int rec_dw = TNr > 0 ? (4 * (TNr + TNh + TNc) + 9 + 3) / 4 * 4 : d.rec_dw;
+    float *O = S + ((rec_dw + 3) & ~3);                // observation staging [Nr][D]
     float *SEN = O + ((Nr * D + 3) & ~3);              // sensor unit vectors [K][2]
     uint64_t *NEAR = reinterpret_cast<uint64_t *>(SEN + ((2 * K + 3) & ~3));  // per rescuer: particles (bit j), key (bit NP), bomb (bit NP + 1) in sensing reach
     uint8_t *COLH = reinterpret_cast<uint8_t *>(NEAR + Nr);  // [Nr][Nh]
@@ -92,19 +128,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
     uint8_t *FLG = COLC + Nr * Nc;                     // ho_caught[Nh] | ho_enc[Nh] | cr_caught[Nc]
 
     for (int k = lane; k < 2 * K; k += 64) SEN[k] = d.sensors[k];
-    const int rec_dw = d.rec_dw;
     const int nreg = (rec_dw + 63) >> 6;  // <= 4
 
     uint32_t cur[4] = {0, 0, 0, 0};
     float cur_act = 0.0f;
     auto fetch = [&](int64_t env, uint32_t (&r)[4], float &a) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(d.state) + env * (int64_t)rec_dw;
+        const auto src = uniform_ptr(reinterpret_cast<const uint32_t *>(DA.state) + env * (int64_t)rec_dw);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k = lane + 64 * q;
-            r[q] = (q < nreg && k < rec_dw) ? src[k] : 0u;
+            const uint32_t k = ulane + 64u * q;
+            r[q] = (q < nreg && (int)k < rec_dw) ? src[k] : 0u;
         }
-        if constexpr (MODE == 1) a = (lane < 2 * Nr) ? io.actions[env * 2 * Nr + lane] : 0.0f;
+        if constexpr (MODE == 1) a = (lane < 2 * Nr) ? uniform_ptr(IOA.actions + env * 2 * Nr)[ulane] : 0.0f;
         else a = 0.0f;
     };
     const EnvWalk walk = env_walk(d.n_envs);  // XCD-aware: neighbouring envs share an L2 (common.hpp)
@@ -112,14 +147,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
     asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur_act));
     wave_sync();
 
-    for (int64_t li = walk.first; li < walk.lim; li += walk.stride) {
-        const int64_t env = walk.base + li;
-        const int64_t nenv = env + walk.stride;
+    const int w_base = (int)walk.base, w_stride = (int)walk.stride, w_lim = (int)walk.lim;  // env indices are 32-bit, byte offsets 64-bit
+    for (int li = (int)walk.first; li < w_lim; li += w_stride) {
+        const int64_t env = w_base + li;
+        const int64_t nenv = env + w_stride;
         uint32_t nxt[4] = {0, 0, 0, 0};
         float nxt_act = 0.0f;
-        if (li + walk.stride < walk.lim) fetch(nenv, nxt, nxt_act);
+        if (li + w_stride < w_lim) fetch(nenv, nxt, nxt_act);
         bool skip = false;
-        if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
+        if constexpr (MODE == 0) skip = (IOA.mask != nullptr && IOA.mask[env] == 0);
         if (!skip) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -131,7 +167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
             uint32_t tick = SU[OFF_TICK];
             uint32_t flags = SU[OFF_FLAGS];  // bit0 gate_open, bit1 bombed, bit2 key sampled
             uint64_t saved = (uint64_t)SU[OFF_SAVED] | ((uint64_t)SU[OFF_SAVED + 1] << 32);
-            const uint32_t gid = d.gid_base + (uint32_t)env;
+            const uint32_t gid = DA.gid_base + (uint32_t)env;
             float act_lane = cur_act;
 
             bool do_init = (MODE == 0);
@@ -140,23 +176,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
                 if (do_init) {
                     // ------------------------------------------------ reset (:137-177); draw index: key 0, particle j -> 1 + j, bomb 1 + NP
                     tstep = 0;
-                    if (lane < NP + 2) {
-                        const uint32_t di = lane < NP ? 1u + (uint32_t)lane : (lane == NP ? 0u : 1u + (uint32_t)NP);
-                        const u32x4 r = philox4x32_10(gid, tick, di, HW_TAG_RESET, d.k0, d.k1);
+                    if (fresh(lane) < NP + 2) {
+                        const uint32_t di = fresh(lane) < NP ? 1u + (uint32_t)lane : (fresh(lane) == NP ? 0u : 1u + (uint32_t)NP);
+                        const u32x4 r = philox4x32_10(gid, tick, di, HW_TAG_RESET, DA.k0, DA.k1);
                         const float u0 = u24(r.x), u1 = u24(r.y), u2 = u24(r.z), u3 = u24(r.w);
-                        if (lane < Nr) {  // :149-153
+                        if (fresh(lane) < Nr) {  // :149-153
                             X[2 * lane] = u0; X[2 * lane + 1] = clipf(u1, 0.55f, 0.95f);
                             V[2 * lane] = 0.f; V[2 * lane + 1] = 0.f;
-                        } else if (lane < Nr + Nh) {  // :156-160
+                        } else if (fresh(lane) < Nr + Nh) {  // :156-160
                             X[2 * lane] = u0; X[2 * lane + 1] = clipf(u1, 0.f, 0.35f + u2 * 0.01f);
                             V[2 * lane] = 0.f; V[2 * lane + 1] = 0.f;
-                        } else if (lane < NP) {  // :165-168 (velocity not centred here)
+                        } else if (fresh(lane) < NP) {  // :165-168 (velocity not centred here)
                             X[2 * lane] = u0; X[2 * lane + 1] = u1;
-                            V[2 * lane] = u2 * d.bad_speed; V[2 * lane + 1] = u3 * d.bad_speed;
-                        } else if (lane == NP) {  // key: the first reset of the env's life only (G2, :143-146)
+                            V[2 * lane] = u2 * DA.bad_speed; V[2 * lane + 1] = u3 * DA.bad_speed;
+                        } else if (fresh(lane) == NP) {  // key: the first reset of the env's life only (G2, :143-146)
                             if (!(flags & 4u)) {
-                                S[OFF_KEY] = d.key_fixed ? d.key_x : 1.f - u0 * 0.1f;
-                                S[OFF_KEY + 1] = d.key_fixed ? d.key_y : 1.f - u1 * 0.1f;
+                                S[OFF_KEY] = DA.key_fixed ? DA.key_x : 1.f - u0 * 0.1f;
+                                S[OFF_KEY + 1] = DA.key_fixed ? DA.key_y : 1.f - u1 * 0.1f;
                             }
                         } else {  // bomb :171
                             S[OFF_BOMB] = clipf(u0, 0.f, 0.25f); S[OFF_BOMB + 1] = clipf(u1, 0.f, 0.25f);
@@ -174,20 +210,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
                 float reward = 0.0f;
                 bool col_bo = false, col_ke = false;
                 {   // phase A: rescuers (:231-260)
-                    const float a_raw0 = __shfl(act_lane, 2 * (lane < Nr ? lane : 0));
-                    const float a_raw1 = __shfl(act_lane, 2 * (lane < Nr ? lane : 0) + 1);
-                    const float a0 = a_raw0 * d.action_scale, a1 = a_raw1 * d.action_scale;
-                    float pen = d.control_penalty * (a0 * a0 + a1 * a1);
-                    if (d.reward_global) {  // (actions**2).sum(), row-major (:241-242)
+                    const float a_raw0 = __shfl(act_lane, 2 * (fresh(lane) < Nr ? lane : 0));
+                    const float a_raw1 = __shfl(act_lane, 2 * (fresh(lane) < Nr ? lane : 0) + 1);
+                    const float a0 = a_raw0 * DA.action_scale, a1 = a_raw1 * DA.action_scale;
+                    float pen = DA.control_penalty * (a0 * a0 + a1 * a1);
+                    if (DA.reward_global) {  // (actions**2).sum(), row-major (:241-242)
                         float s = 0.0f;
                         for (int i = 0; i < Nr; ++i) {
                             const float b0 = __shfl(a0, i), b1 = __shfl(a1, i);
                             s += b0 * b0;
                             s += b1 * b1;
                         }
-                        pen = d.control_penalty * s;
+                        pen = DA.control_penalty * s;
                     }
-                    if (lane < Nr) {
+                    if (fresh(lane) < Nr) {
                         float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
                         vx = vx + a0; vy = vy + a1;
                         x = x + vx; y = y + vy;
@@ -197,14 +233,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
                         if (y != cy) vy = 0.f;
                         x = cx; y = cy;
                         if (!gate0) {  // G3: both coordinates, velocity component flipped (:255-260)
-                            cx = clipf(x, d.gate_lo, 1.f); cy = clipf(y, d.gate_lo, 1.f);
+                            cx = clipf(x, DA.gate_lo, 1.f); cy = clipf(y, DA.gate_lo, 1.f);
                             if (x != cx) vx *= -1.f;
                             if (y != cy) vy *= -1.f;
                             x = cx; y = cy;
                         }
                         X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
-                        col_bo = dist2d(x, y, bx, by) <= d.radius + d.bomb_radius;  // :281-291
-                        col_ke = dist2d(x, y, kx, ky) <= d.radius + d.key_radius;
+                        col_bo = dist2d(x, y, bx, by) <= DA.radius + DA.bomb_radius;  // :281-291
+                        col_ke = dist2d(x, y, kx, ky) <= DA.radius + DA.key_radius;
                     }
                 }
                 wave_sync();
@@ -215,19 +251,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
                     const int n2 = is_ho ? Nh : Nc;
                     const int i = r / n2, m = r % n2;
                     const int j = (is_ho ? Nr : Nr + Nh) + m;
-                    const float thr = d.radius + (is_ho ? d.r_ho : d.radius);
+                    const float thr = DA.radius + (is_ho ? DA.r_ho : DA.radius);
                     (is_ho ? COLH : COLC)[r] = dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= thr;
                 }
                 wave_sync();
                 bool my_caught = false, my_enc = false;  // hostage / criminal lanes count their column (_caught :184-198)
-                if (lane >= Nr && lane < NP) {
-                    const bool is_ho = lane < Nr + Nh;
+                if (fresh(lane) >= Nr && fresh(lane) < NP) {
+                    const bool is_ho = fresh(lane) < Nr + Nh;
                     const int m = is_ho ? lane - Nr : lane - Nr - Nh;
                     const uint8_t *col = is_ho ? COLH : COLC;
                     const int n2 = is_ho ? Nh : Nc;
                     int s = 0;
                     for (int i = 0; i < Nr; ++i) s += col[i * n2 + m];
-                    my_caught = s >= (is_ho ? d.n_coop_save : 1);
+                    my_caught = s >= (is_ho ? DA.n_coop_save : 1);
                     my_enc = is_ho && s >= 1;
                     if (is_ho) { FLG[m] = my_caught; FLG[Nh + m] = my_enc; }
                     else FLG[2 * Nh + m] = my_caught;
@@ -243,17 +279,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
                 {
                     // passes of 64 (rescuer, sensor) pairs held in registers at a time: no more than the specialised shape needs
                     constexpr int PCH = (TNr > 0 && (TNr * TK + 63) / 64 < 3) ? (TNr * TK + 63) / 64 : 3;
-                    const float srange = d.sensor_range, rad2 = d.radius * d.radius;  // G1
-                    const float part_x = lane < NP ? X[2 * lane] : 0.f, part_y = lane < NP ? X[2 * lane + 1] : 0.f;
+                    const float srange = DA.sensor_range, rad2 = DA.radius * DA.radius;  // G1
+                    const float part_x = fresh(lane) < NP ? X[2 * lane] : 0.f, part_y = fresh(lane) < NP ? X[2 * lane + 1] : 0.f;
                     // Conservative cull (as in waterworld.hip): NEAR[i] = objects with d2 <= (rad2 + range^2) * (1 + 1e-4); all others
                     // would yield INFINITY for every sensor of rescuer i and are skipped per pass.
                     {
                         const float thr2 = (rad2 + srange * srange) * 1.0001f + 1e-9f;
-                        const float mx = lane == NP ? kx : (lane == NP + 1 ? bx : part_x), my = lane == NP ? ky : (lane == NP + 1 ? by : part_y);
+                        const float mx = fresh(lane) == NP ? kx : (fresh(lane) == NP + 1 ? bx : part_x), my = fresh(lane) == NP ? ky : (fresh(lane) == NP + 1 ? by : part_y);
                         for (int i = 0; i < Nr; ++i) {
                             const float rx = mx - bcast(part_x, i), ry = my - bcast(part_y, i);
-                            const uint64_t mk = __ballot((lane <= NP + 1) && (rx * rx + ry * ry <= thr2));
-                            if (lane == 0) NEAR[i] = mk;
+                            const uint64_t mk = __ballot((fresh(lane) <= NP + 1) && (rx * rx + ry * ry <= thr2));
+                            if (fresh(lane) == 0) NEAR[i] = mk;
                         }
                         wave_sync();
                     }
@@ -340,7 +376,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
                 }
                 // rescuer lanes: contact flags and who-caught tests for the local rewards (G9)
                 bool w_ho = false, w_enc = false, w_cr = false, t_ho = false, t_cr = false;
-                if (lane < Nr) {
+                if (fresh(lane) < Nr) {
                     for (int j = 0; j < Nh; ++j) {
                         const bool c = COLH[lane * Nh + j];
                         t_ho |= c;
@@ -356,89 +392,89 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
                 wave_sync();
                 // phase D: process collisions (:365-383)
                 saved |= (caught_mask & ho_lanes) >> Nr;
-                if (lane >= Nr + Nh && lane < NP && my_caught) {
+                if (fresh(lane) >= Nr + Nh && fresh(lane) < NP && my_caught) {
                     const int m = lane - Nr - Nh;
                     float x, y, u0, u1;
-                    if (MODE == 1 && io.inj_resp != nullptr && !do_init) {
-                        const float *r = io.inj_resp + (env * Nc + m) * 4;
+                    if (MODE == 1 && IOA.inj_resp != nullptr && !do_init) {
+                        const float *r = IOA.inj_resp + (env * Nc + m) * 4;
                         x = r[0]; y = r[1]; u0 = r[2]; u1 = r[3];
                     } else {
-                        const u32x4 r = philox4x32_10(gid, tick, (uint32_t)m, HW_TAG_RESPAWN, d.k0, d.k1);
+                        const u32x4 r = philox4x32_10(gid, tick, (uint32_t)m, HW_TAG_RESPAWN, DA.k0, DA.k1);
                         x = u24(r.x); y = u24(r.y); u0 = u24(r.z); u1 = u24(r.w);
                     }
                     X[2 * lane] = x; X[2 * lane + 1] = y;
-                    V[2 * lane] = (u0 - 0.5f) * d.bad_speed; V[2 * lane + 1] = (u1 - 0.5f) * d.bad_speed;
+                    V[2 * lane] = (u0 - 0.5f) * DA.bad_speed; V[2 * lane + 1] = (u1 - 0.5f) * DA.bad_speed;
                 }
                 tick += 1;
                 if (bo_caught) flags |= 2u;
                 if (ke_caught) flags |= 1u;
                 const float gate1 = (flags & 1u) ? 1.f : 0.f, bombed1 = (flags & 2u) ? 1.f : 0.f;  // states after processing (G6)
                 // phase E: rewards (:385-396)
-                if (lane < Nr) {
-                    if (d.reward_global) {
-                        reward += ((((float)n_ho_enc * d.encounter_reward) * gate1 + (float)n_ho_caught * d.save_reward) +
-                                   (float)n_cr_caught * d.hit_reward) + bombed1 * d.bomb_reward;
+                if (fresh(lane) < Nr) {
+                    if (DA.reward_global) {
+                        reward += ((((float)n_ho_enc * DA.encounter_reward) * gate1 + (float)n_ho_caught * DA.save_reward) +
+                                   (float)n_cr_caught * DA.hit_reward) + bombed1 * DA.bomb_reward;
                     } else {
-                        if (w_ho) reward += d.save_reward;
-                        if (w_enc) reward += d.encounter_reward * gate1;
-                        if (w_cr) reward += d.hit_reward;
-                        if (col_bo) reward += bombed1 * d.bomb_reward;
+                        if (w_ho) reward += DA.save_reward;
+                        if (w_enc) reward += DA.encounter_reward * gate1;
+                        if (w_cr) reward += DA.hit_reward;
+                        if (col_bo) reward += bombed1 * DA.bomb_reward;
                     }
                 }
                 wave_sync();
                 // phase F: criminals move; velocity flips only if BOTH coordinates left [0,1], no clipping (G7, :402-408)
-                if (lane >= Nr + Nh && lane < NP) {
+                if (fresh(lane) >= Nr + Nh && fresh(lane) < NP) {
                     float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
                     x = x + vx; y = y + vy;
                     const bool outx = !(x >= 0.f && x <= 1.f), outy = !(y >= 0.f && y <= 1.f);
                     if (outx && outy) { vx = -1.0f * vx; vy = -1.0f * vy; }
                     X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
                 }
-                if (lane < Nr) {  // tail of the observation row (:410-425)
+                if (fresh(lane) < Nr) {  // tail of the observation row (:410-425)
                     float *o = O + lane * D + 5 * K;
                     o[0] = t_ho ? 1.f : 0.f; o[1] = t_cr ? 1.f : 0.f; o[2] = col_ke ? 1.f : 0.f; o[3] = col_bo ? 1.f : 0.f;
                     o[4] = gate1;
-                    if (d.addid) o[5] = (float)(lane + 1);
+                    if (DA.addid) o[5] = (float)(lane + 1);
                 }
                 tstep += 1;  // :427
                 const uint64_t all_h = (Nh >= 64) ? ~0ull : ((1ull << Nh) - 1ull);
-                const int limit = d.max_steps > 0 ? d.max_steps : 1000;  // timestep_limit :118-120
+                const int limit = DA.max_steps > 0 ? DA.max_steps : 1000;  // timestep_limit :118-120
                 const bool is_done = (flags & 2u) || ((saved & all_h) == all_h) || tstep >= limit;  // :179-182
-                if (is_done && lane < Nr) reward += (float)(Nh - __popcll(saved & all_h)) * d.not_saved_reward;  // :429-430
+                if (is_done && fresh(lane) < Nr) reward += (float)(Nh - __popcll(saved & all_h)) * DA.not_saved_reward;  // :429-430
                 wave_sync();
 
                 if (pass == 0) asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_act));  // pipeline hinge
                 // ---------------------------------------------------- outputs
 #if MADRL_HW_ABLATE & 8
-                if (d.n_envs < 0)
+                if (DA.n_envs < 0)
 #endif
                 if (MODE == 1 && !do_init) {
-                    if (lane < Nr) io.rew[env * Nr + lane] = reward;
-                    if (lane == 0) {
-                        io.done[env] = (uint8_t)is_done;
-                        io.info[2 * env] = n_ho_caught;
-                        io.info[2 * env + 1] = n_cr_caught;
+                    if (fresh(lane) < Nr) uniform_ptr(IOA.rew + env * Nr)[ulane] = reward;
+                    if (fresh(lane) == 0) {
+                        IOA.done[env] = (uint8_t)is_done;
+                        IOA.info[2 * env] = n_ho_caught;
+                        IOA.info[2 * env + 1] = n_cr_caught;
                     }
-                    if (is_done && d.auto_reset) {  // wave-uniform: run the reset pass next
+                    if (is_done && DA.auto_reset) {  // wave-uniform: run the reset pass next
                         npass = 2;
                         do_init = true;
                     }
                 }
                 if (pass == npass - 1) {
-                    float *orow = io.obs + env * (int64_t)(Nr * D);
+                    const auto orow = uniform_ptr(IOA.obs + env * (int64_t)(Nr * D));
 #if MADRL_HW_ABLATE & 1
-                    if (d.n_envs < 0)
+                    if (DA.n_envs < 0)
 #endif
 #if MADRL_HW_ABLATE & 2
-                    for (int e = lane; e < Nr * D; e += 64) __builtin_nontemporal_store(O[e], &orow[e]);
+                    for (uint32_t e = ulane; e < (uint32_t)(Nr * D); e += 64u) __builtin_nontemporal_store(O[e], &orow[e]);
 #else
-                    for (int e = lane; e < Nr * D; e += 64) orow[e] = O[e];
+                    for (uint32_t e = ulane; e < (uint32_t)(Nr * D); e += 64u) orow[e] = O[e];
 #endif
                 }
                 wave_sync();
             }
             // ---------------------------------------------------------- LDS -> record
-            if (lane == 0) {
+            if (fresh(lane) == 0) {
                 SU[OFF_SAVED] = (uint32_t)saved; SU[OFF_SAVED + 1] = (uint32_t)(saved >> 32);
                 SU[OFF_FLAGS] = flags;
                 SU[OFF_T] = (uint32_t)tstep;
@@ -446,11 +482,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
             }
             wave_sync();
             {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(d.state) + env * (int64_t)rec_dw;
+                const auto dst = uniform_ptr(reinterpret_cast<uint32_t *>(DA.state) + env * (int64_t)rec_dw);
 #if MADRL_HW_ABLATE & 4
-                if (d.n_envs < 0)
+                if (DA.n_envs < 0)
 #endif
-                for (int k = lane; k < rec_dw; k += 64) dst[k] = SU[k];
+                for (uint32_t k = ulane; k < (uint32_t)rec_dw; k += 64u) dst[k] = SU[k];
             }
             wave_sync();
         }
@@ -459,6 +495,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_HW_WAV
         cur_act = nxt_act;
     }
 }
+#undef DA
+#undef IOA
 
 }  // namespace
 
@@ -516,12 +554,12 @@ int hw_launch(const madrl_hostage *h, const HwIO &io, int mode, void *stream) {
     if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
     const HwDev &d = h->dev;
-    const bool ex = d.Nr == 3 && d.Nh == 10 && d.Nc == 5 && d.K == 30;  // the module's own configuration (hostage.py:483), 30 sensors
+    const bool ex = d.Nr == 3 && d.Nh == 10 && d.Nc == 5 && d.K == 30 && d.D == 156;  // the module's own configuration (hostage.py:483), 30 sensors, agent id
     if (mode == 0) {
-        if (ex) hipLaunchKernelGGL((hostage_kernel<0, 3, 10, 5, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+        if (ex) hipLaunchKernelGGL((hostage_kernel<0, 3, 10, 5, 30, 156>), dim3((unsigned)blocks), dim3(64), 0, s, h->dev, io);
         else hipLaunchKernelGGL((hostage_kernel<0, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
     } else {
-        if (ex) hipLaunchKernelGGL((hostage_kernel<1, 3, 10, 5, 30>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
+        if (ex) hipLaunchKernelGGL((hostage_kernel<1, 3, 10, 5, 30, 156>), dim3((unsigned)blocks), dim3(64), 0, s, h->dev, io);
         else hipLaunchKernelGGL((hostage_kernel<1, 0, 0, 0, 0>), dim3((unsigned)blocks), dim3(64), h->lds_bytes, s, h->dev, io);
     }
     MADRL_HIP_TRY(hipGetLastError());
