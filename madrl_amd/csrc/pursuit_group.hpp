@@ -24,6 +24,11 @@
 namespace madrl {
 namespace pw {
 
+// resident wavefronts per SIMD the group kernel's registers are allocated for
+#ifndef MADRL_PG_WAVES
+#define MADRL_PG_WAVES 4
+#endif
+
 template <int XS_, int YS_, int P_, int E_, int R_, int FLATTEN_, int NW_>
 struct GShape {
     static constexpr int XS = XS_, YS = YS_, P = P_, E = E_, A = P_ + E_, R = R_, FLATTEN = FLATTEN_, NW = NW_;
@@ -70,11 +75,12 @@ __device__ __forceinline__ void group_sync() {
 }
 
 template <class S, int MODE, bool INJECT>
-__global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d, const WaveIO io) {
+__global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_WAVES, MADRL_PG_WAVES))) void pursuit_group_kernel(const WaveDev d, const WaveIO io) {
     constexpr int P = S::P, E = S::E, A = S::A, GW = S::GW, PAD = S::PAD, GSZ = S::GSZ, NS = S::NS, NT = S::NT;
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int tid = threadIdx.x;            // = agent index for tid < A
     const int lane = tid & 63;
+    const uint32_t utid = threadIdx.x, ulane = utid & 63u;  // unsigned 32-bit indices: SGPR base + VGPR offset addressing
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_p = tid < P;
     const int eslot = tid - P;
@@ -120,10 +126,10 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
     auto isE = [&]() { return (unsigned)(fresh(tid) - P) < (unsigned)E; };
     auto isAgent = [&]() { return fresh(tid) < A; };
     auto fetch_rec = [&](int64_t env) -> uint32_t {
-        return (fresh(lane) < S::REC_DW) ? reinterpret_cast<const uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] : 0u;
+        return (fresh(lane) < S::REC_DW) ? uniform_ptr(reinterpret_cast<const uint32_t *>(d.state + env * (int64_t)S::REC_BYTES))[ulane] : 0u;
     };
     auto fetch_act = [&](int64_t env) -> int {
-        if constexpr (MODE == 1) return isP() ? io.actions[env * P + tid] : 4;
+        if constexpr (MODE == 1) return isP() ? uniform_ptr(io.actions + env * P)[utid] : 4;
         else return 4;
     };
     // evader-slot mask of a wave-wide predicate, combined over the wavefronts that hold agents
@@ -144,11 +150,13 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
             return ((uint64_t)hi << 32) | lo;
         }
     };
-    auto fetch_zm = [&](int64_t env) -> uint32_t { return d.zmask[env * NT + tid]; };  // stale-zero mask, pursuit_wave.hpp
+    auto fetch_zm = [&](int64_t env) -> uint32_t { return uniform_ptr(d.zmask + env * NT)[utid]; };  // stale-zero mask, pursuit_wave.hpp
     uint32_t cur_rec = 0, cur_zm = 0xFFFFFFFFu;
     int cur_act = 4;
-    auto phys = [&](int64_t e) -> int64_t { return d.reverse ? d.n_envs - 1 - e : e; };
-    if ((int64_t)blockIdx.x < d.n_envs) {
+    // env indices are 32-bit (the fast path is not taken for n_envs >= 2^31 - 2^20), byte offsets 64-bit
+    const int n_envs = (int)d.n_envs, stride = (int)gridDim.x;
+    auto phys = [&](int e) -> int64_t { return (int64_t)(d.reverse ? n_envs - 1 - e : e); };
+    if ((int)blockIdx.x < n_envs) {
         cur_rec = fetch_rec(phys(blockIdx.x));
         cur_act = fetch_act(phys(blockIdx.x));
         cur_zm = fetch_zm(phys(blockIdx.x));
@@ -156,10 +164,10 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
     asm volatile("" : "+v"(cur_rec), "+v"(cur_act), "+v"(cur_zm));
     group_sync();
 
-    for (int64_t e = blockIdx.x; e < d.n_envs; e += gridDim.x) {
+    for (int e = blockIdx.x; e < n_envs; e += stride) {
         const int64_t env = phys(e);
-        const bool has_next = e + gridDim.x < d.n_envs;
-        const int64_t nenv = phys(has_next ? e + gridDim.x : e);
+        const bool has_next = e + stride < n_envs;
+        const int64_t nenv = phys(has_next ? e + stride : e);
         uint32_t nxt_rec = 0, nxt_zm = 0xFFFFFFFFu;
         int nxt_act = 4;
         if (has_next) {
@@ -199,7 +207,8 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
 
             auto load_map = [&](int mid) {
                 if (cached_map == mid) return;
-                const uint32_t *src = d.fmaps + (int64_t)mid * d.fmap_stride;
+                const KArgsPtr ka = cold_args();  // rare-path launch parameters come from the kernarg segment (pursuit_wave.hpp)
+                const uint32_t *src = ka->d.fmaps + (int64_t)mid * ka->d.fmap_stride;
                 for (int k = tid; k < GSZ; k += NT) L[k] = src[k];
                 for (int k = tid; k < (S::XS * S::YS + 3) / 4; k += NT) L[S::X_NEED + k] = src[GSZ + k];
                 cached_map = mid;
@@ -301,6 +310,9 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                     // -------------------------------------------------- reset (:173-207)
                     gone = 0ull;
                     term = 0ull;
+                    const KArgsPtr ka = cold_args();
+                    const double cw = ka->d.cw;
+                    const int max_opponents = ka->d.max_opponents;
                     bool inj_map = false, inj_pos = false;
                     if constexpr (MODE == 0) {
                         inj_map = io.inj_map != nullptr;
@@ -308,20 +320,20 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                     }
                     if (inj_map) {
                         map_id = __builtin_amdgcn_readfirstlane(io.inj_map[env]);
-                    } else if (d.sample_maps) {
+                    } else if (ka->d.sample_maps) {
                         const u32x4 rm = philox4x32_10(gid, tick, 0u, TAG_RESET_ENV, k0, k1);
-                        map_id = (int)__umulhi(rm.x, (uint32_t)d.n_maps);
+                        map_id = (int)__umulhi(rm.x, (uint32_t)ka->d.n_maps);
                     }
                     load_map(map_id);
                     const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, k0, k1);
-                    const double sx = u53(rw.x, rw.y) * (1.0 - d.cw);
-                    const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
-                    const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + d.cw));
-                    const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + d.cw));
+                    const double sx = u53(rw.x, rw.y) * (1.0 - cw);
+                    const double sy = u53(rw.z, rw.w) * (1.0 - cw);
+                    const int xlb = (int)(S::XS * sx), xub = (int)(S::XS * (sx + cw));
+                    const int ylb = (int)(S::YS * sy), yub = (int)(S::YS * (sy + cw));
                     int n_create = E;
-                    if (d.max_opponents > 0 && !inj_pos) {
+                    if (max_opponents > 0 && !inj_pos) {
                         const u32x4 r3 = philox4x32_10(gid, tick, 2u, TAG_RESET_ENV, k0, k1);
-                        n_create = min(1 + (int)__umulhi(r3.x, (uint32_t)(d.max_opponents - 1)), E);
+                        n_create = min(1 + (int)__umulhi(r3.x, (uint32_t)(max_opponents - 1)), E);
                     }
                     bool exists = false;
                     if (isAgent()) {
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                 group_sync();
             }
             if constexpr (MODE == 1) {
-                if (isP()) io.rew[env * P + tid] = rew_out;
+                if (isP()) uniform_ptr(io.rew + env * P)[utid] = rew_out;
                 if (fresh(tid) == 0) {
                     io.done[env] = (uint8_t)done_bits;
                     io.removed[env] = n_removed;
@@ -421,8 +433,8 @@ __global__ __launch_bounds__(S::NT, 4) void pursuit_group_kernel(const WaveDev d
                 if (S::NGW > 1 && lane == S::OFF_GONE / 4 + 1) w = (uint32_t)(gone >> 32);
                 if (own_term) w = ((lane - S::OFF_TERM / 4) & 1) ? (uint32_t)(term >> 32) : (uint32_t)term;
                 if (lane >= S::OFF_TERM / 4 + S::NTW) w = 0u;  // padding dwords
-                if (own_dw) reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES)[lane] = w;
-                d.zmask[env * NT + tid] = zm;
+                if (own_dw) uniform_ptr(reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES))[ulane] = w;
+                uniform_ptr(d.zmask + env * NT)[utid] = zm;
             }
         }
         cur_rec = nxt_rec;
