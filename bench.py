@@ -373,10 +373,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
-            "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset)",
+            "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset: every env "
+                    "reaches the horizon %d time(s) inside the timed region and then runs the two-observation-pass reset path)"
+                    % ((W + K) // args.horizon - W // args.horizon),
             "config": {"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, surround, "
                                    "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (MS, MS, P, E, N, args.horizon),
-                       "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
+                       "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world,
+                       "horizon_resets_per_env_in_timed_region": (W + K) // args.horizon - W // args.horizon},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic[0] if traffic else None,
