@@ -44,6 +44,9 @@ struct HwDev {
     float radius, r_ho, bad_speed, sensor_range, action_scale, gate_lo;
     float save_reward, hit_reward, encounter_reward, not_saved_reward, bomb_reward, bomb_radius, key_radius, control_penalty;
     float key_x, key_y;
+    // sq_*: largest float32 x with sqrtf(x) <= threshold ("distance <= threshold" as one compare of the squared distance, same truth
+    // value for every input; waterworld.hip): rescuer-hostage / rescuer-criminal contact, bomb and key radii
+    float sq_hit_ho, sq_hit_cr, sq_bomb, sq_key;
     int64_t n_envs;
     const float *sensors;  // [K][2]
     float *state;
@@ -94,6 +97,10 @@ __device__ __forceinline__ float u24(uint32_t r) { return (float)(r >> 8) * (1.0
 __device__ __forceinline__ float dist2d(float ax, float ay, float bx, float by) {
     const float dx = ax - bx, dy = ay - by;
     return sqrtf(dx * dx + dy * dy);  // scipy cdist 'euclidean'
+}
+__device__ __forceinline__ bool dist2_le(float ax, float ay, float bx, float by, float sq) {  // dist2d(a, b) <= thr with sq = sq_threshold(thr)
+    const float dx = ax - bx, dy = ay - by;
+    return dx * dx + dy * dy <= sq;
 }
 __device__ __forceinline__ float clipf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
@@ -239,23 +246,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                             x = cx; y = cy;
                         }
                         X[2 * lane] = x; X[2 * lane + 1] = y; V[2 * lane] = vx; V[2 * lane + 1] = vy;
-                        col_bo = dist2d(x, y, bx, by) <= DA.radius + DA.bomb_radius;  // :281-291
-                        col_ke = dist2d(x, y, kx, ky) <= DA.radius + DA.key_radius;
+                        col_bo = dist2_le(x, y, bx, by, DA.sq_bomb);  // dist <= radius + bomb_radius, :281-291
+                        col_ke = dist2_le(x, y, kx, ky, DA.sq_key);   // dist <= radius + key_radius
                     }
                 }
                 wave_sync();
                 // phase B: collisions (:263-279), no saved mask here (G4)
+                // BITROWS (specialised shapes with at most 64 rescuer x hostage and rescuer x criminal pairs): a collision matrix is one
+                // wave-uniform 64-bit ballot (bit i * n + m), columns counted and rows tested with bit operations (waterworld.hip)
+                constexpr bool BITROWS = TNr > 0 && TNr * TNh <= 64 && TNr * TNc <= 64 && TNh < 64 && TNc < 64;
+                uint64_t col_ho = 0ull, col_cr = 0ull;
+                bool my_caught = false, my_enc = false;  // hostage / criminal lanes count their column (_caught :184-198)
+                if constexpr (BITROWS) {
+                    {
+                        const bool in = fresh(lane) < Nr * Nh;
+                        const int i = in ? lane / Nh : 0, m = in ? lane - i * Nh : 0, j = Nr + m;
+                        col_ho = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_ho));
+                    }
+                    {
+                        const bool in = fresh(lane) < Nr * Nc;
+                        const int i = in ? lane / Nc : 0, m = in ? lane - i * Nc : 0, j = Nr + Nh + m;
+                        col_cr = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_cr));
+                    }
+                    uint64_t cm_ho = 0ull, cm_cr = 0ull;  // bit i * n of every row
+#pragma unroll
+                    for (int i = 0; i < (TNr > 0 ? TNr : 1); ++i) { cm_ho |= 1ull << (i * Nh); cm_cr |= 1ull << (i * Nc); }
+                    if (fresh(lane) >= Nr && fresh(lane) < NP) {
+                        const bool is_ho = fresh(lane) < Nr + Nh;
+                        const int m = is_ho ? lane - Nr : lane - Nr - Nh;
+                        const int sc = __popcll((is_ho ? col_ho : col_cr) & ((is_ho ? cm_ho : cm_cr) << m));
+                        my_caught = sc >= (is_ho ? DA.n_coop_save : 1);
+                        my_enc = is_ho && sc >= 1;
+                    }
+                } else {
                 for (int idx = lane; idx < Nr * (Nh + Nc); idx += 64) {
                     const bool is_ho = idx < Nr * Nh;
                     const int r = is_ho ? idx : idx - Nr * Nh;
                     const int n2 = is_ho ? Nh : Nc;
                     const int i = r / n2, m = r % n2;
                     const int j = (is_ho ? Nr : Nr + Nh) + m;
-                    const float thr = DA.radius + (is_ho ? DA.r_ho : DA.radius);
-                    (is_ho ? COLH : COLC)[r] = dist2d(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1]) <= thr;
+                    (is_ho ? COLH : COLC)[r] = dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], is_ho ? DA.sq_hit_ho : DA.sq_hit_cr);
                 }
                 wave_sync();
-                bool my_caught = false, my_enc = false;  // hostage / criminal lanes count their column (_caught :184-198)
                 if (fresh(lane) >= Nr && fresh(lane) < NP) {
                     const bool is_ho = fresh(lane) < Nr + Nh;
                     const int m = is_ho ? lane - Nr : lane - Nr - Nh;
@@ -268,17 +300,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                     if (is_ho) { FLG[m] = my_caught; FLG[Nh + m] = my_enc; }
                     else FLG[2 * Nh + m] = my_caught;
                 }
+                }
                 const uint64_t ho_lanes = ((Nh >= 64) ? ~0ull : ((1ull << Nh) - 1ull)) << Nr;
                 const uint64_t caught_mask = __ballot(my_caught);
                 const int n_ho_caught = __popcll(caught_mask & ho_lanes);
                 const int n_cr_caught = __popcll(caught_mask & ~ho_lanes);
-                const int n_ho_enc = __popcll(__ballot(my_enc));
+                const uint64_t enc_mask = __ballot(my_enc);
+                const int n_ho_enc = __popcll(enc_mask);
                 const bool bo_caught = __ballot(col_bo) != 0ull, ke_caught = __ballot(col_ke) != 0ull;
                 wave_sync();
                 // phase C: sensing (:295-362).  Rows: [criminal dist | criminal speed | hostage dist | key dist | bomb dist] (:398-400)
                 {
                     // passes of 64 (rescuer, sensor) pairs held in registers at a time: no more than the specialised shape needs
-                    constexpr int PCH = (TNr > 0 && (TNr * TK + 63) / 64 < 3) ? (TNr * TK + 63) / 64 : 3;
+                    // ALIGNED (compile-time K <= 64): a pass holds floor(64 / K) whole rescuers, so its reach set is theirs alone (waterworld.hip)
+                    constexpr bool ALIGNED = TK > 0 && TK <= 64;
+                    constexpr int PPP = ALIGNED ? 64 / (TK > 0 ? TK : 1) : 1;
+                    const int n_pass = ALIGNED ? (Nr + PPP - 1) / PPP : (Nr * K + 63) / 64;
+                    constexpr int N_PASS_T = TNr > 0 ? (ALIGNED ? (TNr + PPP - 1) / PPP : (TNr * TK + 63) / 64) : 3;
+                    constexpr int PCH = N_PASS_T < 3 ? N_PASS_T : 3;
                     const float srange = DA.sensor_range, rad2 = DA.radius * DA.radius;  // G1
                     const float part_x = fresh(lane) < NP ? X[2 * lane] : 0.f, part_y = fresh(lane) < NP ? X[2 * lane + 1] : 0.f;
                     // Conservative cull (as in waterworld.hip): NEAR[i] = objects with d2 <= (rad2 + range^2) * (1 + 1e-4); all others
@@ -293,7 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                         }
                         wave_sync();
                     }
-                    for (int base = 0; base < Nr * K; base += 64 * PCH) {
+                    for (int p0 = 0; p0 < n_pass; p0 += PCH) {
                         int ii[PCH], kk[PCH];
                         bool ok[PCH];
                         float sx[PCH], sy[PCH], px[PCH], py[PCH];
@@ -302,17 +341,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                         uint64_t reach[PCH];  // wave-uniform: objects in reach of any rescuer of pass q
 #pragma unroll
                         for (int q = 0; q < PCH; ++q) {
-                            const int idx = base + 64 * q + lane;
-                            ok[q] = idx < Nr * K;
-                            ii[q] = ok[q] ? idx / K : 0;
-                            kk[q] = ok[q] ? idx - ii[q] * K : 0;
+                            const int pass_q = p0 + q;
+                            int i_first, i_last;  // rescuers of this pass
+                            if constexpr (ALIGNED) {
+                                const int li = lane / K;
+                                i_first = pass_q * PPP; i_last = min(i_first + PPP, Nr) - 1;
+                                ok[q] = li < PPP && i_first + li <= i_last;
+                                ii[q] = ok[q] ? i_first + li : 0;
+                                kk[q] = ok[q] ? lane - li * K : 0;
+                            } else {
+                                const int idx = 64 * pass_q + lane;
+                                ok[q] = idx < Nr * K;
+                                ii[q] = ok[q] ? idx / K : 0;
+                                kk[q] = ok[q] ? idx - ii[q] * K : 0;
+                                i_first = 64 * pass_q / K; i_last = min(64 * pass_q + 63, Nr * K - 1) / K;
+                            }
                             sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
                             px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
                             b_cr[q] = INFINITY; b_ho[q] = INFINITY; a_cr[q] = 0;
                             uint64_t u = 0ull;
-                            const int first = base + 64 * q, last = min(first + 63, Nr * K - 1);
-                            if (first < Nr * K)
-                                for (int i = first / K; i <= last / K; ++i) u |= NEAR[i];
+                            if (pass_q < n_pass)
+                                for (int i = i_first; i <= i_last; ++i) u |= NEAR[i];
                             reach[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
                         }
@@ -377,6 +426,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                 // rescuer lanes: contact flags and who-caught tests for the local rewards (G9)
                 bool w_ho = false, w_enc = false, w_cr = false, t_ho = false, t_cr = false;
                 if (fresh(lane) < Nr) {
+                    if constexpr (BITROWS) {
+                        const uint64_t row_ho = (col_ho >> (lane * Nh)) & ((1ull << Nh) - 1ull);
+                        const uint64_t row_cr = (col_cr >> (lane * Nc)) & ((1ull << Nc) - 1ull);
+                        t_ho = row_ho != 0ull;
+                        t_cr = row_cr != 0ull;
+                        w_ho = (row_ho & (caught_mask >> Nr)) != 0ull;          // touches a caught hostage
+                        w_enc = (row_ho & (enc_mask >> Nr)) != 0ull;            // touches an encountered hostage
+                        w_cr = (row_cr & (caught_mask >> (Nr + Nh))) != 0ull;   // touches a caught criminal
+                    } else {
                     for (int j = 0; j < Nh; ++j) {
                         const bool c = COLH[lane * Nh + j];
                         t_ho |= c;
@@ -387,6 +445,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                         const bool c = COLC[lane * Nc + j];
                         t_cr |= c;
                         w_cr |= c && FLG[2 * Nh + j];
+                    }
                     }
                 }
                 wave_sync();
@@ -527,6 +586,18 @@ int hw_validate(const madrl_hostage_config *c) {
 
 int hw_obs_dim_of(const madrl_hostage_config *c) { return c->n_sensors * 5 + 5 + (c->addid ? 1 : 0); }  // CircAgent.__init__ :19-23
 
+// largest float32 x with sqrtf(x) <= thr (thr >= 0 finite); see HwDev::sq_*
+float hw_sq_threshold(float thr) {
+    float x = thr * thr;
+    while (x > 0.0f && sqrtf(x) > thr) x = nextafterf(x, 0.0f);
+    for (;;) {
+        const float up = nextafterf(x, INFINITY);
+        if (!(sqrtf(up) <= thr)) break;
+        x = up;
+    }
+    return x;
+}
+
 void hw_layout(const madrl_hostage_config *c, HwDev *d) {
     memset(d, 0, sizeof(*d));
     d->Nr = c->n_good; d->Nh = c->n_hostages; d->Nc = c->n_bad; d->NP = d->Nr + d->Nh + d->Nc;
@@ -541,6 +612,9 @@ void hw_layout(const madrl_hostage_config *c, HwDev *d) {
     d->not_saved_reward = (float)c->not_saved_reward; d->bomb_reward = (float)c->bomb_reward; d->bomb_radius = (float)c->bomb_radius;
     d->key_radius = (float)c->key_radius; d->control_penalty = (float)c->control_penalty;
     d->key_x = (float)c->key_loc[0]; d->key_y = (float)c->key_loc[1];
+    // the float32 sums the kernel used to form before comparing
+    d->sq_hit_ho = hw_sq_threshold(d->radius + d->r_ho); d->sq_hit_cr = hw_sq_threshold(d->radius + d->radius);
+    d->sq_bomb = hw_sq_threshold(d->radius + d->bomb_radius); d->sq_key = hw_sq_threshold(d->radius + d->key_radius);
 }
 
 size_t hw_lds_bytes(const HwDev &d) {
