@@ -375,32 +375,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                             const bool out = (sv < 0.f) | (sv > srange) | (d2 - sv * sv > rad2);
                             return out ? INFINITY : sv;
                         };
+                        // Objects are visited by walking the SET BITS of the reach mask (ascending = the reference's index order, so the
+                        // first minimum wins as in np.argmin): no test-and-skip per object, which is scalar work on the CU's one scalar pipe.
+                        {
+                            uint64_t todo = reach_any & ((((Nc >= 64) ? ~0ull : ((1ull << Nc) - 1ull))) << (Nr + Nh));
 #pragma nounroll
-                        for (int m = 0; m < Nc; ++m) {
-                            const int bit = Nr + Nh + m;
-                            if (!((reach_any >> bit) & 1ull)) continue;
-                            const float qx = bcast(part_x, Nr + Nh + m), qy = bcast(part_y, Nr + Nh + m);
+                            while (todo != 0ull) {
+                                const int bit = __builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                                const int m = bit - (Nr + Nh);
+                                const float qx = bcast(part_x, bit), qy = bcast(part_y, bit);
 #pragma unroll
-                            for (int q = 0; q < PCH; ++q) {
-                                if (!((reach[q] >> bit) & 1ull)) continue;
-                                const float sv = sense(q, qx, qy);
-                                const bool better = sv < b_cr[q];
-                                b_cr[q] = better ? sv : b_cr[q];
-                                a_cr[q] = better ? m : a_cr[q];
+                                for (int q = 0; q < PCH; ++q) {
+                                    if (!((reach[q] >> bit) & 1ull)) continue;
+                                    const float sv = sense(q, qx, qy);
+                                    const bool better = sv < b_cr[q];
+                                    b_cr[q] = better ? sv : b_cr[q];
+                                    a_cr[q] = better ? m : a_cr[q];
+                                }
                             }
                         }
+                        {   // hostages: the saved ones (mask from before this step's processing, G5, :296) are not sensed
+                            uint64_t todo = reach_any & (((((Nh >= 64) ? ~0ull : ((1ull << Nh) - 1ull))) & ~saved) << Nr);
 #pragma nounroll
-                        for (int m = 0; m < Nh; ++m) {
-                            const int bit = Nr + m;
-                            const bool was_saved = (saved >> m) & 1ull;  // mask from before this step's processing (G5, :296)
-                            if (was_saved || !((reach_any >> bit) & 1ull)) continue;
-                            const float qx = bcast(part_x, Nr + m), qy = bcast(part_y, Nr + m);
+                            while (todo != 0ull) {
+                                const int bit = __builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                                const float qx = bcast(part_x, bit), qy = bcast(part_y, bit);
 #pragma unroll
-                            for (int q = 0; q < PCH; ++q) {
-                                if (!((reach[q] >> bit) & 1ull)) continue;
-                                float sv = sense(q, qx, qy);
-                                sv = was_saved ? INFINITY : sv;
-                                b_ho[q] = sv < b_ho[q] ? sv : b_ho[q];
+                                for (int q = 0; q < PCH; ++q) {
+                                    if (!((reach[q] >> bit) & 1ull)) continue;
+                                    const float sv = sense(q, qx, qy);
+                                    b_ho[q] = sv < b_ho[q] ? sv : b_ho[q];
+                                }
                             }
                         }
 #pragma unroll

@@ -436,12 +436,16 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                         int bi[PCH];
 #pragma unroll
                         for (int q = 0; q < PCH; ++q) { b[q] = INFINITY; bi[q] = 0; }
+                        // the class's objects in reach of any pass, visited by walking the SET BITS of the mask (ascending = the reference's
+                        // index order: the first minimum wins as in np.argmin) -- no test-and-skip per object on the scalar pipe
+                        uint64_t todo = reach_any & (cls == 0 ? (1ull << NP) : ((((cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull))) << lo));
 #pragma nounroll
-                        for (int m = 0; m < cnt; ++m) {
-                            const int bit = cls == 0 ? NP : lo + m;
-                            if (!((reach_any >> bit) & 1ull)) continue;
-                            const float qx = cls == 0 ? ox : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), lo + m));
-                            const float qy = cls == 0 ? oy : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), lo + m));
+                        while (todo != 0ull) {
+                            const int bit = __builtin_ctzll(todo);
+                            todo &= todo - 1ull;
+                            const int m = cls == 0 ? 0 : bit - lo;
+                            const float qx = cls == 0 ? ox : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), bit));
+                            const float qy = cls == 0 ? oy : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), bit));
 #pragma unroll
                             for (int q = 0; q < PCH; ++q) {
                                 if (!((reach[q] >> bit) & 1ull)) continue;
