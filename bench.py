@@ -110,7 +110,7 @@ def bench_other(args, rank, local_rank, world, dev):
         outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
         step = lambda i: _lib.check(L.madrl_waterworld_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
         bytes_per = 40 + 4 * 5 * env.obs_dim + 20 + 1 + 8 + 2 * (env._state.numel() // N)
-        kernel, binding = "waterworld_kernel<1>", "VALU issue (867 VALU + 616 SALU wave-instructions per env-step at 6 waves per SIMD: the VALU port is saturated; profiles/r02_waterworld/pmc_mix.txt), not HBM"
+        kernel, binding = "waterworld_kernel<1>", "VALU issue (770 VALU + 529 SALU wave-instructions per env-step at 6 waves per SIMD: the VALU port is saturated; profiles/r02_waterworld/pmc_mix.txt), not HBM"
         workload = "MAWaterWorld 5 pursuers / 10 evaders / 10 poison / 30 sensors, n_coop 2, %d envs per GPU, timestep_limit 1000" % N
 
         def cpu():
@@ -135,7 +135,7 @@ def bench_other(args, rank, local_rank, world, dev):
         outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
         step = lambda i: _lib.check(L.madrl_hostage_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
         bytes_per = 24 + 4 * 3 * env.obs_dim + 12 + 1 + 8 + 2 * (env._state.numel() // N)
-        kernel, binding = "hostage_kernel<1>", "the CU's scalar pipe (509 VALU + 599 SALU wave-instructions per env-step at 7 waves per SIMD, 28 wavefronts per scalar unit; profiles/r02_hostage/pmc_mix.txt), not HBM"
+        kernel, binding = "hostage_kernel<1>", "the CU's scalar pipe (422 VALU + 343 SALU wave-instructions per env-step at 7 waves per SIMD, 28 wavefronts per scalar unit; profiles/r02_hostage/pmc_mix.txt), not HBM"
         workload = "ContinuousHostageWorld(3, 10, 5, 2, 2) (hostage.py:483), 30 sensors, %d envs per GPU, timestep_limit 1000" % N
 
         def cpu():
