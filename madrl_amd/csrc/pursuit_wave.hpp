@@ -600,6 +600,9 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                     const int origin = isP() ? ((x - S::OFF + PAD) * GW + (y - S::OFF + PAD)) * 4 : 0;
                     // SGPR base + one loop-invariant 32-bit VGPR offset (+ immediate) for every store of the row
                     const char *orow_u = (const char *)uniform_ptr(io.obs + env * (int64_t)(P * S::D));
+                    // if that base came through v_readfirstlane (a VALU write of an SGPR), a vector-memory instruction may read it as its
+                    // scalar address only 5 wait states later; the compiler cannot see the stores inside the asm blocks below
+                    asm volatile("s_nop 4" : "+s"(orow_u));
                     const uint32_t voff = ulane * 16u;
                     const char *Lb = reinterpret_cast<const char *>(L);
                     auto cell_at = [&](int off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(Lb + off); };

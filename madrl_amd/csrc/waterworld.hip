@@ -138,7 +138,7 @@ __device__ __forceinline__ bool dist2_le(float ax, float ay, float bx, float by,
 #define MADRL_WW_WAVES 6
 #endif
 // (the fused-wrapper variant holds float64 statistics: one wave fewer, or it spills)
-#define MADRL_WW_OCC_N (TNp > 0 ? (FUSED ? MADRL_WW_WAVES - 1 : MADRL_WW_WAVES) : 0)
+#define MADRL_WW_OCC_N (TNp > 0 ? (FUSED ? MADRL_WW_WAVES - 1 : MADRL_WW_WAVES) - (TNp > 6 ? 1 : 0) : 0)  // (> 6 pursuers: two words per collision matrix, more live pass state)
 #define MADRL_WW_OCC __attribute__((amdgpu_waves_per_eu(MADRL_WW_OCC_N > 0 ? MADRL_WW_OCC_N : 1, MADRL_WW_OCC_N > 0 ? MADRL_WW_OCC_N : 8)))
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
@@ -297,34 +297,55 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 }
                 wave_sync();
                 // phase B: collisions (:272-293)
-                // BITROWS (specialised shapes with at most 64 pursuer x evader and pursuer x poison pairs): a collision matrix is ONE
-                // wave-uniform 64-bit mask (bit i * n + m = pursuer i touches particle m) made by a ballot; columns are counted and rows
-                // tested with bit operations.  No byte matrices in LDS, no loop over the other side of the pair.
-                constexpr bool BITROWS = TNp > 0 && TNp * TNe <= 64 && TNp * TNpo <= 64 && TNe < 64 && TNpo < 64;
-                uint64_t col_ev = 0ull, col_po = 0ull;
+                // BITROWS (specialised shapes): a collision matrix is a few wave-uniform 64-bit masks (bit r * n + m of word w = pursuer
+                // w * G + r touches particle m) made by ballots; columns are counted and rows tested with bit operations.  No byte
+                // matrices in LDS, no loop over the other side of the pair.
+                // A 64-bit word holds GE = floor(64 / Ne) whole rows; shapes with more pursuers use up to 4 words per matrix.
+                constexpr int GE = (TNe > 0 && TNe < 64) ? 64 / TNe : 1, GP = (TNpo > 0 && TNpo < 64) ? 64 / TNpo : 1;  // rows per word
+                constexpr int WE = TNp > 0 ? (TNp + GE - 1) / GE : 1, WP = TNp > 0 ? (TNp + GP - 1) / GP : 1;              // words per matrix
+                constexpr bool BITROWS = TNp > 0 && TNe < 64 && TNpo < 64 && WE <= 4 && WP <= 4;
+                uint64_t col_ev[WE], col_po[WP];
+#pragma unroll
+                for (int w = 0; w < WE; ++w) col_ev[w] = 0ull;
+#pragma unroll
+                for (int w = 0; w < WP; ++w) col_po[w] = 0ull;
                 bool my_caught = false, my_enc = false;
                 if constexpr (BITROWS) {
-                    {
-                        const bool in = fresh(lane) < Np * Ne;
-                        const int i = in ? lane / Ne : 0, m = in ? lane - i * Ne : 0, j = Np + m;
-                        col_ev = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_ev));
+#pragma unroll
+                    for (int w = 0; w < WE; ++w) {
+                        const int li = lane / Ne, i0 = w * GE + li;
+                        const bool in = fresh(lane) < GE * Ne && i0 < Np;
+                        const int i = in ? i0 : 0, m = in ? lane - li * Ne : 0, j = Np + m;
+                        col_ev[w] = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_ev));
                     }
-                    {
-                        const bool in = fresh(lane) < Np * Npo;
-                        const int i = in ? lane / Npo : 0, m = in ? lane - i * Npo : 0, j = Np + Ne + m;
-                        col_po = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_po));
+#pragma unroll
+                    for (int w = 0; w < WP; ++w) {
+                        const int li = lane / Npo, i0 = w * GP + li;
+                        const bool in = fresh(lane) < GP * Npo && i0 < Np;
+                        const int i = in ? i0 : 0, m = in ? lane - li * Npo : 0, j = Np + Ne + m;
+                        col_po[w] = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_po));
                     }
 #if MADRL_WW_ABLATE & 4
-                    col_ev = col_po = 0ull;
+                    for (int w = 0; w < WE; ++w) col_ev[w] = 0ull;
+                    for (int w = 0; w < WP; ++w) col_po[w] = 0ull;
 #endif
                     // _caught (:180-193): evader lanes / poison lanes count their column
-                    uint64_t cm_ev = 0ull, cm_po = 0ull;  // bit i * n of every row
+                    uint64_t cm_ev = 0ull, cm_po = 0ull;  // bit r * n of every row of a word
 #pragma unroll
-                    for (int i = 0; i < (TNp > 0 ? TNp : 1); ++i) { cm_ev |= 1ull << (i * Ne); cm_po |= 1ull << (i * Npo); }
+                    for (int r = 0; r < GE; ++r) cm_ev |= 1ull << (r * Ne);
+#pragma unroll
+                    for (int r = 0; r < GP; ++r) cm_po |= 1ull << (r * Npo);
                     if (fresh(lane) >= Np && fresh(lane) < NP) {
                         const bool is_ev = fresh(lane) < Np + Ne;
                         const int m = is_ev ? lane - Np : lane - Np - Ne;
-                        const int sc = __popcll((is_ev ? col_ev : col_po) & ((is_ev ? cm_ev : cm_po) << m));
+                        int sc = 0;
+                        if (is_ev) {
+#pragma unroll
+                            for (int w = 0; w < WE; ++w) sc += __popcll(col_ev[w] & (cm_ev << m));
+                        } else {
+#pragma unroll
+                            for (int w = 0; w < WP; ++w) sc += __popcll(col_po[w] & (cm_po << m));
+                        }
                         my_caught = sc >= (is_ev ? DA.n_coop : 1);
                         my_enc = is_ev && sc >= 1;
                     }
@@ -486,8 +507,13 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 if (fresh(lane) < Np) {
                     bool tev = false, tpo = false;
                     if constexpr (BITROWS) {
-                        const uint64_t row_ev = (col_ev >> (lane * Ne)) & ((1ull << Ne) - 1ull);
-                        const uint64_t row_po = (col_po >> (lane * Npo)) & ((1ull << Npo) - 1ull);
+                        uint64_t we_ = col_ev[0], wp_ = col_po[0];  // the word that holds this pursuer's row
+#pragma unroll
+                        for (int w = 1; w < WE; ++w) we_ = (lane / GE == w) ? col_ev[w] : we_;
+#pragma unroll
+                        for (int w = 1; w < WP; ++w) wp_ = (lane / GP == w) ? col_po[w] : wp_;
+                        const uint64_t row_ev = (we_ >> ((lane % GE) * Ne)) & ((1ull << Ne) - 1ull);
+                        const uint64_t row_po = (wp_ >> ((lane % GP) * Npo)) & ((1ull << Npo) - 1ull);
                         tev = row_ev != 0ull;
                         tpo = row_po != 0ull;
                         wc = (row_ev & (caught_mask >> Np)) != 0ull;           // touches a caught evader
@@ -730,22 +756,48 @@ size_t ww_lds_bytes(const WwDev &d) {
     return align_up(b, 16);
 }
 
+struct WwSpec {
+    int Np, Ne, Npo, K, D;
+    void (*launch)(const WwDev &, const WwIO &, int mode, bool fused, dim3 g, hipStream_t s);
+};
+
+template <int TNp, int TNe, int TNpo, int TK, int TD>
+void ww_launch_spec(const WwDev &d, const WwIO &io, int mode, bool fused, dim3 g, hipStream_t s) {
+    const dim3 b(64);  // static LDS layout: 0 dynamic bytes
+    if (mode == 0) {
+        if (fused) hipLaunchKernelGGL((waterworld_kernel<0, TNp, TNe, TNpo, TK, true, TD>), g, b, 0, s, d, io);
+        else hipLaunchKernelGGL((waterworld_kernel<0, TNp, TNe, TNpo, TK, false, TD>), g, b, 0, s, d, io);
+    } else {
+        if (fused) hipLaunchKernelGGL((waterworld_kernel<1, TNp, TNe, TNpo, TK, true, TD>), g, b, 0, s, d, io);
+        else hipLaunchKernelGGL((waterworld_kernel<1, TNp, TNe, TNpo, TK, false, TD>), g, b, 0, s, d, io);
+    }
+}
+
+#define X(NP_, NE_, NPO_, K_, D_) {NP_, NE_, NPO_, K_, D_, ww_launch_spec<NP_, NE_, NPO_, K_, D_>},
+const WwSpec WW_SPECS[] = {
+#include "waterworld_specializations.def"
+};
+#undef X
+
 int ww_launch(const madrl_waterworld *h, const WwIO &io, int mode, void *stream) {
     int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 64;
     if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
     hipStream_t s = (hipStream_t)stream;
     const WwDev &d = h->dev;
-    const bool c3 = d.Np == 5 && d.Ne == 10 && d.Npo == 10 && d.K == 30 && d.D == 213;  // (speed features and agent id: the defaults)  // BASELINE configs[2]: MAWaterWorld(5, 10), 30 sensors
     const dim3 g((unsigned)blocks), b(64);
     const bool fused = io.st != nullptr;
-#define WW_LAUNCH(MODE_, FUSED_)                                                                                                   \
-    do {                                                                                                                          \
-        if (c3) hipLaunchKernelGGL((waterworld_kernel<MODE_, 5, 10, 10, 30, FUSED_, 213>), g, b, 0, s, h->dev, io);               \
-        else hipLaunchKernelGGL((waterworld_kernel<MODE_, 0, 0, 0, 0, FUSED_>), g, b, h->lds_bytes, s, h->dev, io);               \
-    } while (0)
-    if (mode == 0) { if (fused) WW_LAUNCH(0, true); else WW_LAUNCH(0, false); }
-    else { if (fused) WW_LAUNCH(1, true); else WW_LAUNCH(1, false); }
-#undef WW_LAUNCH
+    const WwSpec *spec = nullptr;
+    for (const WwSpec &w : WW_SPECS)
+        if (d.Np == w.Np && d.Ne == w.Ne && d.Npo == w.Npo && d.K == w.K && d.D == w.D) spec = &w;
+    if (spec) {
+        spec->launch(h->dev, io, mode, fused, g, s);
+    } else if (mode == 0) {
+        if (fused) hipLaunchKernelGGL((waterworld_kernel<0, 0, 0, 0, 0, true>), g, b, h->lds_bytes, s, h->dev, io);
+        else hipLaunchKernelGGL((waterworld_kernel<0, 0, 0, 0, 0, false>), g, b, h->lds_bytes, s, h->dev, io);
+    } else {
+        if (fused) hipLaunchKernelGGL((waterworld_kernel<1, 0, 0, 0, 0, true>), g, b, h->lds_bytes, s, h->dev, io);
+        else hipLaunchKernelGGL((waterworld_kernel<1, 0, 0, 0, 0, false>), g, b, h->lds_bytes, s, h->dev, io);
+    }
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }

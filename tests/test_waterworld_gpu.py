@@ -59,6 +59,9 @@ CASES = {
     "global_randobst": dict(n_pursuers=5, n_evaders=10, obstacle_loc=None, reward_mech="global"),
     "small_nospeed": dict(n_pursuers=3, n_evaders=10, n_coop=2, n_poison=5, n_sensors=12, speed_features=False,
                           addid=False, sensor_range=0.3),
+    # runners/run_waterworld.py:16-20 defaults: the second specialised shape (two 64-bit words per collision matrix)
+    "runner_default_8v10": dict(n_pursuers=8, n_evaders=10, n_coop=4, n_poison=10),
+    "runner_default_8v10_coop1": dict(n_pursuers=8, n_evaders=10, n_coop=1, n_poison=10, ev_speed=0.05, radius=0.03),
     "coop1_dense": dict(n_pursuers=6, n_evaders=12, n_coop=1, n_poison=12, ev_speed=0.05, action_scale=0.05, n_sensors=20,
                         radius=0.03),
 }
