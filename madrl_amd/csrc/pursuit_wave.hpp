@@ -317,7 +317,12 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
         s_rel3[s] = (int)t[64 * 4];
         s_src[s] = (int)t[64 * 5] * 4;
     }
-    int cached_map = -1;
+    // Map 0 is staged with the tables above (its loads are in flight together with theirs): with a single map -- every BASELINE
+    // config -- the first env then needs no second round trip to HBM for a map chosen by its record, at a moment when every
+    // wavefront of the launch waits for the same thing.  With a map pool the first env may reload (load_map below).
+    for (int k = lane; k < GSZ; k += 64) L[k] = d.fmaps[k];
+    for (int k = lane; k < (S::XS * S::YS + 3) / 4; k += 64) L[S::X_NEED + k] = d.fmaps[GSZ + k];
+    int cached_map = 0;
     const uint8_t *need_tab = reinterpret_cast<const uint8_t *>(&L[S::X_NEED]);
     uint32_t *const layer = &L[is_p ? GSZ : 2 * GSZ];  // this lane's count layer
     // which lanes feed my dword of the packed state record (agents 2j and 2j+1 for dword 4+j)
