@@ -108,7 +108,10 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
         s_rel3[s] = (int)t[NT * 4];
         s_org[s] = S::X_ORG + (int)t[NT * 5];
     }
-    int cached_map = -1;
+    // map 0 is staged with the tables above (pursuit_wave.hpp); the group_sync before the env loop publishes it
+    for (int k = tid; k < GSZ; k += NT) L[k] = d.fmaps[k];
+    for (int k = tid; k < (S::XS * S::YS + 3) / 4; k += NT) L[S::X_NEED + k] = d.fmaps[GSZ + k];
+    int cached_map = 0;
     const uint8_t *need_tab = reinterpret_cast<const uint8_t *>(&L[S::X_NEED]);
     uint32_t *const layer = &L[is_p ? GSZ : 2 * GSZ];
     // record dword k (held by lane k of every wavefront) is STORED by one wavefront: the agent-pair dwords by the
