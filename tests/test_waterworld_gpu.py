@@ -109,6 +109,54 @@ def test_hip_matches_f32_oracle_free_running(case):
     print("bit-identical observation batches: %d / %d" % (exact, total))
 
 
+@pytest.mark.parametrize("shape", ["c3_bitrows", "generic"])
+def test_contact_tests_at_the_threshold_match_the_sqrt_formulation(shape):
+    """The kernel tests `dx*dx + dy*dy <= sq_threshold(thr)` where the reference (and the float32 oracle) test `sqrt(...) <= thr`.
+    The two must give the same truth value for EVERY input: crafted states put an evader / a poison at the contact distance of a
+    pursuer, and an evader at the rebound distance of the obstacle, within +-8 ulps of the threshold along 256 directions."""
+    from oracle import waterworld as ww
+    kw = dict(n_pursuers=5, n_evaders=10, n_coop=1) if shape == "c3_bitrows" else dict(n_pursuers=3, n_evaders=10, n_coop=1, n_poison=5, n_sensors=12)
+    Np, Ne = kw["n_pursuers"], kw["n_evaders"]
+    Npo = kw.get("n_poison", 10)
+    NP = Np + Ne + Npo
+    N = 17 * 256
+    env = _mk(N, seed=3, max_steps=1000, auto_reset=False, **kw)
+    orc = ww.WaterworldOracle(n_envs=N, seed=3, max_steps=1000, dtype=np.float32, **kw)
+    env.reset(); orc.reset()
+    r = np.float32(0.015)
+    r_pu, r_ev, r_po, r_ob = r, np.float32(np.float64(r) * 2), np.float32(np.float64(r) * 3 / 4), np.float32(0.2)
+    k = np.repeat(np.arange(-8, 9), 256).astype(np.int64)                 # ulps off the threshold
+    th = np.tile(np.arange(256) * (2 * np.pi / 256) + 0.001, 17)           # direction
+    def at_distance(center, thr, k, th):
+        thr = np.full(N, thr, np.float32)
+        d = (thr.view(np.int32) + k.astype(np.int32)).view(np.float32)     # thr moved by k ulps
+        return np.stack([center[:, 0] + d * np.cos(th).astype(np.float32), center[:, 1] + d * np.sin(th).astype(np.float32)], -1).astype(np.float32)
+    pos = np.zeros((N, NP, 2), np.float32)
+    far = np.linspace(0.02, 0.12, NP).astype(np.float32)
+    pos[:, :, 0] = 0.9; pos[:, :, 1] = far[None, :] * 4 + 0.3               # everything parked away from everything else
+    pos[:, 0] = (0.30, 0.12); pos[:, 1] = (0.62, 0.12)
+    pos[:, Np] = at_distance(pos[:, 0], r_pu + r_ev, k, th)                # evader 0 at contact distance of pursuer 0
+    pos[:, Np + Ne] = at_distance(pos[:, 1], r_pu + r_po, k, th)           # poison 0 at contact distance of pursuer 1
+    obst = np.tile(np.float32([0.5, 0.7]), (N, 1))
+    pos[:, Np + 1] = at_distance(obst, r_ev + r_ob, k, th)                 # evader 1 at rebound distance of the obstacle
+    vel = np.zeros((N, NP, 2), np.float32)
+    vel[:, Np + 1] = (0.001, -0.002)
+    st = orc.get_state()
+    for e in (env, orc):
+        e.set_state(pos=pos, vel=vel, obst=obst, t=st["t"], tick=np.asarray(st["tick"]).view(np.int32))
+    act = np.zeros((N, Np, 2), np.float32)
+    obs, rew, done, info = env.step(act)
+    oobs, orew, odone, oinfo = orc.step(act)
+    assert np.array_equal(info["evcatches"].cpu().numpy(), oinfo[:, 0])
+    assert np.array_equal(info["pocatches"].cpu().numpy(), oinfo[:, 1])
+    assert 0 < oinfo[:, 0].sum() < N and 0 < oinfo[:, 1].sum() < N          # both sides of both thresholds were hit
+    gst, ost = env.get_state(), orc.get_state()
+    assert np.array_equal(gst["vel"].cpu().numpy()[:, Np + 1], ost["vel"][:, Np + 1])   # rebound or not: identical
+    flipped = (ost["vel"][:, Np + 1, 0] < 0).sum()
+    assert 0 < flipped < N
+    assert np.abs(obs.cpu().numpy() - oobs).max() <= TOL
+
+
 def test_full_batch_invariants_c3():
     """BASELINE C3 size (32 768 envs): properties that do not need the oracle."""
     N, Np = 32768, 5
