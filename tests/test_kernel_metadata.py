@@ -1,0 +1,71 @@
+"""CPU test (-m "not gpu"): invariants of the BUILT gfx950 code objects that the hand-written parts of the kernels rely on.
+
+* The step kernel of the Pursuit fast path issues its record prefetch through inline asm and waits for it with an exact
+  s_waitcnt (pursuit_wave.hpp, "exact-wait prefetch").  The compiler does not know those registers are in flight, so it must never
+  spill or reload them: the kernels must have NO scratch and no VGPR spills.
+* pursuit_wave / pursuit_group / waterworld / hostage kernels read launch parameters from the kernel-argument segment through a
+  struct {Dev d; IO io;} view (cold_args(), ww_args(), hw_args()): the second by-value argument must start where that view says.
+* The specialised Waterworld / hostage instantiations were tuned to an occupancy at which they do not spill (spill stores reach HBM).
+"""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(os.path.dirname(HERE), "madrl_amd", "libmadrl_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernels():
+    objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(SO) and os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("built library or llvm tools not available")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(SO, tmp)
+        subprocess.run([objdump, "--offloading", "libmadrl_hip.so"], cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if not f.endswith("gfx950"):
+                continue
+            notes = subprocess.run([readelf, "--notes", os.path.join(tmp, f)], capture_output=True, text=True).stdout
+            for blk in re.split(r"\n  - \.agpr_count:", notes)[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk)
+                if not name:
+                    continue
+                args = [(int(o), int(s)) for o, s in re.findall(r"- \.offset:\s+(\d+)\s+\.size:\s+(\d+)\s+\.value_kind:\s+by_value", blk)]
+                out[name.group(1)] = dict(scratch=int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)),
+                                          vgpr_spills=int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)),
+                                          vgprs=int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)), args=args)
+    assert out, "no gfx950 kernels found in the library"
+    return out
+
+
+def test_prefetch_kernels_never_spill():
+    ks = {n: k for n, k in _kernels().items() if "pursuit_wave_kernel" in n and "ELi1ELb0EEE" in n}   # MODE 1, INJECT false
+    assert len(ks) >= 9
+    for n, k in ks.items():
+        assert k["scratch"] == 0 and k["vgpr_spills"] == 0, (n, k)
+
+
+def test_kernarg_views_match_the_argument_layout():
+    ks = _kernels()
+    checked = 0
+    for n, k in ks.items():
+        if any(t in n for t in ("pursuit_wave_kernel", "pursuit_group_kernel", "waterworld_kernel", "hostage_kernel")):
+            (o0, s0), (o1, _s1) = k["args"][:2]
+            assert o0 == 0 and o1 == (s0 + 7) // 8 * 8, (n, k["args"])   # struct {Dev d; IO io;}: io follows d, 8-byte aligned
+            checked += 1
+    assert checked >= 40
+
+
+def test_specialised_particle_kernels_do_not_spill():
+    ks = _kernels()
+    spec = {n: k for n, k in ks.items() if ("waterworld_kernelILi" in n and "ELi0ELi0ELi0ELi0E" not in n) or
+            ("hostage_kernelILi" in n and "ELi0ELi0ELi0ELi0E" not in n)}
+    assert len(spec) >= 10
+    for n, k in spec.items():
+        assert k["scratch"] == 0 and k["vgpr_spills"] == 0, (n, k)
