@@ -72,6 +72,46 @@ def test_hip_matches_f32_oracle_free_running(mech, nh):
     assert n_done > N and n_resp > 50
 
 
+@pytest.mark.parametrize("nh", [10, 6], ids=["specialised-bitrows", "generic"])
+def test_contact_tests_at_the_threshold_match_the_sqrt_formulation(nh):
+    """The kernel tests dx*dx + dy*dy <= sq_threshold(thr) where the reference and the float32 oracle test sqrt(...) <= thr.  Crafted
+    states put a criminal at the contact distance of a rescuer and the bomb / key at their radii, within +-8 ulps of the threshold
+    along 256 directions: every output must equal the oracle's, and both outcomes must occur."""
+    from madrl_amd.hostage import BatchedContinuousHostageWorld
+    from oracle import hostage as ho
+    N = 17 * 256
+    kw = dict(reward_mech="local", max_steps=1000)
+    env = BatchedContinuousHostageWorld(3, nh, 5, 2, 2, n_envs=N, device=DEV, seed=2, auto_reset=False, **kw)
+    orc = ho.HostageOracle(3, nh, 5, 2, 2, n_envs=N, seed=2, dtype=np.float32, **kw)
+    env.reset(); orc.reset()
+    st = orc.get_state()
+    radius = np.float32(env.radius)
+    k = np.repeat(np.arange(-8, 9), 256).astype(np.int32)
+    th = np.tile(np.arange(256) * (2 * np.pi / 256) + 0.001, 17)
+    def at_distance(center, thr):
+        d = (np.full(N, thr, np.float32).view(np.int32) + k).view(np.float32)
+        return np.stack([center[:, 0] + d * np.cos(th).astype(np.float32), center[:, 1] + d * np.sin(th).astype(np.float32)], -1).astype(np.float32)
+    pos = np.array(st["pos"], np.float32, copy=True)
+    vel = np.zeros_like(pos)
+    Nr, Nc = 3, 5
+    pos[:, 0] = (0.20, 0.30); pos[:, 1] = (0.20, 0.60); pos[:, 2] = (0.30, 0.80)
+    pos[:, Nr:Nr + nh] = np.stack([np.full(nh, 0.85, np.float32), np.linspace(0.1, 0.9, nh).astype(np.float32)], -1)[None]   # hostages parked
+    pos[:, Nr + nh:] = np.stack([np.full(Nc, 0.05, np.float32), np.linspace(0.1, 0.9, Nc).astype(np.float32)], -1)[None]      # criminals parked
+    pos[:, Nr + nh] = at_distance(pos[:, 0], radius + radius)                          # criminal 0 at contact distance of rescuer 0
+    bomb = at_distance(pos[:, 1], radius + np.float32(env.bomb_radius))    # bomb at its radius of rescuer 1
+    key = at_distance(pos[:, 2], radius + np.float32(env.key_radius))      # key at its radius of rescuer 2
+    for e in (env, orc):
+        e.set_state(pos=pos, vel=vel, key=key, bomb=bomb, saved=st["saved"], flags=st["flags"], t=st["t"], tick=st["tick"])
+    act = np.zeros((N, 3, 2), np.float32)
+    obs, rew, done, info = env.step(act)
+    oobs, orew, odone, oinfo = orc.step(act)
+    assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew)
+    assert np.array_equal(info["cr_encs"].cpu().numpy(), oinfo[:, 1]) and 0 < oinfo[:, 1].sum() < N
+    gst, ost = env.get_state(), orc.get_state()
+    assert np.array_equal(gst["flags"].cpu().numpy(), ost["flags"]) and np.array_equal(gst["pos"].cpu().numpy(), ost["pos"])
+    assert len(np.unique(ost["flags"])) > 1    # bomb / key reached in some envs and not in others
+
+
 def test_auto_reset_sharding_and_dropin_api():
     from madrl_amd.hostage import BatchedContinuousHostageWorld, ContinuousHostageWorld
     N = 256
