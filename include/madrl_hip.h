@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MADRL_ABI_VERSION 2
+#define MADRL_ABI_VERSION 3
 
 #define MADRL_OK 0
 #define MADRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -63,6 +63,15 @@ typedef struct madrl_pursuit_config {
                               same launch and its obs row holds the new episode's first obs */
     int32_t max_opponents; /* 0: fixed n_evaders; > 0: random_opponents with train_pursuit (:177-181): every reset creates
                               randint(1, max_opponents) evaders (at most n_evaders), the other slots count as gone */
+    int32_t train_pursuit; /* :105; 1 (the reference's default): the actions drive the pursuers.  0: evader control (:204-207,
+                              :215-224) -- action k moves the k-th REMAINING evader (layer order; n_pursuers actions per env, as
+                              many as env.agents has entries), every pursuer moves by one pursuer_controller.act() draw
+                              (in-kernel Philox, or entry j of the injected array, then [n_envs][n_pursuers]); observation row
+                              k shows the window of the k-th remaining evader among slots 0..n_pursuers-1 with id k/n_pursuers
+                              (collect_obs walks range(n_agents()) = range(n_pursuers), :418-428), rows past the last such
+                              evader are left untouched; rewards stay the pursuers' (:213, :254-256).  Needs
+                              n_evaders >= n_pursuers, no random_opponents; generic kernel only. */
+    int32_t reserved0;
     double catchr;            /* :92 */
     double term_pursuit;      /* :95 */
     double urgency_reward;    /* :98 */
@@ -78,9 +87,14 @@ typedef struct madrl_pursuit madrl_pursuit; /* opaque */
  * (DiscreteAgent._obs_shape, utils/DiscreteAgent.py:50-53). */
 int madrl_pursuit_obs_dim(const madrl_pursuit_config *cfg, int32_t *out_dim);
 
-/* Bytes of packed per-env state the caller must allocate (and zero: an all-zero state is the
- * reference's constructor state -- every agent at (0,0) on map 0, pursuit_evade.py:69-75). */
+/* Bytes of per-env state the caller must allocate (and zero: an all-zero state is the
+ * reference's constructor state -- every agent at (0,0) on map 0, pursuit_evade.py:69-75).
+ * Layout: n_envs packed records of madrl_pursuit_record_bytes() each, padding to 256 bytes, then -- for shapes with a
+ * compiled fast path -- the stale-zero masks of that path (256 bytes per env and wavefront, see obs_dev below).
+ * Everything the library knows about an env lives in this buffer and in the observation buffer: copying both clones it. */
 int madrl_pursuit_state_bytes(const madrl_pursuit_config *cfg, int64_t n_envs, uint64_t *out_bytes);
+/* bytes of one packed record: [u32 tick][u32 t][u32 map_id][u32 0][u8 x,y per agent, pursuers first][u32 gone bits][u32 terminal bits], 16-B aligned */
+int madrl_pursuit_record_bytes(const madrl_pursuit_config *cfg, int32_t *out_bytes);
 
 /* Replaces PursuitEvade.__init__ for n_envs instances.  map_pool_host: n_maps*xs*ys int8 on
  * the HOST, row-major [map][x][y], 0 = free, -1 = building (utils/TwoDMaps.py:8-22).
@@ -114,7 +128,12 @@ int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_bloc
  *                persistent `local_obs` (pursuit_evade.py:119-120).  Cells of channels 1-2
  *                that fall outside the map are left untouched, exactly as :438-439 leaves
  *                them; pass the same zero-initialised buffer to every
- *                reset/step call of a handle to get the reference's values. */
+ *                reset/step call of a handle to get the reference's values.
+ *                CONTRACT of the fast path: it remembers (stale-zero masks, in the state buffer) which untouched cells of
+ *                THIS buffer hold 0.0 and stores whole float4s over them.  The memory is forgotten automatically when
+ *                another pointer is passed, after madrl_pursuit_set_state and after a generic-kernel launch; a caller
+ *                that WRITES into the buffer itself (or frees and re-allocates it at the same address) must call
+ *                madrl_pursuit_invalidate_obs() before the next reset/step. */
 int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t *inj_pos_dev,
                         const int32_t *inj_map_dev, float *obs_dev, void *stream);
 
@@ -123,7 +142,8 @@ int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t
  *                else is treated as 4 (stay) -- the reference raises IndexError instead;
  *   inj_evader_actions_dev  int32 [n_envs][E] or NULL: entry k is the action of the k-th
  *                REMAINING evader in layer order (one RandomPolicy.act per remaining evader,
- *                pursuit_evade.py:238-241); NULL = in-kernel Philox draws;
+ *                pursuit_evade.py:238-241); NULL = in-kernel Philox draws.  (train_pursuit = 0: the
+ *                opponents are the pursuers, the array is [n_envs][P], entry j = pursuer j.)
  *   obs_dev      as in reset (IN/OUT);
  *   rew_dev      float32 [n_envs][P]  (computed in float64 like the reference, then rounded);
  *   done_dev     uint8 [n_envs]: bit0 = is_terminal (:383-389), bit1 = max_steps reached;
@@ -146,6 +166,15 @@ int madrl_pursuit_set_state(madrl_pursuit *h, const int32_t *pos_p, const int32_
                             const uint8_t *gone, const uint8_t *term_p, const uint8_t *term_e,
                             const int32_t *map_id, const uint32_t *tick, const int32_t *t,
                             void *stream);
+/* The caller modified the observation buffer behind the library's back (see obs_dev above): forget what is known about it. */
+int madrl_pursuit_invalidate_obs(madrl_pursuit *h);
+
+/* Curriculum (PursuitEvade.update_curriculum, pursuit_evade.py:264-272; set_param_values, madrl_environments/__init__.py:64-67)
+ * without re-creating the handle.  set_params replaces the batch-wide catchr / constraint_window of the config;
+ * set_curriculum binds PER-ENV values: float64 [n_envs] device arrays (caller-owned, valid while bound, may be rewritten
+ * between launches), NULL = the batch-wide scalar.  constraint_window is read by resets, catchr by every step. */
+int madrl_pursuit_set_params(madrl_pursuit *h, double catchr, double constraint_window);
+int madrl_pursuit_set_curriculum(madrl_pursuit *h, const double *constraint_window_dev, const double *catchr_dev);
 
 /* ------------------------------------------------------------------------------------------
  * MAWaterWorld  (reference: madrl_environments/pursuit/waterworld.py), float32 arithmetic

@@ -85,7 +85,7 @@ __host__ __device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 }
 
 // RNG contract tags: counter = (global env id, tick, index, tag | attempt << 8)
-enum : uint32_t { TAG_EVADER_ACT = 0, TAG_RESET_POS = 1, TAG_RESET_ENV = 2 };
+enum : uint32_t { TAG_EVADER_ACT = 0, TAG_RESET_POS = 1, TAG_RESET_ENV = 2, TAG_PURSUER_ACT = 3 };
 
 // uniform double in [0,1) from 53 random bits
 __host__ __device__ inline double u53(uint32_t hi, uint32_t lo) {

@@ -42,6 +42,7 @@ struct PursuitDev {
     int32_t pad, GW, GSZ;  // padded grid: width (y extent), bytes per layer (multiple of 16)
     int32_t n_catch, surround, reward_global, sample_maps, n_maps, max_steps, auto_reset;
     int32_t max_opponents;  // > 0: random_opponents (pursuit_evade.py:177-181)
+    int32_t train_pursuit;  // 0: the ACTIONS drive the evaders, the pursuers move by their controller (pursuit_evade.py:215-224)
     int32_t rec_bytes, off_gone, off_term, ngw, ntw;  // state record layout (byte offsets)
     int32_t map_stride;                               // bytes per map entry in `maps`
     uint32_t k0, k1, gid_base;
@@ -52,6 +53,8 @@ struct PursuitDev {
     const uint8_t *cnt_tmpl; // padded count-layer template [GSZ]: 0 inside, 0xFF outside
     const float *vtab;       // 256 floats: fl32(k / layer_norm), [0xFE] = fl32(1.0 / layer_norm)
     const uint32_t *codes;   // D slot codes
+    const double *cw_env;     // per-env constraint_window / catchr (curriculum, pursuit_evade.py:264-272) or nullptr: the scalars above
+    const double *catchr_env;
     uint8_t *state;
 };
 
@@ -125,6 +128,11 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
     int32_t *s_kpre = reinterpret_cast<int32_t *>(s_misc + 8);         // P ints (pre-move counts)
     double *s_rew = reinterpret_cast<double *>(s_kpre + ((d.P + 3) & ~3));  // P doubles
     uint32_t *s_code = reinterpret_cast<uint32_t *>(s_rew + ((d.P + 1) & ~1));  // D slot codes (float4 observation path)
+    // observers: whose windows the P observation rows show.  train_pursuit: pursuer p.  Evader control (:204-207, :251 with
+    // agent_layer = evader_layer): row k = the k-th remaining evader among slots 0..P-1 (collect_obs :418-428 walks
+    // range(n_agents()) = range(n_pursuers) over evaders_gone and indexes the compacted layer); s_misc[5] = number of rows
+    uint8_t *s_ox = reinterpret_cast<uint8_t *>(s_code + ((d.D + 3) & ~3));
+    uint8_t *s_oy = s_ox + ((d.P + 15) & ~15);
 
     // ---- once per workgroup: value table and this thread's observation slot codes
     for (int k = tid; k < 256; k += nthr) s_vtab[k] = d.vtab[k];
@@ -174,6 +182,19 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             if (d.n_envs >= 0) return;
 #endif
             float *orow = io.obs + env * (int64_t)d.P * d.D;
+            int n_rows = d.P;
+            if (!d.train_pursuit) {  // observers = the remaining evaders of slots 0..P-1, in slot order
+                __syncthreads();
+                if (tid == 0) {
+                    int k = 0;
+                    for (int i = 0; i < d.P && i < d.E; ++i)
+                        if (!((s_gone[i >> 5] >> (i & 31)) & 1u)) { s_ox[k] = s_ax[d.P + i]; s_oy[k] = s_ay[d.P + i]; ++k; }
+                    s_misc[5] = (uint32_t)k;
+                }
+                __syncthreads();
+                n_rows = (int)s_misc[5];
+            }
+            const uint8_t *obx = d.train_pursuit ? s_ax : s_ox, *oby = d.train_pursuit ? s_ay : s_oy;
             if (vec4) {
                 // float4 path (same scheme as the wave kernel): the P*D/4 float4 slots of the env are spread over the threads;
                 // a slot without stale cells is ONE non-temporal 16-byte store, a slot with stale cells falls back to masked
@@ -184,7 +205,8 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
                 int p = tid / DV, f = tid - p * DV;
                 const int dp = nthr / DV, df = nthr - dp * DV;
                 for (int q = tid; q < NQ; q += nthr) {
-                    const int base = (s_ax[p] - obs_off + pad) * GW + (s_ay[p] - obs_off + pad);
+                    if (p >= n_rows) break;  // rows of absent observers keep their old contents
+                    const int base = (obx[p] - obs_off + pad) * GW + (oby[p] - obs_off + pad);
                     float val[4];
                     bool keep[4];
 #pragma unroll
@@ -221,8 +243,8 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
                 return;
             }
             // dword path (rows that are not whole float4s: even obs_range with flatten)
-            for (int p = 0; p < d.P; ++p) {
-                const int base = (s_ax[p] - obs_off + pad) * GW + (s_ay[p] - obs_off + pad);
+            for (int p = 0; p < n_rows; ++p) {
+                const int base = (obx[p] - obs_off + pad) * GW + (oby[p] - obs_off + pad);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int r = tid + t * nthr;
@@ -278,19 +300,33 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
                 if (!is_p && ((s_gone[i >> 5] >> (i & 31)) & 1u)) continue;
                 int x = s_ax[a], y = s_ay[a];
                 int act;
-                if (is_p) {
-                    act = io.actions[env * d.P + a];
-                } else {
+                int k = 0;  // evaders: index in the evader LAYER = alive evaders in slots below i
+                if (!is_p) {
                     lds_byte_sub(g_ec, (x + pad) * GW + y + pad);  // undo the pre-move count
-                    // k = index in the evader LAYER = alive evaders in slots below i
-                    int k = 0;
                     for (int w = 0; w < (i >> 5); ++w) k += 32 - __popc(s_gone[w]);
                     k += (i & 31) - __popc(s_gone[i >> 5] & ((1u << (i & 31)) - 1u));
-                    if (io.inj_eact != nullptr) {
+                }
+                if (d.train_pursuit) {
+                    if (is_p) {
+                        act = io.actions[env * d.P + a];
+                    } else if (io.inj_eact != nullptr) {
                         act = io.inj_eact[env * d.E + k];
                     } else {
                         const u32x4 r = philox4x32_10(gid, tick, (uint32_t)k, TAG_EVADER_ACT, d.k0, d.k1);
                         act = (int)__umulhi(r.x, 5u);  // RandomPolicy.act, Controllers.py:15-16
+                    }
+                } else {
+                    // evader control (:215-224): action k moves the k-th agent of the evader layer (`for i, a in enumerate(actions):
+                    // agent_layer.move_agent(i, a)`, :229-230; the caller passes one action per env.agents entry = n_pursuers of
+                    // them, so evaders past the first n_pursuers of the layer never move); every pursuer moves by one
+                    // pursuer_controller.act() draw (:238-241), injected as entry a of inj_eact [n_envs][P]
+                    if (!is_p) {
+                        act = k < d.P ? io.actions[env * d.P + k] : 4;
+                    } else if (io.inj_eact != nullptr) {
+                        act = io.inj_eact[env * d.P + a];
+                    } else {
+                        const u32x4 r = philox4x32_10(gid, tick, (uint32_t)a, TAG_PURSUER_ACT, d.k0, d.k1);
+                        act = (int)__umulhi(r.x, 5u);
                     }
                 }
                 // DiscreteAgent.step, DiscreteAgent.py:69-97
@@ -352,7 +388,8 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             for (int w = 0; w < d.ngw; ++w) n_alive -= __popc(s_gone[w]);
             for (int p = tid; p < d.P; p += nthr) {
                 const int sur = g_cr[(s_ax[p] + pad) * GW + s_ay[p] + pad];
-                double r = d.catchr * (double)s_kpre[p];
+                const double catchr = d.catchr_env ? d.catchr_env[env] : d.catchr;
+                double r = catchr * (double)s_kpre[p];
                 r += d.term_pursuit * (sur ? 1.0 : 0.0);
                 r += d.urgency;
                 if (d.reward_global) s_rew[p] = r;
@@ -406,10 +443,11 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             }
             // constraint window (:185-191), float64 like the reference
             const u32x4 rw = philox4x32_10(gid, tick, 1u, TAG_RESET_ENV, d.k0, d.k1);
-            const double sx = u53(rw.x, rw.y) * (1.0 - d.cw);
-            const double sy = u53(rw.z, rw.w) * (1.0 - d.cw);
-            const int xlb = (int)(d.xs * sx), xub = (int)(d.xs * (sx + d.cw));
-            const int ylb = (int)(d.ys * sy), yub = (int)(d.ys * (sy + d.cw));
+            const double cw = d.cw_env ? d.cw_env[env] : d.cw;
+            const double sx = u53(rw.x, rw.y) * (1.0 - cw);
+            const double sy = u53(rw.z, rw.w) * (1.0 - cw);
+            const int xlb = (int)(d.xs * sx), xub = (int)(d.xs * (sx + cw));
+            const int ylb = (int)(d.ys * sy), yub = (int)(d.ys * (sy + cw));
             // random_opponents (train_pursuit, :177-181): this episode has n_create <= E evaders; the slots above are not
             // created and count as gone.  An injected position with x < 0 marks a slot that is not created.
             const bool inj = io.inj_pos != nullptr && mode == 0;
@@ -555,8 +593,10 @@ struct madrl_pursuit {
     // one-wavefront-per-env fast path (pursuit_wave.hpp), when a specialisation matches
     const WaveEntry *wave;
     madrl::pw::WaveDev wdev;
-    void *zmask = nullptr;          // stale-zero masks of the fast path, [n_envs][64] dwords (pursuit_wave.hpp)
-    const void *zmask_obs = nullptr; // the observation buffer the masks describe; another buffer (or a generic-kernel launch) resets them
+    void *zmask = nullptr;          // stale-zero masks of the fast path, [n_envs][64 * waves] dwords (pursuit_wave.hpp): the tail of
+                                    // the caller's state buffer (madrl_pursuit_state_bytes), not a library allocation
+    const void *zmask_obs = nullptr; // the observation buffer the masks describe; another buffer, a generic-kernel launch,
+                                    // set_state or madrl_pursuit_invalidate_obs resets them to "nothing known"
     uint64_t step_count = 0;  // step launches so far (parity of the walk direction, see launch())
     int walk_mode = 0;        // 0 auto (alternate above ~375 MB per launch), 1 always alternate, 2 always forward; fixed at create
     void *wtables;
@@ -586,7 +626,7 @@ template <class S>
 void wave_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t blocks, hipStream_t s) {
     if (mode == 0)
         hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 0, false>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
-    else if (io.inj_eact != nullptr)
+    else if (io.flex)
         hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 1, true>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
     else
         hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 1, false>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
@@ -596,7 +636,7 @@ template <class S>
 void group_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t blocks, hipStream_t s) {
     if (mode == 0)
         hipLaunchKernelGGL((pw::pursuit_group_kernel<S, 0, false>), dim3((unsigned)blocks), dim3(S::NT), 0, s, d, io);
-    else if (io.inj_eact != nullptr)
+    else if (io.flex)
         hipLaunchKernelGGL((pw::pursuit_group_kernel<S, 1, true>), dim3((unsigned)blocks), dim3(S::NT), 0, s, d, io);
     else
         hipLaunchKernelGGL((pw::pursuit_group_kernel<S, 1, false>), dim3((unsigned)blocks), dim3(S::NT), 0, s, d, io);
@@ -622,6 +662,7 @@ const WaveEntry WAVE_TABLE[] = {
 
 const WaveEntry *find_wave(const madrl_pursuit_config *c) {
     if (c->flatten && !c->include_id) return nullptr;
+    if (!c->train_pursuit) return nullptr;  // evader control runs on the generic kernel
     for (const WaveEntry &e : WAVE_TABLE) {
         const WaveGeom &g = e.g;
         if (g.xs == c->xs && g.ys == c->ys && g.P == c->n_pursuers && g.E == c->n_evaders && g.R == c->obs_range &&
@@ -647,6 +688,12 @@ int validate(const madrl_pursuit_config *c) {
     if (!(c->layer_norm > 0.0)) return fail(MADRL_EINVAL, "layer_norm must be > 0");
     if (!(c->constraint_window > 0.0 && c->constraint_window <= 1.0))
         return fail(MADRL_EINVAL, "constraint_window must be in (0,1]");
+    if (c->train_pursuit != 0 && c->train_pursuit != 1) return fail(MADRL_EINVAL, "train_pursuit must be 0 or 1");
+    if (!c->train_pursuit && c->n_evaders < c->n_pursuers)
+        return fail(MADRL_EINVAL, "train_pursuit=0: collect_obs walks range(n_pursuers) over evaders_gone (pursuit_evade.py:418-428): n_evaders=%d must be >= n_pursuers=%d",
+                    c->n_evaders, c->n_pursuers);
+    if (!c->train_pursuit && c->max_opponents != 0)
+        return fail(MADRL_EINVAL, "train_pursuit=0 with random_opponents (a per-reset number of pursuers, :180-181) is not supported");
     if (c->max_opponents != 0 && c->max_opponents < 2) return fail(MADRL_EINVAL, "max_opponents=%d: random_opponents draws randint(1, max_opponents)", c->max_opponents);
     return MADRL_OK;
 }
@@ -668,6 +715,7 @@ void layout(const madrl_pursuit_config *c, PursuitDev *d) {
     d->sample_maps = c->sample_maps; d->n_maps = c->n_maps; d->max_steps = c->max_steps;
     d->auto_reset = c->auto_reset;
     d->max_opponents = c->max_opponents;
+    d->train_pursuit = c->train_pursuit;
     d->ngw = (d->E + 31) / 32; if (d->ngw < 1) d->ngw = 1;
     d->ntw = (d->A + 31) / 32;
     d->off_gone = (int)align_up(HDR_BYTES + 2 * (size_t)d->A, 4);
@@ -703,6 +751,7 @@ size_t lds_bytes_for(const PursuitDev &d) {
     b = align_up(b, 8);
     b += 8 * align_up((size_t)d.P, 2);
     b += 4 * align_up((size_t)d.D, 4);  // slot codes
+    b += 2 * align_up((size_t)d.P, 16);  // observer positions (evader control)
     return align_up(b, 16);
 }
 
@@ -724,6 +773,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         pw::WaveIO w;
         w.mask = io.mask; w.inj_pos = io.inj_pos; w.inj_map = io.inj_map; w.actions = io.actions;
         w.inj_eact = io.inj_eact; w.obs = io.obs; w.rew = io.rew; w.done = io.done; w.removed = io.removed;
+        w.flex = (io.inj_eact != nullptr || h->dev.catchr_env != nullptr) ? 1 : 0;
         int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 4 * h->wave->g.occ / h->wave->g.waves;  // exactly the resident capacity
         if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
         // Large batches: successive step launches walk the env range in opposite directions, so the rows written last by
@@ -732,6 +782,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         // (98 304: 4.7e8, 131 072: 4.5e8); alternating holds 6.4-6.7e8 from 81 920 to 131 072 but costs 6 % below.  Hence
         // the switch at ~375 MB of rows + records per launch.  Env results do not depend on the processing order.
         pw::WaveDev wd = h->wdev;
+        wd.catchr = h->dev.catchr; wd.cw = h->dev.cw; wd.cw_env = h->dev.cw_env; wd.catchr_env = h->dev.catchr_env;  // curriculum
         if (h->zmask_obs != (const void *)io.obs) {  // unknown buffer contents: every cell "not known to be zero"
             MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0xFF, (size_t)h->dev.n_envs * 256 * h->wave->g.waves, s));
             h->zmask_obs = io.obs;
@@ -759,6 +810,13 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
     }
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
+}
+
+// caller-owned state buffer = [n_envs packed records][pad to 256 B][stale-zero masks of the fast path, 256 B per env and wavefront]
+uint64_t zmask_offset(int rec_bytes, int64_t n_envs) { return align_up((uint64_t)rec_bytes * (uint64_t)n_envs, 256); }
+uint64_t zmask_bytes(const madrl_pursuit_config *cfg, int64_t n_envs) {
+    const WaveEntry *w = find_wave(cfg);
+    return w ? (uint64_t)n_envs * 256u * (uint64_t)w->g.waves : 0u;
 }
 
 int pick_threads(const PursuitDev &d, int requested) {
@@ -790,7 +848,17 @@ int madrl_pursuit_state_bytes(const madrl_pursuit_config *cfg, int64_t n_envs, u
     if (n_envs < 1 || !out_bytes) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_bytes non-NULL");
     PursuitDev d;
     layout(cfg, &d);
-    *out_bytes = (uint64_t)d.rec_bytes * (uint64_t)n_envs;
+    *out_bytes = zmask_offset(d.rec_bytes, n_envs) + zmask_bytes(cfg, n_envs);
+    return MADRL_OK;
+}
+
+int madrl_pursuit_record_bytes(const madrl_pursuit_config *cfg, int32_t *out_bytes) {
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (!out_bytes) return fail(MADRL_EINVAL, "out_bytes is NULL");
+    PursuitDev d;
+    layout(cfg, &d);
+    *out_bytes = d.rec_bytes;
     return MADRL_OK;
 }
 
@@ -981,12 +1049,7 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             w.cnt_tmpl = reinterpret_cast<const uint32_t *>(h->wtables) + w_tmpl;
             w.slot_tab = reinterpret_cast<const uint32_t *>(h->wtables) + w_slots;
             w.state = d.state;
-            e = hipMalloc(&h->zmask, (size_t)d.n_envs * 256 * g.waves);
-            if (e != hipSuccess) {
-                (void)hipFree(h->wtables); (void)hipFree(h->tables);
-                delete h;
-                return fail(MADRL_EHIP, "stale-zero masks: %s", hipGetErrorString(e));
-            }
+            h->zmask = (uint8_t *)state_dev + zmask_offset(d.rec_bytes, n_envs);  // caller-owned, like the records
             w.zmask = reinterpret_cast<uint32_t *>(h->zmask);
         } else {
             h->wave = nullptr;
@@ -1035,7 +1098,6 @@ void madrl_pursuit_destroy(madrl_pursuit *h) {
     if (!h) return;
     if (h->tables) (void)hipFree(h->tables);
     if (h->wtables) (void)hipFree(h->wtables);
-    if (h->zmask) (void)hipFree(h->zmask);
     delete h;
 }
 
@@ -1101,6 +1163,28 @@ int madrl_pursuit_set_state(madrl_pursuit *h, const int32_t *pos_p, const int32_
     hipLaunchKernelGGL(pursuit_set_state_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, pos_p,
                        pos_e, gone, term_p, term_e, map_id, tick, t);
     MADRL_HIP_TRY(hipGetLastError());
+    h->zmask_obs = nullptr;  // a state written from outside usually comes with an observation buffer written from outside
+    return MADRL_OK;
+}
+
+int madrl_pursuit_invalidate_obs(madrl_pursuit *h) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    h->zmask_obs = nullptr;  // the next fast-path launch starts from "no cell is known to be zero"
+    return MADRL_OK;
+}
+
+int madrl_pursuit_set_params(madrl_pursuit *h, double catchr, double constraint_window) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    if (!(constraint_window > 0.0 && constraint_window <= 1.0)) return fail(MADRL_EINVAL, "constraint_window must be in (0,1]");
+    h->cfg.catchr = catchr; h->cfg.constraint_window = constraint_window;
+    h->dev.catchr = catchr; h->dev.cw = constraint_window;
+    return MADRL_OK;
+}
+
+int madrl_pursuit_set_curriculum(madrl_pursuit *h, const double *constraint_window_dev, const double *catchr_dev) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    h->dev.cw_env = constraint_window_dev;
+    h->dev.catchr_env = catchr_dev;
     return MADRL_OK;
 }
 

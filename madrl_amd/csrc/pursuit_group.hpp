@@ -236,9 +236,12 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                 // ---------------------------------------------------- moves (:229-241)
                 const int kidx = __popcll((~gone) & ((1ull << (eslot & 63)) - 1ull));
                 int act = cur_act;
-                if constexpr (INJECT) {
-                    if (e_alive) act = io.inj_eact[env * E + kidx];
-                } else {
+                bool injected = false;
+                if constexpr (INJECT) {   // the FLEX instantiation, see pursuit_wave.hpp
+                    injected = io.inj_eact != nullptr;
+                    if (injected && e_alive) act = io.inj_eact[env * E + kidx];
+                }
+                if (!injected) {
                     const u32x4 r = philox4x32_10(gid, tick, (uint32_t)kidx, TAG_EVADER_ACT, k0, k1);
                     if (!isP()) act = (int)__umulhi(r.x, 5u);
                 }
@@ -284,7 +287,9 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                     } else {
                         sur = ec[cell] >= CAUGHT;
                     }
-                    r = d.catchr * (double)kpre;
+                    double catchr = d.catchr;
+                    if constexpr (INJECT) { if (d.catchr_env != nullptr) catchr = sload_f64(d.catchr_env, env); }
+                    r = catchr * (double)kpre;
                     r += d.term_pursuit * (sur ? 1.0 : 0.0);
                     r += d.urgency;
                 }
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                     gone = 0ull;
                     term = 0ull;
                     const KArgsPtr ka = cold_args();
-                    const double cw = ka->d.cw;
+                    const double cw = ka->d.cw_env != nullptr ? sload_f64(ka->d.cw_env, env) : ka->d.cw;
                     const int max_opponents = ka->d.max_opponents;
                     bool inj_map = false, inj_pos = false;
                     if constexpr (MODE == 0) {

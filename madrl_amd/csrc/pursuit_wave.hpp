@@ -61,6 +61,8 @@ struct WaveDev {
     // runs it at the same moment, 2.8 us of a 78 us launch when it was computed in the kernel):
     const uint32_t *cnt_tmpl;  // [GSZ] an empty count layer: 0 inside the map, SENT outside
     const uint32_t *slot_tab;  // [NS][6][NT] per thread and float4 slot: 4 cell offsets, element-3-is-relative flag, owning pursuer
+    const double *cw_env;      // per-env constraint_window / catchr (curriculum) or nullptr: the scalars above.  Read with scalar loads
+    const double *catchr_env;  // (constant address space): written by the host or an earlier launch, never by these kernels
     uint8_t *state;
     uint32_t *zmask;         // [n_envs][64]: per lane, which of its observation cells hold a NON-ZERO stale value (see "stale-zero mask")
 };
@@ -75,7 +77,14 @@ struct WaveIO {
     float *rew;
     uint8_t *done;
     int32_t *removed;
+    int32_t flex;            // host side only: 1 = launch the FLEX instantiation (injected evader actions and / or per-env catchr)
 };
+
+// a wave-uniform float64 read through the scalar cache (s_load_dwordx2, counted by lgkmcnt -- not by the vmcnt the
+// store pipeline of these kernels is scheduled around)
+__device__ __forceinline__ double sload_f64(const double *p, int64_t index) {
+    return ((const __attribute__((address_space(4))) double *)(uint64_t)p)[index];
+}
 
 // Launch parameters that only the rare paths read (episode reset, a change of map) are not kept in SGPRs across the env loop: the
 // kernel reads them from its kernel-argument segment (scalar loads) where they are needed.  The loop otherwise runs out of SGPRs
@@ -278,7 +287,8 @@ __device__ __forceinline__ void put_zero_from(uint32_t &w) {
 // "nothing known" is always correct: the library starts there and returns there whenever the caller hands it another buffer.
 //
 // MODE 0: reset(mask)      MODE 1: step (+ fused auto-reset)
-// INJECT (step only): evader actions come from io.inj_eact (parity harness) instead of Philox.
+// INJECT (step only) = the FLEXIBLE instantiation: evader actions come from io.inj_eact when it is given (parity harness)
+// instead of Philox, and the catch reward is d.catchr_env[env] when per-env curriculum arrays are bound.
 // It is a template parameter because a conditional global load in the hot loop makes the
 // compiler's s_waitcnt pass put a vmcnt(0) on the common path (see "pipeline hinge" below).
 template <class S, int MODE, bool INJECT>
@@ -440,9 +450,12 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                 // evader draw: index in the evader layer = alive evaders in lower slots
                 const int kidx = __popcll((~gone) & ((1ull << (eslot & 63)) - 1ull));
                 int act = cur_act;
+                bool injected = false;
                 if constexpr (INJECT) {
-                    if (e_alive) act = io.inj_eact[env * E + kidx];
-                } else {
+                    injected = io.inj_eact != nullptr;
+                    if (injected && e_alive) act = io.inj_eact[env * E + kidx];
+                }
+                if (!injected) {
 #if MADRL_ABLATE & 4
                     u32x4 r; r.x = (gid * 2654435761u + tick * 40503u + (uint32_t)kidx * 2246822519u) ^ k0 ^ k1;
 #else
@@ -493,7 +506,9 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                     } else {
                         sur = ec[cell] >= CAUGHT;  // :503-506
                     }
-                    r = d.catchr * (double)kpre;
+                    double catchr = d.catchr;
+                    if constexpr (INJECT) { if (d.catchr_env != nullptr) catchr = sload_f64(d.catchr_env, env); }
+                    r = catchr * (double)kpre;
                     r += d.term_pursuit * (sur ? 1.0 : 0.0);
                     r += d.urgency;
                 }
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                     gone = 0ull;
                     term = 0ull;
                     const KArgsPtr ka = cold_args();
-                    const double cw = ka->d.cw;
+                    const double cw = ka->d.cw_env != nullptr ? sload_f64(ka->d.cw_env, env) : ka->d.cw;
                     const int max_opponents = ka->d.max_opponents;
                     bool inj_map = false, inj_pos = false;
                     if constexpr (MODE == 0) {

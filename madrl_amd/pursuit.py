@@ -69,8 +69,12 @@ class BatchedPursuitEvade(AbstractMAEnv):
             kw[k] = kwargs[k]
         if kw["random_opponents"] and int(kw["max_opponents"]) < 2:
             raise ValueError("random_opponents draws randint(1, max_opponents): max_opponents must be >= 2")  # :179
-        if not kw["train_pursuit"]:
-            raise NotImplementedError("train_pursuit=False (controlling the evaders) is not supported")
+        if not kw["train_pursuit"]:  # evader control, pursuit_evade.py:105-112, :204-207, :215-224
+            if kw["random_opponents"]:
+                raise NotImplementedError("train_pursuit=False with random_opponents (a per-reset number of pursuers, :180-181)")
+            if int(kw["n_evaders"]) < int(kw["n_pursuers"]):
+                raise ValueError("train_pursuit=False: collect_obs indexes evaders_gone[i] for i < n_pursuers (:418-428); "
+                                 "the reference raises IndexError in reset() when n_evaders < n_pursuers")
         for k, v in kw.items():
             if k == "reward_mech":
                 self._reward_mech = v
@@ -103,6 +107,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
         c.max_steps, c.auto_reset = self.max_steps, int(self.auto_reset)
         # :177-181 (train_pursuit): every reset creates randint(1, max_opponents) evaders, at most the n_evaders slots
         c.max_opponents = int(self.max_opponents) if self.random_opponents else 0
+        c.train_pursuit = int(bool(self.train_pursuit))
         c.catchr, c.term_pursuit = float(self.catchr), float(self.term_pursuit)
         c.urgency_reward, c.layer_norm = float(self.urgency_reward), float(self.layer_norm)
         c.constraint_window = float(self.constraint_window)
@@ -120,8 +125,10 @@ class BatchedPursuitEvade(AbstractMAEnv):
         cfg = self._config()
         dim = C.c_int32()
         _lib.check(L.madrl_pursuit_obs_dim(C.byref(cfg), C.byref(dim)))
-        nbytes = C.c_uint64()
+        nbytes, rbytes = C.c_uint64(), C.c_int32()
         _lib.check(L.madrl_pursuit_state_bytes(C.byref(cfg), self.n_envs, C.byref(nbytes)))
+        _lib.check(L.madrl_pursuit_record_bytes(C.byref(cfg), C.byref(rbytes)))
+        self.record_bytes = rbytes.value
         N, P, E, D = self.n_envs, int(self.n_pursuers), int(self.n_evaders), dim.value
         shape_key = (N, P, E, D, nbytes.value)
         if getattr(self, "_shape_key", None) != shape_key:
@@ -140,6 +147,11 @@ class BatchedPursuitEvade(AbstractMAEnv):
         _lib.check(L.madrl_pursuit_create(C.byref(cfg), self.map_pool.ctypes.data_as(C.c_void_p), N,
                                           dev_index, _lib.ptr(self._state), C.byref(h)))
         self._handle = h
+        self._handle_key = self._create_key()
+        if getattr(self, "_cw_env", None) is not None and self._cw_env.shape[0] == N:   # per-env curriculum follows the new handle
+            _lib.check(L.madrl_pursuit_set_curriculum(h, _lib.ptr(self._cw_env), _lib.ptr(self._catchr_env)))
+        else:
+            self._cw_env = self._catchr_env = None
         if self._threads or self._max_blocks:
             _lib.check(L.madrl_pursuit_set_launch(h, self._threads, self._max_blocks))
         if getattr(self, "_kernel", "auto") != "auto":
@@ -236,7 +248,8 @@ class BatchedPursuitEvade(AbstractMAEnv):
         kernel writes instead of the env's own buffers -- the C ABI takes any device pointer, no copy afterwards."""
         N, P, E = self.n_envs, int(self.n_pursuers), int(self.n_evaders)
         act = self._i32(actions, (N, P), "actions")
-        eact = self._i32(evader_actions, (N, E), "evader_actions")
+        # evader control (train_pursuit=False): the opponents are the pursuers, one injected action per pursuer
+        eact = self._i32(evader_actions, (N, E if self.train_pursuit else P), "evader_actions")
         rew = self._rew if rew_out is None else rew_out
         dn = self._done if done_out is None else done_out
         assert rew.dtype == torch.float32 and rew.numel() == N * P and dn.dtype == torch.uint8 and dn.numel() == N
@@ -247,20 +260,110 @@ class BatchedPursuitEvade(AbstractMAEnv):
         info = {"removed": self._removed, "truncated": (dn & 2).bool(), "done_bits": dn}
         return self._obs_view(), rew, done, info
 
+    def obs_rows_valid(self):
+        """bool [N, P]: which observation rows the last reset / step wrote.  All of them with train_pursuit; in evader control
+        row k is the k-th remaining evader among slots 0..P-1 (pursuit_evade.py:418-428) and the rows past the last one are
+        stale."""
+        N, P = self.n_envs, int(self.n_pursuers)
+        if self.train_pursuit:
+            return torch.ones((N, P), dtype=torch.bool, device=self.device)
+        left = (self.get_state()["gone"][:, :P] == 0).sum(dim=1, keepdim=True)
+        return torch.arange(P, device=self.device)[None, :] < left
+
     @property
     def is_terminal(self):
         """pursuit_evade.py:383-389 per env: no evaders left."""
         return self.get_state()["gone"].bool().all(dim=1)
 
-    def update_curriculum(self, itr):
-        """pursuit_evade.py:264-272"""
-        self.constraint_window = float(np.clip(self.constraint_window + self.curriculum_constrain_rate, 0.0, 1.0))
-        if itr != 0 and itr % self.curriculum_remove_every == 0 and self.n_pursuers > 4:
-            self.n_evaders -= 1
-            self.n_pursuers -= 1
+    # ------------------------------------------------------------------ curriculum (pursuit_evade.py:264-272)
+    def _create_key(self):
+        """everything madrl_pursuit_create bakes into the handle except catchr / constraint_window (those two can be
+        changed in place: madrl_pursuit_set_params)"""
+        c = self._config()
+        return tuple(getattr(c, n) for n, _ in c._fields_ if n not in ("catchr", "constraint_window")) + (self.map_pool.tobytes(),)
+
+    def set_param_values(self, lut):
+        """madrl_environments/__init__.py:64-67: setattr + setup().  The native handle is only re-created when something other
+        than catchr / constraint_window changed."""
+        for k, v in lut.items():
+            if k == "reward_mech":
+                self._reward_mech = v
+            else:
+                setattr(self, k, v)
+        self._apply_params()
+
+    def _apply_params(self):
+        if self._handle is not None and self._create_key() == getattr(self, "_handle_key", None):
+            _lib.check(_lib.lib().madrl_pursuit_set_params(self._handle, float(self.catchr), float(self.constraint_window)))
+        else:
+            self.setup()
+
+    @staticmethod
+    def curriculum_next(itr, constraint_window, n_evaders, n_pursuers, catchr, constrain_rate, remove_every, turn_off_shaping):
+        """One PursuitEvade.update_curriculum(itr) on plain values (pursuit_evade.py:264-272): returns the new
+        (constraint_window, n_evaders, n_pursuers, catchr)."""
+        constraint_window = constraint_window + constrain_rate      # :265
+        constraint_window = np.clip(constraint_window, 0.0, 1.0)    # :266
+        if itr != 0 and itr % remove_every == 0 and n_pursuers > 4:  # :268-270
+            n_evaders -= 1
+            n_pursuers -= 1
+        if itr > turn_off_shaping:                                   # :271-272
+            catchr = 0.0
+        return constraint_window, n_evaders, n_pursuers, catchr
+
+    def update_curriculum(self, itr, mask=None):
+        """pursuit_evade.py:264-272.  Without `mask`: the whole batch moves one curriculum iteration, like the reference object
+        (the handle is re-created only when the agent counts change).  With `mask` (bool / uint8 [N]): only those env
+        instances advance -- constraint_window and catchr become PER-ENV device arrays (`curriculum_state()`), read by the
+        kernels in place; the agent counts of a batch cannot differ per env, so the remove-agents rule is not applied then."""
+        if mask is None and self._cw_env is None:
+            cw, ne, np_, cr = self.curriculum_next(itr, self.constraint_window, self.n_evaders, self.n_pursuers, self.catchr,
+                                                   self.curriculum_constrain_rate, self.curriculum_remove_every,
+                                                   self.curriculum_turn_off_shaping)
+            self.constraint_window, self.n_evaders, self.n_pursuers, self.catchr = cw, ne, np_, cr
+            self._apply_params()
+            return
+        self._bind_curriculum()
+        m = torch.ones(self.n_envs, dtype=torch.bool, device=self.device) if mask is None else \
+            torch.as_tensor(mask, device=self.device).reshape(self.n_envs).bool()
+        # the same float64 operations as :265-266 / :271-272, on the masked elements
+        cw = torch.clamp(self._cw_env + float(self.curriculum_constrain_rate), 0.0, 1.0)
+        self._cw_env.copy_(torch.where(m, cw, self._cw_env))
         if itr > self.curriculum_turn_off_shaping:
-            self.catchr = 0.0
-        self.setup()
+            self._catchr_env.copy_(torch.where(m, torch.zeros_like(self._catchr_env), self._catchr_env))
+
+    def _bind_curriculum(self):
+        if self._cw_env is None:
+            f64 = dict(dtype=torch.float64, device=self.device)
+            self._cw_env = torch.full((self.n_envs,), float(self.constraint_window), **f64)
+            self._catchr_env = torch.full((self.n_envs,), float(self.catchr), **f64)
+            _lib.check(_lib.lib().madrl_pursuit_set_curriculum(self._handle, _lib.ptr(self._cw_env), _lib.ptr(self._catchr_env)))
+
+    def set_curriculum(self, constraint_window=None, catchr=None):
+        """Per-env curriculum values: float64 [N] (anything that converts).  They stay bound until clear_curriculum()."""
+        self._bind_curriculum()
+        if constraint_window is not None:
+            cw = torch.as_tensor(constraint_window, dtype=torch.float64, device=self.device).reshape(self.n_envs)
+            if not bool(((cw > 0) & (cw <= 1)).all()):
+                raise ValueError("constraint_window must be in (0, 1]")
+            self._cw_env.copy_(cw)
+        if catchr is not None:
+            self._catchr_env.copy_(torch.as_tensor(catchr, dtype=torch.float64, device=self.device).reshape(self.n_envs))
+
+    def clear_curriculum(self):
+        self._cw_env = self._catchr_env = None
+        _lib.check(_lib.lib().madrl_pursuit_set_curriculum(self._handle, None, None))
+
+    def curriculum_state(self):
+        """(constraint_window, catchr) as float64 [N] tensors (per-env arrays when bound, else the batch-wide scalars)"""
+        if self._cw_env is not None:
+            return self._cw_env, self._catchr_env
+        f64 = dict(dtype=torch.float64, device=self.device)
+        return torch.full((self.n_envs,), float(self.constraint_window), **f64), torch.full((self.n_envs,), float(self.catchr), **f64)
+
+    def invalidate_obs(self):
+        """Call after writing into `obs_buffer` yourself (include/madrl_hip.h, obs_dev contract)."""
+        _lib.check(_lib.lib().madrl_pursuit_invalidate_obs(self._handle))
 
     # ------------------------------------------------------------------ state exchange
     def get_state(self):
@@ -327,6 +430,10 @@ class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
 
     def __init__(self, map_pool, device="cuda:0", **kwargs):
         self._evader_controller = kwargs.pop("evader_controller", None)
+        if not kwargs.get("train_pursuit", True):  # the opponents are the pursuers then (:220-224)
+            self._evader_controller = kwargs.pop("pursuer_controller", None)
+        else:
+            kwargs.pop("pursuer_controller", None)  # never asked with train_pursuit (:215-219)
         self._reset_positions = []   # parity hook: see script_reset_positions()
         self._alive_at_step_start = None
         self._env = BatchedPursuitEvade(map_pool, n_envs=1, device=device, **kwargs)
@@ -368,7 +475,17 @@ class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
 
     def _obslist(self, obs):
         o = obs[0].detach().cpu().numpy().astype(np.float64)
-        return [o[i] for i in range(o.shape[0])]
+        if self._env.train_pursuit:
+            return [o[i] for i in range(o.shape[0])]
+        # evader control: collect_obs (:418-428) returns None for a gone evader slot, else the next row
+        gone = self._env.get_state()["gone"][0, :o.shape[0]].cpu().numpy()
+        out, k = [], 0
+        for i in range(o.shape[0]):
+            if gone[i]:
+                out.append(None)
+            else:
+                out.append(o[k]); k += 1
+        return out
 
     def reset(self):
         pos = self._reset_positions.pop(0)[None] if self._reset_positions else None
@@ -390,9 +507,12 @@ class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
         if self._evader_controller is not None:  # :238-241
             ms = self.model_state
             alive = self._env.get_state()["gone"][0].cpu().numpy() == 0
-            eact = np.full((1, E), 4, dtype=np.int32)
-            for k in range(int(alive.sum())):
-                eact[0, k] = int(self._evader_controller.act(ms))
+            if self._env.train_pursuit:
+                eact = np.full((1, E), 4, dtype=np.int32)
+                for k in range(int(alive.sum())):
+                    eact[0, k] = int(self._evader_controller.act(ms))
+            else:  # one pursuer_controller.act per pursuer
+                eact = np.array([[int(self._evader_controller.act(ms)) for _ in range(P)]], dtype=np.int32)
             self._alive_at_step_start = alive
         obs, rew, done, info = self._env.step(torch.as_tensor(act.reshape(1, P)), evader_actions=eact)
         r = rew[0].detach().cpu().numpy().astype(np.float64)

@@ -110,10 +110,16 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         _lib.check(L.madrl_waterworld_create(C.byref(cfg), self._sensors.ctypes.data_as(C.c_void_p), N, dev_index,
                                              _lib.ptr(self._state), C.byref(h)))
         self._handle = h
-        self._std = None  # a fused StandardizedEnv binding belongs to the old handle
         if self._max_blocks:
             _lib.check(L.madrl_waterworld_set_launch(h, self._max_blocks))
         self._pursuers = [Archea(i + 1, D) for i in range(Np)]
+        # A fused StandardizedEnv binding belongs to the handle that was just replaced (seed() and set_param_values() come
+        # through here): bind the new handle to the SAME statistics / output tensors, or -- when the shapes changed -- to
+        # fresh ones, so that the wrapper keeps receiving standardised rows.
+        old, self._std = getattr(self, "_std", None), None
+        if old is not None:
+            keep = old if tuple(old["obs_out"].shape) == (N, Np, D) else None
+            self.bind_standardize(tensors=keep, **self._std_kwargs)
 
     def set_launch(self, max_blocks=0):
         self._max_blocks = int(max_blocks)
@@ -162,12 +168,15 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         return std["obs_out"] if std else self._obs
 
     # ------------------------------------------------------------------ fused StandardizedEnv (include/madrl_hip.h)
-    def bind_standardize(self, scale_reward=1.0, enable_obsnorm=False, enable_rewnorm=False, obs_alpha=0.001, rew_alpha=0.001, eps=1e-8):
+    def bind_standardize(self, scale_reward=1.0, enable_obsnorm=False, enable_rewnorm=False, obs_alpha=0.001, rew_alpha=0.001, eps=1e-8,
+                         tensors=None):
         """The kernels normalise observations / rewards on their way out (madrl_waterworld_set_standardize): reset() and
         step() then return the standardised tensors and the raw observation row is not stored.  Returns the dict of
-        state tensors (running statistics, outputs) the wrapper owns."""
+        state tensors (running statistics, outputs) the wrapper owns; `tensors` re-binds an existing dict (setup())."""
         N, Np, D, dev = self.n_envs, self.n_pursuers, self.obs_dim, self.device
-        st = dict(obs_mean=torch.zeros((N, Np, D), dtype=torch.float64, device=dev), obs_var=torch.ones((N, Np, D), dtype=torch.float64, device=dev),
+        self._std_kwargs = dict(scale_reward=scale_reward, enable_obsnorm=enable_obsnorm, enable_rewnorm=enable_rewnorm,
+                                obs_alpha=obs_alpha, rew_alpha=rew_alpha, eps=eps)
+        st = tensors if tensors is not None else dict(obs_mean=torch.zeros((N, Np, D), dtype=torch.float64, device=dev), obs_var=torch.ones((N, Np, D), dtype=torch.float64, device=dev),
                   obs_out=torch.zeros((N, Np, D), dtype=torch.float32, device=dev),
                   rew_mean=torch.zeros((N, Np), dtype=torch.float64, device=dev), rew_var=torch.ones((N, Np), dtype=torch.float64, device=dev),
                   rew_out=torch.zeros((N, Np), dtype=torch.float32, device=dev))

@@ -34,13 +34,15 @@ def lib():
         _LIB.po_get_local_obs.argtypes = [C.c_void_p] * 2
         _LIB.po_obs_dim_of.argtypes = [C.c_void_p]
         _LIB.po_philox4x32_10.argtypes = [C.c_void_p] * 3
+        _LIB.po_set_curriculum.argtypes = [C.c_void_p] * 3
+        _LIB.po_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double]
     return _LIB
 
 
 class PoConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "xs", "ys", "n_pursuers", "n_evaders", "obs_range", "n_catch", "surround", "flatten",
-        "include_id", "reward_global", "sample_maps", "n_maps", "max_opponents", "pad_")] + [(n, C.c_double) for n in (
+        "include_id", "reward_global", "sample_maps", "n_maps", "max_opponents", "train_pursuit")] + [(n, C.c_double) for n in (
             "catchr", "term_pursuit", "urgency_reward", "layer_norm", "constraint_window")]
 
 
@@ -72,7 +74,7 @@ class PursuitOracle(object):
             include_id=int(kw.pop("include_id", True)),
             reward_global=int(kw.pop("reward_mech", "global") == "global"),
             sample_maps=int(kw.pop("sample_maps", False)), n_maps=n_maps,
-            max_opponents=max_opp,
+            max_opponents=max_opp, train_pursuit=int(kw.pop("train_pursuit", True)),
             catchr=kw.pop("catchr", 0.01), term_pursuit=kw.pop("term_pursuit", 5.0),
             urgency_reward=kw.pop("urgency_reward", 0.0), layer_norm=kw.pop("layer_norm", 10),
             constraint_window=kw.pop("constraint_window", 1.0))
@@ -103,11 +105,20 @@ class PursuitOracle(object):
 
     def step(self, actions, inj_evader_actions=None):
         actions = np.ascontiguousarray(actions, np.int32).reshape(self.N, self.P)
-        if inj_evader_actions is not None:
-            inj_evader_actions = np.ascontiguousarray(inj_evader_actions, np.int32).reshape(self.N, self.E)
+        if inj_evader_actions is not None:  # evader control: one entry per pursuer (the opponents)
+            inj_evader_actions = np.ascontiguousarray(inj_evader_actions, np.int32).reshape(self.N, self.E if self.cfg.train_pursuit else self.P)
         lib().po_step(self.h, _p(actions), _p(inj_evader_actions), _p(self.obs), _p(self.rew),
                       _p(self.done), _p(self.removed))
         return self.obs, self.rew, self.done, self.removed
+
+    def set_curriculum(self, constraint_window=None, catchr=None):
+        """per-env float64 [N] arrays (kept alive here), None = the config scalar"""
+        self._cw = None if constraint_window is None else np.ascontiguousarray(constraint_window, np.float64).reshape(self.N)
+        self._cr = None if catchr is None else np.ascontiguousarray(catchr, np.float64).reshape(self.N)
+        lib().po_set_curriculum(self.h, _p(self._cw), _p(self._cr))
+
+    def set_params(self, catchr, constraint_window):
+        lib().po_set_params(self.h, float(catchr), float(constraint_window))
 
     def get_state(self):
         N, P, E = self.N, self.P, self.E
@@ -141,5 +152,6 @@ def config_from_golden(g):
                 sample_maps=bool(g["cfg_sample_maps"]), catchr=float(g["cfg_catchr"]),
                 term_pursuit=float(g["cfg_term_pursuit"]),
                 urgency_reward=float(g["cfg_urgency_reward"]), layer_norm=float(g["cfg_layer_norm"]),
+                **(dict(train_pursuit=False) if "cfg_train_pursuit" in g and not int(g["cfg_train_pursuit"]) else {}),
                 **(dict(random_opponents=True, max_opponents=int(g["cfg_max_opponents"]))
                    if "cfg_random_opponents" in g and int(g["cfg_random_opponents"]) else {}))

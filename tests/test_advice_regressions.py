@@ -117,3 +117,32 @@ def test_multiwalker_time_limit_cuts_episodes_in_the_collector():
     n = int(np.nonzero(alive)[0][0])
     assert np.allclose(ret[H, n], rew[H:, n].sum(axis=0), atol=1e-4)
     assert np.allclose(ret[0, n], rew[:H, n].sum(axis=0), atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_fused_standardize_survives_seed_and_set_param_values():
+    """Round-2 advice: seed() / set_param_values() re-create the native handle; the fused StandardizedEnv binding must follow
+    it, or the wrapper silently returns raw observations and unscaled rewards."""
+    from madrl_amd.waterworld import BatchedMAWaterWorld
+    from madrl_amd.wrappers import StandardizedEnv
+    N = 96
+    mk = lambda: BatchedMAWaterWorld(5, 10, n_envs=N, device=DEV, seed=3)
+    fused, plain = StandardizedEnv(mk(), scale_reward=0.1, enable_obsnorm=True), StandardizedEnv(mk(), scale_reward=0.1, enable_obsnorm=True, fused=False)
+    assert fused._fused and not plain._fused
+    for env in (fused, plain):
+        assert env.seed(11) == [11]
+    a, b = fused.reset(), plain.reset()
+    assert torch.equal(a, b), "after seed() the fused wrapper must still return standardised observations"
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for k in range(5):
+        act = (torch.rand((N, 5, 2), generator=g) * 2 - 1).to(DEV)
+        if k == 2:  # curriculum-style attribute update goes through setup() as well (madrl_environments/__init__.py:64-67)
+            for env in (fused, plain):
+                env.set_param_values(dict(food_reward=2.0))
+            a, b = fused.reset(), plain.reset()
+            assert torch.equal(a, b)
+        o1, r1, d1, _ = fused.step(act)
+        o2, r2, d2, _ = plain.step(act)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), "step %d" % k
+    raw = fused._unwrapped._rew
+    assert not torch.equal(r1, raw) or float(raw.abs().sum()) == 0.0, "rewards are scaled by 0.1 in the wrapper output"

@@ -1,0 +1,115 @@
+"""update_curriculum (pursuit_evade.py:264-272) against the attribute trajectory of the unmodified reference
+(tests/golden/curriculum_pursuit.npz, oracle/make_golden_curriculum.py), batch-wide and per env."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+DEV = "cuda:0"
+
+
+def _golden():
+    return np.load(os.path.join(GOLDEN, "curriculum_pursuit.npz"))
+
+
+def test_curriculum_rule_matches_reference_trajectory_cpu():
+    """the pure rule (no device): 48 iterations, exact float64 equality"""
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    g = _golden()
+    cw, ne, npu, cr = float(g["cfg_constraint_window"]), int(g["cfg_n_evaders"]), int(g["cfg_n_pursuers"]), float(g["cfg_catchr"])
+    for itr in range(len(g["cw"])):
+        cw, ne, npu, cr = BatchedPursuitEvade.curriculum_next(itr, cw, ne, npu, cr, float(g["cfg_curriculum_constrain_rate"]),
+                                                               int(g["cfg_curriculum_remove_every"]), float(g["cfg_curriculum_turn_off_shaping"]))
+        assert (cw, ne, npu, cr) == (g["cw"][itr], g["n_evaders"][itr], g["n_pursuers"][itr], g["catchr"][itr]), itr
+    assert g["n_pursuers"][-1] == 4 and g["catchr"][-1] == 0.0 and g["cw"][-1] == 1.0 and len(g["cw"]) >= 30
+
+
+@pytest.mark.gpu
+def test_update_curriculum_follows_the_reference_and_keeps_the_handle():
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from oracle import pursuit as po
+    g = _golden()
+    cfg = {k[4:]: (float(g[k]) if g[k].dtype.kind == "f" else int(g[k])) for k in g.files if k.startswith("cfg_")}
+    maps = [rectangle_map(16, 16)]
+    N = 64
+    env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=8, reward_mech="local", **cfg)
+    handle_changes, last = 0, env._handle.value
+    rng = np.random.RandomState(0)
+    for itr in range(len(g["cw"])):
+        env.update_curriculum(itr)
+        assert (env.constraint_window, env.n_evaders, env.n_pursuers, env.catchr) == (
+            g["cw"][itr], g["n_evaders"][itr], g["n_pursuers"][itr], g["catchr"][itr]), itr
+        handle_changes += int(env._handle.value != last)
+        last = env._handle.value
+        if itr % 6 == 5:   # the kernels see the values: a reset + two steps against the oracle with the same attributes
+            kw = dict(n_pursuers=env.n_pursuers, n_evaders=env.n_evaders, obs_range=7, reward_mech="local", catchr=env.catchr,
+                      constraint_window=float(env.constraint_window))
+            orc = po.PursuitOracle(maps, n_envs=N, seed=8, **kw)
+            st = env.get_state()
+            # same RNG tick on both sides, then the curriculum-constrained reset
+            ost = orc.get_state(); ost["tick"] = st["tick"].cpu().numpy().view(np.uint32); orc.set_state(ost)
+            # the oracle's persistent local_obs starts from zeros: compare the written cells only through a fresh env buffer
+            env._obs.zero_(); env.invalidate_obs()
+            assert np.array_equal(env.reset().cpu().numpy(), orc.reset()), "reset at iteration %d" % itr
+            for _ in range(2):
+                act = rng.randint(5, size=(N, env.n_pursuers))
+                obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
+                oobs, orew, odone, orem = orc.step(act)
+                assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew.astype(np.float32))
+    assert handle_changes == 4, "the handle is re-created only when the agent counts change (8 -> 4 pursuers)"
+    import pickle
+    clone = pickle.loads(pickle.dumps(env))   # :397-411: the curriculum attributes travel with the pickle
+    assert (clone.constraint_window, clone.n_evaders, clone.n_pursuers, clone.catchr) == (1.0, 26, 4, 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["generic", "auto"])
+def test_per_env_curriculum_matches_oracle(kernel):
+    """Half of the env instances advance through the curriculum, the others stay: per-env constraint_window / catchr device
+    arrays, read in place by the kernels (FLEX instantiation of the fast path), against the oracle given the same arrays."""
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from oracle import pursuit as po
+    maps = [rectangle_map(16, 16)]
+    kw = dict(n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local",
+              catchr=0.1, constraint_window=0.25)
+    N, H = 512, 9
+    env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=13, max_steps=H, auto_reset=True, kernel=kernel,
+                              curriculum_constrain_rate=0.05, curriculum_turn_off_shaping=6, **kw)
+    orc = po.PursuitOracle(maps, n_envs=N, seed=13, **kw)
+    handle = env._handle.value
+    mask = (np.arange(N) % 2 == 0)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    rng = np.random.RandomState(4)
+    cw, cr = np.full(N, 0.25), np.full(N, 0.1)
+    tstep = np.zeros(N, np.int64)
+    for itr in range(10):
+        env.update_curriculum(itr, mask=mask)
+        cw[mask] = np.clip(cw[mask] + 0.05, 0.0, 1.0)
+        if itr > 6:
+            cr[mask] = 0.0
+        gcw, gcr = env.curriculum_state()
+        assert np.array_equal(gcw.cpu().numpy(), cw) and np.array_equal(gcr.cpu().numpy(), cr)
+        orc.set_curriculum(constraint_window=cw, catchr=cr)
+        for _ in range(4):
+            act = rng.randint(5, size=(N, 8))
+            obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
+            oobs, orew, odone, orem = orc.step(act)
+            tstep += 1
+            bits = odone.astype(np.uint8) | ((tstep >= H).astype(np.uint8) << 1)
+            assert np.array_equal(info["done_bits"].cpu().numpy(), bits)
+            assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), "rewards, iteration %d" % itr
+            m = (bits != 0).astype(np.uint8)
+            if m.any():
+                orc.reset(mask=m)
+                tstep[m != 0] = 0
+            assert np.array_equal(obs.cpu().numpy(), orc.obs), "observations, iteration %d" % itr
+    assert env._handle.value == handle, "per-env curriculum never re-creates the handle"
+    st = env.get_state()
+    # envs that stayed at constraint_window 0.25 keep spawning inside a 4 x 4 cell window; the advanced ones spread out
+    span = (st["pos_p"].amax(1) - st["pos_p"].amin(1)).float().mean(-1).cpu().numpy()
+    assert span[mask].mean() > span[~mask].mean()

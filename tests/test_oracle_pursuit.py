@@ -139,3 +139,26 @@ def test_free_running_reset_samples_the_reference_distribution():
     # the window makes the distribution non-uniform (cells near the middle are covered by more windows): the test has power
     flat = g["one"].sum(0).astype(np.float64)
     assert flat.max() > 1.5 * flat[flat > 0].min()
+
+
+from helpers import evadercontrol_golden_files, replay_evadercontrol  # noqa: E402
+
+
+@pytest.mark.parametrize("path", evadercontrol_golden_files(), ids=golden_id)
+def test_oracle_matches_reference_golden_evader_control(path):
+    """train_pursuit=False (pursuit_evade.py:105-112, :204-207, :215-224): the actions drive the evaders, the pursuers move by
+    pursuer_controller, observations are the evaders' windows, rewards stay the pursuers'."""
+    g = np.load(path)
+    assert float(g["obs_cast_err"]) < 1e-7
+    o = po.PursuitOracle(list(g["maps"]), n_envs=1, **po.config_from_golden(g))
+    assert not o.cfg.train_pursuit
+
+    def state():
+        st = o.get_state()
+        return dict(pos_p=st["pos_p"][0], pos_e=st["pos_e"][0], gone=st["gone"][0])
+
+    def step(aa, ao):
+        obs, rew, done, rem = o.step(aa, ao)
+        return obs[0], rew[0], done[0], rem[0]
+
+    replay_evadercontrol(g, lambda pos: o.reset(inj_pos=pos)[0], step, state)

@@ -319,3 +319,68 @@ def test_pickle_roundtrip_and_param_updates():
     assert env2.catchr == 0.5 and env2.constraint_window == 0.5 and env2.n_envs == 16
     o1 = env.reset(); o2 = env2.reset()
     assert torch.equal(o1, o2)
+
+
+from helpers import evadercontrol_golden_files, replay_evadercontrol  # noqa: E402
+
+
+@pytest.mark.parametrize("path", evadercontrol_golden_files(), ids=golden_id)
+def test_hip_matches_reference_golden_evader_control(path):
+    """train_pursuit=False through the C ABI against the record of the unmodified reference."""
+    from oracle import pursuit as po
+    g = np.load(path)
+    env = _mk(list(g["maps"]), 1, **po.config_from_golden(g))
+    assert env.kernel_kind == "generic" and not env.train_pursuit
+
+    def state():
+        st = env.get_state()
+        return dict(pos_p=st["pos_p"][0].cpu().numpy(), pos_e=st["pos_e"][0].cpu().numpy(), gone=st["gone"][0].cpu().numpy())
+
+    def step(aa, ao):
+        obs, rew, done, info = env.step(torch.as_tensor(aa, device=DEV), evader_actions=torch.as_tensor(ao, device=DEV))
+        return obs[0].cpu().numpy(), rew[0].cpu().numpy(), int(info["done_bits"][0]) & 1, int(info["removed"][0])
+
+    replay_evadercontrol(g, lambda pos: env.reset(positions=pos)[0].cpu().numpy(), step, state)
+
+
+def test_evader_control_free_running_and_dropin_types():
+    """train_pursuit=False free-running (in-kernel Philox for the pursuers) against the C oracle, 256 envs with auto-reset; then
+    the N == 1 drop-in's return types: None entries for the gone evader slots below n_pursuers (pursuit_evade.py:418-428)."""
+    from oracle import pursuit as po
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import PursuitEvade
+    maps = [rectangle_map(12, 12)]
+    kw = dict(n_pursuers=5, n_evaders=9, obs_range=5, n_catch=2, surround=True, flatten=True, reward_mech="local", train_pursuit=False)
+    N, T, H = 256, 80, 20
+    env = _mk(maps, N, seed=6, env_id_base=40, max_steps=H, auto_reset=True, **kw)
+    orc = po.PursuitOracle(maps, n_envs=N, seed=6, env_id_base=40, **kw)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    rng = np.random.RandomState(2)
+    tstep = np.zeros(N, np.int64)
+    removed = 0
+    for t in range(T):
+        act = rng.randint(5, size=(N, 5))
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
+        oobs, orew, odone, orem = orc.step(act)
+        tstep += 1
+        bits = odone.astype(np.uint8) | ((tstep >= H).astype(np.uint8) << 1)
+        assert np.array_equal(info["done_bits"].cpu().numpy(), bits) and np.array_equal(info["removed"].cpu().numpy(), orem)
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32))
+        mask = (bits != 0).astype(np.uint8)
+        if mask.any():
+            orc.reset(mask=mask)
+            tstep[mask != 0] = 0
+        removed += int(orem.sum())
+        assert np.array_equal(obs.cpu().numpy(), orc.obs), "step %d" % t   # rows past the last observer stay stale on both sides
+        valid = env.obs_rows_valid().cpu().numpy()
+        assert np.array_equal(valid.sum(1), 5 - orc.get_state()["gone"][:, :5].sum(1))
+    _cmp_state(env.get_state(), orc.get_state(), "end")
+    assert removed > 0
+    one = PursuitEvade(maps, **kw)
+    assert len(one.agents) == 5
+    obs = one.reset()
+    assert len(obs) == 5 and all(o.shape == (76,) for o in obs)
+    one._env.set_state(dict(gone=np.array([[0, 1, 0, 0, 1, 0, 0, 0, 0]], np.uint8)))
+    obs, rew, done, info = one.step([4] * 5)
+    assert [o is None for o in obs] == [False, True, False, False, True] and isinstance(rew, np.ndarray) and rew.shape == (5,)
+    assert obs[2][75] == 1 / 5.0   # id = index in the compacted layer / n_pursuers
