@@ -1,20 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- env-steps/sec of the batched PursuitEvade hot path (BASELINE.json metric).
+"""bench.py -- env-steps/sec of the batched rollout engine (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one pass of the hot path over one batch: a single launch of the fused
-step kernel (pre-move reward, moves, catch resolution, observations, fused auto-reset)
-over `--envs` env instances per GPU (default 65 536 = BASELINE configs[1], PursuitEvade
-16x16, 8 pursuers / 30 evaders, obs_range 7, surround).  Inputs (the pursuer action
-tensors) are resident in HBM before the timed region starts; evader actions are drawn
-in-kernel (Philox).  N > 1: launched by torch.distributed.run, one rank per GPU, env
-index ranges sharded by rank (weak scaling), the compact trajectory (actions, rewards,
-dones) of the timed region is all-gathered over RCCL at the end, inside the timed region.
+One "step" = one pass of the hot path over one batch: a single launch of the fused step kernel (pre-move reward, moves,
+catch resolution, observations, fused auto-reset) over `--envs` env instances per GPU (default 65 536 = BASELINE
+configs[1], PursuitEvade 16x16, 8 pursuers / 30 evaders, obs_range 7, surround).  Inputs (the pursuer action tensors) are
+resident in HBM before the timed region starts; evader actions are drawn in-kernel (Philox).  The env instances start the
+timed region at episode ages spread uniformly over [0, horizon), so EVERY launch carries its N / horizon share of fused
+auto-resets (the two-observation-pass path), as in a steady rollout.  N > 1: launched by torch.distributed.run, one rank
+per GPU, env index ranges sharded by rank (weak scaling), the compact trajectory (actions, rewards, dones) of the timed
+region is all-gathered over RCCL at the end, inside the timed region.
 
-Rank 0 prints ONE JSON line (contract in the task description) with `roofline`, `cpu_baseline`
-(the unmodified reference's NumPy path, quoted from profiles/*_cpu_reference/record.json with its
-host) and `cpu_baseline_port` (the C restatement timed live on this box's host cores).
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` and `cpu_baseline`; at N = 1 the same line
+carries `workloads`: the other BASELINE configs (Waterworld configs[2], MultiWalker configs[3], the per-GPU shard of
+configs[4]) timed the same way for a bounded number of steps, each with its own roofline.
+
+cpu_baseline = the C restatement of the reference algorithm (oracle/, kind "port") timed LIVE on this box's host cores;
+when MADRL_REFERENCE_ROOT names a checkout of the reference (never the case on the GPU box, where the tree does not
+exist) the unmodified reference's NumPy path is timed live instead (kind "reference").  `cpu_reference_recorded` quotes the
+committed record of that NumPy path taken in the build container (profiles/*_cpu_reference/record.json), host labelled.
 """
 import argparse
 import json
@@ -27,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+VALU_PEAK_TFLOPS = 157.3  # FP32 vector peak, same guide
 
 
 def algorithmic_bytes_per_env_step(P, E, D, rec_bytes):
@@ -52,9 +58,8 @@ def measured_traffic(n_envs, workload="pursuit"):
 
 
 def cpu_reference_record(key):
-    """The UNMODIFIED reference's NumPy path, timed by scripts/cpu_reference_bench.py in the build container (the reference
-    tree cannot travel to the GPU box, so bench.py quotes the committed record and labels its host).  `key` selects the
-    workload inside the record.  None when no record is committed."""
+    """The UNMODIFIED reference's NumPy path as recorded by scripts/cpu_reference_bench.py in the build container (the
+    reference tree cannot travel to the GPU box): quoted, host labelled, never re-timed here.  None without a record."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_reference", "record.json")), reverse=True):
         try:
@@ -62,13 +67,35 @@ def cpu_reference_record(key):
             r = j[key]
         except Exception:
             continue
-        return dict(value=r["all_core_steps_per_s"], unit="env-steps/s", cores=r["processes"], kind="reference-numpy",
+        return dict(value=r["all_core_steps_per_s"], unit="env-steps/s", cores=r["processes"], kind="reference-numpy (recorded)",
                     one_process_value=r["one_process_steps_per_s"],
                     host="%s, %d logical cores (%s)" % (j["host"]["cpu_model"], j["host"]["logical_cores"], j["host"]["where"]),
                     source=os.path.relpath(f, ROOT),
                     sample="%s; one env per process x %d processes x %d steps, OMP_NUM_THREADS=1; recorded, not re-timed by this run"
                            % (r["config"], r["processes"], r["steps_per_process"]))
     return None
+
+
+def cpu_reference_live(which, budget_steps=1200):
+    """The unmodified reference timed NOW on this host's cores -- only when MADRL_REFERENCE_ROOT is set and holds the tree
+    (build container / a maintainer's checkout; never on the GPU box).  Runs scripts/cpu_reference_bench.py's workers in a
+    child process (they pin OMP_NUM_THREADS=1 and fork a Pool over all cores)."""
+    root = os.environ.get("MADRL_REFERENCE_ROOT")
+    if not root or not os.path.isdir(os.path.join(root, "madrl_environments")):
+        return None
+    import subprocess
+    code = ("import json, os, sys; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'scripts'))\n"
+            "import cpu_reference_bench as b\n"
+            "r = b.measure(b.run_%s, %d, os.cpu_count()); r['cpu_model'] = b.cpu_model(); print(json.dumps(r))" % (ROOT, ROOT, which, budget_steps))
+    try:
+        out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, MPLBACKEND="Agg"), timeout=180).decode()
+        r = json.loads(out.strip().splitlines()[-1])
+    except Exception as e:  # a broken checkout must not take the bench line down
+        return dict(error="reference timing failed: %r" % (e,))
+    return dict(value=r["all_core_steps_per_s"], unit="env-steps/s", cores=r["processes"], kind="reference",
+                one_process_value=r["one_process_steps_per_s"],
+                sample="unmodified reference (%s) from MADRL_REFERENCE_ROOT, one env per process x %d processes x %d steps, "
+                       "OMP_NUM_THREADS=1, timed live on %s" % (which, r["processes"], r["steps_per_process"], r["cpu_model"]))
 
 
 def cpu_baseline_port(maps, kw, budget_s=12.0):
@@ -94,27 +121,186 @@ def cpu_baseline_port(maps, kw, budget_s=12.0):
                 sample="C oracle (oracle/pursuit_oracle.c, OpenMP), %d envs x %d steps, same config, %.1f s" % (n, steps, dt))
 
 
-def bench_other(args, rank, local_rank, world, dev):
-    """Waterworld (BASELINE configs[2]) and MultiWalker (configs[3]) on the same contract."""
+def attach_cpu_baselines(out, live_ref_key, record_key, port_fn):
+    """cpu_baseline is always a LIVE measurement on this host (the reference when a checkout is reachable through
+    MADRL_REFERENCE_ROOT, else the C port); the committed record of the reference goes under its own key."""
+    live = cpu_reference_live(live_ref_key) if live_ref_key else None
+    port = port_fn()
+    if live is not None and "error" not in live:
+        out["cpu_baseline"], out["cpu_baseline_port"] = live, port
+    else:
+        out["cpu_baseline"] = port
+        if live is not None:
+            out["cpu_baseline_reference_error"] = live["error"]
+    rec = cpu_reference_record(record_key) if record_key else None
+    if rec is not None:
+        out["cpu_reference_recorded"] = rec
+
+
+class Timer(object):
+    """the bench contract: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + synchronize on both sides;
+    HIP events on the launch stream give the average launch duration"""
+
+    def __init__(self, world, dev):
+        self.world, self.dev = world, dev
+
+    def barrier(self):
+        import torch
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, step, K, W, tail=None):
+        import torch
+        for i in range(W):
+            step(i, False)
+        self.barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(K):
+            step(i, True)
+        ev1.record()  # events bracket the K step launches (and the small trajectory copies when N > 1)
+        if tail is not None:
+            tail()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / K  # average launch duration incl. inter-launch gaps
+        if self.world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, kernel_ms
+
+
+def bench_pursuit(args, c5, K, W, rank, world, dev, cpu):
+    import numpy as np
+    import torch
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from madrl_amd import _lib
+    N, P, E, R = (args.envs or (32768 if c5 else 65536)), (16 if c5 else 8), (60 if c5 else 30), 7
+    MS = 32 if c5 else 16
+    H = args.horizon
+    maps = [rectangle_map(MS, MS)]
+    kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, n_catch=2, surround=True, flatten=True, reward_mech="local")
+    env = BatchedPursuitEvade(maps, n_envs=N, device=dev, seed=0, env_id_base=rank * N, max_steps=H,
+                              auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw)
+    D = env.obs_dim
+    rec_bytes = env.record_bytes
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    n_act = 16
+    actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
+    # compact trajectory of the timed region (what a sampler returns to the learner), cut into
+    # chunks whose all-gather over RCCL/xGMI overlaps with the stepping of the next chunk
+    CH = 50
+    n_chunks = (K + CH - 1) // CH
+    chunk_len = [min(CH, K - c * CH) for c in range(n_chunks)]
+    traj = [dict(actions=torch.zeros((chunk_len[c], N, P), dtype=torch.uint8, device=dev),
+                 rewards=torch.zeros((chunk_len[c], N, P), dtype=torch.float32, device=dev),
+                 dones=torch.zeros((chunk_len[c], N), dtype=torch.uint8, device=dev)) for c in range(n_chunks)] if world > 1 else []
+    L = _lib.lib()
+    h = env._handle
+    obs_p, rew_p, done_p, rem_p = (_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._removed))
+    act_p = [_lib.ptr(a) for a in actions]
+    # N > 1: the step kernel writes rewards / dones straight into their slot of the trajectory chunk (the C ABI takes any
+    # device pointer), only the action row is copied (int32 -> uint8)
+    slot_p = [(_lib.ptr(traj[c]["rewards"][j]), _lib.ptr(traj[c]["dones"][j])) for c in range(n_chunks) for j in range(chunk_len[c])] if world > 1 else []
+    gatherer = None
+    if world > 1:
+        from madrl_amd.dist import ChunkedTrajectoryGather
+        gatherer = ChunkedTrajectoryGather()
+        gatherer.reserve(traj)   # receive buffers + RCCL channel setup stay out of the timed region
+
+    def one_step(i, record):
+        rp, dp = slot_p[i] if (record and world > 1) else (rew_p, done_p)
+        _lib.check(L.madrl_pursuit_step(h, act_p[i % n_act], None, obs_p, rp, dp, rem_p, _lib.current_stream(dev)))
+        if record and world > 1:
+            c, j = divmod(i, CH)
+            traj[c]["actions"][j].copy_(actions[i % n_act])
+            if (i + 1) % CH == 0:
+                gatherer.submit(traj[i // CH])      # async: overlaps with the next chunk's steps
+
+    def tail():
+        if gatherer is not None:
+            if K % CH:
+                gatherer.submit(traj[-1])
+            gathered = gatherer.finish()            # episode end: every rank holds every rank's trajectory
+            assert sum(t.shape[1] for t in gathered["rewards"]) == K and gathered["rewards"][0].shape[0] == world
+
+    env.reset()
+    # steady state: episode ages uniform over [0, H) -- env n reaches the horizon (and runs the fused reset) at step H - age
+    env.set_state(dict(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H))
+    dt, kernel_ms = Timer(world, dev).run(one_step, K, W, tail)
+    if rank != 0:
+        return None
+    bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
+    achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
+    name = "pursuit_c5" if c5 else "pursuit"
+    traffic = measured_traffic(N, name)
+    out = {
+        "metric": "env-steps/sec at fixed batch (PursuitEvade %dx%d, %dv%d)" % (MS, MS, P, E),
+        "value": world * N * K / dt,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
+        "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset; episode ages "
+                "start uniform over [0, %d): every launch resets ~%d of its %d envs through the two-observation-pass path)" % (H, N // H, N),
+        "config": {"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, surround, "
+                               "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (MS, MS, P, E, N, H),
+                   "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world,
+                   "horizon_resets_per_env_in_timed_region": K / float(H),
+                   "horizon_resets_per_launch": N / float(H)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": traffic[0] if traffic else None,
+                     "traffic_source": traffic[1] if traffic else None,
+                     "algorithmic_bytes_per_launch": bytes_per * N,
+                     "kernel": ("pursuit_group_kernel<32,32,16,60,7,1,2>" if c5 else "pursuit_wave_kernel<16,16,8,30,7,1>") if env.kernel_kind == "wave" else "pursuit_kernel<NT>",
+                     "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_env_step": bytes_per},
+    }
+    if cpu:
+        attach_cpu_baselines(out, None if c5 else "pursuit", None if c5 else "pursuit_c1", lambda: cpu_baseline_port(maps, kw))
+    del env
+    return out
+
+
+def bench_other(args, workload, K, W, rank, world, dev, cpu):
+    """Waterworld (BASELINE configs[2]), MultiWalker (configs[3]) and the hostage world on the same contract."""
     import numpy as np
     import torch
     from madrl_amd import _lib
     L = _lib.lib()
-    K, W = args.steps, args.warmup
-    if args.workload == "waterworld":
+    extra, flop_per_env_step, live_key, rec_key = {}, None, None, None
+    if workload == "waterworld":
         from madrl_amd.waterworld import BatchedMAWaterWorld
         N = args.envs or 32768
         env = BatchedMAWaterWorld(5, 10, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
                                   max_blocks=args.max_blocks)
         acts = [(torch.rand((N, 5, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)]
         outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
-        step = lambda i: _lib.check(L.madrl_waterworld_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
+        step = lambda i, rec: _lib.check(L.madrl_waterworld_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
         bytes_per = 40 + 4 * 5 * env.obs_dim + 20 + 1 + 8 + 2 * (env._state.numel() // N)
-        kernel, binding = "waterworld_kernel<1>", "VALU issue (770 VALU + 529 SALU wave-instructions per env-step at 6 waves per SIMD: the VALU port is saturated; profiles/r02_waterworld/pmc_mix.txt), not HBM"
-        workload = "MAWaterWorld 5 pursuers / 10 evaders / 10 poison / 30 sensors, n_coop 2, %d envs per GPU, timestep_limit 1000" % N
+        kernel, binding = "waterworld_kernel<1,5,10,10,30>", "VALU / scalar-pipe issue of the sensing loop (profiles/*_waterworld/pmc_mix.txt), not HBM"
+        workload_s = "MAWaterWorld 5 pursuers / 10 evaders / 10 poison / 30 sensors, n_coop 2, %d envs per GPU, timestep_limit 1000" % N
+        H = 1000
+        live_key, rec_key = "waterworld", "waterworld_c3_single_env"
 
-        def cpu():
+        def age():  # steady state: episode ages uniform over [0, 1000)
+            env.set_state(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H)
+
+        def cpu_fn():
             from oracle import waterworld as ww
+            from oracle import pursuit as po
             n = 4096
             o = ww.WaterworldOracle(5, 10, n_envs=n, seed=0, dtype=np.float32)
             o.reset()
@@ -123,22 +309,25 @@ def bench_other(args, rank, local_rank, world, dev):
             while time.time() - t0 < 10:
                 o.step(a); k += 1
             dt = time.time() - t0
-            from oracle import pursuit as po
             return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
                         sample="float32 C oracle (oracle/waterworld_oracle.c, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
-    elif args.workload == "hostage":
+    elif workload == "hostage":
         from madrl_amd.hostage import BatchedContinuousHostageWorld
         N = args.envs or 32768
         env = BatchedContinuousHostageWorld(3, 10, 5, 2, 2, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
                                             max_blocks=args.max_blocks)
         acts = [(torch.rand((N, 3, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)]
         outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
-        step = lambda i: _lib.check(L.madrl_hostage_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
+        step = lambda i, rec: _lib.check(L.madrl_hostage_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
         bytes_per = 24 + 4 * 3 * env.obs_dim + 12 + 1 + 8 + 2 * (env._state.numel() // N)
-        kernel, binding = "hostage_kernel<1>", "the CU's scalar pipe (422 VALU + 343 SALU wave-instructions per env-step at 7 waves per SIMD, 28 wavefronts per scalar unit; profiles/r02_hostage/pmc_mix.txt), not HBM"
-        workload = "ContinuousHostageWorld(3, 10, 5, 2, 2) (hostage.py:483), 30 sensors, %d envs per GPU, timestep_limit 1000" % N
+        kernel, binding = "hostage_kernel<1,3,10,5,30>", "the CU's scalar pipe / VALU issue (profiles/*_hostage/pmc_mix.txt), not HBM"
+        workload_s = "ContinuousHostageWorld(3, 10, 5, 2, 2) (hostage.py:483), 30 sensors, %d envs per GPU, timestep_limit 1000" % N
+        H = 1000
 
-        def cpu():
+        def age():
+            env.set_state(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H)
+
+        def cpu_fn():
             from oracle import hostage as ho
             from oracle import pursuit as po
             n = 4096
@@ -156,25 +345,33 @@ def bench_other(args, rank, local_rank, world, dev):
     else:
         from madrl_amd.multiwalker import BatchedMultiWalkerEnv
         N = args.envs or 16384
+        H = 500
         env = BatchedMultiWalkerEnv(n_walkers=3, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
-                                    max_steps=500, max_blocks=args.max_blocks)
+                                    max_steps=H, max_blocks=args.max_blocks)
         acts = [(torch.rand((N, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)]
         outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done)]
-        step = lambda i: _lib.check(L.madrl_multiwalker_step(env._handle, _lib.ptr(acts[i % 8]), *outs, _lib.current_stream(dev)))
-        # algorithmic HBM bytes per env-step: actions in, observation / reward / done rows out, the hot record (bodies, flags)
-        # read and written once, the cold record (joints, manifold cache, terrain) touched in place: counted as read + written once
-        bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * env.world_bytes
-        kernel = "multiwalker_kernel<1, 4>"
-        # this path is not HBM-bound -- about 1 MFLOP of dependent FP32 work per env-step (180 velocity + up to 60
-        # position Gauss-Seidel sweeps over 12 joints and the active manifolds) against ~14 KB; the binding resource is VALU
-        # instruction issue of wavefronts in which 12-16 of 64 lanes carry constraints (four envs per wavefront)
-        binding = ("FP32 VALU instruction issue / dependent-op latency of the Gauss-Seidel sweeps (not HBM): ~29 k VALU + 9 k SALU + 4 k LDS "
-                   "wave-instructions per env-step (profiles/r02_multiwalker/pmc_mix.txt)")
-        flop_per_env_step = 1.0e6
-        workload = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, parity unpinned)" % N
-        K, W = min(K, 20), min(W, 3)
+        ndone = torch.zeros((), dtype=torch.int64, device=dev)
 
-        def cpu():
+        def step(i, rec):
+            _lib.check(L.madrl_multiwalker_step(env._handle, _lib.ptr(acts[i % 8]), *outs, _lib.current_stream(dev)))
+            if rec:
+                ndone.add_((env._done != 0).sum())   # one tiny launch per 4-ms step: how many envs ended (fused reset) in the timed region
+        # algorithmic HBM bytes per env-step: actions in, observation / reward / done rows out, the per-env record (bodies, joints,
+        # contact cache, terrain) read and written once
+        bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * env.world_bytes
+        kernel = "multiwalker_kernel"
+        # this path is not HBM-bound -- dependent FP32 work of 180 velocity + up to 60 position Gauss-Seidel sweeps
+        # over 12 joints and the active manifolds against ~15 KB; the binding resource is VALU issue / dependent-op latency
+        binding = "FP32 VALU instruction issue / dependent-op latency of the Gauss-Seidel sweeps (not HBM); see profiles/*_multiwalker/pmc_mix.txt"
+        flop_per_env_step, flop_src = env.flops_per_env_step()
+        extra = {"flop_per_env_step": flop_per_env_step, "flop_source": flop_src}
+        workload_s = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % N
+        K, W = min(K, 20), max(W, 60)   # 60 warm-up steps: the walkers have landed and the first falls / resets have happened
+
+        def age():
+            pass   # episodes end by falling long before the horizon; the warm-up above reaches that steady state
+
+        def cpu_fn():
             from oracle import multiwalker as mwo
             from oracle import pursuit as po
             n = 1024
@@ -189,57 +386,32 @@ def bench_other(args, rank, local_rank, world, dev):
             dt = time.time() - t0
             return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
                         sample="CPU build of the solver source (oracle/multiwalker_oracle.cpp, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
-    if world > 1:
-        import torch.distributed as dist
     env.reset()
-    for i in range(W):
-        step(i)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(K):
-        step(i)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    if rank == 0:
-        achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
-        out = {"metric": "env-steps/sec at fixed batch (%s)" % args.workload, "value": world * N * K / dt, "unit": "env-steps/s",
-               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (uniform random actions resident in HBM, in-kernel Philox, fused auto-reset)",
-               "config": {"workload": workload, "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
-               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                            **({"valu_flops_achieved_TFLOPs": flop_per_env_step * N / (kernel_ms * 1e-3) / 1e12, "valu_peak_TFLOPs": 157.3,
-                                "valu_frac": flop_per_env_step * N / (kernel_ms * 1e-3) / 157.3e12,
-                                "flop_per_env_step_estimate": flop_per_env_step} if args.workload == "multiwalker" else {}),
-                            "traffic": (measured_traffic(N, args.workload) or (None, None))[0],
-                            "traffic_source": (measured_traffic(N, args.workload) or (None, None))[1], "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per,
-                            "binding_resource": binding}}
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
-            # cpu_baseline = the reference's own NumPy path where a record of it exists (Waterworld), else the port;
-            # cpu_baseline_port = the C restatement timed live on this box's host cores
-            ref = cpu_reference_record("waterworld_c3_single_env") if args.workload == "waterworld" else None
-            port = cpu()
-            if ref is not None:
-                out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
-            else:
-                out["cpu_baseline"] = port
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    age()
+    dt, kernel_ms = Timer(world, dev).run(step, K, W)
+    if rank != 0:
+        return None
+    achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
+    traffic = measured_traffic(N, workload)
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None, "kernel": kernel,
+            "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per, "binding_resource": binding}
+    cfg = {"workload": workload_s, "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world}
+    if workload == "multiwalker":
+        tf = flop_per_env_step * N / (kernel_ms * 1e-3) / 1e12
+        roof.update({"valu_flops_achieved_TFLOPs": tf, "valu_peak_TFLOPs": VALU_PEAK_TFLOPS, "valu_frac": tf / VALU_PEAK_TFLOPS, **extra})
+        cfg["episode_ends_per_env_in_timed_region"] = float(ndone.item()) / N
+    else:
+        cfg["horizon_resets_per_env_in_timed_region"] = K / float(H)
+    out = {"metric": "env-steps/sec at fixed batch (%s)" % workload, "value": world * N * K / dt, "unit": "env-steps/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic (uniform random actions resident in HBM, in-kernel Philox, fused auto-reset, steady-state episode ages)",
+           "config": cfg, "roofline": roof}
+    if cpu:
+        attach_cpu_baselines(out, live_key, rec_key, cpu_fn)
+    del env
+    return out
 
 
 def main():
@@ -254,15 +426,11 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="headline only: do not time the other BASELINE configs")
     ap.add_argument("--horizon", type=int, default=500, help="max_path_length (runners/__init__.py:88)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
-    from madrl_amd.maps import rectangle_map
-    from madrl_amd.pursuit import BatchedPursuitEvade
-    from madrl_amd import _lib
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -280,126 +448,27 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.workload not in ("pursuit", "pursuit_c5"):
-        return bench_other(args, rank, local_rank, world, dev)
-    c5 = args.workload == "pursuit_c5"
-    N, P, E, R = (args.envs or (32768 if c5 else 65536)), (16 if c5 else 8), (60 if c5 else 30), 7
-    MS = 32 if c5 else 16
-    maps = [rectangle_map(MS, MS)]
-    kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, n_catch=2, surround=True, flatten=True, reward_mech="local")
-    env = BatchedPursuitEvade(maps, n_envs=N, device=dev, seed=0, env_id_base=rank * N, max_steps=args.horizon,
-                              auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw)
-    D = env.obs_dim
-    rec_bytes = env._state.numel() // N
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    n_act = 16
-    actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
     K, W = args.steps, args.warmup
-    # compact trajectory of the timed region (what a sampler returns to the learner), cut into
-    # chunks whose all-gather over RCCL/xGMI overlaps with the stepping of the next chunk
-    CH = 50
-    n_chunks = (K + CH - 1) // CH
-    chunk_len = [min(CH, K - c * CH) for c in range(n_chunks)]
-    traj = [dict(actions=torch.zeros((chunk_len[c], N, P), dtype=torch.uint8, device=dev),
-                 rewards=torch.zeros((chunk_len[c], N, P), dtype=torch.float32, device=dev),
-                 dones=torch.zeros((chunk_len[c], N), dtype=torch.uint8, device=dev)) for c in range(n_chunks)] if world > 1 else []
-
-    L = _lib.lib()
-    h = env._handle
-    obs_p, rew_p, done_p, rem_p = (_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._removed))
-    act_p = [_lib.ptr(a) for a in actions]
-
-    # N > 1: the step kernel writes rewards / dones straight into their slot of the trajectory chunk (the C ABI takes any
-    # device pointer), only the action row is copied (int32 -> uint8)
-    slot_p = [(_lib.ptr(traj[c]["rewards"][j]), _lib.ptr(traj[c]["dones"][j])) for c in range(n_chunks) for j in range(chunk_len[c])] if world > 1 else []
-
-    def one_step(i, record):
-        rp, dp = slot_p[i] if (record and world > 1) else (rew_p, done_p)
-        _lib.check(L.madrl_pursuit_step(h, act_p[i % n_act], None, obs_p, rp, dp, rem_p, _lib.current_stream(dev)))
-        if record and world > 1:
-            c, j = divmod(i, CH)
-            traj[c]["actions"][j].copy_(actions[i % n_act])
-
-    env.reset()
-    for i in range(W):
-        one_step(i, False)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    gatherer = None
-    if world > 1:
-        from madrl_amd.dist import ChunkedTrajectoryGather
-        gatherer = ChunkedTrajectoryGather()
-        gatherer.reserve(traj)   # receive buffers + RCCL channel setup stay out of the timed region
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(K):
-        one_step(i, True)
-        if gatherer is not None and (i + 1) % CH == 0:
-            gatherer.submit(traj[i // CH])      # async: overlaps with the next chunk's steps
-    ev1.record()  # events bracket the K step launches (and the small trajectory copies when N > 1)
-    if gatherer is not None:
-        if K % CH:
-            gatherer.submit(traj[-1])
-        gathered = gatherer.finish()            # episode end: every rank holds every rank's trajectory
-        assert sum(t.shape[1] for t in gathered["rewards"]) == K and gathered["rewards"][0].shape[0] == world
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K  # average launch duration incl. inter-launch gaps
-
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
+    cpu = (not args.no_cpu_baseline) and world == 1   # the CPU baseline is reported with the 1-GPU line only
+    if args.workload in ("pursuit", "pursuit_c5"):
+        out = bench_pursuit(args, args.workload == "pursuit_c5", K, W, rank, world, dev, cpu)
+    else:
+        out = bench_other(args, args.workload, K, W, rank, world, dev, cpu)
+    # The same driver run times every other BASELINE config (N = 1, default workload, default batch): bounded steps each
+    if args.workload == "pursuit" and world == 1 and not args.no_workloads and not args.envs:
+        wl = {}
+        for name, k, w in (("waterworld", min(K, 200), min(W, 20)), ("multiwalker", min(K, 20), W), ("pursuit_c5", min(K, 200), min(W, 20))):
+            try:
+                r = bench_pursuit(args, True, k, w, rank, world, dev, False) if name == "pursuit_c5" else \
+                    bench_other(args, name, k, w, rank, world, dev, False)
+                wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
+            except Exception as e:  # a failing side workload must not take the headline down; it shows up as an error entry
+                wl[name] = {"error": repr(e)}
+        out["workloads"] = wl
     if rank == 0:
-        bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
-        achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
-        traffic = measured_traffic(N, args.workload)
-        out = {
-            "metric": "env-steps/sec at fixed batch (PursuitEvade %dx%d, %dv%d)" % (MS, MS, P, E),
-            "value": world * N * K / dt,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
-            "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset: every env "
-                    "reaches the horizon %d time(s) inside the timed region and then runs the two-observation-pass reset path)"
-                    % ((W + K) // args.horizon - W // args.horizon),
-            "config": {"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, surround, "
-                                   "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (MS, MS, P, E, N, args.horizon),
-                       "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world,
-                       "horizon_resets_per_env_in_timed_region": (W + K) // args.horizon - W // args.horizon},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
-                         "algorithmic_bytes_per_launch": bytes_per * N,
-                         "kernel": ("pursuit_group_kernel<32,32,16,60,7,1,2>" if c5 else "pursuit_wave_kernel<16,16,8,30,7,1>") if env.kernel_kind == "wave" else "pursuit_kernel<NT>",
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_env_step": bytes_per},
-        }
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported with the 1-GPU line only
-            # cpu_baseline: the unmodified reference NumPy path (configs[0]; committed record, host labelled);
-            # cpu_baseline_port: the C restatement of the same algorithm timed live on this box's host cores
-            ref = cpu_reference_record("pursuit_c1") if not c5 else None
-            port = cpu_baseline_port(maps, kw)
-            if ref is not None:
-                out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
-            else:
-                out["cpu_baseline"] = port
         print(json.dumps(out))
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

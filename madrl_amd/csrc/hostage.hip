@@ -698,6 +698,8 @@ int madrl_hostage_create(const madrl_hostage_config *cfg, const double *sensors_
     int rc = hw_validate(cfg);
     if (rc) return rc;
     if (!sensors_host || !state_dev || !out || n_envs < 1) return fail(MADRL_EINVAL, "create: NULL argument or n_envs < 1");
+    if (n_envs >= 0x7FF00000ll)  // the kernel indexes envs with 32-bit integers (index + workgroup count must stay below 2^31)
+        return fail(MADRL_EINVAL, "n_envs=%lld is too large for one handle (limit 2146435071); shard the batch", (long long)n_envs);
     if (n_envs + cfg->env_id_base > 0xFFFFFFFFll) return fail(MADRL_EINVAL, "global env index must fit 32 bits");
     MADRL_HIP_TRY(hipSetDevice(device));
     madrl_hostage *h = new (std::nothrow) madrl_hostage();

@@ -847,6 +847,8 @@ int madrl_waterworld_create(const madrl_waterworld_config *cfg, const double *se
     int rc = ww_validate(cfg);
     if (rc) return rc;
     if (!sensors_host || !state_dev || !out || n_envs < 1) return fail(MADRL_EINVAL, "create: NULL argument or n_envs < 1");
+    if (n_envs >= 0x7FF00000ll)  // the kernel indexes envs with 32-bit integers (index + workgroup count must stay below 2^31)
+        return fail(MADRL_EINVAL, "n_envs=%lld is too large for one handle (limit 2146435071); shard the batch", (long long)n_envs);
     if (n_envs + cfg->env_id_base > 0xFFFFFFFFll) return fail(MADRL_EINVAL, "global env index must fit 32 bits");
     MADRL_HIP_TRY(hipSetDevice(device));
     madrl_waterworld *h = new (std::nothrow) madrl_waterworld();

@@ -164,6 +164,10 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
                                                            _lib.current_stream(self.device)))
         return b, f, t
 
+    def flops_per_env_step(self):
+        """(FP32 operations per env-step, how the figure was obtained) for the roofline line of bench.py"""
+        return 1.0e6, "estimate: ~180 velocity + up to 60 position sweeps over 12 joints and ~10 manifolds (not counted)"
+
     @property
     def state_buffer(self):
         """raw per-env world structs, uint8 [N, world_bytes] (checkpoint / teacher-forcing hook)"""

@@ -148,6 +148,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
                                           dev_index, _lib.ptr(self._state), C.byref(h)))
         self._handle = h
         self._handle_key = self._create_key()
+        self.handle_generation = getattr(self, "handle_generation", 0) + 1   # how many times the native handle was (re-)created
         if getattr(self, "_cw_env", None) is not None and self._cw_env.shape[0] == N:   # per-env curriculum follows the new handle
             _lib.check(L.madrl_pursuit_set_curriculum(h, _lib.ptr(self._cw_env), _lib.ptr(self._catchr_env)))
         else:

@@ -8,12 +8,12 @@ from madrl_amd import _lib
 dev = torch.device("cuda:0"); N, P, E = 32768, 16, 60
 env = BatchedPursuitEvade([rectangle_map(32, 32)], n_envs=N, device=dev, seed=0, max_steps=500, auto_reset=True,
                           n_pursuers=P, n_evaders=E, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local")
-print("kernel:", env.kernel_kind, "record bytes", env._state.numel() // N)
+print("kernel:", env.kernel_kind, "record bytes", env.record_bytes)
 acts = [torch.randint(0, 5, (N, P), device=dev, dtype=torch.int32) for _ in range(8)]
 L = _lib.lib(); h = env._handle
 ptrs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._removed)]
 env.reset()
-B = 4 * P + 4 * P * 148 + 4 * P + 5 + 2 * (env._state.numel() // N)
+B = 4 * P + 4 * P * 148 + 4 * P + 5 + 2 * (env.record_bytes)
 for threads, blocks in ((64, 0), (64, 8192), (128, 0)):
     env.set_launch(threads, blocks)
     for i in range(10): _lib.check(L.madrl_pursuit_step(h, _lib.ptr(acts[i % 8]), None, *ptrs, _lib.current_stream(dev)))

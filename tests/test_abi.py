@@ -119,3 +119,25 @@ def test_rectangle_map_matches_reference_fixture():
     np.testing.assert_array_equal(rectangle_map(32, 32), g["maps"][0])
     g = np.load(os.path.join(ROOT, "tests", "golden", "pursuit_nonsquare_12x20.npz"))
     np.testing.assert_array_equal(rectangle_map(12, 20), g["maps"][0])
+
+
+def test_batch_size_limits_are_checked_at_create():
+    """the kernels index envs with 32-bit integers: every create() refuses a batch that would overflow them (no GPU needed:
+    the check precedes any HIP call)"""
+    from madrl_amd import _lib
+    L = _lib.lib()
+    sens = np.zeros((30, 2))
+    dummy = C.c_void_p(16)
+    out = C.c_void_p()
+    wc = _lib.WaterworldConfig()
+    wc.struct_size = C.sizeof(_lib.WaterworldConfig)
+    wc.n_pursuers, wc.n_evaders, wc.n_coop, wc.n_poison, wc.n_sensors, wc.addid, wc.speed_features, wc.obstacle_fixed = 5, 10, 2, 10, 30, 1, 1, 1
+    wc.radius, wc.obstacle_radius, wc.ev_speed, wc.poison_speed, wc.sensor_range, wc.action_scale = 0.015, 0.2, 0.01, 0.01, 0.2, 0.01
+    assert L.madrl_waterworld_create(C.byref(wc), sens.ctypes.data_as(C.c_void_p), 2**31 - 10, 0, dummy, C.byref(out)) == -1
+    assert b"too large" in L.madrl_last_error()
+    hc = _lib.HostageConfig()
+    hc.struct_size = C.sizeof(_lib.HostageConfig)
+    hc.n_good, hc.n_hostages, hc.n_bad, hc.n_coop_save, hc.n_coop_avoid, hc.n_sensors, hc.addid, hc.key_fixed = 3, 10, 5, 2, 2, 30, 1, 1
+    hc.radius, hc.bad_speed, hc.sensor_range, hc.action_scale, hc.bomb_radius, hc.key_radius = 0.015, 0.01, 0.2, 0.01, 0.03, 0.0225
+    assert L.madrl_hostage_create(C.byref(hc), sens.ctypes.data_as(C.c_void_p), 2**31 - 10, 0, dummy, C.byref(out)) == -1
+    assert b"too large" in L.madrl_last_error()

@@ -38,3 +38,20 @@ def test_two_ranks_gather_path():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 70 and j["config"]["parallelism"] == "env-sharded x2" and "cpu_baseline" not in j
+
+
+def test_default_batch_line_carries_every_baseline_config():
+    """the default invocation (BASELINE batch sizes) times Waterworld, MultiWalker and the configs[4] shard in the same run and
+    reports them under `workloads`; every launch of the headline carries fused resets (steady-state episode ages)"""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert KEYS <= set(j) and j["config"]["envs_per_gpu"] == 65536
+    assert 0 < j["config"]["horizon_resets_per_env_in_timed_region"] < 1 and j["config"]["horizon_resets_per_launch"] > 100
+    wl = j["workloads"]
+    assert set(wl) == {"waterworld", "multiwalker", "pursuit_c5"}
+    for name, w in wl.items():
+        assert "error" not in w, (name, w)
+        assert w["value"] > 1e5 and w["roofline"]["frac"] > 0 and "workload" in w["config"], name
+    assert wl["multiwalker"]["roofline"]["valu_frac"] > 0 and wl["multiwalker"]["config"]["envs_per_gpu"] == 16384

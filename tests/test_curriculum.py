@@ -37,14 +37,12 @@ def test_update_curriculum_follows_the_reference_and_keeps_the_handle():
     maps = [rectangle_map(16, 16)]
     N = 64
     env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=8, reward_mech="local", **cfg)
-    handle_changes, last = 0, env._handle.value
+    gen0 = env.handle_generation
     rng = np.random.RandomState(0)
     for itr in range(len(g["cw"])):
         env.update_curriculum(itr)
         assert (env.constraint_window, env.n_evaders, env.n_pursuers, env.catchr) == (
             g["cw"][itr], g["n_evaders"][itr], g["n_pursuers"][itr], g["catchr"][itr]), itr
-        handle_changes += int(env._handle.value != last)
-        last = env._handle.value
         if itr % 6 == 5:   # the kernels see the values: a reset + two steps against the oracle with the same attributes
             kw = dict(n_pursuers=env.n_pursuers, n_evaders=env.n_evaders, obs_range=7, reward_mech="local", catchr=env.catchr,
                       constraint_window=float(env.constraint_window))
@@ -60,7 +58,7 @@ def test_update_curriculum_follows_the_reference_and_keeps_the_handle():
                 obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
                 oobs, orew, odone, orem = orc.step(act)
                 assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew.astype(np.float32))
-    assert handle_changes == 4, "the handle is re-created only when the agent counts change (8 -> 4 pursuers)"
+    assert env.handle_generation - gen0 == 4, "the handle is re-created only when the agent counts change (8 -> 4 pursuers)"
     import pickle
     clone = pickle.loads(pickle.dumps(env))   # :397-411: the curriculum attributes travel with the pickle
     assert (clone.constraint_window, clone.n_evaders, clone.n_pursuers, clone.catchr) == (1.0, 26, 4, 0.0)
@@ -81,7 +79,7 @@ def test_per_env_curriculum_matches_oracle(kernel):
     env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=13, max_steps=H, auto_reset=True, kernel=kernel,
                               curriculum_constrain_rate=0.05, curriculum_turn_off_shaping=6, **kw)
     orc = po.PursuitOracle(maps, n_envs=N, seed=13, **kw)
-    handle = env._handle.value
+    gen0 = env.handle_generation
     mask = (np.arange(N) % 2 == 0)
     assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
     rng = np.random.RandomState(4)
@@ -108,7 +106,7 @@ def test_per_env_curriculum_matches_oracle(kernel):
                 orc.reset(mask=m)
                 tstep[m != 0] = 0
             assert np.array_equal(obs.cpu().numpy(), orc.obs), "observations, iteration %d" % itr
-    assert env._handle.value == handle, "per-env curriculum never re-creates the handle"
+    assert env.handle_generation == gen0, "per-env curriculum never re-creates the handle"
     st = env.get_state()
     # envs that stayed at constraint_window 0.25 keep spawning inside a 4 x 4 cell window; the advanced ones spread out
     span = (st["pos_p"].amax(1) - st["pos_p"].amin(1)).float().mean(-1).cpu().numpy()

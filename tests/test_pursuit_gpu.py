@@ -383,4 +383,4 @@ def test_evader_control_free_running_and_dropin_types():
     one._env.set_state(dict(gone=np.array([[0, 1, 0, 0, 1, 0, 0, 0, 0]], np.uint8)))
     obs, rew, done, info = one.step([4] * 5)
     assert [o is None for o in obs] == [False, True, False, False, True] and isinstance(rew, np.ndarray) and rew.shape == (5,)
-    assert obs[2][75] == 1 / 5.0   # id = index in the compacted layer / n_pursuers
+    assert obs[2][75] == np.float32(1 / 5.0)   # id = index in the compacted layer (1: slot 1 is gone) / n_pursuers
