@@ -1,19 +1,35 @@
 // multiwalker_core.hpp -- MultiWalkerEnv dynamics: a from-scratch float32 restatement of the
-// subset of Box2D 2.3.x that madrl_environments/walker/multi_walker.py drives
+// subset of Box2D 2.3.0 that madrl_environments/walker/multi_walker.py drives
 // (`self.world.Step(1.0 / FPS, 6 * 30, 2 * 30)`, multi_walker.py:365), plus the env logic
 // around it.  Written once as host/device code: the HIP kernel (multiwalker.hip) runs it with the
 // world resident in LDS.
 //
 // PARITY UNPINNED: the arithmetic lives in third-party Box2D (pybox2d /
-// box2d-py, Box2D 2.3.x; no version pin anywhere in the reference tree, the module is not
+// box2d-py, Box2D 2.3.0 inside; no version pin anywhere in the reference tree, the module is not
 // installable here and the reference has no golden vectors at that boundary).  What follows
-// restates Box2D's published algorithms from their documented structure:
-//   b2World::Step -> Collide -> Solve(islands) ; b2ContactSolver (sequential impulses, block
-//   solver for 2-point manifolds, Baumgarte position correction) ; b2RevoluteJoint (point
-//   constraint + motor + limit) ; b2CollidePolygons ; b2CollideEdgeAndPolygon ; b2EdgeShape::RayCast.
-// Known, deliberate differences from Box2D (documented in DESIGN.md): no TOI / continuous pass,
-// no sleeping, constraint order = this file's deterministic order (Box2D: creation/DFS order),
-// lidar returns the closest terrain hit (Box2D reports the first hit in tree order).
+// restates Box2D's published algorithms from their documented structure -- and, since round 3, in
+// Box2D's own ORDER, which is semantics for a Gauss-Seidel solver:
+//   b2World::Step -> Collide (every contact: b2Contact::Update, feature-id matching, Begin / EndContact) ->
+//   Solve (islands by depth-first search from the body list, newest body first, over the bodies' contact
+//   edges -- newest contact first -- then their joint edges; b2Island::Solve with the island's joint and
+//   contact order, per-island position-iteration exit and SLEEPING) -> SynchronizeFixtures (fat AABBs,
+//   b2_aabbExtension / b2_aabbMultiplier) -> FindNewContacts (pairs created in (proxyIdA, proxyIdB) order, new
+//   contacts go to the FRONT of the lists) -> SolveTOI.
+//   b2ContactSolver (sequential impulses, block solver for 2-point manifolds, Baumgarte position correction);
+//   b2RevoluteJoint (point constraint + motor + limit); b2CollidePolygons as of 2.3.0 (hill-climbing
+//   b2FindMaxSeparation, 0.98 / 0.001 reference-face hysteresis); b2CollideEdgeAndPolygon on plain edges (the
+//   reference builds edgeShape(vertices=[p1, p2]): no ghost vertices); b2EdgeShape::RayCast.
+// The independent check of all of this is oracle/multiwalker_ref.c (plain C, Box2D's own data structures,
+// no code shared with this file): tests/test_multiwalker_*.py compare the two step by step.
+// Lane-parallel execution keeps Box2D's results: the island's constraint sequence is cut into LEVELS by list
+// scheduling (a constraint's level = 1 + the highest level among earlier constraints that share a body with
+// it); constraints of one level touch disjoint bodies and commute exactly, so solving level by level -- on one
+// lane (CPU build) or on 16 (HIP kernel) -- gives the bits of the serial sweep.
+// Stated differences from the real library (same list as the oracle's header): D1 linear scan over
+// fat AABBs instead of b2DynamicTree, proxy ids in creation order as in a fresh b2World; D2 lidar = closest hit;
+// D3 Philox instead of numpy's Mersenne Twister; D4 a contact between two sleeping bodies is updated like any
+// other (same manifold, the bodies have not moved; Box2D skips it); sin / cos from a +,-,* polynomial so that
+// host and device builds agree bit for bit.
 //
 // Reference call sites (file:line in /root/reference/madrl_environments/walker/multi_walker.py):
 //   constants :17-47 ; BipedalWalker._reset :113-192 ; apply_action :194-203 ;
@@ -78,9 +94,10 @@ constexpr int MAX_WALKERS = 4;
 constexpr int MAXB = 5 * MAX_WALKERS + 1;        // package + 5 bodies per walker
 constexpr int MAXJ = 4 * MAX_WALKERS;
 constexpr int MAXT = TERRAIN_LENGTH * MAX_WALKERS / 8;  // terrain points (:301)
-constexpr int EDGE_SLOTS_SMALL = 6, EDGE_SLOTS_PKG = 36;
-constexpr int MAXSLOT = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
-constexpr int MAXM = 36;  // largest active-manifold pool (Model::max_manifolds <= MAXM)
+constexpr int EDGE_SLOTS_LEG = 6, EDGE_SLOTS_HULL = 10, EDGE_SLOTS_PKG_MAX = 48;   // contacts a body's cache holds (Model::slot_cap)
+constexpr int MAXSLOT = 4 * MAX_WALKERS * EDGE_SLOTS_LEG + MAX_WALKERS * EDGE_SLOTS_HULL + EDGE_SLOTS_PKG_MAX + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
+constexpr int MAXM = 40;  // largest active-manifold pool (Model::max_manifolds <= MAXM)
+constexpr double TERRAIN_HEIGHT64 = 400.0 / 30.0 / 4, LEG_H64 = 34.0 / 30.0, LEG_DOWN64 = -8.0 / 30.0;   // the reference's float64 constants (:26-36)
 
 struct V2 { float x, y; };
 MW_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
@@ -126,12 +143,16 @@ MW_HD Xf mulT(Xf A, Xf B) { Xf C; C.q = mulT(A.q, B.q); C.p = mulT(A.q, B.p - A.
 #include "multiwalker_toi.hpp"
 namespace mw {
 
+
 // ---------------------------------------------------------------- static model (per n_walkers)
+constexpr float AABB_EXTENSION = 0.1f, AABB_MULTIPLIER = 2.0f;   // b2_aabbExtension, b2_aabbMultiplier
+constexpr float TIME_TO_SLEEP = 0.5f, LINEAR_SLEEP_TOLERANCE = 0.01f, ANGULAR_SLEEP_TOLERANCE = 2.0f / 180.0f * B2_PI;
 enum { SH_PACKAGE = 0, SH_HULL = 1, SH_UPPER = 2, SH_LOWER = 3, N_SHAPES = 4 };
 struct Shape {
     int n;
     V2 v[5], nrm[5];
-    V2 centroid;      // = body localCenter (one fixture per body)
+    V2 centroid;      // = body localCenter (b2PolygonShape::ComputeMass -> b2Body::ResetMassData; one fixture per body)
+    V2 centroid_geo;  // b2PolygonShape::m_centroid (ComputeCentroid in Set, zero in SetAsBox): what the narrow phase uses
     float inv_mass, inv_I, friction;
     uint16_t category, mask;
 };
@@ -148,15 +169,25 @@ struct Model {
     JointDef jd[MAXJ];
     float package_length, package_scale;
     float start_x[MAX_WALKERS];
-    int slot_base[MAXB], slot_cap[MAXB];  // body-vs-terrain manifold cache ranges
+    double start_x64[MAX_WALKERS], mean_start_x64;
+    double lidar_dx[10], lidar_dy[10];   // sin / cos(1.5 i / 10) * LIDAR_RANGE in float64 (:211-213)
+    float tx[MAXT];       // terrain vertex x = float32(i * TERRAIN_STEP) with the float64 product of the reference (:521, :617)
+    int slot_base[MAXB], slot_cap[MAXB];  // body-vs-terrain contact ranges in Cold::slot (contact with edge e lives in slot e % cap)
+    int list_base[MAXB];                  // Scratch::bm_idx range of the manifolds a body owns in the solver (terrain contacts, and the pairs whose body B it is)
     int dyn_slot_base, n_dyn_pairs;
     int dyn_a[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS], dyn_b[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
 };
 MW_HD int shape_of_body(int b) { return b == 0 ? SH_PACKAGE : (((b - 1) % 5 == 0) ? SH_HULL : (((b - 1) % 5) % 2 == 1 ? SH_UPPER : SH_LOWER)); }
 MW_HD int hull_of(int w) { return 1 + 5 * w; }
-MW_HD int node_of(int b, int n_walkers) { return b == 0 ? n_walkers : (b - 1) / 5; }  // island graph node: walker index, or W for the package
+MW_HD bool is_hull(int b) { return b >= 1 && (b - 1) % 5 == 0; }
+// b2BroadPhase proxy ids, in creation order as in a fresh b2World (D1): package, the NT - 1 terrain edges, then the walkers' bodies
+MW_HD int proxy_of_body(int b, int NT) { return b == 0 ? 0 : NT - 1 + b; }
+MW_HD int proxy_of_edge(int e) { return 1 + e; }
+// the order of the world's contact list: contacts are created batch by batch (one FindNewContacts call each), inside a batch in
+// (proxyIdA, proxyIdB) order, and every new contact goes to the FRONT -- so a LARGER key is EARLIER in the list
+MW_HD uint64_t contact_key(uint32_t batch, int pA, int pB) { return ((uint64_t)batch << 32) | ((uint64_t)(uint32_t)pA << 16) | (uint64_t)(uint32_t)pB; }
 
-// b2PolygonShape::Set (gift wrapping from the right-most, lowest vertex, CCW) + normals
+// b2PolygonShape::Set (gift wrapping from the right-most, lowest vertex, CCW) + normals + ComputeCentroid
 inline void poly_set(Shape &s, const V2 *pts, int count) {
     int i0 = 0;
     float x0 = pts[0].x;
@@ -183,8 +214,23 @@ inline void poly_set(Shape &s, const V2 *pts, int count) {
     for (int i = 0; i < m; ++i) s.v[i] = pts[hull[i]];
     for (int i = 0; i < m; ++i) {
         const V2 e = s.v[(i + 1) % m] - s.v[i];
-        const float len = sqrtf(dot(e, e));
-        s.nrm[i] = v2(e.y / len, -e.x / len);
+        V2 nr = cross(e, 1.0f);                              // b2Cross(edge, 1.0f), then b2Vec2::Normalize: multiply by 1 / length
+        const float inv = 1.0f / sqrtf(nr.x * nr.x + nr.y * nr.y);
+        nr.x *= inv; nr.y *= inv;
+        s.nrm[i] = nr;
+    }
+    {   // ComputeCentroid(m_vertices, m), reference point = origin
+        V2 c = v2(0, 0);
+        float area = 0.0f;
+        const float inv3 = 1.0f / 3.0f;
+        for (int i = 0; i < m; ++i) {
+            const V2 p1 = v2(0, 0), p2 = s.v[i], p3 = i + 1 < m ? s.v[i + 1] : s.v[0];
+            const V2 e1 = p2 - p1, e2 = p3 - p1;
+            const float D = cross(e1, e2), ta = 0.5f * D;
+            area += ta;
+            c = c + (ta * inv3) * ((p1 + p2) + p3);
+        }
+        s.centroid_geo = (1.0f / area) * c;
     }
 }
 // b2PolygonShape::ComputeMass + b2Body::ResetMassData for a single-fixture body
@@ -206,41 +252,54 @@ inline void poly_mass(Shape &s, float density) {
     center = (1.0f / area) * center;
     const V2 c = center + ref;
     float Io = density * I + mass * (dot(c, c) - dot(center, center));  // about the body origin
-    Io -= mass * dot(c, c);                                              // about the centre of mass
-    s.centroid = c;
-    s.inv_mass = 1.0f / mass;
+    // b2Body::ResetMassData: localCenter = (mass * center) * (1 / mass); I -= mass * dot(localCenter, localCenter)
+    const float inv_mass = 1.0f / mass;
+    const V2 lc = inv_mass * (mass * c);
+    Io -= mass * dot(lc, lc);
+    s.centroid = lc;
+    s.inv_mass = inv_mass;
     s.inv_I = 1.0f / Io;
 }
 
 inline void build_model(Model &M, int n_walkers) {
     M.W = n_walkers; M.NB = 5 * n_walkers + 1; M.NJ = 4 * n_walkers;
-    // observed maxima of simultaneously touching pairs over long random / collapsed rollouts: 18, 25, 34 for 2, 3, 4 walkers
     M.continuous = 1;
-    M.max_manifolds = n_walkers <= 1 ? 16 : (n_walkers == 2 ? 24 : (n_walkers == 3 ? 28 : MAXM));
+    // active-manifold pool: observed maxima of simultaneously touching pairs over long random / collapsed rollouts are 18, 25, 34
+    // for 2, 3, 4 walkers; a pair past the pool is ignored for the step and raises the sticky Hot::overflow bit
+    M.max_manifolds = n_walkers <= 1 ? 20 : (n_walkers == 2 ? 28 : (n_walkers == 3 ? 36 : MAXM));
     M.NT = (int)(TERRAIN_LENGTH * n_walkers * 1 / 8.0);          // :301
-    M.package_scale = n_walkers / 1.75f;                          // :293
-    M.package_length = PACKAGE_LENGTH / SCALE * M.package_scale;  // :294
-    const float init_x = TERRAIN_STEP * TERRAIN_STARTPAD / 2;
-    for (int w = 0; w < n_walkers; ++w) M.start_x[w] = init_x + WALKER_SEPERATION * w * TERRAIN_STEP;  // :285-287
-    {   // package :499-514
-        const float hx = 120.0f * M.package_scale / SCALE, hy = 5.0f / SCALE;
-        const V2 p[4] = {v2(-hx, hy), v2(hx, hy), v2(hx, -hy), v2(-hx, -hy)};
+    const double scale64 = n_walkers / 1.75;                      // :293
+    M.package_scale = (float)scale64;
+    M.package_length = (float)(240.0 / 30.0 * scale64);           // :294
+    const double step64 = 14.0 / 30.0, init_x64 = step64 * TERRAIN_STARTPAD / 2;
+    double mean = 0.0;
+    for (int w = 0; w < n_walkers; ++w) { M.start_x64[w] = init_x64 + WALKER_SEPERATION * w * step64; M.start_x[w] = (float)M.start_x64[w]; mean += M.start_x64[w]; }  // :285-287
+    M.mean_start_x64 = mean / n_walkers;
+    for (int i = 0; i < MAXT; ++i) M.tx[i] = (float)(i * step64);
+    for (int i = 0; i < 10; ++i) { M.lidar_dx[i] = sin(1.5 * i / 10.0) * (160 / 30.0); M.lidar_dy[i] = cos(1.5 * i / 10.0) * (160 / 30.0); }
+    {   // package :499-514: vertices (x * package_scale / SCALE, y / SCALE) in float64, then float32
+        V2 p[4];
+        const double px[4] = {-120, 120, 120, -120}, py[4] = {5, 5, -5, -5};
+        for (int k = 0; k < 4; ++k) p[k] = v2((float)(px[k] * scale64 / 30.0), (float)(py[k] / 30.0));
         poly_set(M.shape[SH_PACKAGE], p, 4);
         poly_mass(M.shape[SH_PACKAGE], 1.0f);
         M.shape[SH_PACKAGE].friction = 0.5f; M.shape[SH_PACKAGE].category = 0x004; M.shape[SH_PACKAGE].mask = 0xFFFF;
     }
     {   // hull :118-127
-        const V2 p[5] = {v2(-30 / SCALE, 9 / SCALE), v2(6 / SCALE, 9 / SCALE), v2(34 / SCALE, 1 / SCALE), v2(34 / SCALE, -8 / SCALE), v2(-30 / SCALE, -8 / SCALE)};
+        const double hx[5] = {-30, 6, 34, 34, -30}, hy[5] = {9, 9, 1, -8, -8};
+        V2 p[5];
+        for (int k = 0; k < 5; ++k) p[k] = v2((float)(hx[k] / 30.0), (float)(hy[k] / 30.0));
         poly_set(M.shape[SH_HULL], p, 5);
         poly_mass(M.shape[SH_HULL], 5.0f);
         M.shape[SH_HULL].friction = 0.1f; M.shape[SH_HULL].category = 0x002; M.shape[SH_HULL].mask = 0xFFFF;
     }
     for (int k = 0; k < 2; ++k) {  // legs :136-163: SetAsBox order, default friction 0.2
         Shape &s = M.shape[k == 0 ? SH_UPPER : SH_LOWER];
-        const float hx = (k == 0 ? 1.0f : 0.8f) * LEG_W / 2, hy = LEG_H / 2;
+        const float hx = (float)((k == 0 ? 1.0 : 0.8) * (8.0 / 30.0) / 2), hy = (float)((34.0 / 30.0) / 2);
         s.n = 4;
         s.v[0] = v2(-hx, -hy); s.v[1] = v2(hx, -hy); s.v[2] = v2(hx, hy); s.v[3] = v2(-hx, hy);
         s.nrm[0] = v2(0, -1); s.nrm[1] = v2(1, 0); s.nrm[2] = v2(0, 1); s.nrm[3] = v2(-1, 0);
+        s.centroid_geo = v2(0, 0);
         poly_mass(s, 1.0f);
         s.friction = 0.2f; s.category = k == 0 ? 0x002 : 0x0020; s.mask = 0x001;
     }
@@ -252,16 +311,22 @@ inline void build_model(Model &M, int n_walkers) {
             knee.bA = hip.bB; knee.bB = hip.bB + 1;
             knee.lA = v2(0, -LEG_H / 2); knee.lB = v2(0, LEG_H / 2); knee.lower = -1.6f; knee.upper = -0.1f;
         }
-    int base = 0;
-    for (int b = 0; b < M.NB; ++b) { M.slot_base[b] = base; M.slot_cap[b] = (b == 0) ? EDGE_SLOTS_PKG : EDGE_SLOTS_SMALL; base += M.slot_cap[b]; }
+    int base = 0, lbase = 0;
+    for (int b = 0; b < M.NB; ++b) {
+        M.slot_base[b] = base;
+        // candidate edges = those whose fat AABB overlaps the body's: a run no longer than (fat width + edge margins) / TERRAIN_STEP + 1
+        M.slot_cap[b] = (b == 0) ? (int)((M.package_length + 1.5f) / TERRAIN_STEP) + 4 : (is_hull(b) ? EDGE_SLOTS_HULL : EDGE_SLOTS_LEG);
+        base += M.slot_cap[b];
+        M.list_base[b] = lbase;
+        lbase += M.slot_cap[b] + (is_hull(b) ? n_walkers : 0);   // a hull also owns the pairs whose body B it is: (package, hull) and (hull_i, hull), i < this
+    }
     M.dyn_slot_base = base;
     int np = 0;
-    for (int w = 0; w < n_walkers; ++w) { M.dyn_a[np] = 0; M.dyn_b[np] = hull_of(w); ++np; }          // package (A) - hull
+    for (int w = 0; w < n_walkers; ++w) { M.dyn_a[np] = 0; M.dyn_b[np] = hull_of(w); ++np; }          // package (A, proxy 0) - hull
     for (int i = 0; i < n_walkers; ++i) for (int j = i + 1; j < n_walkers; ++j) { M.dyn_a[np] = hull_of(i); M.dyn_b[np] = hull_of(j); ++np; }
     M.n_dyn_pairs = np;
 }
 
-// ---------------------------------------------------------------- dynamic state
 // ---------------------------------------------------------------- dynamic state
 struct Body { V2 c; float a; V2 v; float w; };  // centre of mass, angle, velocities
 struct Joint {
@@ -269,69 +334,77 @@ struct Joint {
     float motor_speed, max_torque;
     int limit_state;                  // 0 inactive, 1 at lower, 2 at upper, 3 equal
 };
-struct Slot {       // persistent manifold cache of one candidate pair (b2Contact); 32 bytes
-    int16_t edge;   // terrain edge index, or -1: free slot (dyn pairs: always used)
+struct Slot {       // one b2Contact between a fixed pair of fixtures; 32 bytes
+    int16_t edge;   // terrain edge index (dyn pairs: 0), or -1: no contact (the fat AABBs do not overlap)
     uint8_t npts, touching;
     uint32_t id[2];
     float ni[2], ti[2];
-    // continuous pass (b2Contact e_toiFlag / e_enabledFlag / m_toiCount), valid within one step; m_toi lives in Cold::slot_toi
-    uint8_t toi_flags;           // bit 0: the cached time of impact is valid, bit 1: disabled for the rest of this step
-    uint8_t toi_count;
-    uint16_t pad_;
+    uint16_t batch;              // the FindNewContacts call that created it (contact_key): its place in Box2D's lists
+    uint8_t toi_flags;           // bit 0: e_toiFlag (the cached time of impact is valid), bit 1: NOT e_enabledFlag
+    uint8_t toi_count;           // m_toiCount
 };
 struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositionConstraint
     int8_t bA, bB;         // bA = -1: static terrain
     int16_t slot;
-    uint8_t npts, type, block, pad_;  // type 0: faceA, 1: faceB; block: the 2-point block solver applies
+    uint8_t npts, type, block, island;  // npts: points of the VELOCITY constraint (b2ContactSolver drops the second point of an ill-conditioned pair there only);
+                                        // type bit 0: 0 faceA, 1 faceB, bits 1-2: points of the manifold = of the POSITION constraint; block: the 2-point block solver applies
     V2 local_normal, local_point, lp[2];  // b2Manifold (lp in the other body's frame)
     V2 normal, rA[2], rB[2];
     float friction, nm[2], tm[2], ni[2], ti[2];
     float k11, k12, k22, im11, im12, im22;  // block solver K and K^-1
 };
 static_assert(sizeof(Slot) == 32, "HBM record layout");
-static_assert(sizeof(Manifold) == 140, "LDS budget of the HIP kernel: 4 envs x (Hot + Scratch) x 8 wavefronts per CU");
+static_assert(sizeof(Manifold) == 140, "LDS budget of the HIP kernel");
 // The env state is split by how often a step touches it.
 //   Hot:  bodies and flags -- read and written by every one of the 180 + 60 solver sweeps; the HIP kernel keeps it in
 //         LDS for the duration of the step.
-//   Cold: the joints' persistent state, the manifold cache (warm-start impulses of the candidate pairs) and the terrain
-//         heights -- touched once per step (joint init / write-back, Collide, StoreImpulses, lidar); the HIP kernel
-//         reads and writes it in place in HBM (L2).
+//   Cold: the joints' persistent state, the contacts (warm-start impulses, list order), the broad phase's fat AABBs, sleep
+//         times and the terrain heights -- touched once per step; the HIP kernel reads and writes it in place in HBM (L2).
 struct Hot {
     Body b[MAXB];
     float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
-    float prev_shaping[MAX_WALKERS], prev_package_shaping;
-    uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, pad_;
+    double prev_shaping[MAX_WALKERS], prev_package_shaping;   // float64 like the reference's Python side (:403-411)
+    uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, overflow;   // overflow: sticky, a contact did not fit its cache / the pool
     uint32_t tick;
     int32_t t;
+    uint32_t awake;               // bit b: body b is awake (b2Body::e_awakeFlag)
+    uint32_t batch;               // FindNewContacts calls so far in this world (contact_key)
 };
 struct Cold {
     Joint j[MAXJ];                // warm-start impulses, motor targets, limit states: read at the start of a step into the
                                   // owning lane's JointCache, written back at its end
     Slot slot[MAXSLOT];
-    float slot_toi[MAXSLOT];      // continuous pass: cached time of impact per slot (valid while Slot::toi_flags bit 0)
-    V2 sweep_c0[MAXB];            // continuous pass: body centres / angles at the start of the step (b2Sweep::c0, a0) and the
-    float sweep_a0[MAXB];         // time up to which a body has already been advanced (b2Sweep::alpha0)
-    float sweep_alpha0[MAXB];
-    float ty[MAXT];               // terrain heights (x = i * TERRAIN_STEP)
+    float slot_toi[MAXSLOT];      // continuous pass: cached time of impact per contact (valid while Slot::toi_flags bit 0)
+    float fat[MAXB][4];           // the broad phase's fat AABB of every dynamic body's proxy: lower x, y, upper x, y
+    float sleep_time[MAXB];       // b2Body::m_sleepTime
+    V2 sweep_c0[MAXB];            // b2Sweep::c0, a0 (the pose at the start of the step, later the last safe pose of the continuous pass)
+    float sweep_a0[MAXB];
+    float sweep_alpha0[MAXB];     // b2Sweep::alpha0
+    float ty[MAXT];               // terrain heights, float32 as the b2EdgeShapes hold them (x = Model::tx)
 };
 struct World { Hot h; Cold c; };  // the packed per-env record in HBM
 
 constexpr int NDYN = MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
-constexpr int MAXSLOT_TERRAIN = (MAXB - 1) * EDGE_SLOTS_SMALL + EDGE_SLOTS_PKG;
+constexpr int MAXLIST = MAXSLOT + MAX_WALKERS * MAX_WALKERS;   // Model::list_base ranges
+constexpr int MAXISL = MAX_WALKERS + 1;
 struct Scratch {  // per-step workspace (LDS on the GPU)
     int nm;
-    int8_t n_dyn, max_cnt, merge_ok, all_done;
+    int8_t n_isl, n_jlevels, n_clevels, all_done;
+    uint32_t moved;            // bit b: body b's proxy is in the broad phase's move buffer
+    uint32_t in_island;        // bit b: body b was simulated by this step's Solve (b2Body::e_islandFlag after b2World::Solve)
     // mass data of the four shapes (package, hull, upper leg, lower leg), copied once per step
     float sh_im[N_SHAPES], sh_ii[N_SHAPES];
     V2 sh_lc[N_SHAPES];
-    // solver schedule: terrain manifolds per body (indexed like the body's slots) and the active dynamic pairs
-    uint8_t bm_cnt[MAXB], bm_idx[MAXSLOT_TERRAIN];
-    int8_t dyn_midx[NDYN];   // manifold of pair p, or -1
-    int8_t dyn_list[NDYN];   // the active pairs, in pair order ...
-    int8_t dyn_owner[NDYN], dyn_man[NDYN], dyn_a_shape[NDYN];  // ... the body whose lane solves them (the pair's second body), their manifolds, the shape of the first body
-    int8_t comp[MAX_WALKERS + 1];
-    uint8_t isl_done[MAX_WALKERS + 1], walker_ok[MAX_WALKERS];
-    float body_minsep[MAXB], dyn_minsep[NDYN];
+    // solver schedule (island order cut into levels): per body the manifolds it owns, by ascending level
+    uint8_t bm_cnt[MAXB], bm_idx[MAXLIST];
+    uint8_t m_level[MAXM];     // contact phase level of manifold k
+    uint8_t j_level[MAXJ];     // joint phase level of joint j, 255: its island is asleep (not simulated)
+    int8_t j_island[MAXJ];
+    int8_t island_of[MAXB];    // island of body b in this step's Solve, -1: none (asleep and not reached)
+    int8_t dyn_midx[NDYN];     // manifold of pair p, or -1
+    uint8_t isl_done[MAXISL], isl_pos_solved[MAXISL], joint_ok[MAXJ];
+    float body_minsep[MAXB];
+    uint8_t slot_m[MAXSLOT];   // manifold of the (touching) contact in slot s this step, 255: did not fit the pool
     Manifold m[MAXM];  // LAST member: the HIP kernel allocates only Model::max_manifolds of them
 };
 
@@ -364,21 +437,47 @@ MW_HD int clip_segment(ClipV out[2], const ClipV in[2], V2 normal, float offset,
 
 struct ManifoldOut { int npts, type; V2 local_normal, local_point, lp[2]; uint32_t id[2]; };
 
-MW_HD float find_max_separation(int *edge, const Shape &p1, Xf xf1, const Shape &p2, Xf xf2) {
-    const Xf xf = mulT(xf2, xf1);
-    int best = 0;
-    float maxsep = -3.0e38f;
-    for (int i = 0; i < p1.n; ++i) {
-        const V2 n = mul(xf.q, p1.nrm[i]), v1 = mul(xf, p1.v[i]);
-        float si = 3.0e38f;
-        for (int j = 0; j < p2.n; ++j) { const float sij = dot(n, p2.v[j] - v1); if (sij < si) si = sij; }
-        if (si > maxsep) { maxsep = si; best = i; }
+
+// b2CollidePolygon.cpp as of Box2D 2.3.0: the separation of one edge normal of poly1 from poly2 ...
+MW_HD float edge_separation(const Shape &p1, Xf xf1, int edge1, const Shape &p2, Xf xf2) {
+    const V2 normal1_world = mul(xf1.q, p1.nrm[edge1]);
+    const V2 normal1 = mulT(xf2.q, normal1_world);
+    int index = 0;
+    float min_dot = 3.402823466e+38f;
+    for (int i = 0; i < p2.n; ++i) { const float d = dot(p2.v[i], normal1); if (d < min_dot) { min_dot = d; index = i; } }
+    const V2 v1 = mul(xf1, p1.v[edge1]), v2w = mul(xf2, p2.v[index]);
+    return dot(v2w - v1, normal1_world);
+}
+// ... and the hill-climbing search for the edge of maximum separation, started at the edge whose normal looks at poly2's centroid
+MW_HD float find_max_separation(int *edge_index, const Shape &p1, Xf xf1, const Shape &p2, Xf xf2) {
+    const int count1 = p1.n;
+    const V2 d = mul(xf2, p2.centroid_geo) - mul(xf1, p1.centroid_geo);
+    const V2 d_local1 = mulT(xf1.q, d);
+    int edge = 0;
+    float max_dot = -3.402823466e+38f;
+    for (int i = 0; i < count1; ++i) { const float dt = dot(p1.nrm[i], d_local1); if (dt > max_dot) { max_dot = dt; edge = i; } }
+    float s = edge_separation(p1, xf1, edge, p2, xf2);
+    const int prev_edge = edge - 1 >= 0 ? edge - 1 : count1 - 1;
+    const float s_prev = edge_separation(p1, xf1, prev_edge, p2, xf2);
+    const int next_edge = edge + 1 < count1 ? edge + 1 : 0;
+    const float s_next = edge_separation(p1, xf1, next_edge, p2, xf2);
+    int best_edge, increment;
+    float best_sep;
+    if (s_prev > s && s_prev > s_next) { increment = -1; best_edge = prev_edge; best_sep = s_prev; }
+    else if (s_next > s) { increment = 1; best_edge = next_edge; best_sep = s_next; }
+    else { *edge_index = edge; return s; }
+    for (;;) {
+        if (increment == -1) edge = best_edge - 1 >= 0 ? best_edge - 1 : count1 - 1;
+        else edge = best_edge + 1 < count1 ? best_edge + 1 : 0;
+        s = edge_separation(p1, xf1, edge, p2, xf2);
+        if (s > best_sep) { best_edge = edge; best_sep = s; }
+        else break;
     }
-    *edge = best;
-    return maxsep;
+    *edge_index = best_edge;
+    return best_sep;
 }
 
-// b2CollidePolygons
+// b2CollidePolygons (2.3.0: reference face chosen with the 0.98 / 0.001 hysteresis)
 MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shape &pB, Xf xfB) {
     mo.npts = 0;
     const float total_radius = 2.0f * POLY_RADIUS;
@@ -388,13 +487,13 @@ MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shap
     const float sepB = find_max_separation(&edgeB, pB, xfB, pA, xfA);
     if (sepB > total_radius) return;
     const Shape *p1, *p2; Xf xf1, xf2; int edge1, flip;
-    const float k_tol = 0.1f * LINEAR_SLOP;
-    if (sepB > sepA + k_tol) { p1 = &pB; p2 = &pA; xf1 = xfB; xf2 = xfA; edge1 = edgeB; mo.type = 1; flip = 1; }
+    const float k_relative_tol = 0.98f, k_absolute_tol = 0.001f;
+    if (sepB > k_relative_tol * sepA + k_absolute_tol) { p1 = &pB; p2 = &pA; xf1 = xfB; xf2 = xfA; edge1 = edgeB; mo.type = 1; flip = 1; }
     else { p1 = &pA; p2 = &pB; xf1 = xfA; xf2 = xfB; edge1 = edgeA; mo.type = 0; flip = 0; }
     ClipV inc[2];
     {   // b2FindIncidentEdge
         const V2 normal1 = mulT(xf2.q, mul(xf1.q, p1->nrm[edge1]));
-        int index = 0; float mind = 3.0e38f;
+        int index = 0; float mind = 3.402823466e+38f;
         for (int i = 0; i < p2->n; ++i) { const float dd = dot(normal1, p2->nrm[i]); if (dd < mind) { mind = dd; index = i; } }
         const int i1 = index, i2 = (i1 + 1 < p2->n) ? i1 + 1 : 0;
         inc[0].v = mul(xf2, p2->v[i1]); inc[0].id = mk_id(edge1, i1, 1, 0);
@@ -403,7 +502,7 @@ MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shap
     const int iv1 = edge1, iv2 = (edge1 + 1 < p1->n) ? edge1 + 1 : 0;
     V2 v11 = p1->v[iv1], v12 = p1->v[iv2];
     V2 local_tangent = v12 - v11;
-    { const float len = sqrtf(dot(local_tangent, local_tangent)); local_tangent = (1.0f / len) * local_tangent; }
+    { const float inv = 1.0f / sqrtf(dot(local_tangent, local_tangent)); local_tangent.x *= inv; local_tangent.y *= inv; }   // b2Vec2::Normalize
     const V2 local_normal = cross(local_tangent, 1.0f), plane_point = 0.5f * (v11 + v12);
     const V2 tangent = mul(xf1.q, local_tangent), normal = cross(tangent, 1.0f);
     v11 = mul(xf1, v11); v12 = mul(xf1, v12);
@@ -425,16 +524,13 @@ MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shap
     mo.npts = n;
 }
 
-// b2CollideEdgeAndPolygon (b2EPCollider::Collide); edge = shape A, whose body frame is the world.
-// The terrain edges are given their neighbours' vertices (v0 before v1, v3 after v2) like the
-// ghost vertices of a b2ChainShape.  The reference builds plain b2EdgeShapes; Box2D protects those
-// from deep penetration with its continuous (TOI) pass, which this restatement does not have, and
-// without it a foot pressed into a terrain vertex gets wedged by the internal-edge side normals.
-// The adjacency test below is Box2D's own remedy for exactly that artefact.
+
+// b2CollideEdgeAndPolygon (b2EPCollider::Collide); edge = shape A, whose body frame is the world.  has0 / has3: ghost vertices
+// (b2EdgeShape::m_hasVertex0 / 3); the terrain edges of the reference have none.
 MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB, Xf xfB, bool has0, V2 v0, bool has3, V2 v3) {
     mo.npts = 0;
     const Xf xf = xfB;  // edge body transform is identity
-    const V2 centroidB = mul(xf, pB.centroid);
+    const V2 centroidB = mul(xf, pB.centroid_geo);
     V2 edge1 = v2e - v1;
     { const float len = sqrtf(dot(edge1, edge1)); edge1 = (1.0f / len) * edge1; }
     const V2 normal1 = v2(edge1.y, -edge1.x);
@@ -550,136 +646,321 @@ MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB,
     mo.npts = n;
 }
 
-MW_HD void body_aabb(const Model &M, const Hot &Wd, int bi, float &xmin, float &xmax, float &ymin, float &ymax) {
-    const Shape &s = M.shape[shape_of_body(bi)];
-    const Xf t = body_xf(M, Wd.b[bi], bi);
-    xmin = ymin = 3.0e38f; xmax = ymax = -3.0e38f;
-    for (int i = 0; i < s.n; ++i) {
+
+// ---------------------------------------------------------------- broad phase: fat AABBs (b2DynamicTree node boxes; D1)
+struct AABB { float lx, ly, hx, hy; };
+MW_HD AABB poly_aabb(const Shape &s, Xf t) {   // b2PolygonShape::ComputeAABB
+    V2 lower = mul(t, s.v[0]), upper = lower;
+    for (int i = 1; i < s.n; ++i) {
         const V2 p = mul(t, s.v[i]);
-        xmin = fminf(xmin, p.x); xmax = fmaxf(xmax, p.x); ymin = fminf(ymin, p.y); ymax = fmaxf(ymax, p.y);
+        lower = v2(fminf(lower.x, p.x), fminf(lower.y, p.y));
+        upper = v2(fmaxf(upper.x, p.x), fmaxf(upper.y, p.y));
     }
-    xmin -= POLY_RADIUS; xmax += POLY_RADIUS; ymin -= POLY_RADIUS; ymax += POLY_RADIUS;
+    AABB b; b.lx = lower.x - POLY_RADIUS; b.ly = lower.y - POLY_RADIUS; b.hx = upper.x + POLY_RADIUS; b.hy = upper.y + POLY_RADIUS;
+    return b;
+}
+MW_HD AABB fatten(AABB a) { AABB f; f.lx = a.lx - AABB_EXTENSION; f.ly = a.ly - AABB_EXTENSION; f.hx = a.hx + AABB_EXTENSION; f.hy = a.hy + AABB_EXTENSION; return f; }
+// terrain edge e: b2EdgeShape::ComputeAABB at the identity transform, fattened at proxy creation; static, so it never changes
+MW_HD AABB edge_fat_aabb(const Model &M, const Cold &Cd, int e) {
+    const float x1 = M.tx[e], x2 = M.tx[e + 1], y1 = Cd.ty[e], y2 = Cd.ty[e + 1];
+    AABB a; a.lx = fminf(x1, x2) - POLY_RADIUS; a.ly = fminf(y1, y2) - POLY_RADIUS; a.hx = fmaxf(x1, x2) + POLY_RADIUS; a.hy = fmaxf(y1, y2) + POLY_RADIUS;
+    return fatten(a);
+}
+MW_HD bool aabb_overlap(const AABB &a, const AABB &b) {   // b2TestOverlap
+    if (b.lx - a.hx > 0.0f || b.ly - a.hy > 0.0f) return false;
+    if (a.lx - b.hx > 0.0f || a.ly - b.hy > 0.0f) return false;
+    return true;
+}
+MW_HD bool aabb_contains(const AABB &a, const AABB &b) { return a.lx <= b.lx && a.ly <= b.ly && b.hx <= a.hx && b.hy <= a.hy; }
+MW_HD AABB body_fat(const Cold &Cd, int b) { AABB f; f.lx = Cd.fat[b][0]; f.ly = Cd.fat[b][1]; f.hx = Cd.fat[b][2]; f.hy = Cd.fat[b][3]; return f; }
+MW_HD void set_body_fat(Cold &Cd, int b, const AABB &f) { Cd.fat[b][0] = f.lx; Cd.fat[b][1] = f.ly; Cd.fat[b][2] = f.hx; Cd.fat[b][3] = f.hy; }
+// edges whose fat AABB can overlap [lx, hx] in x: a conservative index range, every candidate is then tested exactly
+MW_HD void edge_range(const Model &M, float lx, float hx, int &e0, int &e1) {
+    e0 = (int)floorf((lx - 0.12f) / TERRAIN_STEP) - 1;
+    e1 = (int)floorf((hx + 0.12f) / TERRAIN_STEP) + 1;
+    if (e0 < 0) e0 = 0;
+    if (e1 > M.NT - 2) e1 = M.NT - 2;
 }
 
-// ContactDetector.BeginContact / EndContact (:50-84) for one pair whose touching state changed
-MW_HD void contact_event(const Model &M, Hot &Wd, int bA, int bB, bool begin) {
-    // bA == -1: terrain
-    for (int w = 0; w < M.W; ++w) {
-        const int hull = hull_of(w);
-        if (begin) {
-            if (hull == bA && bB != 0) Wd.fallen[w] = 1;   // hull touches anything but the package
-            if (hull == bB && bA != 0) Wd.fallen[w] = 1;
-        }
-        for (int k = 0; k < 2; ++k) {                      // legs[1], legs[3]: the lower legs
-            const int leg = hull + 2 + 2 * k;
-            if (leg == bA || leg == bB) Wd.ground[w][k] = begin ? 1 : 0;
-        }
-    }
-    if (begin) {
-        if (bA == 0 && !(bB >= 1 && (bB - 1) % 5 == 0)) Wd.game_over = 1;   // package touches a non-hull
-        if (bB == 0 && !(bA >= 1 && (bA - 1) % 5 == 0)) Wd.game_over = 1;
-    }
+// ContactDetector.BeginContact (:56-78) for a pair that started touching, except the lower legs' ground_contact, which also
+// EndContact writes and which therefore depends on the ORDER of the events (see collide_body_terrain).  bA == -1: terrain.
+MW_HD void contact_begin_flags(Hot &Wd, int bA, int bB) {
+    if (bA >= 0 && is_hull(bA) && bB != 0) Wd.fallen[(bA - 1) / 5] = 1;   // a hull touches anything but the package
+    if (is_hull(bB) && bA != 0) Wd.fallen[(bB - 1) / 5] = 1;
+    if (bA == 0 && !is_hull(bB)) Wd.game_over = 1;                        // the package touches a non-hull
+    if (bB == 0 && !(bA >= 0 && is_hull(bA))) Wd.game_over = 1;
 }
+MW_HD bool is_lower_leg(int b) { return b >= 1 && ((b - 1) % 5 == 2 || (b - 1) % 5 == 4); }
+MW_HD void set_ground_flag(Hot &Wd, int b, bool on) { Wd.ground[(b - 1) / 5][(b - 1) % 5 == 2 ? 0 : 1] = on ? 1 : 0; }
 
 // ---------------------------------------------------------------- lane parallelism
 // The step is written once for a group of cooperating lanes (`Par`): SerialPar (CPU build: one lane that owns
-// everything, no-op sync) or a 16-lane group of a wavefront in the HIP kernel (four envs per wavefront).  Work is split
-// so that lanes running concurrently never touch the same body -- bodies and their terrain contacts by lane, the two legs
-// of a walker on two lanes, the package / hull contacts one at a time -- and every pair of constraints that shares a
-// body keeps its serial Gauss-Seidel order, so the lane-parallel schedule produces bit-identical results to the serial
-// one (constraints on disjoint bodies commute exactly).
-// JOINTS = revolute joints a lane may own (joint ji belongs to lane ji % n()); their per-step constants and accumulated
-// impulses live in lane-private storage (registers on the GPU) for the whole step.
+// everything, no-op sync) or a 16-lane group of a wavefront in the HIP kernel (four envs per wavefront).  Bodies and the
+// manifolds they own (their terrain contacts, and the pairs whose body B they are) by lane, one lane per revolute joint.
+// Constraints of one LEVEL of the schedule never share a body, so the lane-parallel sweep produces the bits of Box2D's
+// serial one (see the file header).
 struct SerialPar {
     static constexpr int JOINTS = MAXJ;   // joints a lane may own
     static constexpr int BODIES = MAXB;   // bodies a lane may own
-    static constexpr bool MCACHE = false; // no lane-private manifold copy: the one lane owns every manifold
     MW_HD int lane() const { return 0; }
     MW_HD int n() const { return 1; }
     MW_HD void sync() const {}
     MW_HD int alloc(int *counter) const { return (*counter)++; }
+    MW_HD void or_bits(uint32_t *p, uint32_t v) const { *p |= v; }
 };
 
-// push an active manifold into the solver pool, carrying impulses over from the cached contact
-template <class Par>
-MW_HD int emit_manifold(const Model &M, Hot &Wd, Scratch &S, Par par, Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction, int max_manifolds) {
+// b2Contact::Update of one contact whose new manifold is `mo`: impulses carried over by feature id, touching state, e_enabledFlag
+// set again.  Returns 0: no event, 1: BeginContact, 2: EndContact.
+MW_HD int contact_update(Slot &sl, const ManifoldOut &mo) {
     float ni[2] = {0, 0}, ti[2] = {0, 0};
-    for (int i = 0; i < mo.npts; ++i)  // b2Contact::Update: match ids with the old manifold
+    for (int i = 0; i < mo.npts; ++i)
         for (int k = 0; k < sl.npts; ++k)
             if (sl.id[k] == mo.id[i]) { ni[i] = sl.ni[k]; ti[i] = sl.ti[k]; break; }
-    const bool touching = mo.npts > 0;
-    if (touching != (sl.touching != 0)) contact_event(M, Wd, bA, bB, touching);
-    sl.touching = touching; sl.npts = (uint8_t)mo.npts;
+    const bool touching = mo.npts > 0, was = sl.touching != 0;
+    sl.touching = touching ? 1 : 0; sl.npts = (uint8_t)mo.npts;
     for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
-    if (!touching) return -1;
+    sl.toi_flags &= (uint8_t)~2u;
+    return touching == was ? 0 : (touching ? 1 : 2);
+}
+// a touching contact becomes a solver manifold (pool slot from par.alloc; the solver's order is decided later by build_islands)
+template <class Par>
+MW_HD int emit_manifold(Hot &Wd, Scratch &S, Par par, const Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction, int max_manifolds) {
     const int idx = par.alloc(&S.nm);
-    if (idx >= max_manifolds) return -1;  // pool exhausted: the pair is ignored this step
+    if (idx >= max_manifolds) { Wd.overflow = 1; return -1; }  // pool exhausted: the pair is ignored this step (sticky flag)
     Manifold &m = S.m[idx];
-    m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)mo.type;
+    m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)(mo.type | (mo.npts << 1)); m.island = 0;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
-    for (int i = 0; i < mo.npts; ++i) { m.lp[i] = mo.lp[i]; m.ni[i] = ni[i]; m.ti[i] = ti[i]; }
+    for (int i = 0; i < mo.npts; ++i) { m.lp[i] = mo.lp[i]; m.ni[i] = sl.ni[i]; m.ti[i] = sl.ti[i]; }
     m.friction = friction;
     return idx;
 }
-
-// b2ContactManager::Collide for body `bi` against the terrain polyline (edge e spans x in [e, e+1] * TERRAIN_STEP).
-// The body's cache is direct-mapped: edge e lives in slot e % cap (the candidate range is a run of consecutive edges no
-// longer than the cache; a longer run loses its last edges for this step, like a full cache).
-template <class Par>
-MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int bi) {
-    const Shape &s = M.shape[shape_of_body(bi)];
-    float xmin, xmax, ymin, ymax;
-    body_aabb(M, Wd, bi, xmin, xmax, ymin, ymax);
-    int e0 = (int)floorf(xmin / TERRAIN_STEP), e1 = (int)floorf(xmax / TERRAIN_STEP);
-    if (e0 < 0) e0 = 0;
-    if (e1 > M.NT - 2) e1 = M.NT - 2;
-    Slot *slots = Cd.slot + M.slot_base[bi];
-    const int cap = M.slot_cap[bi];
-    int cnt = 0;
-    // contacts whose edge left the candidate range are destroyed (EndContact if touching)
-    for (int k = 0; k < cap; ++k) {
-        Slot &sl = slots[k];
-        const int ed = sl.edge;
-        if (ed >= 0 && (ed < e0 || ed > e1)) {
-            if (sl.touching) contact_event(M, Wd, -1, bi, false);
-            sl.edge = -1; sl.npts = 0; sl.touching = 0;
-        }
-    }
-    const Xf xfB = body_xf(M, Wd.b[bi], bi);
-    for (int e = e0; e <= e1; ++e) {
-        const int k = e % cap;
-        Slot &sl = slots[k];
-        if (sl.edge >= 0 && sl.edge != e) continue;  // the run is longer than the cache: pair ignored this step
-        if (sl.edge != e) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; }
-        const V2 p1 = v2(e * TERRAIN_STEP, Cd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
-        ManifoldOut mo; mo.npts = 0;
-        const float elo = fminf(p1.y, p2.y) - POLY_RADIUS, ehi = fmaxf(p1.y, p2.y) + POLY_RADIUS;
-        if (!(ymin > ehi + 0.2f || ymax < elo - 0.2f)) {
-            const bool has0 = e > 0, has3 = e < M.NT - 2;
-            const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Cd.ty[e - 1]) : p1;
-            const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Cd.ty[e + 2]) : p2;
-            collide_edge_polygon(mo, p1, p2, s, xfB, has0, p0, has3, p3);
-        }
-        const int idx = emit_manifold(M, Wd, S, par, sl, M.slot_base[bi] + k, mo, -1, bi, sqrtf(FRICTION * s.friction), M.max_manifolds);
-        if (idx >= 0 && cnt < cap) S.bm_idx[M.slot_base[bi] + cnt++] = (uint8_t)idx;
-    }
-    S.bm_cnt[bi] = (uint8_t)cnt;
+MW_HD void edge_polygon_manifold(const Model &M, const Cold &Cd, int e, const Shape &s, Xf xfB, ManifoldOut &mo) {
+    const V2 p1 = v2(M.tx[e], Cd.ty[e]), p2 = v2(M.tx[e + 1], Cd.ty[e + 1]);
+    collide_edge_polygon(mo, p1, p2, s, xfB, false, p1, false, p2);   // plain b2EdgeShape: no ghost vertices (:617-620)
 }
 
-// package - hull and hull - hull pair p
+// b2ContactManager::Collide for the contacts of body `bi` with terrain edges.  Box2D walks the world's contact list (newest
+// first); the only thing that order decides here is a lower leg's ground_contact when one pass holds both a Begin and an End
+// for it: the LAST event of the walk -- the one on the OLDEST contact -- wins.
 template <class Par>
-MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int p) {
+MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int bi, uint8_t *slot_m) {
+    const Shape &s = M.shape[shape_of_body(bi)];
+    const AABB fatb = body_fat(Cd, bi);
+    Slot *slots = Cd.slot + M.slot_base[bi];
+    const int cap = M.slot_cap[bi];
+    const Xf xfB = body_xf(M, Wd.b[bi], bi);
+    const AABB tight = poly_aabb(s, xfB);
+    const int pb = proxy_of_body(bi, M.NT);
+    uint64_t ev_key = ~0ull;
+    int ev_kind = 0;
+    const float fr = sqrtf(FRICTION * s.friction);   // b2MixFriction
+    for (int k = 0; k < cap; ++k) {
+        Slot &sl = slots[k];
+        const int e = sl.edge;
+        if (e < 0) continue;
+        // (0, edge) for the package, (edge, body) for a walker's body: b2Contact::Create stores the edge as fixture A either way
+        const uint64_t key = bi == 0 ? contact_key(sl.batch, 0, proxy_of_edge(e)) : contact_key(sl.batch, proxy_of_edge(e), pb);
+        int ev;
+        if (!aabb_overlap(edge_fat_aabb(M, Cd, e), fatb)) {   // the fat AABBs ceased to overlap: b2ContactManager::Destroy
+            ev = sl.touching ? 2 : 0;
+            sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.toi_flags = 0; sl.toi_count = 0;
+        } else {
+            ManifoldOut mo; mo.npts = 0;
+            // cull (never changes a result): the tight boxes are further apart than any manifold reaches
+            const float elo = fminf(Cd.ty[e], Cd.ty[e + 1]), ehi = fmaxf(Cd.ty[e], Cd.ty[e + 1]);
+            if (!(tight.ly > ehi + 0.1f || tight.hy < elo - 0.1f || tight.lx > M.tx[e + 1] + 0.1f || tight.hx < M.tx[e] - 0.1f))
+                edge_polygon_manifold(M, Cd, e, s, xfB, mo);
+            ev = contact_update(sl, mo);
+            if (ev == 1) contact_begin_flags(Wd, -1, bi);
+            if (sl.touching) {
+                const int idx = emit_manifold(Wd, S, par, sl, M.slot_base[bi] + k, mo, -1, bi, fr, M.max_manifolds);
+                slot_m[M.slot_base[bi] + k] = (uint8_t)(idx < 0 ? 255 : idx);
+            }
+        }
+        if (ev != 0 && key < ev_key) { ev_key = key; ev_kind = ev; }
+    }
+    if (ev_kind != 0 && is_lower_leg(bi)) set_ground_flag(Wd, bi, ev_kind == 1);
+}
+
+// package - hull and hull - hull pair p (two dynamic bodies: filtered by b2ContactFilter, never jointed)
+template <class Par>
+MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int p, uint8_t *slot_m) {
     const int bA = M.dyn_a[p], bB = M.dyn_b[p];
-    const Shape &sA = M.shape[shape_of_body(bA)], &sB = M.shape[shape_of_body(bB)];
     Slot &sl = Cd.slot[M.dyn_slot_base + p];
-    sl.edge = 0;
-    float ax0, ax1, ay0, ay1, bx0, bx1, by0, by1;
-    body_aabb(M, Wd, bA, ax0, ax1, ay0, ay1);
-    body_aabb(M, Wd, bB, bx0, bx1, by0, by1);
+    S.dyn_midx[p] = -1;
+    if (sl.edge < 0) return;
+    if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) {   // Destroy (an EndContact would only clear lower-leg flags: none here)
+        sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.toi_flags = 0; sl.toi_count = 0;
+        return;
+    }
+    const Shape &sA = M.shape[shape_of_body(bA)], &sB = M.shape[shape_of_body(bB)];
     ManifoldOut mo; mo.npts = 0;
-    if (!(ax0 > bx1 + 0.2f || bx0 > ax1 + 0.2f || ay0 > by1 + 0.2f || by0 > ay1 + 0.2f))
-        collide_polygons(mo, sA, body_xf(M, Wd.b[bA], bA), sB, body_xf(M, Wd.b[bB], bB));
-    S.dyn_midx[p] = (int8_t)emit_manifold(M, Wd, S, par, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction), M.max_manifolds);
+    const Xf xfA = body_xf(M, Wd.b[bA], bA), xfB = body_xf(M, Wd.b[bB], bB);
+    const AABB ta = poly_aabb(sA, xfA), tb = poly_aabb(sB, xfB);
+    if (!(ta.lx > tb.hx + 0.1f || tb.lx > ta.hx + 0.1f || ta.ly > tb.hy + 0.1f || tb.ly > ta.hy + 0.1f)) collide_polygons(mo, sA, xfA, sB, xfB);
+    const bool was = sl.touching != 0;
+    const int ev = contact_update(sl, mo);
+    if (ev == 1) contact_begin_flags(Wd, bA, bB);
+    if (ev != 0) {   // "if (touching != wasTouching) bodyA->SetAwake(true), bodyB->SetAwake(true)"
+        for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; } }
+    }
+    (void)was;
+    if (sl.touching) {
+        const int idx = emit_manifold(Wd, S, par, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction), M.max_manifolds);
+        S.dyn_midx[p] = (int8_t)idx;
+        slot_m[M.dyn_slot_base + p] = (uint8_t)(idx < 0 ? 255 : idx);
+    }
+}
+
+// b2Body::SynchronizeFixtures -> b2Fixture::Synchronize -> b2BroadPhase::MoveProxy: the proxy's box is the union of the boxes at
+// the sweep's start pose (c0, a0) and at the current pose; it is re-fattened (extension + twice the displacement) and buffered as
+// moved only when it left its fat AABB.
+MW_HD bool sync_fixture(const Model &M, const Hot &Wd, Cold &Cd, int b) {
+    const Shape &s = M.shape[shape_of_body(b)];
+    const Xf xf1 = xf_from(Cd.sweep_c0[b], Cd.sweep_a0[b], s.centroid), xf2 = body_xf(M, Wd.b[b], b);
+    const AABB a1 = poly_aabb(s, xf1), a2 = poly_aabb(s, xf2);
+    AABB a; a.lx = fminf(a1.lx, a2.lx); a.ly = fminf(a1.ly, a2.ly); a.hx = fmaxf(a1.hx, a2.hx); a.hy = fmaxf(a1.hy, a2.hy);
+    if (aabb_contains(body_fat(Cd, b), a)) return false;
+    AABB f = fatten(a);
+    const V2 d = AABB_MULTIPLIER * (xf2.p - xf1.p);   // predict AABB displacement
+    if (d.x < 0.0f) f.lx += d.x; else f.hx += d.x;
+    if (d.y < 0.0f) f.ly += d.y; else f.hy += d.y;
+    set_body_fat(Cd, b, f);
+    return true;
+}
+// b2ContactManager::FindNewContacts for body b's moved proxy against the terrain: a contact is created (e_enabledFlag set, no
+// points) for every edge whose fat AABB overlaps and that has none yet
+MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, uint32_t batch) {
+    const AABB fatb = body_fat(Cd, b);
+    int e0, e1;
+    edge_range(M, fatb.lx, fatb.hx, e0, e1);
+    Slot *slots = Cd.slot + M.slot_base[b];
+    const int cap = M.slot_cap[b];
+    for (int e = e0; e <= e1; ++e) {
+        if (!aabb_overlap(edge_fat_aabb(M, Cd, e), fatb)) continue;
+        Slot &sl = slots[e % cap];
+        if (sl.edge == e) continue;                    // the contact exists
+        if (sl.edge >= 0) { Wd.overflow = 1; continue; }  // more candidate edges than the body's cache holds (sticky flag): pair ignored
+        sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.toi_flags = 0; sl.toi_count = 0;
+    }
+}
+MW_HD void find_new_pair_contacts(const Model &M, Cold &Cd, uint32_t moved, uint32_t batch) {
+    for (int p = 0; p < M.n_dyn_pairs; ++p) {
+        const int bA = M.dyn_a[p], bB = M.dyn_b[p];
+        Slot &sl = Cd.slot[M.dyn_slot_base + p];
+        if (sl.edge >= 0 || !(((moved >> bA) | (moved >> bB)) & 1u)) continue;
+        if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) continue;
+        sl.edge = 0; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.toi_flags = 0; sl.toi_count = 0;
+    }
+}
+
+// ---------------------------------------------------------------- islands (b2World::Solve) and the level schedule
+// The key of the contact in slot `si` seen from anywhere (its place in the world list and in both bodies' edge lists).
+MW_HD uint64_t slot_key(const Model &M, const Cold &Cd, int si) {
+    const Slot &sl = Cd.slot[si];
+    if (si >= M.dyn_slot_base) { const int p = si - M.dyn_slot_base; return contact_key(sl.batch, proxy_of_body(M.dyn_a[p], M.NT), proxy_of_body(M.dyn_b[p], M.NT)); }
+    int b = 0;
+    while (b + 1 < M.NB && si >= M.slot_base[b + 1]) ++b;
+    return b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
+}
+// The next entry of body b's contact-edge list after the one with key `below` (newest first = descending key), among the contacts
+// that are touching and enabled and have a manifold; returns the slot index or -1.  (b2World::Solve: "for (b2ContactEdge* ce =
+// b->m_contactList; ce; ce = ce->next)".)
+MW_HD int next_contact_edge(const Model &M, const Cold &Cd, const uint8_t *slot_m, int b, uint64_t below, uint64_t &key_out) {
+    int best = -1;
+    uint64_t bk = 0;
+    const int base = M.slot_base[b], cap = M.slot_cap[b];
+    for (int k = 0; k < cap; ++k) {
+        const Slot &sl = Cd.slot[base + k];
+        if (sl.edge < 0 || !sl.touching || (sl.toi_flags & 2) || slot_m[base + k] == 255) continue;
+        const uint64_t key = b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
+        if (key < below && (best < 0 || key > bk)) { best = base + k; bk = key; }
+    }
+    if (b == 0 || is_hull(b))
+        for (int p = 0; p < M.n_dyn_pairs; ++p) {
+            if (M.dyn_a[p] != b && M.dyn_b[p] != b) continue;
+            const Slot &sl = Cd.slot[M.dyn_slot_base + p];
+            if (sl.edge < 0 || !sl.touching || (sl.toi_flags & 2) || slot_m[M.dyn_slot_base + p] == 255) continue;
+            const uint64_t key = contact_key(sl.batch, proxy_of_body(M.dyn_a[p], M.NT), proxy_of_body(M.dyn_b[p], M.NT));
+            if (key < below && (best < 0 || key > bk)) { best = M.dyn_slot_base + p; bk = key; }
+        }
+    key_out = bk;
+    return best;
+}
+
+// b2World::Solve's island construction, run by ONE lane: seeds in body-list order (last created body first), depth-first search
+// over contact edges then joint edges; the islands' joint and contact sequences are cut into levels (file header) and every body
+// gets the list of the manifolds it owns in ascending level.  A sleeping seed is skipped; every body reached is woken.
+MW_HD void build_islands(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, const uint8_t *slot_m) {
+    const int NB = M.NB, NW = M.W;
+    int8_t last_c[MAXB], last_j[MAXB];
+    uint32_t flag = 0;       // e_islandFlag of the bodies
+    uint32_t jflag = 0;      // of the joints
+    uint64_t cflag = 0;      // of the manifolds (pool index)
+    for (int b = 0; b < NB; ++b) { S.island_of[b] = -1; S.bm_cnt[b] = 0; last_c[b] = -1; last_j[b] = -1; }
+    for (int j = 0; j < 4 * NW; ++j) { S.j_level[j] = 255; S.j_island[j] = -1; }
+    int n_isl = 0, max_cl = -1, max_jl = -1;
+    int stack[MAXB + 2];
+    for (int s = 0; s < NB; ++s) {
+        const int seed = s < NB - 1 ? NB - 1 - s : 0;   // body list: the walkers' bodies newest first, (static terrain,) the package last
+        if ((flag >> seed) & 1u) continue;
+        if (!((Wd.awake >> seed) & 1u)) continue;
+        const int isl = n_isl++;
+        S.isl_done[isl] = 0; S.isl_pos_solved[isl] = 0;
+        int sp = 0;
+        stack[sp++] = seed;
+        flag |= 1u << seed;
+        while (sp > 0) {
+            const int b = stack[--sp];
+            S.island_of[b] = (int8_t)isl;
+            if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; }   // "make sure the body is awake"
+            uint64_t below = ~0ull, key;
+            for (int si = next_contact_edge(M, Cd, slot_m, b, below, key); si >= 0; si = next_contact_edge(M, Cd, slot_m, b, below, key)) {
+                below = key;
+                const int mi = slot_m[si];
+                if ((cflag >> mi) & 1ull) continue;     // already in an island (reached from its other body)
+                cflag |= 1ull << mi;
+                Manifold &m = S.m[mi];
+                m.island = (uint8_t)isl;
+                // list scheduling: this contact's level in the contact phase of a sweep
+                const int la = m.bA >= 0 ? last_c[m.bA] : -1, lb = last_c[m.bB];
+                const int lv = (la > lb ? la : lb) + 1;
+                S.m_level[mi] = (uint8_t)lv;
+                if (m.bA >= 0) last_c[m.bA] = (int8_t)lv;
+                last_c[m.bB] = (int8_t)lv;
+                if (lv > max_cl) max_cl = lv;
+                S.bm_idx[M.list_base[m.bB] + S.bm_cnt[m.bB]++] = (uint8_t)mi;   // owner: body B; appended in island order = ascending level
+                const int other = m.bB == b ? m.bA : m.bB;
+                if (other < 0) continue;                // static terrain: islands do not propagate across static bodies
+                if ((flag >> other) & 1u) continue;
+                stack[sp++] = other;
+                flag |= 1u << other;
+            }
+            if (b >= 1) {   // joint edges, newest first: hull [hip1, hip0]; upper leg [knee, hip]; lower leg [knee]
+                const int w = (b - 1) / 5, r = (b - 1) % 5;
+                int jl[2], nj;
+                if (r == 0) { jl[0] = 4 * w + 2; jl[1] = 4 * w; nj = 2; }
+                else if (r == 1 || r == 3) { jl[0] = 4 * w + (r - 1) + 1; jl[1] = 4 * w + (r - 1); nj = 2; }
+                else { jl[0] = 4 * w + (r - 2) + 1; nj = 1; }
+                for (int q = 0; q < nj; ++q) {
+                    const int ji = jl[q];
+                    if ((jflag >> ji) & 1u) continue;
+                    jflag |= 1u << ji;
+                    const int jA = M.jd[ji].bA, jB = M.jd[ji].bB;
+                    const int lv = (last_j[jA] > last_j[jB] ? last_j[jA] : last_j[jB]) + 1;
+                    S.j_level[ji] = (uint8_t)lv; S.j_island[ji] = (int8_t)isl;
+                    last_j[jA] = (int8_t)lv; last_j[jB] = (int8_t)lv;
+                    if (lv > max_jl) max_jl = lv;
+                    const int other = jA == b ? jB : jA;
+                    if ((flag >> other) & 1u) continue;
+                    stack[sp++] = other;
+                    flag |= 1u << other;
+                }
+            }
+        }
+    }
+    S.n_isl = (int8_t)n_isl; S.n_clevels = (int8_t)(max_cl + 1); S.n_jlevels = (int8_t)(max_jl + 1);
+    S.in_island = flag;
 }
 
 // ---------------------------------------------------------------- island solver (b2Island::Solve)
@@ -729,7 +1010,7 @@ MW_HD void contact_init_warm(Hot &Wd, Manifold &m, const MassAB &q) {
     Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = xf_from(Wd.b[m.bA].c, Wd.b[m.bA].a, q.lcA);
     const Xf xfB = xf_from(Wd.b[m.bB].c, Wd.b[m.bB].a, q.lcB);
     V2 normal, pts[2];  // b2WorldManifold::Initialize
-    if (m.type == 0) {
+    if ((m.type & 1) == 0) {
         normal = mul(xfA.q, m.local_normal);
         const V2 plane = mul(xfA, m.local_point);
         MW_UNROLL
@@ -958,18 +1239,19 @@ MW_HD float contact_solve_position(Hot &Wd, const Manifold &m, const MassAB &q) 
     V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
     float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a, aB = Wd.b[m.bB].a;
     const V2 lcA = q.lcA, lcB = q.lcB;
+    const int np = m.type >> 1;   // b2ContactPositionConstraint::pointCount = the manifold's
     MW_UNROLL
-    for (int i = 0; i < 2; ++i) if (i < m.npts) {
+    for (int i = 0; i < 2; ++i) if (i < np) {
         const Xf xfA = xf_from(cA, aA, lcA), xfB = xf_from(cB, aB, lcB);
         V2 normal, point; float sep;
-        if (m.type == 0) {
+        if ((m.type & 1) == 0) {
             normal = mul(xfA.q, m.local_normal);
             const V2 plane = mul(xfA, m.local_point), clip = mul(xfB, m.lp[i]);
-            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+            sep = (dot(clip - plane, normal) - POLY_RADIUS) - POLY_RADIUS; point = clip;  // - pc->radiusA - pc->radiusB
         } else {
             normal = mul(xfB.q, m.local_normal);
             const V2 plane = mul(xfB, m.local_point), clip = mul(xfA, m.lp[i]);
-            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+            sep = (dot(clip - plane, normal) - POLY_RADIUS) - POLY_RADIUS; point = clip;  // - pc->radiusA - pc->radiusB
             normal = -normal;
         }
         const V2 rA = point - cA, rB = point - cB;
@@ -1022,13 +1304,14 @@ MW_HD bool joint_solve_position(Hot &Wd, const JointCache &c) {
     return pos_err <= LINEAR_SLOP && ang_err <= ANGULAR_SLOP;
 }
 
+
 // ---------------------------------------------------------------- continuous pass (b2World::SolveTOI)
-// After the discrete solve Box2D looks, for every contact between a dynamic body and a static one (here: terrain edges; in
-// the known-answer scene the static ground box), for the first time in this step at which the two shapes come within
-// linearSlop of each other (multiwalker_toi.hpp), takes the earliest such event, moves the body back to that time, solves
-// a sub-step for the remaining time on a mini island (that body and its touching static contacts: 20 TOI position
-// iterations at Baumgarte 0.75, the step's velocity iterations without warm starting, integration) and repeats until no
-// event is left (at most 8 sub-steps per contact).  Joints take no part (b2Island::SolveTOI ignores them).
+// After the discrete solve Box2D looks, for every contact between an awake dynamic body and a static one (here: terrain edges),
+// for the first time in this step at which the two shapes come within linearSlop of each other (multiwalker_toi.hpp), takes the
+// earliest such event, moves the body back to that time, solves a sub-step for the remaining time on a mini island (that body and
+// its touching static contacts: 20 TOI position iterations at Baumgarte 0.75, the step's velocity iterations without warm starting,
+// integration) and repeats until no event is left (at most 8 sub-steps per contact).  Joints take no part (b2Island::SolveTOI
+// ignores them); two dynamic non-bullet bodies are never tested against each other.
 MW_HD void poly_aabb_at(const Shape &s, V2 c, float a, float &xmin, float &xmax, float &ymin, float &ymax) {
     const Xf t = xf_from(c, a, s.centroid);
     for (int i = 0; i < s.n; ++i) {
@@ -1048,12 +1331,24 @@ MW_HD Sweep sweep_of_body(const Model &M, const Hot &Wd, const Cold &Cd, int b) 
     s.c = Wd.b[b].c; s.a = Wd.b[b].a;
     return s;
 }
-// time of impact of body `bi` (dynamic) with terrain edge e, as b2World::SolveTOI computes it for one contact
-MW_HD float toi_alpha_terrain(const Model &M, const Hot &Wd, const Cold &Cd, int bi, int e, const Sweep &sB, float xmin, float xmax, float ymin, float ymax) {
-    const V2 p1 = v2(e * TERRAIN_STEP, Cd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
-    // conservative cull (never changes a result): the swept vertex box of the body, inflated by what TOI calls touching, misses the edge
-    const float m = 4.0f * LINEAR_SLOP;
-    if (xmin - m > p2.x || xmax + m < p1.x || ymin - m > fmaxf(p1.y, p2.y) || ymax + m < fminf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
+// the box a body's vertices stay in while it goes from (c0, a0) to (c, a): used to cull time-of-impact computations that cannot
+// report an event (never changes a result)
+struct SweptBox { float xmin, xmax, ymin, ymax; };
+MW_HD SweptBox swept_box(const Shape &sh, const Sweep &sB) {
+    SweptBox q; q.xmin = 3.0e38f; q.xmax = -3.0e38f; q.ymin = 3.0e38f; q.ymax = -3.0e38f;
+    poly_aabb_at(sh, sB.c0, sB.a0, q.xmin, q.xmax, q.ymin, q.ymax);
+    poly_aabb_at(sh, sB.c, sB.a, q.xmin, q.xmax, q.ymin, q.ymax);
+    float r2 = 0.0f;   // a vertex leaves the box of its two end poses by at most |r| (1 - cos(da / 2)) <= |r| da^2 / 8 in between
+    for (int i = 0; i < sh.n; ++i) { const V2 r = sh.v[i] - sh.centroid; r2 = fmaxf(r2, dot(r, r)); }
+    const float da = sB.a - sB.a0, mrg = sqrtf(r2) * da * da * 0.125f + LINEAR_SLOP;
+    q.xmin -= mrg; q.xmax += mrg; q.ymin -= mrg; q.ymax += mrg;
+    return q;
+}
+// time of impact of body `bi` with terrain edge e, as b2World::SolveTOI computes it for one contact
+MW_HD float toi_alpha_terrain(const Model &M, const Cold &Cd, int bi, int e, const Sweep &sB, const SweptBox &box) {
+    const V2 p1 = v2(M.tx[e], Cd.ty[e]), p2 = v2(M.tx[e + 1], Cd.ty[e + 1]);
+    const float m = 4.0f * LINEAR_SLOP;   // what the root finder calls touching, with margin
+    if (box.xmin - m > p2.x || box.xmax + m < p1.x || box.ymin - m > fmaxf(p1.y, p2.y) || box.ymax + m < fminf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
     MW_STAT(toi_full, 1);
     Proxy pA, pB;
     pA.n = 2; pA.v[0] = p1; pA.v[1] = p2;
@@ -1067,64 +1362,26 @@ MW_HD float toi_alpha_terrain(const Model &M, const Hot &Wd, const Cold &Cd, int
     const float alpha0 = sB.alpha0;
     return state == TOI_TOUCHING ? fminf(alpha0 + (1.0f - alpha0) * beta, 1.0f) : 1.0f;
 }
-// the same for dynamic pair p when one of its bodies is static (known-answer scene)
-MW_HD float toi_alpha_pair(const Model &M, const Hot &Wd, const Cold &Cd, int bA, int bB) {
-    Proxy pA, pB;
-    proxy_of_shape(pA, M.shape[shape_of_body(bA)]); proxy_of_shape(pB, M.shape[shape_of_body(bB)]);
-    Sweep sA = sweep_of_body(M, Wd, Cd, bA), sB = sweep_of_body(M, Wd, Cd, bB);
-    float alpha0 = sA.alpha0;
-    if (sA.alpha0 < sB.alpha0) { alpha0 = sB.alpha0; sweep_advance(sA, alpha0); }
-    else if (sB.alpha0 < sA.alpha0) { alpha0 = sA.alpha0; sweep_advance(sB, alpha0); }
-    float beta;
-    const int state = time_of_impact(beta, pA, sA, pB, sB);
-    return state == TOI_TOUCHING ? fminf(alpha0 + (1.0f - alpha0) * beta, 1.0f) : 1.0f;
-}
-// b2Contact::Update of a cached pair at the bodies' current poses: new manifold, impulses carried over by feature id,
-// Begin / EndContact; returns whether the pair touches.  bA < 0: terrain edge `sl.edge`.
-MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl, int bA, int bB, ManifoldOut &mo) {
-    mo.npts = 0;
-    const Shape &sB = M.shape[shape_of_body(bB)];
-    const Xf xfB = body_xf(M, Wd.b[bB], bB);
-    if (bA < 0) {
-        const int e = sl.edge;
-        const V2 p1 = v2(e * TERRAIN_STEP, Cd.ty[e]), p2 = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
-        const bool has0 = e > 0, has3 = e < M.NT - 2;
-        const V2 p0 = has0 ? v2((e - 1) * TERRAIN_STEP, Cd.ty[e - 1]) : p1;
-        const V2 p3 = has3 ? v2((e + 2) * TERRAIN_STEP, Cd.ty[e + 2]) : p2;
-        collide_edge_polygon(mo, p1, p2, sB, xfB, has0, p0, has3, p3);
-    } else {
-        collide_polygons(mo, M.shape[shape_of_body(bA)], body_xf(M, Wd.b[bA], bA), sB, xfB);
-    }
-    float ni[2] = {0, 0}, ti[2] = {0, 0};
-    for (int i = 0; i < mo.npts; ++i)
-        for (int k = 0; k < sl.npts; ++k)
-            if (sl.id[k] == mo.id[i]) { ni[i] = sl.ni[k]; ti[i] = sl.ti[k]; break; }
-    const bool touching = mo.npts > 0;
-    if (touching != (sl.touching != 0)) contact_event(M, Wd, bA, bB, touching);
-    sl.touching = touching; sl.npts = (uint8_t)mo.npts;
-    for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
-    return touching;
-}
 // b2ContactSolver::SolveTOIPositionConstraints for one manifold: only the TOI body (B; A is static) moves
 MW_HD float contact_solve_toi_position(Hot &Wd, const Manifold &m, const MassAB &q) {
     float min_sep = 0.0f;
     const float mB = q.mB, iB = q.iB;
-    const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c;
-    const float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a;
     V2 cB = Wd.b[m.bB].c;
     float aB = Wd.b[m.bB].a;
+    Xf xfA; xfA.p = v2(0, 0); xfA.q.s = 0.0f; xfA.q.c = 1.0f;
+    const int np = m.type >> 1;
     MW_UNROLL
-    for (int i = 0; i < 2; ++i) if (i < m.npts) {
-        const Xf xfA = xf_from(cA, aA, q.lcA), xfB = xf_from(cB, aB, q.lcB);
+    for (int i = 0; i < 2; ++i) if (i < np) {
+        const Xf xfB = xf_from(cB, aB, q.lcB);
         V2 normal, point; float sep;
-        if (m.type == 0) {
+        if ((m.type & 1) == 0) {
             normal = mul(xfA.q, m.local_normal);
             const V2 plane = mul(xfA, m.local_point), clip = mul(xfB, m.lp[i]);
-            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+            sep = (dot(clip - plane, normal) - POLY_RADIUS) - POLY_RADIUS; point = clip;  // - pc->radiusA - pc->radiusB
         } else {
             normal = mul(xfB.q, m.local_normal);
             const V2 plane = mul(xfB, m.local_point), clip = mul(xfA, m.lp[i]);
-            sep = dot(clip - plane, normal) - 2.0f * POLY_RADIUS; point = clip;
+            sep = (dot(clip - plane, normal) - POLY_RADIUS) - POLY_RADIUS; point = clip;  // - pc->radiusA - pc->radiusB
             normal = -normal;
         }
         const V2 rB = point - cB;
@@ -1143,118 +1400,85 @@ MW_HD float contact_solve_toi_position(Hot &Wd, const Manifold &m, const MassAB 
 constexpr int MAX_TOI_CONTACTS = 32;  // b2_maxTOIContacts
 constexpr int MAX_SUB_STEPS = 8;      // b2_maxSubSteps
 
-// (re)compute the invalidated times of impact of a body's terrain contacts and its earliest remaining event
-MW_HD void toi_refresh_body(const Model &M, const Hot &Wd, Cold &Cd, Scratch &S, int bi) {
-    const int base = M.slot_base[bi], cap = M.slot_cap[bi];
-    const Sweep sB = sweep_of_body(M, Wd, Cd, bi);
-    const Shape &sh = M.shape[shape_of_body(bi)];
-    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
-    poly_aabb_at(sh, sB.c0, sB.a0, xmin, xmax, ymin, ymax);
-    poly_aabb_at(sh, sB.c, sB.a, xmin, xmax, ymin, ymax);
-    {
-        float r2 = 0.0f;
-        for (int i = 0; i < sh.n; ++i) { const V2 r = sh.v[i] - sh.centroid; r2 = fmaxf(r2, dot(r, r)); }
-        const float da = sB.a - sB.a0, mrg = sqrtf(r2) * da * da * 0.125f + LINEAR_SLOP;
-        xmin -= mrg; xmax += mrg; ymin -= mrg; ymax += mrg;
-    }
-    float body_min = 1.0f;
+// the next terrain contact of body b after the one with key `below` in its contact-edge list (descending key), touching or not
+MW_HD int next_terrain_slot(const Model &M, const Cold &Cd, int b, uint64_t below, uint64_t &key_out) {
+    int best = -1;
+    uint64_t bk = 0;
+    const int base = M.slot_base[b], cap = M.slot_cap[b];
     for (int k = 0; k < cap; ++k) {
-        Slot &sl = Cd.slot[base + k];
-        if (sl.edge < 0 || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS) continue;
-        if (!(sl.toi_flags & 1)) {
-            Cd.slot_toi[base + k] = toi_alpha_terrain(M, Wd, Cd, bi, sl.edge, sB, xmin, xmax, ymin, ymax);
-            sl.toi_flags |= 1;
-        }
-        body_min = fminf(body_min, Cd.slot_toi[base + k]);
+        const Slot &sl = Cd.slot[base + k];
+        if (sl.edge < 0) continue;
+        const uint64_t key = b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
+        if (key < below && (best < 0 || key > bk)) { best = base + k; bk = key; }
     }
-    S.body_minsep[bi] = body_min;
+    key_out = bk;
+    return best;
+}
+// b2Contact::Update inside the continuous pass: events take effect at once, in call order (ContactDetector, :50-84)
+MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl, int b, ManifoldOut &mo) {
+    mo.npts = 0;
+    edge_polygon_manifold(M, Cd, sl.edge, M.shape[shape_of_body(b)], body_xf(M, Wd.b[b], b), mo);
+    const int ev = contact_update(sl, mo);
+    if (ev == 1) contact_begin_flags(Wd, -1, b);
+    if (ev != 0 && is_lower_leg(b)) set_ground_flag(Wd, b, ev == 1);
+    return sl.touching != 0;
 }
 
-// b2World::SolveTOI.  `par`: the TOI of every candidate is computed by the lane that owns the body; the event loop itself
-// (rare: a body arriving at the terrain within this step) runs on lane 0 of the env.
+// b2World::SolveTOI.  `par`: the first time of impact of every contact is computed by the lane that owns the body; the event loop
+// (a body arriving at the terrain within this step: about one event per three env-steps) runs on lane 0 of the env.
 template <class Par>
 MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, float h) {
     const int L0 = par.lane(), LN = par.n();
     const int NB = M.NB, NDP = M.n_dyn_pairs;
-    // ---- pass 0 (by body): candidate contacts over the swept box (SynchronizeFixtures + FindNewContacts of the previous
-    // step, done here where the sweep is known), flags reset, first time-of-impact of every contact
+    // ---- "if (m_stepComplete)": alpha0 = 0 for every body, every contact's cached TOI invalid and its sub-step count 0; then
+    // (by body) the first time of impact of every contact of an awake body with the terrain
     for (int bi = L0; bi < NB; bi += LN) {
-        const Shape &sh = M.shape[shape_of_body(bi)];
-        S.body_minsep[bi] = 1.0f;
-        if (sh.inv_mass == 0.0f) continue;  // static body
-        const Sweep sB = sweep_of_body(M, Wd, Cd, bi);
-        float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
-        poly_aabb_at(sh, sB.c0, sB.a0, xmin, xmax, ymin, ymax);
-        poly_aabb_at(sh, sB.c, sB.a, xmin, xmax, ymin, ymax);
-        {   // a vertex leaves the box of its two end poses by at most |r| (1 - cos(da / 2)) <= |r| da^2 / 8 in between
-            float r2 = 0.0f;
-            for (int i = 0; i < sh.n; ++i) { const V2 r = sh.v[i] - sh.centroid; r2 = fmaxf(r2, dot(r, r)); }
-            const float da = sB.a - sB.a0, mrg = sqrtf(r2) * da * da * 0.125f + LINEAR_SLOP;
-            xmin -= mrg; xmax += mrg; ymin -= mrg; ymax += mrg;
-        }
-        int e0 = (int)floorf((xmin - 0.1f) / TERRAIN_STEP), e1 = (int)floorf((xmax + 0.1f) / TERRAIN_STEP);  // b2_aabbExtension
-        if (e0 < 0) e0 = 0;
-        if (e1 > M.NT - 2) e1 = M.NT - 2;
+        Cd.sweep_alpha0[bi] = 0.0f;
         Slot *slots = Cd.slot + M.slot_base[bi];
         const int cap = M.slot_cap[bi];
-        for (int e = e0; e <= e1; ++e) {  // new candidates (not touching yet)
-            Slot &sl = slots[e % cap];
-            if (sl.edge < 0) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; }
-        }
-        float body_min = 1.0f;
+        const bool awake = (Wd.awake >> bi) & 1u;
+        const Shape &sh = M.shape[shape_of_body(bi)];
+        const Sweep sB = sweep_of_body(M, Wd, Cd, bi);
+        const SweptBox box = swept_box(sh, sB);
         for (int k = 0; k < cap; ++k) {
             Slot &sl = slots[k];
-            sl.toi_flags = 0; sl.toi_count = 0;
             if (sl.edge < 0) continue;
-            const float alpha = toi_alpha_terrain(M, Wd, Cd, bi, sl.edge, sB, xmin, xmax, ymin, ymax);
-            Cd.slot_toi[M.slot_base[bi] + k] = alpha;
-            sl.toi_flags = 1;
-            body_min = fminf(body_min, alpha);
+            sl.toi_flags &= (uint8_t)~1u; sl.toi_count = 0;
+            if (!awake || (sl.toi_flags & 2)) continue;   // a sleeping body against static terrain: no active body; disabled contact
+            Cd.slot_toi[M.slot_base[bi] + k] = toi_alpha_terrain(M, Cd, bi, sl.edge, sB, box);
+            sl.toi_flags |= 1;
         }
-        S.body_minsep[bi] = body_min;  // (the array is free after the position iterations) earliest event of this body
     }
-    for (int p = L0; p < NDP; p += LN) {
-        Slot &sl = Cd.slot[M.dyn_slot_base + p];
-        sl.toi_flags = 0; sl.toi_count = 0;
-        const int bA = M.dyn_a[p], bB = M.dyn_b[p];
-        const bool stA = M.shape[shape_of_body(bA)].inv_mass == 0.0f, stB = M.shape[shape_of_body(bB)].inv_mass == 0.0f;
-        if (stA == stB) continue;  // two dynamic (non-bullet) bodies: no continuous collision between them; two static: nothing moves
-        Cd.slot_toi[M.dyn_slot_base + p] = toi_alpha_pair(M, Wd, Cd, bA, bB);
-        sl.toi_flags = 1;
-    }
+    for (int p = L0; p < NDP; p += LN) { Slot &sl = Cd.slot[M.dyn_slot_base + p]; sl.toi_flags &= (uint8_t)~1u; sl.toi_count = 0; }
     par.sync();
     if (L0 != 0 || M.continuous == 2) { par.sync(); return; }   // continuous == 2: timing experiments only (candidates without events)
     // ---- event loop (lane 0)
-    for (int guard = 0; guard < 4 * MAX_TOI_CONTACTS; ++guard) {
-        // the earliest event: per-body minima are kept in LDS (pass 0 / the end of the previous sub-step), only the winning
-        // body's slots are looked at in HBM
-        int min_slot = -1, min_bA = 0, min_bB = 0;
+    for (int guard = 0; guard < 8 * MAX_TOI_CONTACTS; ++guard) {
+        // the contact with the smallest time of impact; among equal times the first of the world's contact list (largest key)
+        int min_slot = -1, mover = -1;
         float min_alpha = 1.0f;
-        int min_body = -1;
-        for (int bi = 0; bi < NB; ++bi) { const float a = S.body_minsep[bi]; if (a < min_alpha) { min_alpha = a; min_body = bi; } }
-        if (min_body >= 0) {
-            const int base = M.slot_base[min_body], cap = M.slot_cap[min_body];
-            float best = 1.0f;
+        uint64_t min_key = 0;
+        for (int bi = 0; bi < NB; ++bi) {
+            if (!((Wd.awake >> bi) & 1u)) continue;
+            const int base = M.slot_base[bi], cap = M.slot_cap[bi];
+            bool have_box = false;
+            Sweep sB; SweptBox box;
             for (int k = 0; k < cap; ++k) {
-                const Slot &sl = Cd.slot[base + k];
-                if (sl.edge < 0 || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS || !(sl.toi_flags & 1)) continue;
+                Slot &sl = Cd.slot[base + k];
+                if (sl.edge < 0 || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS) continue;
+                if (!(sl.toi_flags & 1)) {   // invalidated by a sub-step of this body: compute it on its new sweep
+                    if (!have_box) { sB = sweep_of_body(M, Wd, Cd, bi); box = swept_box(M.shape[shape_of_body(bi)], sB); have_box = true; }
+                    Cd.slot_toi[base + k] = toi_alpha_terrain(M, Cd, bi, sl.edge, sB, box);
+                    sl.toi_flags |= 1;
+                }
                 const float alpha = Cd.slot_toi[base + k];
-                if (alpha < best) { best = alpha; min_slot = base + k; min_bA = -1; min_bB = min_body; }
+                if (alpha > min_alpha) continue;
+                const uint64_t key = bi == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(bi, M.NT));
+                if (alpha < min_alpha || (min_slot >= 0 && key > min_key)) { min_alpha = alpha; min_slot = base + k; mover = bi; min_key = key; }
             }
-            min_alpha = best;
         }
-        for (int p = 0; p < NDP; ++p) {
-            Slot &sl = Cd.slot[M.dyn_slot_base + p];
-            const int bA = M.dyn_a[p], bB = M.dyn_b[p];
-            const bool stA = M.shape[shape_of_body(bA)].inv_mass == 0.0f, stB = M.shape[shape_of_body(bB)].inv_mass == 0.0f;
-            if (stA == stB || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS) continue;
-            if (!(sl.toi_flags & 1)) { Cd.slot_toi[M.dyn_slot_base + p] = toi_alpha_pair(M, Wd, Cd, bA, bB); sl.toi_flags |= 1; }
-            const float alpha = Cd.slot_toi[M.dyn_slot_base + p];
-            if (alpha < min_alpha) { min_alpha = alpha; min_slot = M.dyn_slot_base + p; min_bA = bA; min_bB = bB; }
-        }
-        if (min_slot < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha) break;
-        // ---- advance the moving body of the event to the time of impact (b2Body::Advance)
-        const int mover = (min_bA >= 0 && M.shape[shape_of_body(min_bB)].inv_mass == 0.0f) ? min_bA : min_bB;  // the dynamic one
+        if (min_slot < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha) break;   // no more TOI events
+        // ---- advance the body to the time of impact (b2Body::Advance); the static edge does not move
         const V2 bk_c0 = Cd.sweep_c0[mover], bk_c = Wd.b[mover].c;
         const float bk_a0 = Cd.sweep_a0[mover], bk_a = Wd.b[mover].a, bk_alpha0 = Cd.sweep_alpha0[mover];
         {
@@ -1265,66 +1489,55 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
         }
         Slot &ms = Cd.slot[min_slot];
         ManifoldOut mo;
-        const bool touching = toi_update_contact(M, Wd, Cd, ms, min_bA, min_bB, mo);
+        const bool touching = toi_update_contact(M, Wd, Cd, ms, mover, mo);   // the TOI contact likely has some new contact points
         ms.toi_flags &= (uint8_t)~1u;
         ms.toi_count = (uint8_t)(ms.toi_count + 1);
         MW_STAT(toi_events, 1);
-        if (!touching) {  // not solid after all: undo, and leave this contact alone for the rest of the step
+        if (!touching) {  // not solid after all: disable the contact, restore the sweep
             MW_STAT(toi_undone, 1);
             ms.toi_flags |= 2;
             Cd.sweep_c0[mover] = bk_c0; Cd.sweep_a0[mover] = bk_a0; Cd.sweep_alpha0[mover] = bk_alpha0;
             Wd.b[mover].c = bk_c; Wd.b[mover].a = bk_a;
-            toi_refresh_body(M, Wd, Cd, S, mover);
             continue;
         }
-        // ---- mini island: the event's contact and the mover's other touching contacts with static bodies
+        // ---- mini island: the event's contact, then the body's other contacts with static bodies in its contact-edge order, each
+        // updated at the time-of-impact pose and added when it touches
         int n_isl = 0;
-        auto add_manifold = [&](const ManifoldOut &o, int bA, int bB, int slot_index, float friction) {
-            if (n_isl >= MAX_TOI_CONTACTS || n_isl >= M.max_manifolds) return;
-            Manifold &m = S.m[n_isl++];
-            m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)o.npts; m.type = (uint8_t)o.type;
-            m.local_normal = o.local_normal; m.local_point = o.local_point;
-            for (int i = 0; i < 2; ++i) { m.lp[i] = i < o.npts ? o.lp[i] : v2(0, 0); m.ni[i] = 0.0f; m.ti[i] = 0.0f; }  // no warm starting
-            m.friction = friction;
-        };
         const Shape &msh = M.shape[shape_of_body(mover)];
-        if (min_bA < 0) add_manifold(mo, -1, mover, min_slot, sqrtf(FRICTION * msh.friction));
-        else add_manifold(mo, min_bA, min_bB, min_slot, sqrtf(M.shape[shape_of_body(min_bA)].friction * M.shape[shape_of_body(min_bB)].friction));
+        const float fr = sqrtf(FRICTION * msh.friction);
+        auto add_manifold = [&](const ManifoldOut &o, int slot_index) {
+            if (n_isl >= MAX_TOI_CONTACTS) return;
+            if (n_isl >= M.max_manifolds) { Wd.overflow = 1; return; }
+            Manifold &m = S.m[n_isl++];
+            m.bA = -1; m.bB = (int8_t)mover; m.slot = (int16_t)slot_index; m.npts = (uint8_t)o.npts; m.type = (uint8_t)(o.type | (o.npts << 1)); m.island = 0;
+            m.local_normal = o.local_normal; m.local_point = o.local_point;
+            for (int i = 0; i < 2; ++i) { m.lp[i] = i < o.npts ? o.lp[i] : v2(0, 0); m.ni[i] = 0.0f; m.ti[i] = 0.0f; }  // subStep.warmStarting = false
+            m.friction = fr;
+        };
+        add_manifold(mo, min_slot);
         {
-            const int base = M.slot_base[mover], cap = M.slot_cap[mover];
-            float mv_x0 = 3.0e38f, mv_x1 = -3.0e38f, mv_y0 = 3.0e38f, mv_y1 = -3.0e38f;
-            poly_aabb_at(msh, Wd.b[mover].c, Wd.b[mover].a, mv_x0, mv_x1, mv_y0, mv_y1);
-            for (int k = 0; k < cap; ++k) {
-                Slot &sl = Cd.slot[base + k];
-                if (base + k == min_slot || sl.edge < 0) continue;
-                if (!sl.touching) {  // an edge the body's box (at the time of impact) does not reach cannot start touching: nothing to update
-                    const float ex0 = sl.edge * TERRAIN_STEP, ex1 = (sl.edge + 1) * TERRAIN_STEP;
-                    const float ey0 = fminf(Cd.ty[sl.edge], Cd.ty[sl.edge + 1]), ey1 = fmaxf(Cd.ty[sl.edge], Cd.ty[sl.edge + 1]);
-                    const float mg = 4.0f * POLY_RADIUS;
-                    if (mv_x0 - mg > ex1 || mv_x1 + mg < ex0 || mv_y0 - mg > ey1 || mv_y1 + mg < ey0) continue;
-                }
+            uint64_t below = ~0ull, key;
+            for (int si = next_terrain_slot(M, Cd, mover, below, key); si >= 0; si = next_terrain_slot(M, Cd, mover, below, key)) {
+                below = key;
+                if (si == min_slot) continue;
+                if (n_isl >= MAX_TOI_CONTACTS) break;
                 ManifoldOut o2;
-                if (toi_update_contact(M, Wd, Cd, sl, -1, mover, o2)) add_manifold(o2, -1, mover, base + k, sqrtf(FRICTION * msh.friction));
+                if (toi_update_contact(M, Wd, Cd, Cd.slot[si], mover, o2)) add_manifold(o2, si);
             }
         }
         // ---- b2Island::SolveTOI
-        const MassAB qm = mass_of_pair(S, -1, mover);  // the static side carries no mass whichever slot it sits in
-        auto mass_for = [&](const Manifold &m) -> MassAB {
-            MassAB q = mass_of_pair(S, m.bA, m.bB);
-            if (m.bA >= 0 && m.bA != mover) { q.mA = 0.0f; q.iA = 0.0f; }
-            return q;
-        };
-        (void)qm;
-        for (int it = 0; it < 20; ++it) {
+        const MassAB qm = mass_of_pair(S, -1, mover);
+        for (int it = 0; it < 20; ++it) {   // subStep.positionIterations = 20
             float ms_min = 0.0f;
-            for (int k = 0; k < n_isl; ++k) {
-                const Manifold &m = S.m[k];
-                if (m.bB == mover) ms_min = fminf(ms_min, contact_solve_toi_position(Wd, m, mass_for(m)));
-            }
+            for (int k = 0; k < n_isl; ++k) ms_min = fminf(ms_min, contact_solve_toi_position(Wd, S.m[k], qm));
             if (ms_min >= -1.5f * LINEAR_SLOP) break;
         }
         Cd.sweep_c0[mover] = Wd.b[mover].c; Cd.sweep_a0[mover] = Wd.b[mover].a;  // "leap of faith to new safe state"
-        for (int k = 0; k < n_isl; ++k) contact_init_warm(Wd, S.m[k], mass_for(S.m[k]));  // impulses are zero: no warm start
+        {   // InitializeVelocityConstraints on velocities that stay untouched (impulses are zero: nothing to warm start)
+            const V2 v_keep = Wd.b[mover].v; const float w_keep = Wd.b[mover].w;
+            for (int k = 0; k < n_isl; ++k) contact_init_warm(Wd, S.m[k], qm);
+            Wd.b[mover].v = v_keep; Wd.b[mover].w = w_keep;
+        }
         {
             // Box2D runs all the step's velocity iterations; once a whole sweep leaves every accumulated impulse and the body's
             // velocity exactly unchanged, every further sweep is the same no-op, so stopping there changes no bit of the result.
@@ -1352,11 +1565,7 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
             };
             for (int it = 0; it < VEL_ITERS; ++it) {
                 MW_STAT(toi_vel_iters, 1);
-                for (int k = 0; k < n_isl; ++k) {
-                    Manifold &m = S.m[k];
-                    if (m.bB == mover) contact_solve_velocity_on(m, mass_for(m), vA, wA, vB, wB);
-                    else { V2 z = v2(0, 0); float zw = 0.0f; contact_solve_velocity_on(m, mass_for(m), vB, wB, z, zw); }  // the mover is body A (known-answer scene only)
-                }
+                for (int k = 0; k < n_isl; ++k) contact_solve_velocity_on(S.m[k], qm, vA, wA, vB, wB);
                 if (!track) { if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1); continue; }
                 float cur[NST];
                 snapshot(cur);
@@ -1389,217 +1598,164 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
             b.c = b.c + hs * b.v;
             b.a += hs * b.w;
         }
-        // the displaced body's cached times of impact are stale; its candidate set follows its new sweep (FindNewContacts)
+        // ---- the displaced body: SynchronizeFixtures, every one of its contacts loses its cached time of impact, FindNewContacts
         {
+            const bool moved = sync_fixture(M, Wd, Cd, mover);
             const int base = M.slot_base[mover], cap = M.slot_cap[mover];
             for (int k = 0; k < cap; ++k) Cd.slot[base + k].toi_flags &= (uint8_t)~1u;
-            float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
-            poly_aabb_at(msh, Cd.sweep_c0[mover], Cd.sweep_a0[mover], xmin, xmax, ymin, ymax);
-            poly_aabb_at(msh, Wd.b[mover].c, Wd.b[mover].a, xmin, xmax, ymin, ymax);
-            int e0 = (int)floorf((xmin - 0.1f) / TERRAIN_STEP), e1 = (int)floorf((xmax + 0.1f) / TERRAIN_STEP);
-            if (e0 < 0) e0 = 0;
-            if (e1 > M.NT - 2) e1 = M.NT - 2;
-            for (int e = e0; e <= e1; ++e) {
-                Slot &sl = Cd.slot[base + e % cap];
-                if (sl.edge < 0) { sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.toi_flags = 0; sl.toi_count = 0; }
-            }
             for (int p = 0; p < NDP; ++p) if (M.dyn_a[p] == mover || M.dyn_b[p] == mover) Cd.slot[M.dyn_slot_base + p].toi_flags &= (uint8_t)~1u;
-            toi_refresh_body(M, Wd, Cd, S, mover);
+            Wd.batch += 1;
+            if (moved) {
+                find_new_terrain_contacts(M, Wd, Cd, mover, Wd.batch);
+                find_new_pair_contacts(M, Cd, 1u << mover, Wd.batch);
+            }
         }
     }
     par.sync();
 }
 
 // b2World::Step(1/50, 180, 60) for the lanes of `par`.
-//
-// Schedule of one Gauss-Seidel sweep (Box2D: all joints in creation order, then all contacts):
-//   joints   three slots.  A walker's joints in creation order are hip0, knee0, hip1, knee1; hip0 -> knee0 share the
-//            upper leg, hip0 -> hip1 the hull, hip1 -> knee1 the other upper leg, while knee0 and hip1 share nothing.
-//            One lane per JOINT: slot 0 = hip0, slot 1 = knee0 | hip1, slot 2 = knee1, i.e. joint 4 w + 2 s + r (leg s,
-//            r = 0 hip / 1 knee) runs in slot s + r; the three slots are one loop over the same lane-private JointCache.
-//   contacts sub-slot i = the i-th terrain manifold of every body (by lane) and, while neither the package nor a hull
-//            touches the terrain (`merge_ok`), the i-th active package-hull / hull-hull pair, solved by the lane that
-//            owns the pair's second body -- leg-terrain and package-hull constraints share no body.  Otherwise the
-//            dynamic pairs follow in sub-slots of their own, exactly the serial order.
 template <class Par>
 MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     const float h = 1.0f / FPS;
     const int L0 = par.lane(), LN = par.n();
     // the model scalars are read once: the solver loops below must not go back to memory for them
-    const int NB = M.NB, NW = M.W, NDP = M.n_dyn_pairs, MAXMAN = M.max_manifolds;
-    const int NODES = NW + 1;  // island graph nodes: walkers, then the package
-    // lane-private constants of the bodies this lane owns (bi = L0 + kb * LN): manifold-list base, mass data, island node
-    int own_sb[Par::BODIES], own_node[Par::BODIES];
-    MassAB own_q[Par::BODIES];   // as body B of a terrain contact (A = terrain: zeros)
+    const int NB = M.NB, NW = M.W, NDP = M.n_dyn_pairs;
+    // lane-private constants of the bodies this lane owns (bi = L0 + kb * LN): manifold-list base, mass data
+    int own_lb[Par::BODIES];
+    MassAB own_q[Par::BODIES];   // as body B of a contact with the terrain (A: zeros)
     MW_UNROLL
     for (int kb = 0; kb < Par::BODIES; ++kb) {
         const int bi = L0 + kb * LN;
-        own_sb[kb] = 0; own_node[kb] = 0;
+        own_lb[kb] = 0;
         own_q[kb].mA = 0.0f; own_q[kb].iA = 0.0f; own_q[kb].lcA = v2(0, 0); own_q[kb].mB = 0.0f; own_q[kb].iB = 0.0f; own_q[kb].lcB = v2(0, 0);
         if (bi >= NB) continue;
         const Shape &sh = M.shape[shape_of_body(bi)];
         own_q[kb].mB = sh.inv_mass; own_q[kb].iB = sh.inv_I; own_q[kb].lcB = sh.centroid;
-        own_node[kb] = node_of(bi, NW);
-        own_sb[kb] = M.slot_base[bi];
+        own_lb[kb] = M.list_base[bi];
     }
     for (int sh = L0; sh < N_SHAPES; sh += LN) { S.sh_im[sh] = M.shape[sh].inv_mass; S.sh_ii[sh] = M.shape[sh].inv_I; S.sh_lc[sh] = M.shape[sh].centroid; }
-    if (L0 == 0) S.nm = 0;
+    if (L0 == 0) { S.nm = 0; S.moved = 0; }
     par.sync();
-    // ---- Collide: terrain candidates by body, then the dynamic pairs
-    for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi);
+    // ---- b2ContactManager::Collide: every contact is updated (D4); Begin / EndContact -> ContactDetector flags
+    for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi, S.slot_m);
     par.sync();
-    for (int p = L0; p < NDP; p += LN) collide_dyn_pair(M, Wd, Cd, S, par, p);
+    if (L0 == 0) for (int p = 0; p < NDP; ++p) collide_dyn_pair(M, Wd, Cd, S, par, p, S.slot_m);   // may wake bodies: one lane
     par.sync();
-    if (L0 == 0) {  // islands: walkers (+ package) joined by touching hull-hull / hull-package contacts; contact schedule
-        for (int i = 0; i < NODES; ++i) { S.comp[i] = (int8_t)i; S.isl_done[i] = 0; }
-        int nd = 0;
-        for (int p = 0; p < NDP; ++p) {
-            if (S.dyn_midx[p] < 0) continue;
-            S.dyn_owner[nd] = (int8_t)M.dyn_b[p]; S.dyn_man[nd] = S.dyn_midx[p]; S.dyn_a_shape[nd] = (int8_t)shape_of_body(M.dyn_a[p]);
-            S.dyn_list[nd++] = (int8_t)p;
-            const int ca = S.comp[node_of(M.dyn_a[p], NW)], cb = S.comp[node_of(M.dyn_b[p], NW)];
-            if (ca != cb) for (int i = 0; i < NODES; ++i) if (S.comp[i] == cb) S.comp[i] = (int8_t)ca;
-        }
-        S.n_dyn = (int8_t)nd;
-        int mc = 0;
-        bool merge = S.bm_cnt[0] == 0;
-        for (int bi = 0; bi < NB; ++bi) {
-            if (S.bm_cnt[bi] > mc) mc = S.bm_cnt[bi];
-            if (bi >= 1 && (bi - 1) % 5 == 0 && S.bm_cnt[bi] != 0) merge = false;
-        }
-        S.max_cnt = (int8_t)mc; S.merge_ok = merge ? 1 : 0;
-    }
-    // ---- integrate velocities (gravity + the pending initial push)
+    // ---- b2World::Solve: islands, constraint order and levels (one lane)
+    if (L0 == 0) build_islands(M, Wd, Cd, S, S.slot_m);
+    par.sync();
+    const int n_jl = S.n_jlevels, n_cl = S.n_clevels;
+    // ---- integrate velocities (gravity + the pending initial push) of the bodies of this step's islands
     MW_UNROLL
     for (int kb = 0; kb < Par::BODIES; ++kb) {
         const int bi = L0 + kb * LN;
-        if (bi >= NB) continue;
+        if (bi >= NB || S.island_of[bi] < 0) continue;
         Body &b = Wd.b[bi];
+        Cd.sweep_c0[bi] = b.c; Cd.sweep_a0[bi] = b.a;   // b2Island::Solve: "store positions for continuous collision"
         float fx = 0.0f;
-        if (bi >= 1 && (bi - 1) % 5 == 0) { const int w = (bi - 1) / 5; fx = Wd.push_x[w]; }
+        if (is_hull(bi)) fx = Wd.push_x[(bi - 1) / 5];
         const float im = own_q[kb].mB;
-        if (im == 0.0f) continue;  // static body (b2Island::Solve integrates dynamic bodies only); the env has none
-        b.v.x += h * (im * fx);
+        b.v.x += h * (GRAVITY_Y * 0.0f + im * fx);
         b.v.y += h * (GRAVITY_Y + im * 0.0f);
-        // linear/angular damping are 0: v *= 1/(1 + h*0)
+        // linear / angular damping are 0: v *= 1 / (1 + h * 0)
     }
     par.sync();
-    for (int w = L0; w < NW; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces
-    const int n_dyn = S.n_dyn;
-    const int nsubA = S.merge_ok ? (S.max_cnt > n_dyn ? S.max_cnt : n_dyn) : S.max_cnt;
-    const int nsubB = S.merge_ok ? 0 : n_dyn;
-    const bool merge_ok = S.merge_ok != 0;
-    MW_STAT(steps, 1); MW_STAT(sub_a, nsubA); MW_STAT(sub_b, nsubB); MW_STAT(manifolds, S.nm); MW_STAT(merged, merge_ok ? 1 : 0);
-    // One contact sweep.  F_TERRAIN / F_DYN are statements over the manifold `m_`, the body `bi` (F_DYN also the pair `p_`).
-    // MC: on the GPU every lane keeps ONE manifold of its first body in registers for the whole step -- its first terrain
-    // manifold, or (a hull, while merge_ok) its package / hull pair -- so the common sub-slot needs no LDS look-ups.
-    Manifold MC;
-    int mc_idx = -1;
-#define MW_MANIFOLD_DO(K_, F_) { const int k_ = (K_); if (Par::MCACHE && k_ == mc_idx) { Manifold &m_ = MC; F_; } else { Manifold &m_ = S.m[k_]; F_; } }
-    /* a dynamic pair: B = this lane's body, A = the package (pair package-hull) or another hull */                            \
-#define MW_DYN_MASS MassAB q_ = own_q[kb]; { const int sa_ = S.dyn_a_shape[i]; q_.mA = S.sh_im[sa_]; q_.iA = S.sh_ii[sa_]; q_.lcA = S.sh_lc[sa_]; }
-#define MW_CONTACT_SWEEP(F_TERRAIN, F_DYN)                                                                   \
-    for (int i = 0; i < nsubA; ++i) {                                                                        \
-        const int dyn_own_ = (merge_ok && i < n_dyn) ? S.dyn_owner[i] : -1;                                  \
-        MW_UNROLL                                                                                            \
-        for (int kb = 0; kb < Par::BODIES; ++kb) {                                                           \
-            const int bi = L0 + kb * LN;                                                                     \
-            if (bi >= NB) continue;                                                                          \
-            if (i < S.bm_cnt[bi]) { const MassAB &q_ = own_q[kb]; MW_MANIFOLD_DO(S.bm_idx[own_sb[kb] + i], F_TERRAIN) } \
-            if (dyn_own_ == bi) { const int p_ = S.dyn_list[i]; (void)p_; MW_DYN_MASS MW_MANIFOLD_DO(S.dyn_man[i], F_DYN) } \
-        }                                                                                                    \
-        par.sync();                                                                                          \
-    }                                                                                                        \
-    for (int i = 0; i < nsubB; ++i) {                                                                        \
-        const int dyn_own_ = S.dyn_owner[i];                                                                 \
-        MW_UNROLL                                                                                            \
-        for (int kb = 0; kb < Par::BODIES; ++kb) {                                                           \
-            const int bi = L0 + kb * LN;                                                                     \
-            if (bi < NB && dyn_own_ == bi) { const int p_ = S.dyn_list[i]; (void)p_; MW_DYN_MASS MW_MANIFOLD_DO(S.dyn_man[i], F_DYN) } \
-        }                                                                                                    \
-        par.sync();                                                                                          \
+    for (int w = L0; w < NW; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces (at the end of Step; nothing reads it in between)
+    MW_STAT(steps, 1); MW_STAT(sub_a, n_cl); MW_STAT(sub_b, n_jl); MW_STAT(manifolds, S.nm);
+    // One contact sweep: level by level, every lane walks the (ascending-level) lists of the bodies it owns.  F_ is a statement
+    // over the manifold `m_`, its mass data `q_` and the owning body `bi`.
+#define MW_CONTACT_SWEEP(F_)                                                                                  \
+    {                                                                                                         \
+        int ptr_[Par::BODIES];                                                                                \
+        MW_UNROLL                                                                                             \
+        for (int kb = 0; kb < Par::BODIES; ++kb) ptr_[kb] = 0;                                                \
+        for (int lv_ = 0; lv_ < n_cl; ++lv_) {                                                                \
+            MW_UNROLL                                                                                         \
+            for (int kb = 0; kb < Par::BODIES; ++kb) {                                                        \
+                const int bi = L0 + kb * LN;                                                                  \
+                if (bi >= NB || ptr_[kb] >= S.bm_cnt[bi]) continue;                                           \
+                const int k_ = S.bm_idx[own_lb[kb] + ptr_[kb]];                                               \
+                if (S.m_level[k_] != lv_) continue;                                                           \
+                ++ptr_[kb];                                                                                   \
+                Manifold &m_ = S.m[k_];                                                                       \
+                MassAB q_ = own_q[kb];                                                                        \
+                if (m_.bA >= 0) { const int sa_ = shape_of_body(m_.bA); q_.mA = S.sh_im[sa_]; q_.iA = S.sh_ii[sa_]; q_.lcA = S.sh_lc[sa_]; } \
+                F_;                                                                                           \
+            }                                                                                                 \
+            par.sync();                                                                                       \
+        }                                                                                                     \
     }
-    // ---- contact constraints: init + warm start
-    MW_CONTACT_SWEEP(contact_init_warm(Wd, m_, q_), contact_init_warm(Wd, m_, q_))
-    if (Par::MCACHE && L0 < NB) {
-        if (S.bm_cnt[L0] > 0) mc_idx = S.bm_idx[own_sb[0]];
-        else if (merge_ok) { for (int i = 0; i < n_dyn; ++i) if (S.dyn_owner[i] == L0) { mc_idx = S.dyn_man[i]; break; } }
-        if (mc_idx >= 0) MC = S.m[mc_idx];
-    }
-    // ---- joints: init + warm start, in the three-slot order
+    // ---- contact constraints: b2ContactSolver::InitializeVelocityConstraints + WarmStart, in the island's order
+    MW_CONTACT_SWEEP(contact_init_warm(Wd, m_, q_))
+    // ---- joints: InitVelocityConstraints (+ warm start), one lane per joint, level by level
     JointCache JC[Par::JOINTS];
-    int jslot[Par::JOINTS];
+    int jlv[Par::JOINTS];
     MW_UNROLL
-    for (int kq = 0; kq < Par::JOINTS; ++kq) { const int ji = L0 + kq * LN; jslot[kq] = ji < 4 * NW ? ((ji >> 1) & 1) + (ji & 1) : -1; }
-    for (int t = 0; t < 3; ++t) {
+    for (int kq = 0; kq < Par::JOINTS; ++kq) { const int ji = L0 + kq * LN; jlv[kq] = (ji < 4 * NW && S.j_level[ji] != 255) ? S.j_level[ji] : -1; }
+    for (int t = 0; t < n_jl; ++t) {
         MW_UNROLL
         for (int kq = 0; kq < Par::JOINTS; ++kq)
-            if (jslot[kq] == t) joint_init_warm(M, Wd, Cd, S, L0 + kq * LN, h, JC[kq]);
+            if (jlv[kq] == t) joint_init_warm(M, Wd, Cd, S, L0 + kq * LN, h, JC[kq]);
         par.sync();
     }
-    // ---- velocity iterations (islands are disjoint, so iterating them together changes nothing)
+    // ---- velocity iterations: all joints of an island, then all its contacts (islands are disjoint, so iterating them together
+    // changes nothing)
     for (int it = 0; it < VEL_ITERS; ++it) {
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < n_jl; ++t) {
             MW_UNROLL
             for (int kq = 0; kq < Par::JOINTS; ++kq)
-                if (jslot[kq] == t) joint_solve_velocity(Wd, JC[kq]);
+                if (jlv[kq] == t) joint_solve_velocity(Wd, JC[kq]);
             par.sync();
         }
-        MW_CONTACT_SWEEP(contact_solve_velocity(Wd, m_, q_), contact_solve_velocity(Wd, m_, q_))
+        MW_CONTACT_SWEEP(contact_solve_velocity(Wd, m_, q_))
     }
-    if (Par::MCACHE && mc_idx >= 0) { S.m[mc_idx].ni[0] = MC.ni[0]; S.m[mc_idx].ni[1] = MC.ni[1]; S.m[mc_idx].ti[0] = MC.ti[0]; S.m[mc_idx].ti[1] = MC.ti[1]; }
     // the accumulated joint impulses and limit states go back to the world (warm start of the next step)
     MW_UNROLL
     for (int kq = 0; kq < Par::JOINTS; ++kq) {
-        if (jslot[kq] < 0) continue;
+        if (jlv[kq] < 0) continue;
         Joint &j = Cd.j[L0 + kq * LN];
         j.ix = JC[kq].ix; j.iy = JC[kq].iy; j.iz = JC[kq].iz; j.motor_impulse = JC[kq].motor_impulse; j.limit_state = JC[kq].limit_state;
     }
     // ---- integrate positions
     for (int bi = L0; bi < NB; bi += LN) {
+        if (S.island_of[bi] < 0) continue;
         Body &b = Wd.b[bi];
         V2 tr = h * b.v;
         if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) { const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr)); b.v = ratio * b.v; }
         const float ro = h * b.w;
         if (ro * ro > MAX_ROTATION * MAX_ROTATION) { const float ratio = MAX_ROTATION / fabsf(ro); b.w *= ratio; }
-        Cd.sweep_c0[bi] = b.c; Cd.sweep_a0[bi] = b.a; Cd.sweep_alpha0[bi] = 0.0f;  // b2Island::Solve: sweep.c0 / a0 = the pose at the start of the step
         b.c = b.c + h * b.v;
         b.a += h * b.w;
     }
     par.sync();
-    // ---- position iterations, each island stops on its own (b2Island::Solve early exit)
+    // ---- position iterations: contacts then joints; each island stops on its own (b2Island::Solve early exit)
+    const int n_isl = S.n_isl;
     for (int it = 0; it < POS_ITERS; ++it) {
         MW_STAT(pos_iters, 1);
         for (int bi = L0; bi < NB; bi += LN) S.body_minsep[bi] = 0.0f;
-        for (int p = L0; p < NDYN; p += LN) S.dyn_minsep[p] = 0.0f;
+        for (int j = L0; j < 4 * NW; j += LN) S.joint_ok[j] = 1;
         par.sync();
-        MW_CONTACT_SWEEP(
-            if (!S.isl_done[S.comp[own_node[kb]]]) S.body_minsep[bi] = fminf(S.body_minsep[bi], contact_solve_position(Wd, m_, q_)),
-            if (!S.isl_done[S.comp[own_node[kb]]]) S.dyn_minsep[p_] = contact_solve_position(Wd, m_, q_))
-        for (int w = L0; w < NW; w += LN) S.walker_ok[w] = 1;
-        par.sync();
-        for (int t = 0; t < 3; ++t) {
+        MW_CONTACT_SWEEP(if (!S.isl_done[m_.island]) S.body_minsep[bi] = fminf(S.body_minsep[bi], contact_solve_position(Wd, m_, q_)))
+        for (int t = 0; t < n_jl; ++t) {
             MW_UNROLL
             for (int kq = 0; kq < Par::JOINTS; ++kq) {
-                if (jslot[kq] != t) continue;
-                const int w = (L0 + kq * LN) >> 2;
-                if (S.isl_done[S.comp[w]]) continue;
-                if (!joint_solve_position(Wd, JC[kq])) S.walker_ok[w] = 0;
+                if (jlv[kq] != t) continue;
+                const int ji = L0 + kq * LN;
+                if (S.isl_done[S.j_island[ji]]) continue;
+                if (!joint_solve_position(Wd, JC[kq])) S.joint_ok[ji] = 0;
             }
             par.sync();
         }
         if (L0 == 0) {
             bool all_done = true;
-            for (int c = 0; c < NODES; ++c) {
-                bool any = false;
-                for (int i = 0; i < NODES; ++i) any |= (S.comp[i] == c);
-                if (!any || S.isl_done[c]) continue;
+            for (int c = 0; c < n_isl; ++c) {
+                if (S.isl_done[c]) continue;
                 float ms = 0.0f;
                 bool jok = true;
-                for (int bi = 0; bi < NB; ++bi) if (S.comp[node_of(bi, NW)] == c) ms = fminf(ms, S.body_minsep[bi]);
-                for (int i = 0; i < n_dyn; ++i) if (S.comp[node_of(S.dyn_owner[i], NW)] == c) ms = fminf(ms, S.dyn_minsep[S.dyn_list[i]]);
-                for (int w = 0; w < NW; ++w) if (S.comp[w] == c) jok = jok && S.walker_ok[w];
-                if (ms >= -3.0f * LINEAR_SLOP && jok) S.isl_done[c] = 1;
+                for (int bi = 0; bi < NB; ++bi) if (S.island_of[bi] == c) ms = fminf(ms, S.body_minsep[bi]);
+                for (int j = 0; j < 4 * NW; ++j) if (S.j_island[j] == c) jok = jok && S.joint_ok[j];
+                if (ms >= -3.0f * LINEAR_SLOP && jok) { S.isl_done[c] = 1; S.isl_pos_solved[c] = 1; }
                 else all_done = false;
             }
             S.all_done = all_done ? 1 : 0;
@@ -1608,33 +1764,66 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
         if (S.all_done) break;
     }
     par.sync();
-    // b2ContactSolver::StoreImpulses -> manifold cache (warm start of the next step)
-    const int nm = S.nm < MAXMAN ? S.nm : MAXMAN;
+    // b2ContactSolver::StoreImpulses -> the contacts (warm start of the next step)
+    const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
     for (int k = L0; k < nm; k += LN) {
         const Manifold &m = S.m[k];
         Slot &sl = Cd.slot[m.slot];
         for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
     }
+    // ---- sleeping (b2Island::Solve, allowSleep): an island whose slowest-to-rest body has been below the tolerances for half a
+    // second, and whose position constraints were solved, goes to sleep: velocities zeroed, awake flags cleared
+    if (L0 == 0) {
+        for (int c = 0; c < n_isl; ++c) {
+            float min_sleep = 3.402823466e+38f;
+            for (int bi = 0; bi < NB; ++bi) {
+                if (S.island_of[bi] != c) continue;
+                const Body &b = Wd.b[bi];
+                if (b.w * b.w > ANGULAR_SLEEP_TOLERANCE * ANGULAR_SLEEP_TOLERANCE || dot(b.v, b.v) > LINEAR_SLEEP_TOLERANCE * LINEAR_SLEEP_TOLERANCE) {
+                    Cd.sleep_time[bi] = 0.0f; min_sleep = 0.0f;
+                } else {
+                    Cd.sleep_time[bi] += h;
+                    min_sleep = fminf(min_sleep, Cd.sleep_time[bi]);
+                }
+            }
+            if (min_sleep >= TIME_TO_SLEEP && S.isl_pos_solved[c])
+                for (int bi = 0; bi < NB; ++bi) {
+                    if (S.island_of[bi] != c) continue;
+                    Wd.awake &= ~(1u << bi); Cd.sleep_time[bi] = 0.0f;
+                    Wd.b[bi].v = v2(0, 0); Wd.b[bi].w = 0.0f;
+                }
+        }
+        Wd.batch += 1;   // this step's FindNewContacts call
+    }
+    par.sync();
+    // ---- SynchronizeFixtures of the simulated bodies, then FindNewContacts for the proxies that moved
+    {
+        uint32_t mv = 0;
+        for (int bi = L0; bi < NB; bi += LN)
+            if (S.island_of[bi] >= 0 && sync_fixture(M, Wd, Cd, bi)) { mv |= 1u << bi; find_new_terrain_contacts(M, Wd, Cd, bi, Wd.batch); }
+        if (mv) par.or_bits(&S.moved, mv);
+    }
+    par.sync();
+    if (L0 == 0 && S.moved) find_new_pair_contacts(M, Cd, S.moved, Wd.batch);
     par.sync();
     // ---- continuous pass (b2World::Step: "if (m_continuousPhysics && step.dt > 0) SolveTOI(step)")
     if (M.continuous) solve_toi(M, Wd, Cd, S, par, h);
 }
 #undef MW_CONTACT_SWEEP
-#undef MW_MANIFOLD_DO
-#undef MW_DYN_MASS
 
-// ---------------------------------------------------------------- lidar: b2EdgeShape::RayCast over the terrain
+
+// ---------------------------------------------------------------- lidar: b2World::RayCast -> b2EdgeShape::RayCast over the terrain, closest hit (D2)
 MW_HD float lidar_fraction(const Model &M, const Cold &Cd, V2 p1, V2 p2) {
     const V2 d = p2 - p1;
     float best = 1.0f;  // LidarCallback.fraction starts at 1.0 (:210)
-    int e0 = (int)floorf(fminf(p1.x, p2.x) / TERRAIN_STEP), e1 = (int)floorf(fmaxf(p1.x, p2.x) / TERRAIN_STEP);
+    int e0 = (int)floorf(fminf(p1.x, p2.x) / TERRAIN_STEP) - 1, e1 = (int)floorf(fmaxf(p1.x, p2.x) / TERRAIN_STEP) + 1;
     if (e0 < 0) e0 = 0;
     if (e1 > M.NT - 2) e1 = M.NT - 2;
     for (int e = e0; e <= e1; ++e) {
-        const V2 v1 = v2(e * TERRAIN_STEP, Cd.ty[e]), v2e = v2((e + 1) * TERRAIN_STEP, Cd.ty[e + 1]);
+        const V2 v1 = v2(M.tx[e], Cd.ty[e]), v2e = v2(M.tx[e + 1], Cd.ty[e + 1]);
         const V2 ee = v2e - v1;
         V2 normal = v2(ee.y, -ee.x);
-        { const float len = sqrtf(dot(normal, normal)); normal = (1.0f / len) * normal; }
+        { const float inv = 1.0f / sqrtf(dot(normal, normal)); normal.x *= inv; normal.y *= inv; }
         const float num = dot(normal, v1 - p1), den = dot(normal, d);
         if (den == 0.0f) continue;
         const float t = num / den;
@@ -1669,31 +1858,33 @@ MW_HD void philox10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
 }
 enum : uint32_t { TAG_MW_TERRAIN = 32, TAG_MW_PUSH = 33, TAG_MW_NOISE = 34 };
 MW_HD float u24f(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+MW_HD double u24d(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 
 MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done);
 
-// MultiWalkerEnv.reset (:330-357) without its trailing step
-MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, uint32_t gid) {
+// MultiWalkerEnv.reset (:330-357) without its trailing step: a fresh b2World (D1) with the package, the terrain edges and the
+// walkers created in the reference's order.  terrain_in (NT float64 heights) / push_in (W float64) replace the Philox draws (D3).
+MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, uint32_t gid, const double *terrain_in = nullptr, const double *push_in = nullptr) {
     const uint32_t tick = Wd.tick;
-    Wd.game_over = 0; Wd.prev_package_shaping = 0.0f; Wd.t = 0;
-    for (int w = 0; w < M.W; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0f; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
-    for (int k = 0; k < MAXSLOT; ++k) { Cd.slot[k].edge = -1; Cd.slot[k].npts = 0; Cd.slot[k].touching = 0; }
-    // _generate_terrain, non-hardcore branch (:516-612)
+    Wd.game_over = 0; Wd.overflow = 0; Wd.prev_package_shaping = 0.0; Wd.t = 0;
+    for (int w = 0; w < MAX_WALKERS; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
+    for (int k = 0; k < MAXSLOT; ++k) { Slot &sl = Cd.slot[k]; sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.batch = 0; sl.toi_flags = 0; sl.toi_count = 0; }
+    // _generate_terrain, non-hardcore branch (:516-612): float64 like the reference's Python loop, float32 when it enters Box2D
     {
-        float velocity = 0.0f, y = TERRAIN_HEIGHT;
+        double velocity = 0.0, y = TERRAIN_HEIGHT64;
         int counter = TERRAIN_STARTPAD;
         bool oneshot = false;
         for (int i = 0; i < M.NT; ++i) {
             uint32_t r[4];
             philox10(gid, tick, (uint32_t)i, TAG_MW_TERRAIN, C.k0, C.k1, r);
             if (!oneshot) {
-                const float sgn = (TERRAIN_HEIGHT - y) > 0.0f ? 1.0f : ((TERRAIN_HEIGHT - y) < 0.0f ? -1.0f : 0.0f);
-                velocity = 0.8f * velocity + 0.01f * sgn;
-                if (i > TERRAIN_STARTPAD) velocity += (2.0f * u24f(r[0]) - 1.0f) / SCALE;  // np_random.uniform(-1, 1) / SCALE
+                const double d = TERRAIN_HEIGHT64 - y;
+                velocity = 0.8 * velocity + 0.01 * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));
+                if (i > TERRAIN_STARTPAD) velocity += (2.0 * u24d(r[0]) - 1.0) / 30.0;  // np_random.uniform(-1, 1) / SCALE
                 y += velocity;
             }
             oneshot = false;
-            Cd.ty[i] = y;
+            Cd.ty[i] = (float)(terrain_in ? terrain_in[i] : y);
             counter -= 1;
             if (counter == 0) {
                 counter = TERRAIN_GRASS / 2 + (int)(((uint64_t)r[1] * (uint64_t)(TERRAIN_GRASS - TERRAIN_GRASS / 2)) >> 32);  // randint(5, 10)
@@ -1702,38 +1893,47 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, u
         }
     }
     // _generate_package (:499-514)
-    float sx = 0.0f;
-    for (int w = 0; w < M.W; ++w) sx += M.start_x[w];
-    sx /= (float)M.W;
     {
         Body &b = Wd.b[0];
         b.a = 0.0f; b.v = v2(0, 0); b.w = 0.0f;
-        b.c = v2(sx, TERRAIN_HEIGHT + 3 * LEG_H) + M.shape[SH_PACKAGE].centroid;
+        b.c = v2((float)M.mean_start_x64, (float)(TERRAIN_HEIGHT64 + 3 * LEG_H64)) + M.shape[SH_PACKAGE].centroid;
     }
     // BipedalWalker._reset (:113-192)
-    const float init_y = TERRAIN_HEIGHT + 2 * LEG_H;
+    const double init_y = TERRAIN_HEIGHT64 + 2 * LEG_H64;
     for (int w = 0; w < M.W; ++w) {
         const float init_x = M.start_x[w];
         Body &hull = Wd.b[hull_of(w)];
         hull.a = 0.0f; hull.v = v2(0, 0); hull.w = 0.0f;
-        hull.c = v2(init_x, init_y) + M.shape[SH_HULL].centroid;
-        uint32_t r[4];
-        philox10(gid, tick, (uint32_t)w, TAG_MW_PUSH, C.k0, C.k1, r);
-        Wd.push_x[w] = (2.0f * u24f(r[0]) - 1.0f) * INITIAL_RANDOM;  // uniform(-INITIAL_RANDOM, INITIAL_RANDOM)
+        hull.c = v2(init_x, (float)init_y) + M.shape[SH_HULL].centroid;
+        double push;
+        if (push_in) push = push_in[w];
+        else { uint32_t r[4]; philox10(gid, tick, (uint32_t)w, TAG_MW_PUSH, C.k0, C.k1, r); push = (2.0 * u24d(r[0]) - 1.0) * 5.0; }  // uniform(-INITIAL_RANDOM, INITIAL_RANDOM)
+        Wd.push_x[w] = (float)push;
         for (int side = 0; side < 2; ++side) {
-            const float sgn = side == 0 ? -1.0f : 1.0f;
+            const double sgn = side == 0 ? -1.0 : 1.0;
             Body &up = Wd.b[hull_of(w) + 1 + 2 * side], &lo = Wd.b[hull_of(w) + 2 + 2 * side];
-            up.a = sgn * 0.05f; up.v = v2(0, 0); up.w = 0.0f;
-            up.c = v2(init_x, init_y - LEG_H / 2 - LEG_DOWN) + mul(rot(up.a), M.shape[SH_UPPER].centroid);
-            lo.a = sgn * 0.05f; lo.v = v2(0, 0); lo.w = 0.0f;
-            lo.c = v2(init_x, init_y - LEG_H * 3 / 2 - LEG_DOWN) + mul(rot(lo.a), M.shape[SH_LOWER].centroid);
+            up.a = (float)(sgn * 0.05); up.v = v2(0, 0); up.w = 0.0f;
+            up.c = v2(init_x, (float)(init_y - LEG_H64 / 2 - LEG_DOWN64)) + mul(rot(up.a), M.shape[SH_UPPER].centroid);
+            lo.a = (float)(sgn * 0.05); lo.v = v2(0, 0); lo.w = 0.0f;
+            lo.c = v2(init_x, (float)(init_y - LEG_H64 * 3 / 2 - LEG_DOWN64)) + mul(rot(lo.a), M.shape[SH_LOWER].centroid);
             Joint &hip = Cd.j[4 * w + 2 * side], &knee = Cd.j[4 * w + 2 * side + 1];
             hip.ix = hip.iy = hip.iz = hip.motor_impulse = 0.0f; hip.limit_state = 0;
-            hip.motor_speed = sgn; hip.max_torque = MOTORS_TORQUE;
+            hip.motor_speed = (float)sgn; hip.max_torque = MOTORS_TORQUE;
             knee.ix = knee.iy = knee.iz = knee.motor_impulse = 0.0f; knee.limit_state = 0;
             knee.motor_speed = 1.0f; knee.max_torque = MOTORS_TORQUE;
         }
     }
+    // broad phase: every proxy is created with its tight box fattened by b2_aabbExtension and buffered as moved; the first Step
+    // begins with FindNewContacts (e_newFixture): batch 0
+    Wd.awake = (1u << M.NB) - 1u;
+    Wd.batch = 0;
+    for (int b = 0; b < M.NB; ++b) {
+        Cd.sleep_time[b] = 0.0f;
+        Cd.sweep_c0[b] = Wd.b[b].c; Cd.sweep_a0[b] = Wd.b[b].a; Cd.sweep_alpha0[b] = 0.0f;
+        set_body_fat(Cd, b, fatten(poly_aabb(M.shape[shape_of_body(b)], body_xf(M, Wd.b[b], b))));
+    }
+    for (int b = 0; b < M.NB; ++b) find_new_terrain_contacts(M, Wd, Cd, b, 0);
+    find_new_pair_contacts(M, Cd, (1u << M.NB) - 1u, 0);
     Wd.tick = tick + 1;
 }
 
@@ -1750,6 +1950,9 @@ MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, S
             j.max_torque = MOTORS_TORQUE * clampf(fabsf(a), 0.0f, 1.0f);
         }
     }
+    if (par.lane() == 0) {   // b2RevoluteJoint::SetMotorSpeed / SetMaxMotorTorque wake both bodies of every joint: all the walkers' bodies
+        for (int b = 1; b < M.NB; ++b) if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; }
+    }
     par.sync();
     world_step(M, Wd, Cd, S, par);  // :365
     if (par.lane() == 0) {
@@ -1761,10 +1964,12 @@ MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, S
 }
 
 MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
+    // the Python side of the reference computes in float64 on the float32 values Box2D hands it; so does this function
     const Body &pkg = Wd.b[0];
     const V2 pkg_pos = body_xf(M, pkg, 0).p;
-    float rewards[MAX_WALKERS];
+    double rewards[MAX_WALKERS];
     V2 hull_pos[MAX_WALKERS];
+    const double package_length = 240.0 / 30.0 * (M.W / 1.75);   // :293-294
     for (int w = 0; w < M.W; ++w) hull_pos[w] = body_xf(M, Wd.b[hull_of(w)], hull_of(w)).p;
     for (int w = 0; w < M.W; ++w) {
         const Body &hull = Wd.b[hull_of(w)];
@@ -1772,21 +1977,19 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd,
         float *o = obs + w * obs_dim_of(C);
         // get_observation (:205-237)
         o[0] = hull.a;
-        o[1] = 2.0f * hull.w / FPS;
-        o[2] = 0.3f * hull.v.x * (VIEWPORT_W / SCALE) / FPS;
-        o[3] = 0.3f * hull.v.y * (VIEWPORT_H / SCALE) / FPS;
+        o[1] = (float)(2.0 * (double)hull.w / 50.0);
+        o[2] = (float)(0.3 * (double)hull.v.x * (600.0 / 30.0) / 50.0);
+        o[3] = (float)(0.3 * (double)hull.v.y * (400.0 / 30.0) / 50.0);
         for (int side = 0; side < 2; ++side) {
             const Body &up = Wd.b[hull_of(w) + 1 + 2 * side], &lo = Wd.b[hull_of(w) + 2 + 2 * side];
-            o[4 + 5 * side + 0] = up.a - hull.a;                       // joints[0/2].angle
-            o[4 + 5 * side + 1] = (up.w - hull.w) / SPEED_HIP;          // .speed / SPEED_HIP
-            o[4 + 5 * side + 2] = (lo.a - up.a) + 1.0f;                 // joints[1/3].angle + 1.0
-            o[4 + 5 * side + 3] = (lo.w - up.w) / SPEED_KNEE;
+            o[4 + 5 * side + 0] = up.a - hull.a;                                        // joints[0/2].angle (float32 in Box2D)
+            o[4 + 5 * side + 1] = (float)((double)(up.w - hull.w) / 4.0);               // .speed / SPEED_HIP
+            o[4 + 5 * side + 2] = (float)((double)(lo.a - up.a) + 1.0);                 // joints[1/3].angle + 1.0
+            o[4 + 5 * side + 3] = (float)((double)(lo.w - up.w) / 6.0);
             o[4 + 5 * side + 4] = Wd.ground[w][side] ? 1.0f : 0.0f;
         }
-        for (int i = 0; i < 10; ++i) {  // lidar (:209-214)
-            float ls, lc;
-            sincos_det(1.5f * i / 10.0f, ls, lc);
-            const V2 p2 = v2(pos.x + ls * LIDAR_RANGE, pos.y - lc * LIDAR_RANGE);
+        for (int i = 0; i < 10; ++i) {  // lidar (:209-214): p2 in float64, float32 when it enters RayCast
+            const V2 p2 = v2((float)((double)pos.x + M.lidar_dx[i]), (float)((double)pos.y - M.lidar_dy[i]));
             o[14 + i] = lidar_fraction(M, Cd, pos, p2);
         }
         // neighbours and package (:380-400), gaussian noise via Box-Muller on keyed uniforms
@@ -1808,35 +2011,35 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd,
             const int j = w + dj;
             if (j < 0 || j == M.W) { o[n++] = 0.0f; o[n++] = 0.0f; }
             else {
-                const float xm = (hull_pos[j].x - pos.x) / M.package_length, ym = (hull_pos[j].y - pos.y) / M.package_length;
-                o[n++] = xm + C.position_noise * nz[zi++];
-                o[n++] = ym + C.position_noise * nz[zi++];
+                const double xm = ((double)hull_pos[j].x - (double)pos.x) / package_length, ym = ((double)hull_pos[j].y - (double)pos.y) / package_length;
+                o[n++] = (float)(xm + (double)C.position_noise * (double)nz[zi++]);
+                o[n++] = (float)(ym + (double)C.position_noise * (double)nz[zi++]);
             }
         }
-        const float xd = (pkg_pos.x - pos.x) / M.package_length, yd = (pkg_pos.y - pos.y) / M.package_length;
-        o[n++] = xd + C.position_noise * nz[4];
-        o[n++] = yd + C.position_noise * nz[5];
-        o[n++] = pkg.a + C.angle_noise * nz[6];
+        const double xd = ((double)pkg_pos.x - (double)pos.x) / package_length, yd = ((double)pkg_pos.y - (double)pos.y) / package_length;
+        o[n++] = (float)(xd + (double)C.position_noise * (double)nz[4]);
+        o[n++] = (float)(yd + (double)C.position_noise * (double)nz[5]);
+        o[n++] = (float)((double)pkg.a + (double)C.angle_noise * (double)nz[6]);
         if (C.one_hot) { for (int k = 0; k < MAX_AGENTS_ID; ++k) o[n++] = (k == w) ? 1.0f : 0.0f; }  // np.eye(MAX_AGENTS)[i] :397-398
-        else o[n++] = (float)w / (float)M.W;  // :400
+        else o[n++] = (float)((double)w / (double)M.W);  // :400
         // shaping (:403-407)
-        const float shaping = 0.0f - 5.0f * fabsf(o[0]);
+        const double shaping = 0.0 - 5.0 * fabs((double)hull.a);
         rewards[w] = shaping - Wd.prev_shaping[w];
         Wd.prev_shaping[w] = shaping;
     }
-    const float package_shaping = C.forward_reward * 130.0f * pkg_pos.x / SCALE;  // :409-411
+    const double package_shaping = (double)C.forward_reward * 130 * (double)pkg_pos.x / 30.0;  // :409-411
     for (int w = 0; w < M.W; ++w) rewards[w] += (package_shaping - Wd.prev_package_shaping);
     Wd.prev_package_shaping = package_shaping;
     bool dn = false;
-    const float last_x = hull_pos[M.W - 1].x;  // `pos` leaks out of the loop: the LAST walker (:417, :420)
-    if (Wd.game_over || last_x < 0.0f) { for (int w = 0; w < M.W; ++w) rewards[w] += C.drop_reward; dn = true; }
-    if (last_x > (M.NT - TERRAIN_GRASS) * TERRAIN_STEP) dn = true;
+    const double last_x = (double)hull_pos[M.W - 1].x;  // `pos` leaks out of the loop: the LAST walker (:417, :420)
+    if (Wd.game_over || last_x < 0.0) { for (int w = 0; w < M.W; ++w) rewards[w] += (double)C.drop_reward; dn = true; }
+    if (last_x > (M.NT - TERRAIN_GRASS) * (14.0 / 30.0)) dn = true;
     int nfallen = 0;
-    for (int w = 0; w < M.W; ++w) { rewards[w] += C.fall_reward * (Wd.fallen[w] ? 1.0f : 0.0f); nfallen += Wd.fallen[w]; }
+    for (int w = 0; w < M.W; ++w) { rewards[w] += (double)C.fall_reward * (Wd.fallen[w] ? 1.0 : 0.0); nfallen += Wd.fallen[w]; }
     if (C.terminate_on_fall && nfallen > 0) dn = true;
     if (rew) {
-        if (C.reward_global) { float s = 0.0f; for (int w = 0; w < M.W; ++w) s += rewards[w]; s /= (float)M.W; for (int w = 0; w < M.W; ++w) rew[w] = s; }
-        else for (int w = 0; w < M.W; ++w) rew[w] = rewards[w];
+        if (C.reward_global) { double s = 0.0; for (int w = 0; w < M.W; ++w) s += rewards[w]; s /= (double)M.W; for (int w = 0; w < M.W; ++w) rew[w] = (float)s; }
+        else for (int w = 0; w < M.W; ++w) rew[w] = (float)rewards[w];
     }
     if (done) *done = dn ? 1 : 0;
 }

@@ -22,11 +22,13 @@ class MultiWalkerOracle(object):
                                  C.c_int64, C.c_uint64, C.c_int64]
         for name, n in (("mwo_destroy", 1), ("mwo_reset", 3), ("mwo_step", 5), ("mwo_get_worlds", 2), ("mwo_set_worlds", 2),
                         ("mwo_get_bodies", 3), ("mwo_get_terrain", 2), ("mwo_num_terrain", 1), ("mwo_num_bodies", 1),
-                        ("mwo_model_masses", 2), ("mwo_obs_dim", 1)):
+                        ("mwo_model_masses", 2), ("mwo_obs_dim", 1), ("mwo_reset_with", 5), ("mwo_set_bodies", 2), ("mwo_get_joints", 2),
+                        ("mwo_get_aux", 2)):
             getattr(L, name).argtypes = [C.c_void_p] * n
         self.N, self.W = int(n_envs), n_walkers
         self.h = L.mwo_create(n_walkers, int(reward_mech == "global"), int(terminate_on_fall), position_noise, angle_noise,
                               forward_reward, fall_reward, drop_reward, self.N, int(seed), int(env_id_base))
+        L.mwo_get_contacts.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         L.mwo_set_one_hot.argtypes = [C.c_void_p, C.c_int]
         L.mwo_set_one_hot(self.h, int(bool(one_hot)))
         self.D = L.mwo_obs_dim(self.h)
@@ -46,6 +48,31 @@ class MultiWalkerOracle(object):
             mask = np.ascontiguousarray(mask, np.uint8)
         self.L.mwo_reset(self.h, _p(mask), _p(self.obs))
         return self.obs
+
+    def reset_with(self, mask=None, terrain=None, push=None):
+        conv = lambda a, dt, shape: None if a is None else np.ascontiguousarray(np.asarray(a, dt).reshape(shape))
+        self._keep = (conv(mask, np.uint8, (self.N,)), conv(terrain, np.float64, (self.N, self.NT)), conv(push, np.float64, (self.N, self.W)))
+        self.L.mwo_reset_with(self.h, _p(self._keep[0]), _p(self._keep[1]), _p(self._keep[2]), _p(self.obs))
+        return self.obs
+
+    def set_bodies(self, b):
+        b = np.ascontiguousarray(np.asarray(b, np.float32).reshape(self.N, self.NB, 6))
+        self.L.mwo_set_bodies(self.h, _p(b))
+
+    def joints(self):
+        out = np.zeros((self.N, 4 * self.W, 6), np.float32)
+        self.L.mwo_get_joints(self.h, _p(out))
+        return out
+
+    def aux(self):
+        out = np.zeros((self.N, self.NB, 6), np.float32)
+        self.L.mwo_get_aux(self.h, _p(out))
+        return out
+
+    def contacts(self, n, max_contacts=256):
+        ints, flts = np.zeros((max_contacts, 8), np.int32), np.zeros((max_contacts, 4), np.float32)
+        k = self.L.mwo_get_contacts(self.h, int(n), _p(ints), _p(flts), max_contacts)
+        return ints[:k], flts[:k]
 
     def step(self, actions):
         a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.N, self.W, 4))

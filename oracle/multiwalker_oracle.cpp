@@ -3,12 +3,12 @@
  *
  * TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: the reference's arithmetic for this env lives in
  * third-party Box2D (pybox2d), which cannot be imported or built in this image and for which the
- * reference holds no golden vectors; the only published anchor, Box2D's HelloWorld output,
- * is checked by box2d_kat.cpp.  Unlike the Pursuit / Waterworld oracles this
- * file is therefore NOT an independent restatement pinned to the reference: it compiles the same
- * solver source the HIP kernel uses (madrl_amd/csrc/multiwalker_core.hpp, host/device code) with
- * g++ for the CPU.  What it checks is the GPU *port* (LDS staging, lane mapping, device math
- * library) step by step; the algorithm itself is covered by physical-invariant tests.
+ * reference holds no golden vectors.  This file is NOT the independent restatement
+ * (that is oracle/multiwalker_ref.c, which also replays Box2D's published HelloWorld output): it
+ * compiles the same solver source the HIP kernel uses (madrl_amd/csrc/multiwalker_core.hpp,
+ * host/device code) with g++ for the CPU.  It serves two checks: the GPU *port* (LDS staging, lane
+ * mapping, level schedule) bit for bit against this build, and the ALGORITHM of that source against
+ * multiwalker_ref.c step by step (tests/test_multiwalker_cpu.py, no GPU needed).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -61,6 +61,21 @@ void mwo_reset(MwOracle *o, const uint8_t *mask, float *obs) {
     }
 }
 
+/* reset with the terrain heights [N][NT] / initial pushes [N][W] given (float64; either may be NULL = Philox) */
+void mwo_reset_with(MwOracle *o, const uint8_t *mask, const double *terrain, const double *push, float *obs) {
+    const int W = o->M.W, NT = o->M.NT;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < o->n_envs; ++n) {
+        if (mask && !mask[n]) continue;
+        mw::Scratch S;
+        float zero[4 * mw::MAX_WALKERS] = {0};
+        const uint32_t gid = (uint32_t)(o->env_id_base + n);
+        mw::env_reset_world(o->M, o->C, o->worlds[n].h, o->worlds[n].c, gid, terrain ? terrain + n * NT : nullptr, push ? push + n * W : nullptr);
+        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, mw::SerialPar(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
+        o->worlds[n].h.t = 0;
+    }
+}
+
 void mwo_step(MwOracle *o, const float *actions, float *obs, float *rew, uint8_t *done) {
     const int W = o->M.W;
 #pragma omp parallel for schedule(static)
@@ -90,6 +105,64 @@ void mwo_get_bodies(const MwOracle *o, float *out, uint8_t *flags) {
             for (int k = 0; k < W; ++k) { f[1 + k] = w.fallen[k]; f[1 + W + 2 * k] = w.ground[k][0]; f[1 + W + 2 * k + 1] = w.ground[k][1]; }
         }
     }
+}
+/* teacher forcing: pose and velocity of the dynamic bodies [N][NB][6]; contacts, joints, fat AABBs, sleep times stay */
+void mwo_set_bodies(MwOracle *o, const float *in) {
+    const int NB = o->M.NB;
+    for (int64_t n = 0; n < o->n_envs; ++n)
+        for (int b = 0; b < NB; ++b) {
+            const float *p = in + (n * NB + b) * 6;
+            mw::Body &q = o->worlds[n].h.b[b];
+            q.c = mw::v2(p[0], p[1]); q.a = p[2]; q.v = mw::v2(p[3], p[4]); q.w = p[5];
+        }
+}
+/* joints [N][NJ][6] = impulse x, y, z, motor impulse, limit state, motor speed; aux [N][NB][6] = fat AABB, sleep time, awake */
+void mwo_get_joints(const MwOracle *o, float *out) {
+    const int NJ = o->M.NJ;
+    for (int64_t n = 0; n < o->n_envs; ++n)
+        for (int j = 0; j < NJ; ++j) {
+            const mw::Joint &q = o->worlds[n].c.j[j];
+            float *p = out + (n * NJ + j) * 6;
+            p[0] = q.ix; p[1] = q.iy; p[2] = q.iz; p[3] = q.motor_impulse; p[4] = (float)q.limit_state; p[5] = q.motor_speed;
+        }
+}
+void mwo_get_aux(const MwOracle *o, float *out) {
+    const int NB = o->M.NB;
+    for (int64_t n = 0; n < o->n_envs; ++n)
+        for (int b = 0; b < NB; ++b) {
+            float *p = out + (n * NB + b) * 6;
+            for (int k = 0; k < 4; ++k) p[k] = o->worlds[n].c.fat[b][k];
+            p[4] = o->worlds[n].c.sleep_time[b]; p[5] = (float)((o->worlds[n].h.awake >> b) & 1u);
+        }
+}
+/* the contacts of env n in WORLD LIST ORDER (descending key), same record as mwr_get_contacts of multiwalker_ref.c */
+int mwo_get_contacts(const MwOracle *o, int64_t n, int32_t *ints, float *flts, int max_contacts) {
+    const mw::Model &M = o->M;
+    const mw::Cold &Cd = o->worlds[n].c;
+    int total = 0;
+    for (int s = 0; s < M.dyn_slot_base + M.n_dyn_pairs; ++s) if (Cd.slot[s].edge >= 0 && (s >= M.dyn_slot_base || s < M.slot_base[M.NB - 1] + M.slot_cap[M.NB - 1])) ++total;
+    uint64_t below = ~0ull;
+    int count = 0;
+    for (int it = 0; it < total; ++it) {
+        int best = -1; uint64_t bk = 0;
+        for (int s = 0; s < M.dyn_slot_base + M.n_dyn_pairs; ++s) {
+            if (Cd.slot[s].edge < 0) continue;
+            const uint64_t key = mw::slot_key(M, Cd, s);
+            if (key < below && (best < 0 || key > bk)) { best = s; bk = key; }
+        }
+        if (best < 0) break;
+        below = bk;
+        if (count < max_contacts) {
+            const mw::Slot &sl = Cd.slot[best];
+            int32_t *p = ints + (size_t)count * 8; float *f = flts + (size_t)count * 4;
+            if (best >= M.dyn_slot_base) { p[0] = M.dyn_a[best - M.dyn_slot_base]; p[1] = M.dyn_b[best - M.dyn_slot_base]; p[2] = -1; }
+            else { int b = 0; while (b + 1 < M.NB && best >= M.slot_base[b + 1]) ++b; p[0] = -1; p[1] = b; p[2] = sl.edge; }
+            p[3] = sl.touching; p[4] = sl.npts; p[5] = sl.npts > 0 ? (int32_t)sl.id[0] : 0; p[6] = sl.npts > 1 ? (int32_t)sl.id[1] : 0; p[7] = sl.toi_count;
+            for (int k = 0; k < 2; ++k) { f[2 * k] = k < sl.npts ? sl.ni[k] : 0.0f; f[2 * k + 1] = k < sl.npts ? sl.ti[k] : 0.0f; }
+        }
+        ++count;
+    }
+    return count;
 }
 void mwo_get_terrain(const MwOracle *o, float *out) {
     for (int64_t n = 0; n < o->n_envs; ++n) memcpy(out + n * o->M.NT, o->worlds[n].c.ty, sizeof(float) * o->M.NT);
