@@ -292,8 +292,9 @@ int madrl_hostage_set_state(madrl_hostage *h, const float *pos, const float *vel
 /* ------------------------------------------------------------------------------------------
  * MultiWalkerEnv  (reference: madrl_environments/walker/multi_walker.py), float32.
  * The rigid-body dynamics the reference delegates to Box2D (`world.Step(1/50, 180, 60)`,
- * multi_walker.py:365) are restated from scratch; parity with Box2D itself is UNPINNED
- * (DESIGN.md "MultiWalker").
+ * multi_walker.py:365) are restated from scratch in Box2D 2.3.0's own order (islands by depth-first search, contact list
+ * order, sleeping, fat-AABB broad phase, continuous pass); parity with Box2D itself is UNPINNED (DESIGN.md "MultiWalker"):
+ * the checker is an independent plain-C restatement (oracle/multiwalker_ref.c), not the library.
  * ---------------------------------------------------------------------------------------- */
 
 /* Constructor arguments of MultiWalkerEnv.__init__ (multi_walker.py:256-270). */
@@ -333,6 +334,27 @@ int madrl_multiwalker_step(madrl_multiwalker *h, const float *actions_dev, float
  * terrain float32 [N][NT] heights.  Any pointer may be NULL. */
 int madrl_multiwalker_get_bodies(madrl_multiwalker *h, float *bodies_dev, uint8_t *flags_dev, float *terrain_dev,
                                  void *stream);
+/* Unpacked view of the world state (checkpoint / teacher-forcing hook; device pointers, any may be NULL):
+ *   bodies float32 [N][NB][6] as above (b2Body: m_sweep.c, m_sweep.a, m_linearVelocity, m_angularVelocity);
+ *   joints float32 [N][4W][6] = accumulated impulse x, y, z, motor impulse, limit state (0 inactive, 1 at lower, 2 at upper,
+ *          3 equal), motor speed (b2RevoluteJoint: m_impulse, m_motorImpulse, m_limitState, m_motorSpeed), per walker
+ *          hip / knee of the left leg, hip / knee of the right leg;
+ *   aux    float32 [N][NB][6] = the broad phase's fat AABB of the body's proxy (lower x, y, upper x, y), b2Body::m_sleepTime,
+ *          awake flag;
+ *   flags  uint8 [N][2+3W] = game_over, fallen[W], ground_contact[W][2], overflow (sticky: a contact did not fit its cache or
+ *          the step's manifold pool and was ignored);
+ *   terrain float32 [N][NT].
+ * The contacts (b2Contact list: pairs, creation order, feature ids, warm-start impulses) stay in the raw state buffer; its
+ * layout is mw::World in madrl_amd/csrc/multiwalker_core.hpp.
+ * set_state overwrites body poses / velocities and (optionally) the joints' accumulated impulses; contacts, fat AABBs and sleep
+ * times stay as they are. */
+int madrl_multiwalker_get_state(madrl_multiwalker *h, float *bodies_dev, float *joints_dev, float *aux_dev, uint8_t *flags_dev,
+                                float *terrain_dev, void *stream);
+int madrl_multiwalker_set_state(madrl_multiwalker *h, const float *bodies_dev, const float *joints_dev, void *stream);
+/* reset with the random draws given (parity hook): terrain float64 [N][NT] heights instead of the _generate_terrain walk
+ * (:516-612), push float64 [N][W] instead of uniform(-INITIAL_RANDOM, INITIAL_RANDOM) (:130-131); either may be NULL */
+int madrl_multiwalker_reset_with(madrl_multiwalker *h, const uint8_t *mask_dev, const double *terrain_dev, const double *push_dev,
+                                 float *obs_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Env wrappers as epilogue kernels (reference: madrl_environments/__init__.py:143-389).

@@ -124,6 +124,9 @@ SIGNATURES = {
     "madrl_multiwalker_reset": (C.c_int, [_vp] * 4),
     "madrl_multiwalker_step": (C.c_int, [_vp] * 6),
     "madrl_multiwalker_get_bodies": (C.c_int, [_vp] * 5),
+    "madrl_multiwalker_get_state": (C.c_int, [_vp] * 7),
+    "madrl_multiwalker_set_state": (C.c_int, [_vp] * 4),
+    "madrl_multiwalker_reset_with": (C.c_int, [_vp] * 6),
     "madrl_wrap_obsnorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, C.c_double, C.c_double, _vp]),
     "madrl_wrap_rewnorm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, C.c_double, C.c_double, C.c_double, C.c_int32, _vp]),
     "madrl_wrap_obsbuffer": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),

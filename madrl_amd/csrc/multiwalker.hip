@@ -36,6 +36,8 @@ struct MwDev {
     uint32_t *state;
 };
 struct MwIO {
+    const double *inj_terrain;  // reset only, parity hook: [N][NT] terrain heights instead of the Philox walk (or NULL)
+    const double *inj_push;     // reset only, parity hook: [N][W] initial pushes (or NULL)
     const uint8_t *mask;
     const float *actions;  // [N][W][4]
     float *obs;            // [N][W][32]
@@ -58,12 +60,12 @@ struct GroupPar {
     static constexpr int NL = 64 / EPW;
     static constexpr int JOINTS = (mw::MAXJ + NL - 1) / NL;
     static constexpr int BODIES = (mw::MAXB + NL - 1) / NL;
-    static constexpr bool MCACHE = true;
     int l;
     __device__ __forceinline__ int lane() const { return l; }
     __device__ __forceinline__ int n() const { return NL; }
     __device__ __forceinline__ void sync() const { lds_sync(); }
     __device__ __forceinline__ int alloc(int *counter) const { return atomicAdd(counter, 1); }
+    __device__ __forceinline__ void or_bits(uint32_t *p, uint32_t v) const { atomicOr(p, v); }
 };
 
 // MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(64, 2) void multiwalker_kernel(const MwDev d, const
                     dn = *s_done;  // uniform over the group
                     if (!(MODE == 0 || (dn != 0 && d.cfg.auto_reset))) break;
                     for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = 0.0f;
-                    if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, Cd, gid);
+                    if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, Cd, gid, (MODE == 0 && io.inj_terrain) ? io.inj_terrain + env * M.NT : nullptr,
+                                                       (MODE == 0 && io.inj_push) ? io.inj_push + env * W : nullptr);
                     lds_sync();
                 }
                 mw::env_step(M, d.cfg, Wd, Cd, S, par, gid, s_act, obs_row, pass == 0 ? s_rew : (float *)nullptr,
@@ -145,6 +148,57 @@ __global__ void mw_get_bodies_kernel(const MwDev d, float *bodies, uint8_t *flag
         for (int k = 0; k < W; ++k) { f[1 + k] = w->fallen[k]; f[1 + W + 2 * k] = w->ground[k][0]; f[1 + W + 2 * k + 1] = w->ground[k][1]; }
     }
     if (terrain) for (int i = 0; i < NT; ++i) terrain[env * NT + i] = wr->c.ty[i];
+}
+
+// unpacked state (checkpoint / teacher-forcing hook); any pointer may be NULL
+__global__ void mw_get_state_kernel(const MwDev d, float *bodies, float *joints, float *aux, uint8_t *flags, float *terrain) {
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    const mw::World *wr = reinterpret_cast<const mw::World *>(d.state + env * (int64_t)d.world_dw);
+    const mw::Hot *w = &wr->h;
+    const int NB = d.model->NB, W = d.model->W, NT = d.model->NT, NJ = d.model->NJ;
+    if (bodies)
+        for (int b = 0; b < NB; ++b) {
+            float *p = bodies + (env * NB + b) * 6;
+            p[0] = w->b[b].c.x; p[1] = w->b[b].c.y; p[2] = w->b[b].a; p[3] = w->b[b].v.x; p[4] = w->b[b].v.y; p[5] = w->b[b].w;
+        }
+    if (joints)
+        for (int j = 0; j < NJ; ++j) {
+            const mw::Joint &q = wr->c.j[j];
+            float *p = joints + (env * NJ + j) * 6;
+            p[0] = q.ix; p[1] = q.iy; p[2] = q.iz; p[3] = q.motor_impulse; p[4] = (float)q.limit_state; p[5] = q.motor_speed;
+        }
+    if (aux)
+        for (int b = 0; b < NB; ++b) {
+            float *p = aux + (env * NB + b) * 6;
+            for (int k = 0; k < 4; ++k) p[k] = wr->c.fat[b][k];
+            p[4] = wr->c.sleep_time[b]; p[5] = (float)((w->awake >> b) & 1u);
+        }
+    if (flags) {
+        uint8_t *f = flags + env * (2 + 3 * W);
+        f[0] = w->game_over;
+        for (int k = 0; k < W; ++k) { f[1 + k] = w->fallen[k]; f[1 + W + 2 * k] = w->ground[k][0]; f[1 + W + 2 * k + 1] = w->ground[k][1]; }
+        f[1 + 3 * W] = w->overflow;
+    }
+    if (terrain) for (int i = 0; i < NT; ++i) terrain[env * NT + i] = wr->c.ty[i];
+}
+__global__ void mw_set_state_kernel(const MwDev d, const float *bodies, const float *joints) {
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    mw::World *wr = reinterpret_cast<mw::World *>(d.state + env * (int64_t)d.world_dw);
+    const int NB = d.model->NB, NJ = d.model->NJ;
+    if (bodies)
+        for (int b = 0; b < NB; ++b) {
+            const float *p = bodies + (env * NB + b) * 6;
+            mw::Body &q = wr->h.b[b];
+            q.c = mw::v2(p[0], p[1]); q.a = p[2]; q.v = mw::v2(p[3], p[4]); q.w = p[5];
+        }
+    if (joints)
+        for (int j = 0; j < NJ; ++j) {
+            const float *p = joints + (env * NJ + j) * 6;
+            mw::Joint &q = wr->c.j[j];
+            q.ix = p[0]; q.iy = p[1]; q.iz = p[2]; q.motor_impulse = p[3]; q.limit_state = (int)p[4]; q.motor_speed = p[5];
+        }
 }
 
 }  // namespace
@@ -282,6 +336,36 @@ int madrl_multiwalker_reset(madrl_multiwalker *h, const uint8_t *mask_dev, float
     io.mask = mask_dev;
     io.obs = obs_dev;
     return mw_launch(h, io, 0, stream);
+}
+
+int madrl_multiwalker_reset_with(madrl_multiwalker *h, const uint8_t *mask_dev, const double *terrain_dev, const double *push_dev,
+                                 float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(MADRL_EINVAL, "reset: handle/obs is NULL");
+    MwIO io;
+    memset(&io, 0, sizeof(io));
+    io.mask = mask_dev;
+    io.inj_terrain = terrain_dev;
+    io.inj_push = push_dev;
+    io.obs = obs_dev;
+    return mw_launch(h, io, 0, stream);
+}
+
+int madrl_multiwalker_get_state(madrl_multiwalker *h, float *bodies_dev, float *joints_dev, float *aux_dev, uint8_t *flags_dev,
+                                float *terrain_dev, void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 63) / 64);
+    hipLaunchKernelGGL(mw_get_state_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->dev, bodies_dev, joints_dev, aux_dev,
+                       flags_dev, terrain_dev);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
+}
+
+int madrl_multiwalker_set_state(madrl_multiwalker *h, const float *bodies_dev, const float *joints_dev, void *stream) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    const unsigned blocks = (unsigned)((h->dev.n_envs + 63) / 64);
+    hipLaunchKernelGGL(mw_set_state_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->dev, bodies_dev, joints_dev);
+    MADRL_HIP_TRY(hipGetLastError());
+    return MADRL_OK;
 }
 
 int madrl_multiwalker_step(madrl_multiwalker *h, const float *actions_dev, float *obs_dev, float *rew_dev,

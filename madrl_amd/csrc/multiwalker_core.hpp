@@ -19,8 +19,8 @@
 //   b2RevoluteJoint (point constraint + motor + limit); b2CollidePolygons as of 2.3.0 (hill-climbing
 //   b2FindMaxSeparation, 0.98 / 0.001 reference-face hysteresis); b2CollideEdgeAndPolygon on plain edges (the
 //   reference builds edgeShape(vertices=[p1, p2]): no ghost vertices); b2EdgeShape::RayCast.
-// The independent check of all of this is oracle/multiwalker_ref.c (plain C, Box2D's own data structures,
-// no code shared with this file): tests/test_multiwalker_*.py compare the two step by step.
+// The independent check of all of this is the test infrastructure's multiwalker_ref.c (plain C, Box2D's own data
+// structures, no code shared with this file): tests/test_multiwalker_*.py compare the two step by step.
 // Lane-parallel execution keeps Box2D's results: the island's constraint sequence is cut into LEVELS by list
 // scheduling (a constraint's level = 1 + the highest level among earlier constraints that share a body with
 // it); constraints of one level touch disjoint bodies and commute exactly, so solving level by level -- on one
@@ -94,7 +94,9 @@ constexpr int MAX_WALKERS = 4;
 constexpr int MAXB = 5 * MAX_WALKERS + 1;        // package + 5 bodies per walker
 constexpr int MAXJ = 4 * MAX_WALKERS;
 constexpr int MAXT = TERRAIN_LENGTH * MAX_WALKERS / 8;  // terrain points (:301)
-constexpr int EDGE_SLOTS_LEG = 6, EDGE_SLOTS_HULL = 10, EDGE_SLOTS_PKG_MAX = 48;   // contacts a body's cache holds (Model::slot_cap)
+// contacts a body's cache holds (Model::slot_cap): the edges under its fat AABB (leg <= 6, hull <= 8 at the speeds of this env) PLUS the
+// ones it has just left, which Box2D destroys only in the next step's Collide
+constexpr int EDGE_SLOTS_LEG = 12, EDGE_SLOTS_HULL = 16, EDGE_SLOTS_PKG_MAX = 56;
 constexpr int MAXSLOT = 4 * MAX_WALKERS * EDGE_SLOTS_LEG + MAX_WALKERS * EDGE_SLOTS_HULL + EDGE_SLOTS_PKG_MAX + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
 constexpr int MAXM = 40;  // largest active-manifold pool (Model::max_manifolds <= MAXM)
 constexpr double TERRAIN_HEIGHT64 = 400.0 / 30.0 / 4, LEG_H64 = 34.0 / 30.0, LEG_DOWN64 = -8.0 / 30.0;   // the reference's float64 constants (:26-36)
@@ -109,7 +111,10 @@ MW_HD float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
 MW_HD float cross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
 MW_HD V2 cross(V2 a, float s) { return v2(s * a.y, -s * a.x); }
 MW_HD V2 cross(float s, V2 a) { return v2(-s * a.y, s * a.x); }
-MW_HD float clampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }
+// b2Min / b2Max / b2Clamp: plain comparisons (a < b ? a : b), whose result for signed zeros is the same on every target, unlike fminf / fmaxf
+MW_HD float mnf(float a, float b) { return a < b ? a : b; }
+MW_HD float mxf(float a, float b) { return a > b ? a : b; }
+MW_HD float clampf(float a, float lo, float hi) { return mxf(lo, mnf(a, hi)); }
 struct Rot { float s, c; };
 // sin/cos from +,-,* only (Cody-Waite reduction by pi/2, cephes single-precision minimax
 // polynomials on [-pi/4, pi/4]): the host build and the device build of this file then agree
@@ -315,7 +320,7 @@ inline void build_model(Model &M, int n_walkers) {
     for (int b = 0; b < M.NB; ++b) {
         M.slot_base[b] = base;
         // candidate edges = those whose fat AABB overlaps the body's: a run no longer than (fat width + edge margins) / TERRAIN_STEP + 1
-        M.slot_cap[b] = (b == 0) ? (int)((M.package_length + 1.5f) / TERRAIN_STEP) + 4 : (is_hull(b) ? EDGE_SLOTS_HULL : EDGE_SLOTS_LEG);
+        M.slot_cap[b] = (b == 0) ? (int)((M.package_length + 1.5f) / TERRAIN_STEP) + 12 : (is_hull(b) ? EDGE_SLOTS_HULL : EDGE_SLOTS_LEG);
         base += M.slot_cap[b];
         M.list_base[b] = lbase;
         lbase += M.slot_cap[b] + (is_hull(b) ? n_walkers : 0);   // a hull also owns the pairs whose body B it is: (package, hull) and (hull_i, hull), i < this
@@ -600,7 +605,7 @@ MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB,
     const V2 perp = v2(-m_normal.y, m_normal.x);
     for (int i = 0; i < pB.n; ++i) {
         const V2 n = -bn[i];
-        const float s1 = dot(n, bv[i] - v1), s2 = dot(n, bv[i] - v2e), s = fminf(s1, s2);
+        const float s1 = dot(n, bv[i] - v1), s2 = dot(n, bv[i] - v2e), s = mnf(s1, s2);
         if (s > radius) { poly_type = 2; poly_index = i; poly_sep = s; break; }
         if (dot(n, perp) >= 0.0f) { if (dot(n - upper, m_normal) < -ANGULAR_SLOP) continue; }
         else { if (dot(n - lower, m_normal) < -ANGULAR_SLOP) continue; }
@@ -653,8 +658,8 @@ MW_HD AABB poly_aabb(const Shape &s, Xf t) {   // b2PolygonShape::ComputeAABB
     V2 lower = mul(t, s.v[0]), upper = lower;
     for (int i = 1; i < s.n; ++i) {
         const V2 p = mul(t, s.v[i]);
-        lower = v2(fminf(lower.x, p.x), fminf(lower.y, p.y));
-        upper = v2(fmaxf(upper.x, p.x), fmaxf(upper.y, p.y));
+        lower = v2(mnf(lower.x, p.x), mnf(lower.y, p.y));
+        upper = v2(mxf(upper.x, p.x), mxf(upper.y, p.y));
     }
     AABB b; b.lx = lower.x - POLY_RADIUS; b.ly = lower.y - POLY_RADIUS; b.hx = upper.x + POLY_RADIUS; b.hy = upper.y + POLY_RADIUS;
     return b;
@@ -663,7 +668,7 @@ MW_HD AABB fatten(AABB a) { AABB f; f.lx = a.lx - AABB_EXTENSION; f.ly = a.ly - 
 // terrain edge e: b2EdgeShape::ComputeAABB at the identity transform, fattened at proxy creation; static, so it never changes
 MW_HD AABB edge_fat_aabb(const Model &M, const Cold &Cd, int e) {
     const float x1 = M.tx[e], x2 = M.tx[e + 1], y1 = Cd.ty[e], y2 = Cd.ty[e + 1];
-    AABB a; a.lx = fminf(x1, x2) - POLY_RADIUS; a.ly = fminf(y1, y2) - POLY_RADIUS; a.hx = fmaxf(x1, x2) + POLY_RADIUS; a.hy = fmaxf(y1, y2) + POLY_RADIUS;
+    AABB a; a.lx = mnf(x1, x2) - POLY_RADIUS; a.ly = mnf(y1, y2) - POLY_RADIUS; a.hx = mxf(x1, x2) + POLY_RADIUS; a.hy = mxf(y1, y2) + POLY_RADIUS;
     return fatten(a);
 }
 MW_HD bool aabb_overlap(const AABB &a, const AABB &b) {   // b2TestOverlap
@@ -726,7 +731,7 @@ MW_HD int contact_update(Slot &sl, const ManifoldOut &mo) {
 template <class Par>
 MW_HD int emit_manifold(Hot &Wd, Scratch &S, Par par, const Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction, int max_manifolds) {
     const int idx = par.alloc(&S.nm);
-    if (idx >= max_manifolds) { Wd.overflow = 1; return -1; }  // pool exhausted: the pair is ignored this step (sticky flag)
+    if (idx >= max_manifolds) { Wd.overflow |= 1; return -1; }  // pool exhausted: the pair is ignored this step (sticky flag)
     Manifold &m = S.m[idx];
     m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)(mo.type | (mo.npts << 1)); m.island = 0;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
@@ -767,7 +772,7 @@ MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, P
         } else {
             ManifoldOut mo; mo.npts = 0;
             // cull (never changes a result): the tight boxes are further apart than any manifold reaches
-            const float elo = fminf(Cd.ty[e], Cd.ty[e + 1]), ehi = fmaxf(Cd.ty[e], Cd.ty[e + 1]);
+            const float elo = mnf(Cd.ty[e], Cd.ty[e + 1]), ehi = mxf(Cd.ty[e], Cd.ty[e + 1]);
             if (!(tight.ly > ehi + 0.1f || tight.hy < elo - 0.1f || tight.lx > M.tx[e + 1] + 0.1f || tight.hx < M.tx[e] - 0.1f))
                 edge_polygon_manifold(M, Cd, e, s, xfB, mo);
             ev = contact_update(sl, mo);
@@ -819,7 +824,7 @@ MW_HD bool sync_fixture(const Model &M, const Hot &Wd, Cold &Cd, int b) {
     const Shape &s = M.shape[shape_of_body(b)];
     const Xf xf1 = xf_from(Cd.sweep_c0[b], Cd.sweep_a0[b], s.centroid), xf2 = body_xf(M, Wd.b[b], b);
     const AABB a1 = poly_aabb(s, xf1), a2 = poly_aabb(s, xf2);
-    AABB a; a.lx = fminf(a1.lx, a2.lx); a.ly = fminf(a1.ly, a2.ly); a.hx = fmaxf(a1.hx, a2.hx); a.hy = fmaxf(a1.hy, a2.hy);
+    AABB a; a.lx = mnf(a1.lx, a2.lx); a.ly = mnf(a1.ly, a2.ly); a.hx = mxf(a1.hx, a2.hx); a.hy = mxf(a1.hy, a2.hy);
     if (aabb_contains(body_fat(Cd, b), a)) return false;
     AABB f = fatten(a);
     const V2 d = AABB_MULTIPLIER * (xf2.p - xf1.p);   // predict AABB displacement
@@ -840,7 +845,13 @@ MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, u
         if (!aabb_overlap(edge_fat_aabb(M, Cd, e), fatb)) continue;
         Slot &sl = slots[e % cap];
         if (sl.edge == e) continue;                    // the contact exists
-        if (sl.edge >= 0) { Wd.overflow = 1; continue; }  // more candidate edges than the body's cache holds (sticky flag): pair ignored
+        if (sl.edge >= 0) {
+            // The cache slot holds another edge.  If that contact is not touching and its edge has left the body's new fat AABB, Box2D
+            // would destroy it in the next Collide and nothing can observe it before (it cannot be hit inside a fat AABB that holds the
+            // whole sweep): it is dropped now (sticky bit 1).  Otherwise the new pair is ignored (sticky bit 0).
+            if (!sl.touching && !aabb_overlap(edge_fat_aabb(M, Cd, sl.edge), fatb)) Wd.overflow |= 2;
+            else { Wd.overflow |= 1; continue; }
+        }
         sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.toi_flags = 0; sl.toi_count = 0;
     }
 }
@@ -1195,7 +1206,7 @@ MW_HD void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float
             const V2 dv = vB + cross(wB, m.rB[i]) - vA - cross(wA, m.rA[i]);
             const float vn = dot(dv, normal);
             float lambda = -m.nm[i] * (vn - 0.0f);  // restitution 0 -> velocityBias 0
-            const float newi = fmaxf(m.ni[i] + lambda, 0.0f);
+            const float newi = mxf(m.ni[i] + lambda, 0.0f);
             lambda = newi - m.ni[i];
             m.ni[i] = newi;
             const V2 P = lambda * normal;
@@ -1255,7 +1266,7 @@ MW_HD float contact_solve_position(Hot &Wd, const Manifold &m, const MassAB &q) 
             normal = -normal;
         }
         const V2 rA = point - cA, rB = point - cB;
-        min_sep = fminf(min_sep, sep);
+        min_sep = mnf(min_sep, sep);
         const float C = clampf(BAUMGARTE * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);
         const float rnA = cross(rA, normal), rnB = cross(rB, normal);
         const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
@@ -1316,7 +1327,7 @@ MW_HD void poly_aabb_at(const Shape &s, V2 c, float a, float &xmin, float &xmax,
     const Xf t = xf_from(c, a, s.centroid);
     for (int i = 0; i < s.n; ++i) {
         const V2 p = mul(t, s.v[i]);
-        xmin = fminf(xmin, p.x); xmax = fmaxf(xmax, p.x); ymin = fminf(ymin, p.y); ymax = fmaxf(ymax, p.y);
+        xmin = mnf(xmin, p.x); xmax = mxf(xmax, p.x); ymin = mnf(ymin, p.y); ymax = mxf(ymax, p.y);
     }
 }
 MW_HD void proxy_of_shape(Proxy &p, const Shape &s) {
@@ -1339,7 +1350,7 @@ MW_HD SweptBox swept_box(const Shape &sh, const Sweep &sB) {
     poly_aabb_at(sh, sB.c0, sB.a0, q.xmin, q.xmax, q.ymin, q.ymax);
     poly_aabb_at(sh, sB.c, sB.a, q.xmin, q.xmax, q.ymin, q.ymax);
     float r2 = 0.0f;   // a vertex leaves the box of its two end poses by at most |r| (1 - cos(da / 2)) <= |r| da^2 / 8 in between
-    for (int i = 0; i < sh.n; ++i) { const V2 r = sh.v[i] - sh.centroid; r2 = fmaxf(r2, dot(r, r)); }
+    for (int i = 0; i < sh.n; ++i) { const V2 r = sh.v[i] - sh.centroid; r2 = mxf(r2, dot(r, r)); }
     const float da = sB.a - sB.a0, mrg = sqrtf(r2) * da * da * 0.125f + LINEAR_SLOP;
     q.xmin -= mrg; q.xmax += mrg; q.ymin -= mrg; q.ymax += mrg;
     return q;
@@ -1348,7 +1359,7 @@ MW_HD SweptBox swept_box(const Shape &sh, const Sweep &sB) {
 MW_HD float toi_alpha_terrain(const Model &M, const Cold &Cd, int bi, int e, const Sweep &sB, const SweptBox &box) {
     const V2 p1 = v2(M.tx[e], Cd.ty[e]), p2 = v2(M.tx[e + 1], Cd.ty[e + 1]);
     const float m = 4.0f * LINEAR_SLOP;   // what the root finder calls touching, with margin
-    if (box.xmin - m > p2.x || box.xmax + m < p1.x || box.ymin - m > fmaxf(p1.y, p2.y) || box.ymax + m < fminf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
+    if (box.xmin - m > p2.x || box.xmax + m < p1.x || box.ymin - m > mxf(p1.y, p2.y) || box.ymax + m < mnf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
     MW_STAT(toi_full, 1);
     Proxy pA, pB;
     pA.n = 2; pA.v[0] = p1; pA.v[1] = p2;
@@ -1360,7 +1371,7 @@ MW_HD float toi_alpha_terrain(const Model &M, const Cold &Cd, int bi, int e, con
     float beta;
     const int state = time_of_impact(beta, pA, sA, pB, sB);
     const float alpha0 = sB.alpha0;
-    return state == TOI_TOUCHING ? fminf(alpha0 + (1.0f - alpha0) * beta, 1.0f) : 1.0f;
+    return state == TOI_TOUCHING ? mnf(alpha0 + (1.0f - alpha0) * beta, 1.0f) : 1.0f;
 }
 // b2ContactSolver::SolveTOIPositionConstraints for one manifold: only the TOI body (B; A is static) moves
 MW_HD float contact_solve_toi_position(Hot &Wd, const Manifold &m, const MassAB &q) {
@@ -1385,7 +1396,7 @@ MW_HD float contact_solve_toi_position(Hot &Wd, const Manifold &m, const MassAB 
             normal = -normal;
         }
         const V2 rB = point - cB;
-        min_sep = fminf(min_sep, sep);
+        min_sep = mnf(min_sep, sep);
         const float C = clampf(0.75f * (sep + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);  // b2_toiBaugarte
         const float rnB = cross(rB, normal);
         const float K = mB + iB * rnB * rnB;   // the static body contributes nothing
@@ -1507,7 +1518,7 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
         const float fr = sqrtf(FRICTION * msh.friction);
         auto add_manifold = [&](const ManifoldOut &o, int slot_index) {
             if (n_isl >= MAX_TOI_CONTACTS) return;
-            if (n_isl >= M.max_manifolds) { Wd.overflow = 1; return; }
+            if (n_isl >= M.max_manifolds) { Wd.overflow |= 1; return; }
             Manifold &m = S.m[n_isl++];
             m.bA = -1; m.bB = (int8_t)mover; m.slot = (int16_t)slot_index; m.npts = (uint8_t)o.npts; m.type = (uint8_t)(o.type | (o.npts << 1)); m.island = 0;
             m.local_normal = o.local_normal; m.local_point = o.local_point;
@@ -1529,7 +1540,7 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
         const MassAB qm = mass_of_pair(S, -1, mover);
         for (int it = 0; it < 20; ++it) {   // subStep.positionIterations = 20
             float ms_min = 0.0f;
-            for (int k = 0; k < n_isl; ++k) ms_min = fminf(ms_min, contact_solve_toi_position(Wd, S.m[k], qm));
+            for (int k = 0; k < n_isl; ++k) ms_min = mnf(ms_min, contact_solve_toi_position(Wd, S.m[k], qm));
             if (ms_min >= -1.5f * LINEAR_SLOP) break;
         }
         Cd.sweep_c0[mover] = Wd.b[mover].c; Cd.sweep_a0[mover] = Wd.b[mover].a;  // "leap of faith to new safe state"
@@ -1736,7 +1747,7 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
         for (int bi = L0; bi < NB; bi += LN) S.body_minsep[bi] = 0.0f;
         for (int j = L0; j < 4 * NW; j += LN) S.joint_ok[j] = 1;
         par.sync();
-        MW_CONTACT_SWEEP(if (!S.isl_done[m_.island]) S.body_minsep[bi] = fminf(S.body_minsep[bi], contact_solve_position(Wd, m_, q_)))
+        MW_CONTACT_SWEEP(if (!S.isl_done[m_.island]) S.body_minsep[bi] = mnf(S.body_minsep[bi], contact_solve_position(Wd, m_, q_)))
         for (int t = 0; t < n_jl; ++t) {
             MW_UNROLL
             for (int kq = 0; kq < Par::JOINTS; ++kq) {
@@ -1753,7 +1764,7 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
                 if (S.isl_done[c]) continue;
                 float ms = 0.0f;
                 bool jok = true;
-                for (int bi = 0; bi < NB; ++bi) if (S.island_of[bi] == c) ms = fminf(ms, S.body_minsep[bi]);
+                for (int bi = 0; bi < NB; ++bi) if (S.island_of[bi] == c) ms = mnf(ms, S.body_minsep[bi]);
                 for (int j = 0; j < 4 * NW; ++j) if (S.j_island[j] == c) jok = jok && S.joint_ok[j];
                 if (ms >= -3.0f * LINEAR_SLOP && jok) { S.isl_done[c] = 1; S.isl_pos_solved[c] = 1; }
                 else all_done = false;
@@ -1783,7 +1794,7 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
                     Cd.sleep_time[bi] = 0.0f; min_sleep = 0.0f;
                 } else {
                     Cd.sleep_time[bi] += h;
-                    min_sleep = fminf(min_sleep, Cd.sleep_time[bi]);
+                    min_sleep = mnf(min_sleep, Cd.sleep_time[bi]);
                 }
             }
             if (min_sleep >= TIME_TO_SLEEP && S.isl_pos_solved[c])
@@ -1816,7 +1827,7 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
 MW_HD float lidar_fraction(const Model &M, const Cold &Cd, V2 p1, V2 p2) {
     const V2 d = p2 - p1;
     float best = 1.0f;  // LidarCallback.fraction starts at 1.0 (:210)
-    int e0 = (int)floorf(fminf(p1.x, p2.x) / TERRAIN_STEP) - 1, e1 = (int)floorf(fmaxf(p1.x, p2.x) / TERRAIN_STEP) + 1;
+    int e0 = (int)floorf(mnf(p1.x, p2.x) / TERRAIN_STEP) - 1, e1 = (int)floorf(mxf(p1.x, p2.x) / TERRAIN_STEP) + 1;
     if (e0 < 0) e0 = 0;
     if (e1 > M.NT - 2) e1 = M.NT - 2;
     for (int e = e0; e <= e1; ++e) {

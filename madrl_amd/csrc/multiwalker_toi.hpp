@@ -196,7 +196,7 @@ MW_HD int time_of_impact(float &t_out, const Proxy &pA, Sweep sA, const Proxy &p
     t_out = 1.0f;
     sweep_normalize(sA); sweep_normalize(sB);
     const float t_max = 1.0f, total_radius = 2.0f * POLY_RADIUS;
-    const float target = fmaxf(LINEAR_SLOP, total_radius - 3.0f * LINEAR_SLOP), tolerance = 0.25f * LINEAR_SLOP;
+    const float target = mxf(LINEAR_SLOP, total_radius - 3.0f * LINEAR_SLOP), tolerance = 0.25f * LINEAR_SLOP;
     float t1 = 0.0f;
     int iter = 0;
     SimplexCache cache;

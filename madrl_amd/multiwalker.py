@@ -164,6 +164,35 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
                                                            _lib.current_stream(self.device)))
         return b, f, t
 
+    def get_state(self):
+        """Unpacked world state (include/madrl_hip.h madrl_multiwalker_get_state): dict of tensors bodies [N, NB, 6], joints
+        [N, 4W, 6], aux [N, NB, 6] (fat AABB, sleep time, awake), flags [N, 2 + 3W], terrain [N, NT]."""
+        N, W, dev = self.n_envs, int(self.n_walkers), self.device
+        st = dict(bodies=torch.zeros((N, self.n_bodies, 6), dtype=torch.float32, device=dev),
+                  joints=torch.zeros((N, 4 * W, 6), dtype=torch.float32, device=dev),
+                  aux=torch.zeros((N, self.n_bodies, 6), dtype=torch.float32, device=dev),
+                  flags=torch.zeros((N, 2 + 3 * W), dtype=torch.uint8, device=dev),
+                  terrain=torch.zeros((N, self.n_terrain), dtype=torch.float32, device=dev))
+        _lib.check(_lib.lib().madrl_multiwalker_get_state(self._handle, *[_lib.ptr(st[k]) for k in ("bodies", "joints", "aux", "flags", "terrain")],
+                                                          _lib.current_stream(self.device)))
+        return st
+
+    def set_state(self, bodies=None, joints=None):
+        """Overwrite body poses / velocities [N, NB, 6] and, optionally, the joints' accumulated impulses [N, 4W, 6]."""
+        conv = lambda a, shape: None if a is None else torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a, device=self.device).reshape(shape).to(torch.float32).contiguous()
+        b, j = conv(bodies, (self.n_envs, self.n_bodies, 6)), conv(joints, (self.n_envs, 4 * int(self.n_walkers), 6))
+        self._keepalive = (b, j)
+        _lib.check(_lib.lib().madrl_multiwalker_set_state(self._handle, _lib.ptr(b), _lib.ptr(j), _lib.current_stream(self.device)))
+
+    def reset_with(self, mask=None, terrain=None, push=None):
+        """reset() with the random draws given (parity hook): terrain float64 [N, NT], push float64 [N, W]."""
+        conv = lambda a, dt, shape: None if a is None else torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a, device=self.device).reshape(shape).to(dt).contiguous()
+        m, t, p = conv(mask, torch.uint8, (self.n_envs,)), conv(terrain, torch.float64, (self.n_envs, self.n_terrain)), conv(push, torch.float64, (self.n_envs, int(self.n_walkers)))
+        self._keepalive = (m, t, p)
+        _lib.check(_lib.lib().madrl_multiwalker_reset_with(self._handle, _lib.ptr(m), _lib.ptr(t), _lib.ptr(p), _lib.ptr(self._obs),
+                                                           _lib.current_stream(self.device)))
+        return self._obs
+
     def flops_per_env_step(self):
         """(FP32 operations per env-step, how the figure was obtained) for the roofline line of bench.py"""
         return 1.0e6, "estimate: ~180 velocity + up to 60 position sweeps over 12 joints and ~10 manifolds (not counted)"

@@ -107,7 +107,10 @@ static inline float vnormalize(Vec2 *a) {   /* b2Vec2::Normalize */
     a->x *= inv; a->y *= inv;
     return length;
 }
-static inline float fclampf(float a, float lo, float hi) { return fmaxf(lo, fminf(a, hi)); }   /* b2Clamp = b2Max(low, b2Min(a, high)) */
+/* b2Min / b2Max / b2Clamp are plain comparisons in Box2D (b2Math.h): a < b ? a : b, a > b ? a : b, b2Max(low, b2Min(a, high)) */
+static inline float b2minf(float a, float b) { return a < b ? a : b; }
+static inline float b2maxf(float a, float b) { return a > b ? a : b; }
+static inline float fclampf(float a, float lo, float hi) { return b2maxf(lo, b2minf(a, hi)); }
 
 /* b2Rot::Set.  Box2D calls sinf / cosf; the kernels of this repo use a +,-,* polynomial so that their host and device builds
  * agree to the bit.  MWR_POLY_SINCOS restates that polynomial (Cody-Waite reduction by pi/2, single-precision minimax
@@ -270,8 +273,8 @@ static AABB shape_aabb(const Shape *s, Xform xf) {                       /* b2Po
     Vec2 lower = xmul(xf, s->v[0]), upper = lower;
     for (int i = 1; i < n; ++i) {
         const Vec2 v = xmul(xf, s->v[i]);
-        lower = V(fminf(lower.x, v.x), fminf(lower.y, v.y));
-        upper = V(fmaxf(upper.x, v.x), fmaxf(upper.y, v.y));
+        lower = V(b2minf(lower.x, v.x), b2minf(lower.y, v.y));
+        upper = V(b2maxf(upper.x, v.x), b2maxf(upper.y, v.y));
     }
     b.lo = V(lower.x - s->radius, lower.y - s->radius);
     b.hi = V(upper.x + s->radius, upper.y + s->radius);
@@ -456,7 +459,7 @@ static void collide_edge_and_polygon(Manifold *manifold, const Shape *edgeA, Xfo
     for (int i = 0; i < count; ++i) {
         const Vec2 n = vneg(pn[i]);
         const float s1 = vdot(n, vsub(pv[i], v1)), s2 = vdot(n, vsub(pv[i], v2));
-        const float s = fminf(s1, s2);
+        const float s = b2minf(s1, s2);
         if (s > radius) { polyType = 2; polyIndex = i; polySep = s; break; }   /* no collision */
         if (vdot(n, perp) >= 0.0f) { if (vdot(vsub(n, upperLimit), m_normal) < -b2_angularSlop) continue; }
         else { if (vdot(vsub(n, lowerLimit), m_normal) < -b2_angularSlop) continue; }
@@ -761,7 +764,7 @@ static int time_of_impact(float *t_out, const DProxy *pA, const Sweep *sweepA_in
     Sweep sweepA = *sweepA_in, sweepB = *sweepB_in;
     sweep_normalize(&sweepA); sweep_normalize(&sweepB);   /* large rotations can make the root finder fail */
     const float totalRadius = pA->radius + pB->radius;
-    const float target = fmaxf(b2_linearSlop, totalRadius - 3.0f * b2_linearSlop);
+    const float target = b2maxf(b2_linearSlop, totalRadius - 3.0f * b2_linearSlop);
     const float tolerance = 0.25f * b2_linearSlop;
     float t1 = 0.0f;
     const int k_maxIterations = 20;
@@ -1140,8 +1143,8 @@ static void body_sync_fixtures(World *w, Body *b) {
     xf1.p = vsub(b->sweep.c0, rmul(xf1.q, b->sweep.localCenter));
     const AABB aabb1 = shape_aabb(&b->shape, xf1), aabb2 = shape_aabb(&b->shape, b->xf);
     AABB aabb;   /* covers the swept shape (may miss some rotation effect) */
-    aabb.lo = V(fminf(aabb1.lo.x, aabb2.lo.x), fminf(aabb1.lo.y, aabb2.lo.y));
-    aabb.hi = V(fmaxf(aabb1.hi.x, aabb2.hi.x), fmaxf(aabb1.hi.y, aabb2.hi.y));
+    aabb.lo = V(b2minf(aabb1.lo.x, aabb2.lo.x), b2minf(aabb1.lo.y, aabb2.lo.y));
+    aabb.hi = V(b2maxf(aabb1.hi.x, aabb2.hi.x), b2maxf(aabb1.hi.y, aabb2.hi.y));
     const Vec2 displacement = vsub(b->xf.p, xf1.p);
     if (aabb_contains(&b->fatAABB, &aabb)) return;          /* still inside the fat AABB: nothing to do */
     AABB fat;
@@ -1315,7 +1318,7 @@ static void solver_solve_velocity_constraints(Island *is) {   /* b2ContactSolver
             const Vec2 dv = vsub(vsub(vadd(vB, vcross_sv(wB, vcp->rB)), vA), vcross_sv(wA, vcp->rA));
             const float vn = vdot(dv, normal);
             float lambda = -vcp->normalMass * (vn - vcp->velocityBias);
-            const float newImpulse = fmaxf(vcp->normalImpulse + lambda, 0.0f);
+            const float newImpulse = b2maxf(vcp->normalImpulse + lambda, 0.0f);
             lambda = newImpulse - vcp->normalImpulse;
             vcp->normalImpulse = newImpulse;
             const Vec2 P = vscale(lambda, normal);
@@ -1405,7 +1408,7 @@ static int solver_solve_position_constraints(Island *is, int toiIndexA, int toiI
             float separation;
             position_manifold(pc, xfA, xfB, j, &normal, &point, &separation);
             const Vec2 rA = vsub(point, cA), rB = vsub(point, cB);
-            minSeparation = fminf(minSeparation, separation);   /* track max constraint error */
+            minSeparation = b2minf(minSeparation, separation);   /* track max constraint error */
             const float C = fclampf((toi ? b2_toiBaugarte : b2_baumgarte) * (separation + b2_linearSlop), -b2_maxLinearCorrection, 0.0f);
             const float rnA = vcross(rA, normal), rnB = vcross(rB, normal);
             const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
@@ -1649,7 +1652,7 @@ static void island_solve(World *w, Island *is, float dt, float dtRatio, int velo
                 b->sleepTime = 0.0f; minSleepTime = 0.0f;
             } else {
                 b->sleepTime += h;
-                minSleepTime = fminf(minSleepTime, b->sleepTime);
+                minSleepTime = b2minf(minSleepTime, b->sleepTime);
             }
         }
         if (minSleepTime >= b2_timeToSleep && positionSolved)
@@ -1783,7 +1786,7 @@ static void world_solve_toi(World *w, float dt, int velocityIterations) {   /* b
                 const DProxy pA = dproxy_of(&bA->shape), pB = dproxy_of(&bB->shape);
                 float beta;                                   /* the fraction of the remaining portion of the step */
                 const int state = time_of_impact(&beta, &pA, &bA->sweep, &pB, &bB->sweep, 1.0f);
-                if (state == TOI_TOUCHING) alpha = fminf(alpha0 + (1.0f - alpha0) * beta, 1.0f);
+                if (state == TOI_TOUCHING) alpha = b2minf(alpha0 + (1.0f - alpha0) * beta, 1.0f);
                 else alpha = 1.0f;
                 c->toi = alpha;
                 c->toiFlag = 1;

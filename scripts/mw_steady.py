@@ -5,8 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madrl_amd.multiwalker import BatchedMultiWalkerEnv
 dev = torch.device("cuda:0"); N, W = 16384, 3
-for cont in (True, False):
-    for tof in (True, False):
+import itertools
+combos = [(True, True), (False, True)] if '--quick' in sys.argv else list(itertools.product((True, False), (True, False)))
+for cont, tof in combos:
+    if True:
         env = BatchedMultiWalkerEnv(n_walkers=W, n_envs=N, device=dev, seed=0, auto_reset=True, max_steps=500, continuous_physics=cont,
                                     terminate_on_fall=tof)
         acts = [(torch.rand((N, W, 4), device=dev) * 2 - 1).contiguous() for _ in range(4)]

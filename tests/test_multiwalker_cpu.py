@@ -1,6 +1,11 @@
-"""CPU tests (-m "not gpu") of the MultiWalker dynamics (CPU build of the solver source).
-PARITY UNPINNED: Box2D, where the reference's arithmetic for this env lives, is not available
-(SURVEY.md 8(c)); these tests check physical invariants and the env logic around the solver."""
+"""CPU tests (-m "not gpu") of the MultiWalker dynamics.
+PARITY UNPINNED: Box2D, where the reference's arithmetic for this env lives, is not available.  What IS checked:
+  * the INDEPENDENT Box2D-2.3.0-ordered restatement (oracle/multiwalker_ref.c: plain C, Box2D's own lists / islands / sweeps, no
+    code shared with the product) against the one published output of the library, the manual's "Hello Box2D" lines;
+  * the PRODUCT's solver source (madrl_amd/csrc/multiwalker_core.hpp, compiled by g++: oracle/multiwalker_oracle.cpp) against
+    that independent restatement, step by step: every body pose / velocity BIT FOR BIT, every contact of Box2D's world list
+    (pair, order, touching, feature ids, warm-start impulses), every joint impulse, every ContactDetector flag, done, rewards;
+  * physical invariants and the env logic around the solver."""
 import numpy as np
 import pytest
 
@@ -82,7 +87,8 @@ def test_constraints_hold_under_random_actions():
         # knees: a lower leg that hits the terrain is moved by the continuous (TOI) sub-step, whose island holds contacts only
         # -- Box2D solves no joints there (b2Island::SolveTOI) -- so a hard foot strike may leave the knee beyond its limit
         # until the next step's joint position correction: bounded absolutely, rare beyond 0.4 rad
-        assert (knee > -1.6 - 1.5).all() and (knee < -0.1 + 1.5).all(), (knee.min(), knee.max())
+        # (the independent Box2D-ordered restatement shows the same excursions bit for bit: test_product_source_matches_...)
+        assert (knee > -1.6 - 1.3).all() and (knee < -0.1 + 1.3).all(), (knee.min(), knee.max())
         knee_over.append(np.maximum(knee - (-0.1), -1.6 - knee).clip(0))
         # hip anchor: hull origin + R(hull) (0, LEG_DOWN)  ==  upper-leg centre + R(leg) (0, LEG_H / 2)
         for w in range(3):
@@ -94,7 +100,7 @@ def test_constraints_hold_under_random_actions():
             # "Continuous collision does not handle joints ... you may see joint stretching on fast moving objects" (Box2D manual):
             # the TOI sub-step of a foot strike moves the lower leg alone; the joint is pulled together again over the next steps
             gap = np.abs(a_up - a_lo).max(axis=1)
-            assert gap.max() < 0.6, gap.max()
+            assert gap.max() < 0.45, gap.max()
             anchor_gaps.append(gap)
         if done.any():
             o.reset(mask=done)
@@ -165,26 +171,126 @@ def test_observation_noise_has_the_requested_scale():
     assert np.array_equal(on[..., :24], oq[..., :24])
 
 
-def test_box2d_helloworld_known_answer():
-    """The one published numeric output of the absent dependency: Box2D v2.3 manual, "Hello Box2D" (a 2x2 box dropped from
-    y = 4 onto static ground, 60 steps of 1/60 s, 6/2 iterations, printed "%4.2f %4.2f %4.2f"):
+def test_independent_oracle_replays_box2d_helloworld():
+    """The one published numeric output of the absent dependency: Box2D v2.3 manual, "Hello Box2D" (a 2 x 2 box dropped from
+    y = 4 onto static ground, 60 steps of 1/60 s, 6 / 2 iterations, printed "%4.2f %4.2f %4.2f"):
         0.00 4.00 0.00 / 0.00 3.99 0.00 / 0.00 3.98 0.00 / ... / 0.00 1.25 0.00 / 0.00 1.13 0.00 / 0.00 1.01 0.00
-    replayed through the env's own world_step (oracle/box2d_kat.cpp).  Steps 44-46 are the three tail lines: the box
-    would reach y = 0.997 at step 46; the continuous (TOI) pass stops it at the surface and its sub-step leaves it at the
-    published 1.01.  All six published lines are asserted."""
-    import ctypes
-    import os
-    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libmadrl_b2kat.so")
-    if not os.path.exists(so):
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.dirname(os.path.dirname(so))])
-    L = ctypes.CDLL(so)
-    out = np.zeros((60, 3), np.float32)
-    assert L.b2kat_falling_box(out.ctypes.data_as(ctypes.c_void_p), 60) == 0
-    line = lambda i: ("%4.2f %4.2f %4.2f" % tuple(out[i - 1])).replace("-0.00", "0.00")
-    assert [line(1), line(2), line(3)] == ["0.00 4.00 0.00", "0.00 3.99 0.00", "0.00 3.98 0.00"]
-    assert [line(44), line(45)] == ["0.00 1.25 0.00", "0.00 1.13 0.00"]
-    assert line(46) == "0.00 1.01 0.00"                              # the sixth published line: needs the continuous pass
-    assert all(line(i) == "0.00 1.01 0.00" for i in range(46, 61))   # ... and the box rests there
-    # the resting height approaches polygonRadius * 2 - linearSlop = 0.015 above the surface from below, like Box2D's solver
-    assert 1.0135 < out[59, 1] < 1.015 and abs(out[59, 2]) < 1e-3
+    replayed through the independent restatement's b2World::Step (polygon - polygon contact of a static and a dynamic body, island
+    solve, continuous pass).  The box would reach y = 0.997 at step 46; the TOI sub-step leaves it at the published 1.01."""
+    from oracle import multiwalker_ref as mwr
+    for poly in (False, True):
+        out = mwr.helloworld(60, poly=poly)
+        line = lambda i: ("%4.2f %4.2f %4.2f" % tuple(out[i - 1])).replace("-0.00", "0.00")
+        assert [line(1), line(2), line(3)] == ["0.00 4.00 0.00", "0.00 3.99 0.00", "0.00 3.98 0.00"]
+        assert [line(44), line(45)] == ["0.00 1.25 0.00", "0.00 1.13 0.00"]
+        assert line(46) == "0.00 1.01 0.00"                              # the sixth published line: needs the continuous pass
+        assert all(line(i) == "0.00 1.01 0.00" for i in range(46, 61))   # ... and the box rests there
+        # the resting height approaches polygonRadius * 2 - linearSlop = 0.015 above the surface from below, like Box2D's solver
+        assert 1.0135 < out[59, 1] < 1.0151 and abs(out[59, 2]) < 1e-3
+
+
+def _contacts_equal(a, b):
+    (ai, af), (bi, bf) = a, b
+    return len(ai) == len(bi) and np.array_equal(ai, bi) and np.array_equal(af, bf)
+
+
+@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local")])
+def test_product_source_matches_the_independent_oracle_bit_for_bit(n_walkers, reward_mech):
+    """Teacher-forced on the bodies (the product takes the oracle's poses and velocities at the start of every step; contacts,
+    joint impulses, fat AABBs and sleep times are each side's own), random actions with stretches of zero actions (limp walkers
+    collapse: hull contacts, game over, resets), auto-reset on done.  Both sides use the same sin / cos polynomial here."""
+    from oracle import multiwalker_ref as mwr
+    W, N, T = n_walkers, 24, 160
+    ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=5, env_id_base=3, position_noise=0, angle_noise=0, reward_mech=reward_mech, poly=True)
+    core = _mk(N, n_walkers=W, seed=5, env_id_base=3, reward_mech=reward_mech)
+    ro, co = ref.reset(), core.reset()
+    assert np.array_equal(ref.terrain(), core.terrain())
+    # mass, inertia (the product stores the reciprocals: compare those)
+    assert np.array_equal(np.float32(1) / ref.model()[:, 0], np.float32(1) / core.masses()[0::2]) and np.allclose(ref.model()[:, 1], core.masses()[1::2], rtol=1e-6)
+    assert np.array_equal(ref.bodies(), core.bodies()[0]) and np.abs(ro - co).max() < 1e-6
+    rng = np.random.RandomState(2)
+    n_done = n_touch = 0
+    for t in range(T):
+        a = rng.uniform(-1, 1, (N, W, 4)).astype(np.float32)
+        if t % 50 > 38:
+            a[:] = 0
+        core.set_bodies(ref.bodies())
+        ro, rr, rd = ref.step(a)
+        co, cr, cd = core.step(a)
+        cb, cf = core.bodies()
+        assert np.array_equal(ref.bodies(), cb), "step %d: body poses / velocities differ in their bits" % t
+        assert np.array_equal(ref.flags(), cf) and np.array_equal(rd, cd), "step %d: ContactDetector flags / done" % t
+        assert np.array_equal(ref.joints(), core.joints()), "step %d: joint impulses / limit states" % t
+        assert np.array_equal(ref.aux(), core.aux()), "step %d: fat AABBs / sleep times / awake flags" % t
+        for e in range(0, N, 5):
+            assert _contacts_equal(ref.contacts(e), core.contacts(e)), "step %d env %d: the world's contact list" % (t, e)
+            n_touch += int(ref.contacts(e)[0][:, 3].sum())
+        assert np.abs(ro - co).max() <= 1e-6 * max(1.0, np.abs(ro).max()), "observations (float32 of the float64 expression)"
+        assert np.abs(rr - cr).max() <= 1e-6 * max(1.0, np.abs(rr).max()), "rewards"
+        n_done += int(rd.sum())
+        if rd.any():
+            ref.reset(mask=rd); core.reset(mask=rd)
+    assert n_done > 0 and n_touch > 0 and ref.stats()["toi_events"] > 50
+
+
+def test_product_source_matches_the_independent_oracle_free_running():
+    """No re-synchronisation at all: both are deterministic and identical in every bit, so 250 free-running steps stay identical."""
+    from oracle import multiwalker_ref as mwr
+    W, N = 3, 16
+    ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=8, position_noise=0, angle_noise=0, poly=True)
+    core = _mk(N, n_walkers=W, seed=8)
+    ref.reset(); core.reset()
+    rng = np.random.RandomState(4)
+    for t in range(250):
+        a = rng.uniform(-1, 1, (N, W, 4)).astype(np.float32)
+        ro, rr, rd = ref.step(a)
+        co, cr, cd = core.step(a)
+        assert np.array_equal(ref.bodies(), core.bodies()[0]) and np.array_equal(rd, cd), t
+        if rd.any():
+            ref.reset(mask=rd); core.reset(mask=rd)
+
+
+def test_injected_terrain_and_push_and_libm_sensitivity():
+    """reset_with(terrain, push): the parity hooks a recorded Box2D episode would be replayed through.  And how sensitive this
+    contact system is to the last bit of sin / cos: the independent oracle built with libm's sinf / cosf (what Box2D calls)
+    instead of the product's polynomial stays within 1e-5 (relative to max(1, |x|)) of the product on most env-steps, and the
+    rest are amplified rounding, not different contact sets -- the share is reported so that a future comparison with a real
+    Box2D build is read against it."""
+    from oracle import multiwalker_ref as mwr
+    W, N, T = 3, 32, 120
+    rng = np.random.RandomState(7)
+    terrain = 400 / 30.0 / 4 + np.cumsum(rng.uniform(-0.03, 0.03, (N, 75)), axis=1) * (np.arange(75) > 20)
+    push = rng.uniform(-5, 5, (N, W))
+    ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=1, position_noise=0, angle_noise=0, poly=True)
+    lib = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=1, position_noise=0, angle_noise=0, poly=False)
+    core = _mk(N, n_walkers=W, seed=1)
+    ref.reset(terrain=terrain, push=push); lib.reset(terrain=terrain, push=push); core.reset_with(terrain=terrain, push=push)
+    assert np.array_equal(core.terrain(), terrain.astype(np.float32)) and np.array_equal(ref.bodies(), core.bodies()[0])
+    within = []
+    for t in range(T):
+        a = rng.uniform(-1, 1, (N, W, 4)).astype(np.float32)
+        core.set_bodies(lib.bodies()); ref.set_bodies(lib.bodies())
+        lib.step(a); ref.step(a); core.step(a)
+        assert np.array_equal(ref.bodies(), core.bodies()[0])
+        lb = lib.bodies()
+        within.append((np.abs(lb - core.bodies()[0]) / np.maximum(1.0, np.abs(lb))).reshape(N, -1).max(1) <= 1e-5)
+    share = float(np.mean(within))
+    print("libm-sin/cos oracle vs product: %.4f of env-steps within 1e-5" % share)
+    assert share > 0.85
+
+
+def test_sleeping_and_waking():
+    """b2Island::Solve sleeping: limp walkers that have come to rest are put to sleep (velocities exactly zero) after half a
+    second below the tolerances; apply_action wakes the walkers' bodies at the start of every step (SetMotorSpeed)."""
+    o = _mk(4, seed=6, terminate_on_fall=False)
+    o.reset()
+    slept = 0
+    for t in range(500):
+        obs, rew, done = o.step(np.zeros((4, 3, 4)))
+        aux = o.aux()
+        asleep = aux[:, :, 5] == 0
+        if asleep.any():
+            slept += 1
+            b = o.bodies()[0]
+            assert (b[asleep][:, 3:] == 0).all(), "a sleeping body has zero velocity"
+    assert slept > 0
