@@ -316,13 +316,17 @@ typedef struct madrl_multiwalker_config {
 typedef struct madrl_multiwalker madrl_multiwalker; /* opaque */
 
 int madrl_multiwalker_obs_dim(const madrl_multiwalker_config *cfg, int32_t *out_dim);        /* 32 (:243) */
-/* one opaque world struct per env (bodies, joints, manifold cache, terrain); caller allocates + zeroes */
+/* one world record + step scratch per env (see madrl_multiwalker_record_bytes) plus one byte per env; caller allocates + zeroes */
 int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n_envs, uint64_t *out_bytes);
 int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device, void *state_dev,
                              madrl_multiwalker **out);
 void madrl_multiwalker_destroy(madrl_multiwalker *h);
 int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks);
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain);
+/* layout of the state buffer: n_envs blocks of stride_bytes each -- the world record (world_bytes: bodies, flags, joints, contacts,
+ * broad phase, terrain) followed by the step's scratch (manifolds and solver schedule, handed from launch to launch: one step is a
+ * sequence of kernel launches) -- then one byte per env (pending trailing step of a reset) */
+int madrl_multiwalker_record_bytes(const madrl_multiwalker *h, int32_t *stride_bytes, int32_t *world_bytes);
 /* MultiWalkerEnv.reset (:330-357) incl. its trailing zero-action step; obs float32 [N][W][obs_dim] (32, or 71 with one_hot) */
 int madrl_multiwalker_reset(madrl_multiwalker *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
 /* MultiWalkerEnv.step (:359-428): actions float32 [N][W][4]; rew float32 [N][W]; done uint8 [N]

@@ -121,6 +121,7 @@ SIGNATURES = {
     "madrl_multiwalker_destroy": (None, [_vp]),
     "madrl_multiwalker_set_launch": (C.c_int, [_vp, C.c_int64]),
     "madrl_multiwalker_dims": (C.c_int, [_vp, _vp, _vp]),
+    "madrl_multiwalker_record_bytes": (C.c_int, [_vp, _vp, _vp]),
     "madrl_multiwalker_reset": (C.c_int, [_vp] * 4),
     "madrl_multiwalker_step": (C.c_int, [_vp] * 6),
     "madrl_multiwalker_get_bodies": (C.c_int, [_vp] * 5),

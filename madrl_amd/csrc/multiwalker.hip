@@ -28,9 +28,13 @@ using namespace madrl;
 struct MwDev {
     mw::EnvCfg cfg;
     uint32_t gid_base;
-    int32_t world_dw;      // dwords per env in the state buffer
+    int32_t world_dw;      // dwords per env in the state buffer: mw::World, then the step's Scratch
+    int32_t scratch_off_dw; // where the Scratch starts inside an env's block
+    uint8_t *pending;      // [n_envs] at the end of the state buffer: this env runs the trailing step of a reset in pass 1
     int32_t scratch_bytes; // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
-    int32_t env_lds_bytes; // LDS per env: Hot | Scratch | actions, rewards, done
+    int32_t env_lds_bytes; // LDS per env in the solver launch: Hot | Scratch | actions, rewards, done
+    int32_t env_lds_bytes_staged;  // ... in the other launches, which also stage Cold: | the used part of mw::Cold
+    int32_t cold_dw;       // dwords of mw::Cold in use (up to the last slot of this walker count)
     int64_t n_envs;
     const mw::Model *model;
     uint32_t *state;
@@ -45,6 +49,9 @@ struct MwIO {
     uint8_t *done;         // [N]
 };
 
+#ifndef MADRL_MW_SOLVE_WAVES
+#define MADRL_MW_SOLVE_WAVES 2   // resident wavefronts per SIMD the solver launch's registers are allocated for
+#endif
 constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
 constexpr int IO_BYTES = (4 * mw::MAX_WALKERS + mw::MAX_WALKERS + 4) * 4;  // s_act | s_rew | s_done
 
@@ -68,62 +75,116 @@ struct GroupPar {
     __device__ __forceinline__ void or_bits(uint32_t *p, uint32_t v) const { atomicOr(p, v); }
 };
 
-// MODE 0: reset(mask)   MODE 1: step (+ fused auto-reset)
-template <int MODE, int EPW>
-__global__ __launch_bounds__(64, 2) void multiwalker_kernel(const MwDev d, const MwIO io) {
+// One API call is a SEQUENCE of launches over the same per-env records (Hot in LDS for the duration of a launch, Cold in place in
+// HBM, the step's Scratch -- manifolds and schedule -- handed from launch to launch through the caller's state buffer):
+//   PH_COLLIDE  apply_action, b2ContactManager::Collide, islands + level schedule        (mw::step_collide)
+//   PH_SOLVE    b2Island::Solve by levels, sleeping, SynchronizeFixtures, FindNewContacts (mw::step_solve)
+//   PH_TOI      b2World::SolveTOI, then the observation / reward / done of the step       (mw::solve_toi, mw::env_observe)
+//   PH_RESET    MultiWalkerEnv.reset (:330-357) without its trailing step                 (mw::env_reset_world)
+// Three kernels instead of one because a kernel's register allocation is the maximum over its phases: the narrow phase and the
+// time-of-impact root finder (GJK) need 250+ VGPRs, and in one kernel the 180-sweep solver loop ran at two wavefronts per SIMD with
+// its joint state spilled to scratch memory.
+// pass 0 = the step proper (every env, the caller's actions, rewards / done written); pass 1 = the trailing zero-action step of a
+// reset (:357), only for the envs whose byte in `pending` is set -- by PH_RESET (reset(mask)) or by PH_TOI of pass 0 (auto-reset).
+enum { PH_RESET = 0, PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 3 };
+
+// Collide, the continuous pass and reset walk the contacts, the terrain and the broad phase's boxes with data-dependent, mostly
+// single-lane access chains: from HBM / L2 every link costs a memory round trip.  Those launches copy the env's Cold record into LDS
+// (coalesced), work there and copy it back; the solver launch touches Cold once per step and leaves it in HBM.
+template <int PHASE> struct PhaseStage { static constexpr bool value = true; };
+template <> struct PhaseStage<PH_SOLVE> { static constexpr bool value = false; };
+template <int PHASE> struct PhaseOcc { static constexpr int value = 2; };
+template <> struct PhaseOcc<PH_SOLVE> { static constexpr int value = MADRL_MW_SOLVE_WAVES; };
+
+template <int PHASE, int EPW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PhaseOcc<PHASE>::value, PhaseOcc<PHASE>::value)))
+void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
     const mw::Model &M = *d.model;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NL = 64 / EPW;
     const int g = threadIdx.x / NL, lane = threadIdx.x % NL;
     const GroupPar<EPW> par{lane};
-    unsigned char *base = smem + g * d.env_lds_bytes;
+    constexpr bool STAGE = PhaseStage<PHASE>::value;
+    unsigned char *base = smem + g * (STAGE ? d.env_lds_bytes_staged : d.env_lds_bytes);
     mw::Hot &Wd = *reinterpret_cast<mw::Hot *>(base);
     mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES);
     float *s_act = reinterpret_cast<float *>(base + HOT_BYTES + d.scratch_bytes);
     float *s_rew = s_act + 4 * mw::MAX_WALKERS;
     uint32_t *s_done = reinterpret_cast<uint32_t *>(s_rew + mw::MAX_WALKERS);
     const int W = M.W;
+    constexpr int SCR_HDR_DW = (int)(offsetof(mw::Scratch, m) / 4);
     for (int64_t e0 = (int64_t)blockIdx.x * EPW; e0 < d.n_envs; e0 += (int64_t)gridDim.x * EPW) {
         const int64_t env = e0 + g;
         bool active = env < d.n_envs;
-        if (MODE == 0 && active && io.mask != nullptr && io.mask[env] == 0) active = false;
+        if (active) {
+            if (PHASE == PH_RESET) active = io.mask ? io.mask[env] != 0 : (pass == 0 || d.pending[env] != 0);   // reset(mask) / auto-reset
+            else if (pass == 1) active = d.pending[env] != 0;
+        }
         if (active) {
             uint32_t *rec = d.state + env * (int64_t)d.world_dw;
-            mw::Cold &Cd = *reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
+            uint32_t *cold_g = rec + sizeof(mw::Hot) / 4;
+            uint32_t *cold_l = reinterpret_cast<uint32_t *>(base + d.env_lds_bytes);   // staged copy (launches with STAGE)
+            mw::Cold &Cd = *reinterpret_cast<mw::Cold *>(STAGE ? cold_l : cold_g);
+            uint32_t *scr = rec + d.scratch_off_dw;   // the step's Scratch between launches
             {
                 uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
                 for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = rec[k];
-                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (MODE == 1 && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
-                if (lane == 0) *s_done = 0;
+                if (STAGE) for (int k = lane; k < d.cold_dw; k += NL) cold_l[k] = cold_g[k];
+                if (PHASE == PH_SOLVE || PHASE == PH_TOI) {
+                    uint32_t *sd = reinterpret_cast<uint32_t *>(&S);
+                    for (int k = lane; k < SCR_HDR_DW; k += NL) sd[k] = scr[k];
+                }
             }
             lds_sync();
-            const uint32_t gid = d.gid_base + (uint32_t)env;
-            float *obs_row = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM
-            // pass 0: the step proper (MODE 1); pass 1: MultiWalkerEnv.reset (:330-357), which ends with step(zeros).
-            // One call site, so that env_step is inlined here and keeps LDS addressing for Wd / S.
-            uint32_t dn = 0;
-            for (int pass = (MODE == 1 ? 0 : 1); pass < 2; ++pass) {
-                if (pass == 1) {
-                    dn = *s_done;  // uniform over the group
-                    if (!(MODE == 0 || (dn != 0 && d.cfg.auto_reset))) break;
-                    for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = 0.0f;
-                    if (lane == 0) mw::env_reset_world(M, d.cfg, Wd, Cd, gid, (MODE == 0 && io.inj_terrain) ? io.inj_terrain + env * M.NT : nullptr,
-                                                       (MODE == 0 && io.inj_push) ? io.inj_push + env * W : nullptr);
-                    lds_sync();
-                }
-                mw::env_step(M, d.cfg, Wd, Cd, S, par, gid, s_act, obs_row, pass == 0 ? s_rew : (float *)nullptr,
-                             pass == 0 ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
-                if (pass == 0) { if (lane == 0 && d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2; }
-                else if (lane == 0) Wd.t = 0;
+            if (PHASE == PH_SOLVE) {   // the manifolds the collide launch emitted
+                const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
+                uint32_t *sd = reinterpret_cast<uint32_t *>(&S);
+                for (int k = SCR_HDR_DW + lane; k < SCR_HDR_DW + nm * (int)(sizeof(mw::Manifold) / 4); k += NL) sd[k] = scr[k];
                 lds_sync();
             }
-            if (MODE == 1) {
-                if (lane < W) io.rew[env * W + lane] = s_rew[lane];
-                if (lane == 0) io.done[env] = (uint8_t)dn;
+            const uint32_t gid = d.gid_base + (uint32_t)env;
+            if (PHASE == PH_RESET) {
+                if (lane == 0) {
+                    mw::env_reset_world(M, d.cfg, Wd, Cd, gid, io.inj_terrain ? io.inj_terrain + env * M.NT : nullptr, io.inj_push ? io.inj_push + env * W : nullptr);
+                    d.pending[env] = 1;
+                }
+            } else if (PHASE == PH_COLLIDE) {
+                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (pass == 0 && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
+                lds_sync();
+                mw::env_apply_actions(M, Wd, Cd, par, s_act);
+                mw::step_collide(M, Wd, Cd, S, par);
+                const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
+                const uint32_t *sd = reinterpret_cast<const uint32_t *>(&S);
+                for (int k = lane; k < SCR_HDR_DW + nm * (int)(sizeof(mw::Manifold) / 4); k += NL) scr[k] = sd[k];
+            } else if (PHASE == PH_SOLVE) {
+                mw::step_solve(M, Wd, Cd, S, par);
+            } else {
+                if (M.continuous) mw::solve_toi(M, Wd, Cd, S, par, 1.0f / mw::FPS);
+                float *obs_row = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM
+                if (lane == 0) {
+                    *s_done = 0;
+                    mw::env_observe(M, d.cfg, Wd, Cd, gid, obs_row, pass == 0 ? s_rew : (float *)nullptr, pass == 0 ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
+                    Wd.t += 1;
+                    Wd.tick += 1;
+                    if (pass == 0) {
+                        if (d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2;
+                        d.pending[env] = (d.cfg.auto_reset && *s_done != 0) ? 1 : 0;
+                    } else {
+                        Wd.t = 0;   // the reset's trailing step does not count (:357)
+                        d.pending[env] = 0;
+                    }
+                }
+                lds_sync();
+                if (pass == 0) {
+                    if (lane < W) io.rew[env * W + lane] = s_rew[lane];
+                    if (lane == 0) io.done[env] = (uint8_t)*s_done;
+                }
             }
+            lds_sync();
             {
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
                 for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
+                if (STAGE) for (int k = lane; k < d.cold_dw; k += NL) cold_g[k] = cold_l[k];
             }
         }
         // the next env of this group reuses the LDS block; its Cold part is other memory, nothing to wait for
@@ -207,13 +268,17 @@ struct madrl_multiwalker {
     madrl_multiwalker_config cfg;
     MwDev dev;
     int device;
-    int epw;  // envs per wavefront: 4 (default), 2 or 1 (MADRL_MW_EPW at create: experiments)
+    int epw_staged;  // envs per wavefront in the launches that stage Cold in LDS: 2 (default) or 4 (MADRL_MW_EPW_STAGED at create: experiments)
     int64_t max_blocks;
     void *model_dev;
     int NB, NT;
 };
 
 namespace {
+
+size_t mw_scratch_bytes(const mw::Model &M) {   // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
+    return align_up(sizeof(mw::Scratch) - (size_t)(mw::MAXM - M.max_manifolds) * sizeof(mw::Manifold), 16);
+}
 
 int mw_validate(const madrl_multiwalker_config *c) {
     if (!c) return fail(MADRL_EINVAL, "config is NULL");
@@ -225,20 +290,33 @@ int mw_validate(const madrl_multiwalker_config *c) {
     return MADRL_OK;
 }
 
-template <int EPW>
-void mw_launch_epw(const madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
+template <int PH, int EPW>
+void mw_launch_phase(const madrl_multiwalker *h, const MwIO &io, int pass, hipStream_t s) {
     int64_t blocks = (h->dev.n_envs + EPW - 1) / EPW;   // default: every group of EPW envs gets its own wavefront
     if (h->max_blocks > 0 && blocks > h->max_blocks) blocks = h->max_blocks;
-    const size_t lds = (size_t)EPW * h->dev.env_lds_bytes;
-    if (mode == 0) hipLaunchKernelGGL((multiwalker_kernel<0, EPW>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io);
-    else hipLaunchKernelGGL((multiwalker_kernel<1, EPW>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io);
+    const size_t lds = (size_t)EPW * (PhaseStage<PH>::value ? h->dev.env_lds_bytes_staged : h->dev.env_lds_bytes);
+    hipLaunchKernelGGL((mw_phase_kernel<PH, EPW>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io, pass);
+}
+// EPW envs per wavefront in the solver launch (16 lanes per env: one per joint / body), ES in the launches that stage Cold in LDS
+template <int EPW, int ES>
+void mw_launch_epw(const madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
+#define MW_PHASE(PH, PASS) mw_launch_phase<PH, (PH == PH_SOLVE ? EPW : ES)>(h, io, PASS, s)
+    if (mode == 1) {   // MultiWalkerEnv.step
+        MW_PHASE(PH_COLLIDE, 0); MW_PHASE(PH_SOLVE, 0); MW_PHASE(PH_TOI, 0);
+        if (!h->cfg.auto_reset) return;
+    }
+    // MultiWalkerEnv.reset(mask), or the fused auto-reset of the envs whose step just ended their episode: reset, then step(zeros)
+    MwIO r = io;
+    if (mode == 1) { r.mask = nullptr; r.inj_terrain = nullptr; r.inj_push = nullptr; }
+    mw_launch_phase<PH_RESET, ES>(h, r, mode == 1 ? 1 : 0, s);
+    MW_PHASE(PH_COLLIDE, 1); MW_PHASE(PH_SOLVE, 1); MW_PHASE(PH_TOI, 1);
+#undef MW_PHASE
 }
 
 int mw_launch(const madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (h->epw == 1) mw_launch_epw<1>(h, io, mode, s);
-    else if (h->epw == 2) mw_launch_epw<2>(h, io, mode, s);
-    else mw_launch_epw<4>(h, io, mode, s);
+    if (h->epw_staged == 4) mw_launch_epw<4, 4>(h, io, mode, s);
+    else mw_launch_epw<4, 2>(h, io, mode, s);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }
@@ -259,7 +337,11 @@ int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n
     int rc = mw_validate(cfg);
     if (rc) return rc;
     if (n_envs < 1 || !out_bytes) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_bytes non-NULL");
-    *out_bytes = (uint64_t)align_up(sizeof(mw::World), 16) * (uint64_t)n_envs;
+    mw::Model M;
+    memset(&M, 0, sizeof(M));
+    mw::build_model(M, cfg->n_walkers);
+    // per env: the world record, then the step's Scratch (manifolds + schedule handed from launch to launch); then one byte per env
+    *out_bytes = (uint64_t)(align_up(sizeof(mw::World), 16) + mw_scratch_bytes(M)) * (uint64_t)n_envs + align_up((uint64_t)n_envs, 16);
     return MADRL_OK;
 }
 
@@ -297,12 +379,16 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     d.cfg.drop_reward = (float)cfg->drop_reward;
     d.cfg.k0 = (uint32_t)cfg->seed; d.cfg.k1 = (uint32_t)(cfg->seed >> 32);
     d.gid_base = (uint32_t)cfg->env_id_base;
-    d.world_dw = (int32_t)(align_up(sizeof(mw::World), 16) / 4);
-    d.scratch_bytes = (int32_t)align_up(sizeof(mw::Scratch) - (size_t)(mw::MAXM - M.max_manifolds) * sizeof(mw::Manifold), 16);
+    d.scratch_bytes = (int32_t)mw_scratch_bytes(M);
+    d.scratch_off_dw = (int32_t)(align_up(sizeof(mw::World), 16) / 4);
+    d.world_dw = d.scratch_off_dw + d.scratch_bytes / 4;
+    d.pending = (uint8_t *)state_dev + (size_t)d.world_dw * 4 * (size_t)n_envs;
     d.env_lds_bytes = HOT_BYTES + d.scratch_bytes + (int32_t)align_up(IO_BYTES, 16);
+    d.cold_dw = (int32_t)(align_up(offsetof(mw::Cold, slot) + (size_t)M.n_slots * sizeof(mw::Slot), 16) / 4);
+    d.env_lds_bytes_staged = d.env_lds_bytes + d.cold_dw * 4;
     // 8 resident wavefronts per CU (two per SIMD) need 4 envs x env_lds_bytes <= 20 KB; three walkers: 5 040 bytes per env
-    h->epw = 4;
-    if (const char *e = getenv("MADRL_MW_EPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->epw = v; }
+    h->epw_staged = 2;
+    if (const char *e = getenv("MADRL_MW_EPW_STAGED")) { const int v = atoi(e); if (v == 2 || v == 4) h->epw_staged = v; }
     d.n_envs = n_envs;
     d.model = (const mw::Model *)h->model_dev;
     d.state = (uint32_t *)state_dev;
@@ -326,6 +412,13 @@ int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_
     if (!h) return fail(MADRL_EINVAL, "handle is NULL");
     if (n_bodies) *n_bodies = h->NB;
     if (n_terrain) *n_terrain = h->NT;
+    return MADRL_OK;
+}
+
+int madrl_multiwalker_record_bytes(const madrl_multiwalker *h, int32_t *stride_bytes, int32_t *world_bytes) {
+    if (!h) return fail(MADRL_EINVAL, "handle is NULL");
+    if (stride_bytes) *stride_bytes = h->dev.world_dw * 4;
+    if (world_bytes) *world_bytes = (int32_t)sizeof(mw::World);
     return MADRL_OK;
 }
 

@@ -178,6 +178,8 @@ struct Model {
     double lidar_dx[10], lidar_dy[10];   // sin / cos(1.5 i / 10) * LIDAR_RANGE in float64 (:211-213)
     float tx[MAXT];       // terrain vertex x = float32(i * TERRAIN_STEP) with the float64 product of the reference (:521, :617)
     int slot_base[MAXB], slot_cap[MAXB];  // body-vs-terrain contact ranges in Cold::slot (contact with edge e lives in slot e % cap)
+    uint8_t slot_body[MAXSLOT];           // the body whose cache holds terrain slot s
+    int n_slots;                          // slots in use: the terrain caches and the pairs
     int list_base[MAXB];                  // Scratch::bm_idx range of the manifolds a body owns in the solver (terrain contacts, and the pairs whose body B it is)
     int dyn_slot_base, n_dyn_pairs;
     int dyn_a[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS], dyn_b[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
@@ -330,6 +332,8 @@ inline void build_model(Model &M, int n_walkers) {
     for (int w = 0; w < n_walkers; ++w) { M.dyn_a[np] = 0; M.dyn_b[np] = hull_of(w); ++np; }          // package (A, proxy 0) - hull
     for (int i = 0; i < n_walkers; ++i) for (int j = i + 1; j < n_walkers; ++j) { M.dyn_a[np] = hull_of(i); M.dyn_b[np] = hull_of(j); ++np; }
     M.n_dyn_pairs = np;
+    M.n_slots = M.dyn_slot_base + np;
+    for (int b = 0; b < M.NB; ++b) for (int k = 0; k < M.slot_cap[b]; ++k) M.slot_body[M.slot_base[b] + k] = (uint8_t)b;
 }
 
 // ---------------------------------------------------------------- dynamic state
@@ -345,8 +349,7 @@ struct Slot {       // one b2Contact between a fixed pair of fixtures; 32 bytes
     uint32_t id[2];
     float ni[2], ti[2];
     uint16_t batch;              // the FindNewContacts call that created it (contact_key): its place in Box2D's lists
-    uint8_t toi_flags;           // bit 0: e_toiFlag (the cached time of impact is valid), bit 1: NOT e_enabledFlag
-    uint8_t toi_count;           // m_toiCount
+    uint16_t reserved_;          // (e_toiFlag, m_toi, m_toiCount and e_enabledFlag only live inside one SolveTOI: Scratch::toi_*)
 };
 struct Manifold {   // one active b2ContactVelocityConstraint + b2ContactPositionConstraint
     int8_t bA, bB;         // bA = -1: static terrain
@@ -370,6 +373,7 @@ struct Hot {
     float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
     double prev_shaping[MAX_WALKERS], prev_package_shaping;   // float64 like the reference's Python side (:403-411)
     uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, overflow;   // overflow: sticky, a contact did not fit its cache / the pool
+    uint8_t pending_reset, pad_;  // HIP build: this env runs the reset's trailing step in the current launch sequence (multiwalker.hip)
     uint32_t tick;
     int32_t t;
     uint32_t awake;               // bit b: body b is awake (b2Body::e_awakeFlag)
@@ -378,14 +382,14 @@ struct Hot {
 struct Cold {
     Joint j[MAXJ];                // warm-start impulses, motor targets, limit states: read at the start of a step into the
                                   // owning lane's JointCache, written back at its end
-    Slot slot[MAXSLOT];
-    float slot_toi[MAXSLOT];      // continuous pass: cached time of impact per contact (valid while Slot::toi_flags bit 0)
     float fat[MAXB][4];           // the broad phase's fat AABB of every dynamic body's proxy: lower x, y, upper x, y
     float sleep_time[MAXB];       // b2Body::m_sleepTime
     V2 sweep_c0[MAXB];            // b2Sweep::c0, a0 (the pose at the start of the step, later the last safe pose of the continuous pass)
     float sweep_a0[MAXB];
     float sweep_alpha0[MAXB];     // b2Sweep::alpha0
     float ty[MAXT];               // terrain heights, float32 as the b2EdgeShapes hold them (x = Model::tx)
+    Slot slot[MAXSLOT];           // LAST member: a world of W walkers uses the first Model::n_slots of them (the HIP kernels that stage
+                                  // this struct in LDS copy only that much)
 };
 struct World { Hot h; Cold c; };  // the packed per-env record in HBM
 
@@ -410,6 +414,12 @@ struct Scratch {  // per-step workspace (LDS on the GPU)
     uint8_t isl_done[MAXISL], isl_pos_solved[MAXISL], joint_ok[MAXJ];
     float body_minsep[MAXB];
     uint8_t slot_m[MAXSLOT];   // manifold of the (touching) contact in slot s this step, 255: did not fit the pool
+    // continuous pass (one SolveTOI): per contact its cached time of impact and bit 0 e_toiFlag, bit 1 NOT e_enabledFlag, bits 2.. m_toiCount;
+    // per body the box its vertices sweep this step; the lanes' candidates of the event selection
+    float toi_alpha[MAXSLOT];
+    uint8_t toi_meta[MAXSLOT];
+    float sbox[MAXB][4];
+    uint64_t red_key[64]; float red_alpha[64]; int32_t red_slot[64];   // one entry per lane of the largest group (one env per wavefront)
     Manifold m[MAXM];  // LAST member: the HIP kernel allocates only Model::max_manifolds of them
 };
 
@@ -724,7 +734,6 @@ MW_HD int contact_update(Slot &sl, const ManifoldOut &mo) {
     const bool touching = mo.npts > 0, was = sl.touching != 0;
     sl.touching = touching ? 1 : 0; sl.npts = (uint8_t)mo.npts;
     for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
-    sl.toi_flags &= (uint8_t)~2u;
     return touching == was ? 0 : (touching ? 1 : 2);
 }
 // a touching contact becomes a solver manifold (pool slot from par.alloc; the solver's order is decided later by build_islands)
@@ -768,7 +777,7 @@ MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, P
         int ev;
         if (!aabb_overlap(edge_fat_aabb(M, Cd, e), fatb)) {   // the fat AABBs ceased to overlap: b2ContactManager::Destroy
             ev = sl.touching ? 2 : 0;
-            sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.toi_flags = 0; sl.toi_count = 0;
+            sl.edge = -1; sl.npts = 0; sl.touching = 0;
         } else {
             ManifoldOut mo; mo.npts = 0;
             // cull (never changes a result): the tight boxes are further apart than any manifold reaches
@@ -795,7 +804,7 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par p
     S.dyn_midx[p] = -1;
     if (sl.edge < 0) return;
     if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) {   // Destroy (an EndContact would only clear lower-leg flags: none here)
-        sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.toi_flags = 0; sl.toi_count = 0;
+        sl.edge = -1; sl.npts = 0; sl.touching = 0;
         return;
     }
     const Shape &sA = M.shape[shape_of_body(bA)], &sB = M.shape[shape_of_body(bB)];
@@ -852,7 +861,7 @@ MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, u
             if (!sl.touching && !aabb_overlap(edge_fat_aabb(M, Cd, sl.edge), fatb)) Wd.overflow |= 2;
             else { Wd.overflow |= 1; continue; }
         }
-        sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.toi_flags = 0; sl.toi_count = 0;
+        sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch;
     }
 }
 MW_HD void find_new_pair_contacts(const Model &M, Cold &Cd, uint32_t moved, uint32_t batch) {
@@ -861,7 +870,7 @@ MW_HD void find_new_pair_contacts(const Model &M, Cold &Cd, uint32_t moved, uint
         Slot &sl = Cd.slot[M.dyn_slot_base + p];
         if (sl.edge >= 0 || !(((moved >> bA) | (moved >> bB)) & 1u)) continue;
         if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) continue;
-        sl.edge = 0; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.toi_flags = 0; sl.toi_count = 0;
+        sl.edge = 0; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch;
     }
 }
 
@@ -875,7 +884,7 @@ MW_HD uint64_t slot_key(const Model &M, const Cold &Cd, int si) {
     return b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
 }
 // The next entry of body b's contact-edge list after the one with key `below` (newest first = descending key), among the contacts
-// that are touching and enabled and have a manifold; returns the slot index or -1.  (b2World::Solve: "for (b2ContactEdge* ce =
+// that are touching and have a manifold (every contact is enabled when Solve runs: Collide has just updated it); returns the slot index or -1.  (b2World::Solve: "for (b2ContactEdge* ce =
 // b->m_contactList; ce; ce = ce->next)".)
 MW_HD int next_contact_edge(const Model &M, const Cold &Cd, const uint8_t *slot_m, int b, uint64_t below, uint64_t &key_out) {
     int best = -1;
@@ -883,7 +892,7 @@ MW_HD int next_contact_edge(const Model &M, const Cold &Cd, const uint8_t *slot_
     const int base = M.slot_base[b], cap = M.slot_cap[b];
     for (int k = 0; k < cap; ++k) {
         const Slot &sl = Cd.slot[base + k];
-        if (sl.edge < 0 || !sl.touching || (sl.toi_flags & 2) || slot_m[base + k] == 255) continue;
+        if (sl.edge < 0 || !sl.touching || slot_m[base + k] == 255) continue;
         const uint64_t key = b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
         if (key < below && (best < 0 || key > bk)) { best = base + k; bk = key; }
     }
@@ -891,7 +900,7 @@ MW_HD int next_contact_edge(const Model &M, const Cold &Cd, const uint8_t *slot_
         for (int p = 0; p < M.n_dyn_pairs; ++p) {
             if (M.dyn_a[p] != b && M.dyn_b[p] != b) continue;
             const Slot &sl = Cd.slot[M.dyn_slot_base + p];
-            if (sl.edge < 0 || !sl.touching || (sl.toi_flags & 2) || slot_m[M.dyn_slot_base + p] == 255) continue;
+            if (sl.edge < 0 || !sl.touching || slot_m[M.dyn_slot_base + p] == 255) continue;
             const uint64_t key = contact_key(sl.batch, proxy_of_body(M.dyn_a[p], M.NT), proxy_of_body(M.dyn_b[p], M.NT));
             if (key < below && (best < 0 || key > bk)) { best = M.dyn_slot_base + p; bk = key; }
         }
@@ -1435,60 +1444,64 @@ MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl,
     return sl.touching != 0;
 }
 
-// b2World::SolveTOI.  `par`: the first time of impact of every contact is computed by the lane that owns the body; the event loop
-// (a body arriving at the terrain within this step: about one event per three env-steps) runs on lane 0 of the env.
+// b2World::SolveTOI.  Box2D's loop -- find the contact with the smallest time of impact, handle it, repeat -- with its two halves
+// mapped differently on the lanes of `par`: the SEARCH (time-of-impact root finder for every contact whose cached value is invalid,
+// minimum over all contacts) is shared by all lanes, contact by contact; the EVENT (a body arriving at the terrain within this step:
+// about one per three env-steps) is handled by lane 0.  Results do not depend on the mapping: the minimum is taken over (time, place in
+// the world's contact list), the same total order Box2D's serial walk realises.
 template <class Par>
 MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, float h) {
     const int L0 = par.lane(), LN = par.n();
-    const int NB = M.NB, NDP = M.n_dyn_pairs;
-    // ---- "if (m_stepComplete)": alpha0 = 0 for every body, every contact's cached TOI invalid and its sub-step count 0; then
-    // (by body) the first time of impact of every contact of an awake body with the terrain
+    const int NB = M.NB, NDP = M.n_dyn_pairs, NTS = M.dyn_slot_base;
+    // ---- "if (m_stepComplete)": alpha0 = 0 for every body, every contact's cached TOI invalid, its sub-step count 0, enabled (Collide
+    // has updated every contact in this step); per body the box it sweeps
     for (int bi = L0; bi < NB; bi += LN) {
         Cd.sweep_alpha0[bi] = 0.0f;
-        Slot *slots = Cd.slot + M.slot_base[bi];
-        const int cap = M.slot_cap[bi];
-        const bool awake = (Wd.awake >> bi) & 1u;
-        const Shape &sh = M.shape[shape_of_body(bi)];
-        const Sweep sB = sweep_of_body(M, Wd, Cd, bi);
-        const SweptBox box = swept_box(sh, sB);
-        for (int k = 0; k < cap; ++k) {
-            Slot &sl = slots[k];
-            if (sl.edge < 0) continue;
-            sl.toi_flags &= (uint8_t)~1u; sl.toi_count = 0;
-            if (!awake || (sl.toi_flags & 2)) continue;   // a sleeping body against static terrain: no active body; disabled contact
-            Cd.slot_toi[M.slot_base[bi] + k] = toi_alpha_terrain(M, Cd, bi, sl.edge, sB, box);
-            sl.toi_flags |= 1;
-        }
+        const SweptBox box = swept_box(M.shape[shape_of_body(bi)], sweep_of_body(M, Wd, Cd, bi));
+        S.sbox[bi][0] = box.xmin; S.sbox[bi][1] = box.xmax; S.sbox[bi][2] = box.ymin; S.sbox[bi][3] = box.ymax;
     }
-    for (int p = L0; p < NDP; p += LN) { Slot &sl = Cd.slot[M.dyn_slot_base + p]; sl.toi_flags &= (uint8_t)~1u; sl.toi_count = 0; }
+    for (int s = L0; s < M.n_slots; s += LN) S.toi_meta[s] = 0;
     par.sync();
-    if (L0 != 0 || M.continuous == 2) { par.sync(); return; }   // continuous == 2: timing experiments only (candidates without events)
-    // ---- event loop (lane 0)
+    if (M.continuous == 3) return;   // timing experiments only: 3 = set-up, 2 = set-up and one search without events
     for (int guard = 0; guard < 8 * MAX_TOI_CONTACTS; ++guard) {
-        // the contact with the smallest time of impact; among equal times the first of the world's contact list (largest key)
-        int min_slot = -1, mover = -1;
+        // ---- the contact with the smallest time of impact; among equal times the first of the world's contact list (largest key).  Two
+        // dynamic non-bullet bodies are never tested (the pairs), a sleeping body against static terrain has no active body.
+        float my_alpha = 1.0f;
+        uint64_t my_key = 0;
+        int my_slot = -1;
+        for (int s = L0; s < NTS; s += LN) {
+            const Slot &sl = Cd.slot[s];
+            if (sl.edge < 0) continue;
+            const int bi = M.slot_body[s];
+            if (!((Wd.awake >> bi) & 1u)) continue;
+            uint8_t meta = S.toi_meta[s];
+            if ((meta & 2) || (meta >> 2) > MAX_SUB_STEPS) continue;
+            if (!(meta & 1)) {   // no valid cached TOI: compute it on the body's current sweep
+                SweptBox box; box.xmin = S.sbox[bi][0]; box.xmax = S.sbox[bi][1]; box.ymin = S.sbox[bi][2]; box.ymax = S.sbox[bi][3];
+                S.toi_alpha[s] = toi_alpha_terrain(M, Cd, bi, sl.edge, sweep_of_body(M, Wd, Cd, bi), box);
+                S.toi_meta[s] = (uint8_t)(meta | 1);
+            }
+            const float alpha = S.toi_alpha[s];
+            if (alpha > my_alpha) continue;
+            const uint64_t key = bi == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(bi, M.NT));
+            if (alpha < my_alpha || (my_slot >= 0 && key > my_key)) { my_alpha = alpha; my_slot = s; my_key = key; }
+        }
+        S.red_alpha[L0] = my_alpha; S.red_key[L0] = my_key; S.red_slot[L0] = my_slot;
+        par.sync();
+        int min_slot = -1;
         float min_alpha = 1.0f;
         uint64_t min_key = 0;
-        for (int bi = 0; bi < NB; ++bi) {
-            if (!((Wd.awake >> bi) & 1u)) continue;
-            const int base = M.slot_base[bi], cap = M.slot_cap[bi];
-            bool have_box = false;
-            Sweep sB; SweptBox box;
-            for (int k = 0; k < cap; ++k) {
-                Slot &sl = Cd.slot[base + k];
-                if (sl.edge < 0 || (sl.toi_flags & 2) || sl.toi_count > MAX_SUB_STEPS) continue;
-                if (!(sl.toi_flags & 1)) {   // invalidated by a sub-step of this body: compute it on its new sweep
-                    if (!have_box) { sB = sweep_of_body(M, Wd, Cd, bi); box = swept_box(M.shape[shape_of_body(bi)], sB); have_box = true; }
-                    Cd.slot_toi[base + k] = toi_alpha_terrain(M, Cd, bi, sl.edge, sB, box);
-                    sl.toi_flags |= 1;
-                }
-                const float alpha = Cd.slot_toi[base + k];
-                if (alpha > min_alpha) continue;
-                const uint64_t key = bi == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(bi, M.NT));
-                if (alpha < min_alpha || (min_slot >= 0 && key > min_key)) { min_alpha = alpha; min_slot = base + k; mover = bi; min_key = key; }
-            }
+        for (int l = 0; l < LN; ++l) {   // every lane reduces the LN candidates: the same result everywhere
+            const int sl_ = S.red_slot[l];
+            if (sl_ < 0) continue;
+            const float a_ = S.red_alpha[l];
+            const uint64_t k_ = S.red_key[l];
+            if (a_ < min_alpha || (a_ == min_alpha && min_slot >= 0 && k_ > min_key)) { min_alpha = a_; min_slot = sl_; min_key = k_; }
         }
-        if (min_slot < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha) break;   // no more TOI events
+        par.sync();
+        if (min_slot < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha || M.continuous == 2) break;   // no more TOI events
+        if (L0 != 0) { par.sync(); continue; }   // the event itself: lane 0
+        const int mover = M.slot_body[min_slot];
         // ---- advance the body to the time of impact (b2Body::Advance); the static edge does not move
         const V2 bk_c0 = Cd.sweep_c0[mover], bk_c = Wd.b[mover].c;
         const float bk_a0 = Cd.sweep_a0[mover], bk_a = Wd.b[mover].a, bk_alpha0 = Cd.sweep_alpha0[mover];
@@ -1501,14 +1514,14 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
         Slot &ms = Cd.slot[min_slot];
         ManifoldOut mo;
         const bool touching = toi_update_contact(M, Wd, Cd, ms, mover, mo);   // the TOI contact likely has some new contact points
-        ms.toi_flags &= (uint8_t)~1u;
-        ms.toi_count = (uint8_t)(ms.toi_count + 1);
+        S.toi_meta[min_slot] = (uint8_t)((S.toi_meta[min_slot] & ~1u) + 4u);   // e_toiFlag cleared, ++m_toiCount
         MW_STAT(toi_events, 1);
         if (!touching) {  // not solid after all: disable the contact, restore the sweep
             MW_STAT(toi_undone, 1);
-            ms.toi_flags |= 2;
+            S.toi_meta[min_slot] |= 2;
             Cd.sweep_c0[mover] = bk_c0; Cd.sweep_a0[mover] = bk_a0; Cd.sweep_alpha0[mover] = bk_alpha0;
             Wd.b[mover].c = bk_c; Wd.b[mover].a = bk_a;
+            par.sync();
             continue;
         }
         // ---- mini island: the event's contact, then the body's other contacts with static bodies in its contact-edge order, each
@@ -1613,25 +1626,49 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
         {
             const bool moved = sync_fixture(M, Wd, Cd, mover);
             const int base = M.slot_base[mover], cap = M.slot_cap[mover];
-            for (int k = 0; k < cap; ++k) Cd.slot[base + k].toi_flags &= (uint8_t)~1u;
-            for (int p = 0; p < NDP; ++p) if (M.dyn_a[p] == mover || M.dyn_b[p] == mover) Cd.slot[M.dyn_slot_base + p].toi_flags &= (uint8_t)~1u;
+            for (int k = 0; k < cap; ++k) S.toi_meta[base + k] &= (uint8_t)~1u;
             Wd.batch += 1;
             if (moved) {
                 find_new_terrain_contacts(M, Wd, Cd, mover, Wd.batch);
                 find_new_pair_contacts(M, Cd, 1u << mover, Wd.batch);
             }
+            const SweptBox box = swept_box(msh, sweep_of_body(M, Wd, Cd, mover));   // its new sweep: from the safe pose to the end of the sub-step
+            S.sbox[mover][0] = box.xmin; S.sbox[mover][1] = box.xmax; S.sbox[mover][2] = box.ymin; S.sbox[mover][3] = box.ymax;
         }
+        par.sync();
     }
+    par.sync();
+    (void)NDP;
+}
+
+// b2World::Step(1/50, 180, 60) for the lanes of `par`, in three phases -- the HIP build runs them as three kernels (the registers of
+// the narrow phase and of the time-of-impact root finder would otherwise be charged to the 180-sweep solver loop):
+//   step_collide   b2ContactManager::Collide + the island construction and level schedule of b2World::Solve
+//   step_solve     b2Island::Solve of every island (level by level), sleeping, SynchronizeFixtures, FindNewContacts
+//   solve_toi      b2World::SolveTOI
+template <class Par>
+MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+    const int L0 = par.lane(), LN = par.n();
+    const int NB = M.NB, NDP = M.n_dyn_pairs;
+    for (int sh = L0; sh < N_SHAPES; sh += LN) { S.sh_im[sh] = M.shape[sh].inv_mass; S.sh_ii[sh] = M.shape[sh].inv_I; S.sh_lc[sh] = M.shape[sh].centroid; }
+    if (L0 == 0) { S.nm = 0; S.moved = 0; }
+    par.sync();
+    // ---- b2ContactManager::Collide: every contact is updated (D4); Begin / EndContact -> ContactDetector flags
+    for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi, S.slot_m);
+    par.sync();
+    if (L0 == 0) for (int p = 0; p < NDP; ++p) collide_dyn_pair(M, Wd, Cd, S, par, p, S.slot_m);   // may wake bodies: one lane
+    par.sync();
+    // ---- b2World::Solve: islands, constraint order and levels (one lane)
+    if (L0 == 0) build_islands(M, Wd, Cd, S, S.slot_m);
     par.sync();
 }
 
-// b2World::Step(1/50, 180, 60) for the lanes of `par`.
 template <class Par>
-MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     const float h = 1.0f / FPS;
     const int L0 = par.lane(), LN = par.n();
     // the model scalars are read once: the solver loops below must not go back to memory for them
-    const int NB = M.NB, NW = M.W, NDP = M.n_dyn_pairs;
+    const int NB = M.NB, NW = M.W;
     // lane-private constants of the bodies this lane owns (bi = L0 + kb * LN): manifold-list base, mass data
     int own_lb[Par::BODIES];
     MassAB own_q[Par::BODIES];   // as body B of a contact with the terrain (A: zeros)
@@ -1645,17 +1682,6 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
         own_q[kb].mB = sh.inv_mass; own_q[kb].iB = sh.inv_I; own_q[kb].lcB = sh.centroid;
         own_lb[kb] = M.list_base[bi];
     }
-    for (int sh = L0; sh < N_SHAPES; sh += LN) { S.sh_im[sh] = M.shape[sh].inv_mass; S.sh_ii[sh] = M.shape[sh].inv_I; S.sh_lc[sh] = M.shape[sh].centroid; }
-    if (L0 == 0) { S.nm = 0; S.moved = 0; }
-    par.sync();
-    // ---- b2ContactManager::Collide: every contact is updated (D4); Begin / EndContact -> ContactDetector flags
-    for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi, S.slot_m);
-    par.sync();
-    if (L0 == 0) for (int p = 0; p < NDP; ++p) collide_dyn_pair(M, Wd, Cd, S, par, p, S.slot_m);   // may wake bodies: one lane
-    par.sync();
-    // ---- b2World::Solve: islands, constraint order and levels (one lane)
-    if (L0 == 0) build_islands(M, Wd, Cd, S, S.slot_m);
-    par.sync();
     const int n_jl = S.n_jlevels, n_cl = S.n_clevels;
     // ---- integrate velocities (gravity + the pending initial push) of the bodies of this step's islands
     MW_UNROLL
@@ -1817,10 +1843,16 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
     par.sync();
     if (L0 == 0 && S.moved) find_new_pair_contacts(M, Cd, S.moved, Wd.batch);
     par.sync();
-    // ---- continuous pass (b2World::Step: "if (m_continuousPhysics && step.dt > 0) SolveTOI(step)")
-    if (M.continuous) solve_toi(M, Wd, Cd, S, par, h);
 }
 #undef MW_CONTACT_SWEEP
+
+template <class Par>
+MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+    step_collide(M, Wd, Cd, S, par);
+    step_solve(M, Wd, Cd, S, par);
+    // ---- continuous pass (b2World::Step: "if (m_continuousPhysics && step.dt > 0) SolveTOI(step)")
+    if (M.continuous) solve_toi(M, Wd, Cd, S, par, 1.0f / FPS);
+}
 
 
 // ---------------------------------------------------------------- lidar: b2World::RayCast -> b2EdgeShape::RayCast over the terrain, closest hit (D2)
@@ -1879,7 +1911,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, u
     const uint32_t tick = Wd.tick;
     Wd.game_over = 0; Wd.overflow = 0; Wd.prev_package_shaping = 0.0; Wd.t = 0;
     for (int w = 0; w < MAX_WALKERS; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
-    for (int k = 0; k < MAXSLOT; ++k) { Slot &sl = Cd.slot[k]; sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.batch = 0; sl.toi_flags = 0; sl.toi_count = 0; }
+    for (int k = 0; k < M.n_slots; ++k) { Slot &sl = Cd.slot[k]; sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.batch = 0; sl.reserved_ = 0; }
     // _generate_terrain, non-hardcore branch (:516-612): float64 like the reference's Python loop, float32 when it enters Box2D
     {
         double velocity = 0.0, y = TERRAIN_HEIGHT64;
@@ -1949,10 +1981,10 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, u
 }
 
 // MultiWalkerEnv.step (:359-428).  obs: [W][32], rew: [W]
+// apply_action (:194-203) for all walkers: the first thing MultiWalkerEnv.step does
 template <class Par>
-MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
-                    float *rew, uint8_t *done) {
-    for (int w = par.lane(); w < M.W; w += par.n()) {  // apply_action (:194-203)
+MW_HD_INLINE void env_apply_actions(const Model &M, Hot &Wd, Cold &Cd, Par par, const float *actions) {
+    for (int w = par.lane(); w < M.W; w += par.n()) {
         for (int k = 0; k < 4; ++k) {
             const float a = actions[4 * w + k];
             Joint &j = Cd.j[4 * w + k];
@@ -1965,6 +1997,11 @@ MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, S
         for (int b = 1; b < M.NB; ++b) if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; }
     }
     par.sync();
+}
+template <class Par>
+MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
+                    float *rew, uint8_t *done) {
+    env_apply_actions(M, Wd, Cd, par, actions);
     world_step(M, Wd, Cd, S, par);  // :365
     if (par.lane() == 0) {
         env_observe(M, C, Wd, Cd, gid, obs, rew, done);

@@ -92,7 +92,9 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         nb, nt = C.c_int32(), C.c_int32()
         _lib.check(L.madrl_multiwalker_dims(h, C.byref(nb), C.byref(nt)))
         self.n_bodies, self.n_terrain = nb.value, nt.value
-        self.world_bytes = nbytes.value // N
+        stride, wb = C.c_int32(), C.c_int32()
+        _lib.check(L.madrl_multiwalker_record_bytes(h, C.byref(stride), C.byref(wb)))
+        self.record_stride, self.world_bytes = stride.value, wb.value   # block per env (world record + step scratch), world record alone
         self.walkers = [BipedalWalker(self.obs_dim) for _ in range(W)]
         self.package_scale = W / 1.75
         self.package_length = 240 / 30.0 * self.package_scale
@@ -199,8 +201,8 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
 
     @property
     def state_buffer(self):
-        """raw per-env world structs, uint8 [N, world_bytes] (checkpoint / teacher-forcing hook)"""
-        return self._state.view(self.n_envs, self.world_bytes)
+        """raw per-env blocks, uint8 [N, record_stride]: the world record (first world_bytes) and the step scratch (checkpoint hook)"""
+        return self._state[:self.n_envs * self.record_stride].view(self.n_envs, self.record_stride)
 
     def __getstate__(self):
         return dict(self._ctor)

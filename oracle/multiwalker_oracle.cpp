@@ -157,7 +157,7 @@ int mwo_get_contacts(const MwOracle *o, int64_t n, int32_t *ints, float *flts, i
             int32_t *p = ints + (size_t)count * 8; float *f = flts + (size_t)count * 4;
             if (best >= M.dyn_slot_base) { p[0] = M.dyn_a[best - M.dyn_slot_base]; p[1] = M.dyn_b[best - M.dyn_slot_base]; p[2] = -1; }
             else { int b = 0; while (b + 1 < M.NB && best >= M.slot_base[b + 1]) ++b; p[0] = -1; p[1] = b; p[2] = sl.edge; }
-            p[3] = sl.touching; p[4] = sl.npts; p[5] = sl.npts > 0 ? (int32_t)sl.id[0] : 0; p[6] = sl.npts > 1 ? (int32_t)sl.id[1] : 0; p[7] = sl.toi_count;
+            p[3] = sl.touching; p[4] = sl.npts; p[5] = sl.npts > 0 ? (int32_t)sl.id[0] : 0; p[6] = sl.npts > 1 ? (int32_t)sl.id[1] : 0; p[7] = 0;
             for (int k = 0; k < 2; ++k) { f[2 * k] = k < sl.npts ? sl.ni[k] : 0.0f; f[2 * k + 1] = k < sl.npts ? sl.ti[k] : 0.0f; }
         }
         ++count;

@@ -2302,7 +2302,7 @@ void mwr_get_terrain(const mwr_handle *h, float *out) {
         for (int i = 0; i < NT; ++i) out[(size_t)n * NT + i] = (float)h->envs[n].terrain_y[i];
 }
 /* The contact list of env n in WORLD LIST ORDER (newest first): per contact int32 [8] = body A (C-ABI order, -1 = terrain), body B,
- * terrain edge index (-1 = none), touching, point count, feature key of point 0 / 1, toi count; float32 [4] = normal / tangent impulse
+ * terrain edge index (-1 = none), touching, point count, feature key of point 0 / 1, 0; float32 [4] = normal / tangent impulse
  * of point 0, 1.  Returns the number of contacts (at most max_contacts are written). */
 int mwr_get_contacts(const mwr_handle *h, int64_t n, int32_t *ints, float *flts, int max_contacts) {
     const MwEnv *e = &h->envs[n];
@@ -2322,7 +2322,7 @@ int mwr_get_contacts(const mwr_handle *h, int64_t n, int32_t *ints, float *flts,
         o[3] = c->touching; o[4] = c->manifold.pointCount;
         o[5] = c->manifold.pointCount > 0 ? (int32_t)feature_key(c->manifold.points[0].id) : 0;
         o[6] = c->manifold.pointCount > 1 ? (int32_t)feature_key(c->manifold.points[1].id) : 0;
-        o[7] = c->toiCount;
+        o[7] = 0;   /* (m_toiCount only lives inside one SolveTOI) */
         for (int k = 0; k < 2; ++k) {
             f[2 * k] = k < c->manifold.pointCount ? c->manifold.points[k].normalImpulse : 0.0f;
             f[2 * k + 1] = k < c->manifold.pointCount ? c->manifold.points[k].tangentImpulse : 0.0f;

@@ -6,7 +6,7 @@ import torch
 from madrl_amd.multiwalker import BatchedMultiWalkerEnv
 dev = torch.device("cuda:0"); N, W = 16384, 3
 import itertools
-combos = [(True, True), (False, True)] if '--quick' in sys.argv else list(itertools.product((True, False), (True, False)))
+combos = [(True, True)] if '--one' in sys.argv else [(True, True), (False, True)] if '--quick' in sys.argv else list(itertools.product((True, False), (True, False)))
 for cont, tof in combos:
     if True:
         env = BatchedMultiWalkerEnv(n_walkers=W, n_envs=N, device=dev, seed=0, auto_reset=True, max_steps=500, continuous_physics=cont,

@@ -36,7 +36,7 @@ def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
                                 n_envs=N, seed=11, env_id_base=7, one_hot=one_hot)
     if one_hot:
         assert env.obs_dim == 71 and env.agents[0].observation_space.shape == (71,)
-    assert env.world_bytes >= orc.world_bytes and env.world_bytes - orc.world_bytes < 16
+    assert env.world_bytes >= orc.world_bytes   # the device record is followed by the step's scratch (manifolds, schedule)
     obs = env.reset()
     oobs = orc.reset()
     assert np.array_equal(obs.cpu().numpy(), oobs), "reset obs"
@@ -136,7 +136,8 @@ def test_determinism_and_launch_shape():
         for t in range(15):
             a = (torch.rand((300, 3, 4), generator=g) * 2 - 1).to(DEV)
             obs, rew, done, _ = env.step(a)
-        outs.append((obs.cpu().clone(), env.state_buffer.cpu().clone()))
+        outs.append((obs.cpu().clone(), env.state_buffer[:, :env.world_bytes].cpu().clone()))   # the world records (the step scratch behind them holds
+        # the manifolds in pool order, i.e. in the order the lanes' atomic allocations happened to land)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
