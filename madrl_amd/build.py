@@ -15,6 +15,9 @@ SO = os.path.join(HERE, "libmadrl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# per-source additions.  multiwalker: the SLP vectorizer pairs the solver's scalar float math into packed-fp32 instructions, which
+# need every loop constant replicated into register pairs -- the 180-sweep loop then runs out of VGPRs (AGPR copies, scratch)
+EXTRA_FLAGS = {"multiwalker.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -36,7 +39,7 @@ def build(force=False, verbose=False):
         stale = force or not os.path.exists(obj) or any(
             os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps())
         if stale:
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

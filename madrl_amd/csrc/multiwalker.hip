@@ -32,8 +32,9 @@ struct MwDev {
     int32_t scratch_off_dw; // where the Scratch starts inside an env's block
     uint8_t *pending;      // [n_envs] at the end of the state buffer: this env runs the trailing step of a reset in pass 1
     int32_t scratch_bytes; // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
-    int32_t env_lds_bytes; // LDS per env in the solver launch: Hot | Scratch | actions, rewards, done
-    int32_t env_lds_bytes_staged;  // ... in the other launches, which also stage Cold: | the used part of mw::Cold
+    int32_t env_lds_bytes; // LDS per env outside the solver launch, first part: Hot | Scratch | actions, rewards, done
+    int32_t env_lds_bytes_staged;  // ... all of it: | the used part of mw::Cold | mw::ToiWork
+    int32_t env_lds_bytes_solve;   // LDS per env in the solver launch: Hot | the solver's part of Scratch
     int32_t cold_dw;       // dwords of mw::Cold in use (up to the last slot of this walker count)
     int64_t n_envs;
     const mw::Model *model;
@@ -50,7 +51,15 @@ struct MwIO {
 };
 
 #ifndef MADRL_MW_SOLVE_WAVES
-#define MADRL_MW_SOLVE_WAVES 2   // resident wavefronts per SIMD the solver launch's registers are allocated for
+#define MADRL_MW_SOLVE_WAVES 1   // resident wavefronts per SIMD the solver launch's registers are allocated for
+#endif
+#ifndef MADRL_MW_SOLVE_MREG
+#define MADRL_MW_SOLVE_MREG 3    // manifolds a solver lane holds in registers for the whole solve
+#endif
+constexpr int SOLVE_EPW = 64 / mw::SOLVE_LANES;   // envs per wavefront in the solver launch: one lane per walker
+constexpr int SOLVE_HDR_BYTES = (int)((offsetof(mw::Scratch, dyn_midx) + 15) / 16 * 16);   // the part of Scratch the solver works on
+#ifndef MADRL_MW_SOLVE_OVERFLOW
+#define MADRL_MW_SOLVE_OVERFLOW 8   // manifolds per env the solver launch can hold in LDS on top of the lanes' register copies
 #endif
 constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
 constexpr int IO_BYTES = (4 * mw::MAX_WALKERS + mw::MAX_WALKERS + 4) * 4;  // s_act | s_rew | s_done
@@ -65,9 +74,10 @@ __device__ __forceinline__ void lds_sync() {
 template <int EPW>
 struct GroupPar {
     static constexpr int NL = 64 / EPW;
-    static constexpr int JOINTS = (mw::MAXJ + NL - 1) / NL;
-    static constexpr int BODIES = (mw::MAXB + NL - 1) / NL;
+    static constexpr int SOLVE_EMU = 1;                    // mw::step_solve: this lane IS one solver lane
+    static constexpr int MREG = MADRL_MW_SOLVE_MREG;
     int l;
+    __device__ __forceinline__ int solve_lane(int) const { return l; }
     __device__ __forceinline__ int lane() const { return l; }
     __device__ __forceinline__ int n() const { return NL; }
     __device__ __forceinline__ void sync() const { lds_sync(); }
@@ -105,7 +115,8 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
     const int g = threadIdx.x / NL, lane = threadIdx.x % NL;
     const GroupPar<EPW> par{lane};
     constexpr bool STAGE = PhaseStage<PHASE>::value;
-    unsigned char *base = smem + g * (STAGE ? d.env_lds_bytes_staged : d.env_lds_bytes);
+    static_assert(PHASE != PH_SOLVE || NL == mw::SOLVE_LANES, "the solver launch runs one lane per walker");
+    unsigned char *base = smem + g * (STAGE ? d.env_lds_bytes_staged : d.env_lds_bytes_solve);
     mw::Hot &Wd = *reinterpret_cast<mw::Hot *>(base);
     mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES);
     float *s_act = reinterpret_cast<float *>(base + HOT_BYTES + d.scratch_bytes);
@@ -130,18 +141,12 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
                 uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
                 for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = rec[k];
                 if (STAGE) for (int k = lane; k < d.cold_dw; k += NL) cold_l[k] = cold_g[k];
-                if (PHASE == PH_SOLVE || PHASE == PH_TOI) {
+                if (PHASE == PH_SOLVE || PHASE == PH_TOI) {   // the schedule the collide launch built (the solver: only its part)
                     uint32_t *sd = reinterpret_cast<uint32_t *>(&S);
-                    for (int k = lane; k < SCR_HDR_DW; k += NL) sd[k] = scr[k];
+                    for (int k = lane; k < (PHASE == PH_SOLVE ? SOLVE_HDR_BYTES / 4 : SCR_HDR_DW); k += NL) sd[k] = scr[k];
                 }
             }
             lds_sync();
-            if (PHASE == PH_SOLVE) {   // the manifolds the collide launch emitted
-                const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
-                uint32_t *sd = reinterpret_cast<uint32_t *>(&S);
-                for (int k = SCR_HDR_DW + lane; k < SCR_HDR_DW + nm * (int)(sizeof(mw::Manifold) / 4); k += NL) sd[k] = scr[k];
-                lds_sync();
-            }
             const uint32_t gid = d.gid_base + (uint32_t)env;
             if (PHASE == PH_RESET) {
                 if (lane == 0) {
@@ -157,9 +162,12 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
                 const uint32_t *sd = reinterpret_cast<const uint32_t *>(&S);
                 for (int k = lane; k < SCR_HDR_DW + nm * (int)(sizeof(mw::Manifold) / 4); k += NL) scr[k] = sd[k];
             } else if (PHASE == PH_SOLVE) {
-                mw::step_solve(M, Wd, Cd, S, par);
+                // the manifolds the collide launch emitted stay in the state buffer: every lane copies the ones it owns into registers
+                mw::step_solve(M, Wd, Cd, S, reinterpret_cast<mw::Manifold *>(scr + SCR_HDR_DW),
+                               reinterpret_cast<mw::Manifold *>(base + HOT_BYTES + SOLVE_HDR_BYTES), MADRL_MW_SOLVE_OVERFLOW, par);
             } else {
-                if (M.continuous) mw::solve_toi(M, Wd, Cd, S, par, 1.0f / mw::FPS);
+                mw::step_post(M, Wd, Cd, S, par);
+                if (M.continuous) mw::solve_toi(M, Wd, Cd, S, *reinterpret_cast<mw::ToiWork *>(base + d.env_lds_bytes + d.cold_dw * 4), par, 1.0f / mw::FPS);
                 float *obs_row = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM
                 if (lane == 0) {
                     *s_done = 0;
@@ -294,7 +302,7 @@ template <int PH, int EPW>
 void mw_launch_phase(const madrl_multiwalker *h, const MwIO &io, int pass, hipStream_t s) {
     int64_t blocks = (h->dev.n_envs + EPW - 1) / EPW;   // default: every group of EPW envs gets its own wavefront
     if (h->max_blocks > 0 && blocks > h->max_blocks) blocks = h->max_blocks;
-    const size_t lds = (size_t)EPW * (PhaseStage<PH>::value ? h->dev.env_lds_bytes_staged : h->dev.env_lds_bytes);
+    const size_t lds = (size_t)EPW * (PhaseStage<PH>::value ? h->dev.env_lds_bytes_staged : h->dev.env_lds_bytes_solve);
     hipLaunchKernelGGL((mw_phase_kernel<PH, EPW>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io, pass);
 }
 // EPW envs per wavefront in the solver launch (16 lanes per env: one per joint / body), ES in the launches that stage Cold in LDS
@@ -315,8 +323,8 @@ void mw_launch_epw(const madrl_multiwalker *h, const MwIO &io, int mode, hipStre
 
 int mw_launch(const madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (h->epw_staged == 4) mw_launch_epw<4, 4>(h, io, mode, s);
-    else mw_launch_epw<4, 2>(h, io, mode, s);
+    if (h->epw_staged == 4) mw_launch_epw<SOLVE_EPW, 4>(h, io, mode, s);
+    else mw_launch_epw<SOLVE_EPW, 2>(h, io, mode, s);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }
@@ -385,7 +393,10 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     d.pending = (uint8_t *)state_dev + (size_t)d.world_dw * 4 * (size_t)n_envs;
     d.env_lds_bytes = HOT_BYTES + d.scratch_bytes + (int32_t)align_up(IO_BYTES, 16);
     d.cold_dw = (int32_t)(align_up(offsetof(mw::Cold, slot) + (size_t)M.n_slots * sizeof(mw::Slot), 16) / 4);
-    d.env_lds_bytes_staged = d.env_lds_bytes + d.cold_dw * 4;
+    d.env_lds_bytes_solve = HOT_BYTES + SOLVE_HDR_BYTES + MADRL_MW_SOLVE_OVERFLOW * (int32_t)sizeof(mw::Manifold);
+    d.env_lds_bytes_solve = (d.env_lds_bytes_solve + 255 - 16) / 256 * 256 + 16;   // env g's block starts 4 LDS banks after env g-1's: the lanes
+                                                                                    // of a wavefront (16 envs) then hit disjoint banks with 16-byte accesses
+    d.env_lds_bytes_staged = d.env_lds_bytes + d.cold_dw * 4 + (int32_t)align_up(sizeof(mw::ToiWork), 16);
     // 8 resident wavefronts per CU (two per SIMD) need 4 envs x env_lds_bytes <= 20 KB; three walkers: 5 040 bytes per env
     h->epw_staged = 2;
     if (const char *e = getenv("MADRL_MW_EPW_STAGED")) { const int v = atoi(e); if (v == 2 || v == 4) h->epw_staged = v; }

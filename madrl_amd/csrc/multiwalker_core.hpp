@@ -54,7 +54,7 @@ namespace mw {
 
 // optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
 #ifdef MW_STATS
-struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6]; };
+struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], pairs_hist[40], posit_hist[8]; };
 extern Stats g_stats;
 #define MW_STAT(f, v) (g_stats.f += (v))
 #else
@@ -180,7 +180,6 @@ struct Model {
     int slot_base[MAXB], slot_cap[MAXB];  // body-vs-terrain contact ranges in Cold::slot (contact with edge e lives in slot e % cap)
     uint8_t slot_body[MAXSLOT];           // the body whose cache holds terrain slot s
     int n_slots;                          // slots in use: the terrain caches and the pairs
-    int list_base[MAXB];                  // Scratch::bm_idx range of the manifolds a body owns in the solver (terrain contacts, and the pairs whose body B it is)
     int dyn_slot_base, n_dyn_pairs;
     int dyn_a[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS], dyn_b[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
 };
@@ -318,14 +317,12 @@ inline void build_model(Model &M, int n_walkers) {
             knee.bA = hip.bB; knee.bB = hip.bB + 1;
             knee.lA = v2(0, -LEG_H / 2); knee.lB = v2(0, LEG_H / 2); knee.lower = -1.6f; knee.upper = -0.1f;
         }
-    int base = 0, lbase = 0;
+    int base = 0;
     for (int b = 0; b < M.NB; ++b) {
         M.slot_base[b] = base;
         // candidate edges = those whose fat AABB overlaps the body's: a run no longer than (fat width + edge margins) / TERRAIN_STEP + 1
         M.slot_cap[b] = (b == 0) ? (int)((M.package_length + 1.5f) / TERRAIN_STEP) + 12 : (is_hull(b) ? EDGE_SLOTS_HULL : EDGE_SLOTS_LEG);
         base += M.slot_cap[b];
-        M.list_base[b] = lbase;
-        lbase += M.slot_cap[b] + (is_hull(b) ? n_walkers : 0);   // a hull also owns the pairs whose body B it is: (package, hull) and (hull_i, hull), i < this
     }
     M.dyn_slot_base = base;
     int np = 0;
@@ -394,33 +391,41 @@ struct Cold {
 struct World { Hot h; Cold c; };  // the packed per-env record in HBM
 
 constexpr int NDYN = MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
-constexpr int MAXLIST = MAXSLOT + MAX_WALKERS * MAX_WALKERS;   // Model::list_base ranges
 constexpr int MAXISL = MAX_WALKERS + 1;
+// The island solver runs on SOLVE_LANES lanes per env: lane w owns the four joints of walker w, and the step's contacts are dealt out to
+// the lanes by build_islands.  (The CPU build executes the lanes one after the other.)
+constexpr int SOLVE_LANES = MAX_WALKERS;
 struct Scratch {  // per-step workspace (LDS on the GPU)
+    // ---- what the solver launch keeps in LDS (up to `dyn_midx`)
     int nm;
-    int8_t n_isl, n_jlevels, n_clevels, all_done;
+    int8_t n_isl, n_rounds, max_cnt, all_done;
     uint32_t moved;            // bit b: body b's proxy is in the broad phase's move buffer
     uint32_t in_island;        // bit b: body b was simulated by this step's Solve (b2Body::e_islandFlag after b2World::Solve)
     // mass data of the four shapes (package, hull, upper leg, lower leg), copied once per step
     float sh_im[N_SHAPES], sh_ii[N_SHAPES];
     V2 sh_lc[N_SHAPES];
-    // solver schedule (island order cut into levels): per body the manifolds it owns, by ascending level
-    uint8_t bm_cnt[MAXB], bm_idx[MAXLIST];
-    uint8_t m_level[MAXM];     // contact phase level of manifold k
-    uint8_t j_level[MAXJ];     // joint phase level of joint j, 255: its island is asleep (not simulated)
-    int8_t j_island[MAXJ];
+    // solver schedule (build_islands): per lane its manifolds in island order; manifold k runs in round m_round[k], inside a round in the
+    // order of its position in the lane's list; per walker its joints in island order
+    uint8_t lane_cnt[SOLVE_LANES], lane_list[SOLVE_LANES][MAXM];
+    uint8_t m_round[MAXM];
+    uint8_t jn[MAX_WALKERS], jorder[MAX_WALKERS][4];
+    int8_t j_island[MAXJ];     // island of joint j, -1: none (its bodies are asleep and were not reached)
     int8_t island_of[MAXB];    // island of body b in this step's Solve, -1: none (asleep and not reached)
-    int8_t dyn_midx[NDYN];     // manifold of pair p, or -1
     uint8_t isl_done[MAXISL], isl_pos_solved[MAXISL], joint_ok[MAXJ];
     float body_minsep[MAXB];
+    // ---- the other launches
+    int8_t dyn_midx[NDYN];     // manifold of pair p, or -1
     uint8_t slot_m[MAXSLOT];   // manifold of the (touching) contact in slot s this step, 255: did not fit the pool
-    // continuous pass (one SolveTOI): per contact its cached time of impact and bit 0 e_toiFlag, bit 1 NOT e_enabledFlag, bits 2.. m_toiCount;
-    // per body the box its vertices sweep this step; the lanes' candidates of the event selection
-    float toi_alpha[MAXSLOT];
-    uint8_t toi_meta[MAXSLOT];
-    float sbox[MAXB][4];
+    Manifold m[MAXM];  // LAST member: the HIP kernels allocate only Model::max_manifolds of them
+};
+
+// workspace of one SolveTOI (LDS in the HIP kernel of the continuous pass): per contact its cached time of impact and bit 0 e_toiFlag,
+// bit 1 NOT e_enabledFlag, bits 2.. m_toiCount; per body the box its vertices sweep this step; the lanes' candidates of the event selection
+struct ToiWork {
     uint64_t red_key[64]; float red_alpha[64]; int32_t red_slot[64];   // one entry per lane of the largest group (one env per wavefront)
-    Manifold m[MAXM];  // LAST member: the HIP kernel allocates only Model::max_manifolds of them
+    float toi_alpha[MAXSLOT];
+    float sbox[MAXB][4];
+    uint8_t toi_meta[MAXSLOT];
 };
 
 MW_HD Xf body_xf(const Model &M, const Body &b, int bi) {
@@ -715,10 +720,15 @@ MW_HD void set_ground_flag(Hot &Wd, int b, bool on) { Wd.ground[(b - 1) / 5][(b 
 // Constraints of one LEVEL of the schedule never share a body, so the lane-parallel sweep produces the bits of Box2D's
 // serial one (see the file header).
 struct SerialPar {
-    static constexpr int JOINTS = MAXJ;   // joints a lane may own
-    static constexpr int BODIES = MAXB;   // bodies a lane may own
+    static constexpr int SOLVE_EMU = SOLVE_LANES;   // solver lanes this thread executes, one after the other
+    static constexpr int MREG = 2;                  // manifolds a solver lane keeps in lane-private storage (the rest: the pool)
+    static constexpr int SOLVE_OVERFLOW = 3;        // room for that many manifolds in the overflow copies (the HIP launch: LDS)
+    Manifold ovf[SOLVE_OVERFLOW];
+    MW_HD Manifold *solve_overflow() { return ovf; }
+    bool rev = false;                               // test hook: run the solver lanes in descending order
     MW_HD int lane() const { return 0; }
     MW_HD int n() const { return 1; }
+    MW_HD int solve_lane(int i) const { return rev ? SOLVE_LANES - 1 - i : i; }
     MW_HD void sync() const {}
     MW_HD int alloc(int *counter) const { return (*counter)++; }
     MW_HD void or_bits(uint32_t *p, uint32_t v) const { *p |= v; }
@@ -913,13 +923,17 @@ MW_HD int next_contact_edge(const Model &M, const Cold &Cd, const uint8_t *slot_
 // gets the list of the manifolds it owns in ascending level.  A sleeping seed is skipped; every body reached is woken.
 MW_HD void build_islands(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, const uint8_t *slot_m) {
     const int NB = M.NB, NW = M.W;
-    int8_t last_c[MAXB], last_j[MAXB];
+    // the last contact constraint scheduled on body b: its lane, position in that lane's list and round (lane -1: none yet)
+    int8_t b_lane[MAXB], b_pos[MAXB], b_round[MAXB];
+    int8_t lane_round[SOLVE_LANES];
     uint32_t flag = 0;       // e_islandFlag of the bodies
     uint32_t jflag = 0;      // of the joints
     uint64_t cflag = 0;      // of the manifolds (pool index)
-    for (int b = 0; b < NB; ++b) { S.island_of[b] = -1; S.bm_cnt[b] = 0; last_c[b] = -1; last_j[b] = -1; }
-    for (int j = 0; j < 4 * NW; ++j) { S.j_level[j] = 255; S.j_island[j] = -1; }
-    int n_isl = 0, max_cl = -1, max_jl = -1;
+    for (int b = 0; b < NB; ++b) { S.island_of[b] = -1; b_lane[b] = -1; b_pos[b] = 0; b_round[b] = 0; }
+    for (int j = 0; j < 4 * NW; ++j) S.j_island[j] = -1;
+    for (int l = 0; l < SOLVE_LANES; ++l) { S.lane_cnt[l] = 0; lane_round[l] = 0; }
+    for (int w = 0; w < NW; ++w) S.jn[w] = 0;
+    int n_isl = 0, max_round = -1, max_cnt = 0;
     int stack[MAXB + 2];
     for (int s = 0; s < NB; ++s) {
         const int seed = s < NB - 1 ? NB - 1 - s : 0;   // body list: the walkers' bodies newest first, (static terrain,) the package last
@@ -942,14 +956,27 @@ MW_HD void build_islands(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, const ui
                 cflag |= 1ull << mi;
                 Manifold &m = S.m[mi];
                 m.island = (uint8_t)isl;
-                // list scheduling: this contact's level in the contact phase of a sweep
-                const int la = m.bA >= 0 ? last_c[m.bA] : -1, lb = last_c[m.bB];
-                const int lv = (la > lb ? la : lb) + 1;
-                S.m_level[mi] = (uint8_t)lv;
-                if (m.bA >= 0) last_c[m.bA] = (int8_t)lv;
-                last_c[m.bB] = (int8_t)lv;
-                if (lv > max_cl) max_cl = lv;
-                S.bm_idx[M.list_base[m.bB] + S.bm_cnt[m.bB]++] = (uint8_t)mi;   // owner: body B; appended in island order = ascending level
+                // schedule: a sweep runs round by round and inside a round position by position of the lanes' lists, all lanes at once.
+                // Any lane may hold any contact (the bodies live in shared memory): the contact goes to the lane that can run it earliest,
+                // where it must sit lexicographically after the last constraint of either body that another lane holds.
+                int ln = 0, pos = 0, rd = 0, best = 1 << 30;
+                for (int l = 0; l < SOLVE_LANES; ++l) {
+                    const int p_ = S.lane_cnt[l];
+                    int r_ = lane_round[l];
+                    for (int q = 0; q < 2; ++q) {
+                        const int x = q ? m.bB : m.bA;
+                        if (x < 0 || b_lane[x] < 0 || b_lane[x] == l) continue;
+                        const int need = b_pos[x] < p_ ? b_round[x] : b_round[x] + 1;
+                        if (need > r_) r_ = need;
+                    }
+                    const int key = r_ * 64 + p_;
+                    if (key < best) { best = key; ln = l; pos = p_; rd = r_; }
+                }
+                S.lane_list[ln][pos] = (uint8_t)mi; S.m_round[mi] = (uint8_t)rd; S.lane_cnt[ln] = (uint8_t)(pos + 1);
+                lane_round[ln] = (int8_t)rd;
+                for (int q = 0; q < 2; ++q) { const int x = q ? m.bB : m.bA; if (x >= 0) { b_lane[x] = (int8_t)ln; b_pos[x] = (int8_t)pos; b_round[x] = (int8_t)rd; } }
+                if (rd > max_round) max_round = rd;
+                if (pos + 1 > max_cnt) max_cnt = pos + 1;
                 const int other = m.bB == b ? m.bA : m.bB;
                 if (other < 0) continue;                // static terrain: islands do not propagate across static bodies
                 if ((flag >> other) & 1u) continue;
@@ -967,10 +994,8 @@ MW_HD void build_islands(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, const ui
                     if ((jflag >> ji) & 1u) continue;
                     jflag |= 1u << ji;
                     const int jA = M.jd[ji].bA, jB = M.jd[ji].bB;
-                    const int lv = (last_j[jA] > last_j[jB] ? last_j[jA] : last_j[jB]) + 1;
-                    S.j_level[ji] = (uint8_t)lv; S.j_island[ji] = (int8_t)isl;
-                    last_j[jA] = (int8_t)lv; last_j[jB] = (int8_t)lv;
-                    if (lv > max_jl) max_jl = lv;
+                    S.j_island[ji] = (int8_t)isl;
+                    S.jorder[w][S.jn[w]++] = (uint8_t)ji;   // a walker's joints only share bodies with each other: its lane runs them in island order
                     const int other = jA == b ? jB : jA;
                     if ((flag >> other) & 1u) continue;
                     stack[sp++] = other;
@@ -979,14 +1004,14 @@ MW_HD void build_islands(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, const ui
             }
         }
     }
-    S.n_isl = (int8_t)n_isl; S.n_clevels = (int8_t)(max_cl + 1); S.n_jlevels = (int8_t)(max_jl + 1);
+    S.n_isl = (int8_t)n_isl; S.n_rounds = (int8_t)(max_round + 1); S.max_cnt = (int8_t)max_cnt;
     S.in_island = flag;
 }
 
 // ---------------------------------------------------------------- island solver (b2Island::Solve)
 // inverse mass, inverse inertia and local centre of the two bodies of a constraint; A = static terrain: zeros
 struct MassAB { float mA, iA, mB, iB; V2 lcA, lcB; };
-MW_HD MassAB mass_of_pair(const Scratch &S, int bA, int bB) {
+MW_HD_INLINE MassAB mass_of_pair(const Scratch &S, int bA, int bB) {
     MassAB q;
     if (bA < 0) { q.mA = 0.0f; q.iA = 0.0f; q.lcA = v2(0, 0); }
     else { const int sa = shape_of_body(bA); q.mA = S.sh_im[sa]; q.iA = S.sh_ii[sa]; q.lcA = S.sh_lc[sa]; }
@@ -997,13 +1022,13 @@ MW_HD MassAB mass_of_pair(const Scratch &S, int bA, int bB) {
 
 // k = [ex.x ex.y ex.z ey.x ey.y ey.z ez.x ez.y ez.z]; Cramer's rule as b2Mat33::Solve33, split into the part that only
 // depends on the matrix (constant over the sweeps of a step) and the part that depends on the right-hand side
-MW_HD void solve33_prepare(const float *k, float &cx, float &cy, float &cz, float &det) {
+MW_HD_INLINE void solve33_prepare(const float *k, float &cx, float &cy, float &cz, float &det) {
     const float exx = k[0], exy = k[1], exz = k[2], eyx = k[3], eyy = k[4], eyz = k[5], ezx = k[6], ezy = k[7], ezz = k[8];
     cx = eyy * ezz - eyz * ezy; cy = eyz * ezx - eyx * ezz; cz = eyx * ezy - eyy * ezx;  // cross(ey, ez)
     det = exx * cx + exy * cy + exz * cz;
     if (det != 0.0f) det = 1.0f / det;
 }
-MW_HD void solve33(const float *k, float cx, float cy, float cz, float det, float bx, float by, float bz, float &x, float &y, float &z) {
+MW_HD_INLINE void solve33(const float *k, float cx, float cy, float cz, float det, float bx, float by, float bz, float &x, float &y, float &z) {
     const float exx = k[0], exy = k[1], exz = k[2], eyx = k[3], eyy = k[4], eyz = k[5], ezx = k[6], ezy = k[7], ezz = k[8];
     x = det * (bx * cx + by * cy + bz * cz);
     const float dx = by * ezz - bz * ezy, dy = bz * ezx - bx * ezz, dz = bx * ezy - by * ezx;        // cross(b, ez)
@@ -1024,7 +1049,7 @@ MW_HD void solve22(const float *k, float det, float bx, float by, float &x, floa
 }
 
 // b2ContactSolver::InitializeVelocityConstraints + WarmStart for manifold k
-MW_HD void contact_init_warm(Hot &Wd, Manifold &m, const MassAB &q) {
+MW_HD_INLINE void contact_init_warm(Hot &Wd, Manifold &m, const MassAB &q) {
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
     Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = xf_from(Wd.b[m.bA].c, Wd.b[m.bA].a, q.lcA);
@@ -1105,7 +1130,7 @@ struct JointCache {
 };
 
 // b2RevoluteJoint::InitVelocityConstraints (+ warm start)
-MW_HD void joint_init_warm(const Model &M, Hot &Wd, const Cold &Cd, Scratch &S, int ji, float h, JointCache &c) {
+MW_HD_INLINE void joint_init_warm(const Model &M, Hot &Wd, const Cold &Cd, Scratch &S, int ji, float h, JointCache &c) {
     const JointDef &jd = M.jd[ji];
     const Joint &j = Cd.j[ji];
     c.bA = jd.bA; c.bB = jd.bB;
@@ -1144,7 +1169,7 @@ MW_HD void joint_init_warm(const Model &M, Hot &Wd, const Cold &Cd, Scratch &S, 
 }
 
 // b2RevoluteJoint::SolveVelocityConstraints
-MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
+MW_HD_INLINE void joint_solve_velocity(Hot &Wd, JointCache &c) {
     Body &A = Wd.b[c.bA], &B = Wd.b[c.bB];
     const float mA = c.mA, iA = c.iA, mB = c.mB, iB = c.iB;
     const V2 rA = c.rA, rB = c.rB;
@@ -1193,7 +1218,7 @@ MW_HD void joint_solve_velocity(Hot &Wd, JointCache &c) {
 
 // b2ContactSolver::SolveVelocityConstraints for manifold k
 // ... on velocities the caller holds (the continuous pass keeps its one moving body in registers over all sweeps)
-MW_HD void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float &wA, V2 &vB, float &wB) {
+MW_HD_INLINE void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float &wA, V2 &vB, float &wB) {
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     const V2 normal = m.normal, tangent = cross(normal, 1.0f);
     MW_UNROLL
@@ -1244,7 +1269,7 @@ MW_HD void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float
         }
     }
 }
-MW_HD void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
+MW_HD_INLINE void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
     V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
     float wA = m.bA < 0 ? 0.0f : Wd.b[m.bA].w, wB = Wd.b[m.bB].w;
     contact_solve_velocity_on(m, q, vA, wA, vB, wB);
@@ -1253,7 +1278,7 @@ MW_HD void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
 }
 
 // b2ContactSolver::SolvePositionConstraints for manifold k; returns its minimum separation
-MW_HD float contact_solve_position(Hot &Wd, const Manifold &m, const MassAB &q) {
+MW_HD_INLINE float contact_solve_position(Hot &Wd, const Manifold &m, const MassAB &q) {
     float min_sep = 0.0f;
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
@@ -1290,7 +1315,7 @@ MW_HD float contact_solve_position(Hot &Wd, const Manifold &m, const MassAB &q) 
 }
 
 // b2RevoluteJoint::SolvePositionConstraints; returns whether the joint is within tolerance
-MW_HD bool joint_solve_position(Hot &Wd, const JointCache &c) {
+MW_HD_INLINE bool joint_solve_position(Hot &Wd, const JointCache &c) {
     Body &A = Wd.b[c.bA], &B = Wd.b[c.bB];
     const float mA = c.mA, iA = c.iA, mB = c.mB, iB = c.iB;
     float ang_err = 0.0f;
@@ -1450,7 +1475,7 @@ MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl,
 // about one per three env-steps) is handled by lane 0.  Results do not depend on the mapping: the minimum is taken over (time, place in
 // the world's contact list), the same total order Box2D's serial walk realises.
 template <class Par>
-MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, float h) {
+MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, Par par, float h) {
     const int L0 = par.lane(), LN = par.n();
     const int NB = M.NB, NDP = M.n_dyn_pairs, NTS = M.dyn_slot_base;
     // ---- "if (m_stepComplete)": alpha0 = 0 for every body, every contact's cached TOI invalid, its sub-step count 0, enabled (Collide
@@ -1458,9 +1483,9 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
     for (int bi = L0; bi < NB; bi += LN) {
         Cd.sweep_alpha0[bi] = 0.0f;
         const SweptBox box = swept_box(M.shape[shape_of_body(bi)], sweep_of_body(M, Wd, Cd, bi));
-        S.sbox[bi][0] = box.xmin; S.sbox[bi][1] = box.xmax; S.sbox[bi][2] = box.ymin; S.sbox[bi][3] = box.ymax;
+        T.sbox[bi][0] = box.xmin; T.sbox[bi][1] = box.xmax; T.sbox[bi][2] = box.ymin; T.sbox[bi][3] = box.ymax;
     }
-    for (int s = L0; s < M.n_slots; s += LN) S.toi_meta[s] = 0;
+    for (int s = L0; s < M.n_slots; s += LN) T.toi_meta[s] = 0;
     par.sync();
     if (M.continuous == 3) return;   // timing experiments only: 3 = set-up, 2 = set-up and one search without events
     for (int guard = 0; guard < 8 * MAX_TOI_CONTACTS; ++guard) {
@@ -1474,28 +1499,28 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
             if (sl.edge < 0) continue;
             const int bi = M.slot_body[s];
             if (!((Wd.awake >> bi) & 1u)) continue;
-            uint8_t meta = S.toi_meta[s];
+            uint8_t meta = T.toi_meta[s];
             if ((meta & 2) || (meta >> 2) > MAX_SUB_STEPS) continue;
             if (!(meta & 1)) {   // no valid cached TOI: compute it on the body's current sweep
-                SweptBox box; box.xmin = S.sbox[bi][0]; box.xmax = S.sbox[bi][1]; box.ymin = S.sbox[bi][2]; box.ymax = S.sbox[bi][3];
-                S.toi_alpha[s] = toi_alpha_terrain(M, Cd, bi, sl.edge, sweep_of_body(M, Wd, Cd, bi), box);
-                S.toi_meta[s] = (uint8_t)(meta | 1);
+                SweptBox box; box.xmin = T.sbox[bi][0]; box.xmax = T.sbox[bi][1]; box.ymin = T.sbox[bi][2]; box.ymax = T.sbox[bi][3];
+                T.toi_alpha[s] = toi_alpha_terrain(M, Cd, bi, sl.edge, sweep_of_body(M, Wd, Cd, bi), box);
+                T.toi_meta[s] = (uint8_t)(meta | 1);
             }
-            const float alpha = S.toi_alpha[s];
+            const float alpha = T.toi_alpha[s];
             if (alpha > my_alpha) continue;
             const uint64_t key = bi == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(bi, M.NT));
             if (alpha < my_alpha || (my_slot >= 0 && key > my_key)) { my_alpha = alpha; my_slot = s; my_key = key; }
         }
-        S.red_alpha[L0] = my_alpha; S.red_key[L0] = my_key; S.red_slot[L0] = my_slot;
+        T.red_alpha[L0] = my_alpha; T.red_key[L0] = my_key; T.red_slot[L0] = my_slot;
         par.sync();
         int min_slot = -1;
         float min_alpha = 1.0f;
         uint64_t min_key = 0;
         for (int l = 0; l < LN; ++l) {   // every lane reduces the LN candidates: the same result everywhere
-            const int sl_ = S.red_slot[l];
+            const int sl_ = T.red_slot[l];
             if (sl_ < 0) continue;
-            const float a_ = S.red_alpha[l];
-            const uint64_t k_ = S.red_key[l];
+            const float a_ = T.red_alpha[l];
+            const uint64_t k_ = T.red_key[l];
             if (a_ < min_alpha || (a_ == min_alpha && min_slot >= 0 && k_ > min_key)) { min_alpha = a_; min_slot = sl_; min_key = k_; }
         }
         par.sync();
@@ -1514,11 +1539,11 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
         Slot &ms = Cd.slot[min_slot];
         ManifoldOut mo;
         const bool touching = toi_update_contact(M, Wd, Cd, ms, mover, mo);   // the TOI contact likely has some new contact points
-        S.toi_meta[min_slot] = (uint8_t)((S.toi_meta[min_slot] & ~1u) + 4u);   // e_toiFlag cleared, ++m_toiCount
+        T.toi_meta[min_slot] = (uint8_t)((T.toi_meta[min_slot] & ~1u) + 4u);   // e_toiFlag cleared, ++m_toiCount
         MW_STAT(toi_events, 1);
         if (!touching) {  // not solid after all: disable the contact, restore the sweep
             MW_STAT(toi_undone, 1);
-            S.toi_meta[min_slot] |= 2;
+            T.toi_meta[min_slot] |= 2;
             Cd.sweep_c0[mover] = bk_c0; Cd.sweep_a0[mover] = bk_a0; Cd.sweep_alpha0[mover] = bk_alpha0;
             Wd.b[mover].c = bk_c; Wd.b[mover].a = bk_a;
             par.sync();
@@ -1626,14 +1651,14 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, flo
         {
             const bool moved = sync_fixture(M, Wd, Cd, mover);
             const int base = M.slot_base[mover], cap = M.slot_cap[mover];
-            for (int k = 0; k < cap; ++k) S.toi_meta[base + k] &= (uint8_t)~1u;
+            for (int k = 0; k < cap; ++k) T.toi_meta[base + k] &= (uint8_t)~1u;
             Wd.batch += 1;
             if (moved) {
                 find_new_terrain_contacts(M, Wd, Cd, mover, Wd.batch);
                 find_new_pair_contacts(M, Cd, 1u << mover, Wd.batch);
             }
             const SweptBox box = swept_box(msh, sweep_of_body(M, Wd, Cd, mover));   // its new sweep: from the safe pose to the end of the sub-step
-            S.sbox[mover][0] = box.xmin; S.sbox[mover][1] = box.xmax; S.sbox[mover][2] = box.ymin; S.sbox[mover][3] = box.ymax;
+            T.sbox[mover][0] = box.xmin; T.sbox[mover][1] = box.xmax; T.sbox[mover][2] = box.ymin; T.sbox[mover][3] = box.ymax;
         }
         par.sync();
     }
@@ -1663,96 +1688,158 @@ MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Pa
     par.sync();
 }
 
+// what SolvePositionConstraints reads of a manifold / a joint, fetched again (see step_solve)
+MW_HD_INLINE void manifold_position_part(Manifold &m, const Manifold &src) {
+    m.bA = src.bA; m.bB = src.bB; m.type = src.type; m.island = src.island;
+    m.local_normal = src.local_normal; m.local_point = src.local_point; m.lp[0] = src.lp[0]; m.lp[1] = src.lp[1];
+}
+MW_HD_INLINE void joint_position_part(const Model &M, const Scratch &S, int ji, JointCache &c) {
+    const JointDef &jd = M.jd[ji];
+    const MassAB q = mass_of_pair(S, jd.bA, jd.bB);
+    c.bA = jd.bA; c.bB = jd.bB;
+    c.mA = q.mA; c.iA = q.iA; c.mB = q.mB; c.iB = q.iB;
+    c.lA = jd.lA - q.lcA; c.lB = jd.lB - q.lcB;
+    c.lower = jd.lower; c.upper = jd.upper;
+    float mm = q.iA + q.iB;
+    if (mm > 0.0f) mm = 1.0f / mm;
+    c.motor_mass = mm;
+}
+
+// One lane of the island solver: its walker's joints (in island order) and the first Par::MREG manifolds of its list
+template <int NREG>
+struct SolveLane {
+    JointCache jc[4];
+    int ji[4], jn;
+    Manifold mc[NREG];
+    MassAB mq[NREG];
+    int mrd[NREG], mix[NREG];   // round and pool index of mc[r] (-1: none)
+    int cnt;                    // manifolds in the lane's list
+    int mo_base;                // MO slot of the lane's first manifold past mc[]
+};
+
+// b2Island::Solve of every island of the step at once (islands share nothing, so running them together changes nothing), then the
+// sleep test.  MP = the manifold pool of the step (Scratch::m).  The HIP solver launch leaves it in HBM: a lane works on register
+// copies of the first Par::MREG manifolds of its list and on copies in MO -- LDS, room for `mo_cap` manifolds per env -- of the rest;
+// whatever does not fit there either is solved in place in MP.
 template <class Par>
-MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Manifold *MP, Manifold *MO, int mo_cap, Par par) {
     const float h = 1.0f / FPS;
     const int L0 = par.lane(), LN = par.n();
-    // the model scalars are read once: the solver loops below must not go back to memory for them
-    const int NB = M.NB, NW = M.W;
-    // lane-private constants of the bodies this lane owns (bi = L0 + kb * LN): manifold-list base, mass data
-    int own_lb[Par::BODIES];
-    MassAB own_q[Par::BODIES];   // as body B of a contact with the terrain (A: zeros)
-    MW_UNROLL
-    for (int kb = 0; kb < Par::BODIES; ++kb) {
-        const int bi = L0 + kb * LN;
-        own_lb[kb] = 0;
-        own_q[kb].mA = 0.0f; own_q[kb].iA = 0.0f; own_q[kb].lcA = v2(0, 0); own_q[kb].mB = 0.0f; own_q[kb].iB = 0.0f; own_q[kb].lcB = v2(0, 0);
-        if (bi >= NB) continue;
-        const Shape &sh = M.shape[shape_of_body(bi)];
-        own_q[kb].mB = sh.inv_mass; own_q[kb].iB = sh.inv_I; own_q[kb].lcB = sh.centroid;
-        own_lb[kb] = M.list_base[bi];
-    }
-    const int n_jl = S.n_jlevels, n_cl = S.n_clevels;
+    const int NB = M.NB, NW = M.W;   // the model scalars are read once: the solver loops below must not go back to memory for them
+    const int n_rounds = S.n_rounds, max_cnt = S.max_cnt;
     // ---- integrate velocities (gravity + the pending initial push) of the bodies of this step's islands
-    MW_UNROLL
-    for (int kb = 0; kb < Par::BODIES; ++kb) {
-        const int bi = L0 + kb * LN;
-        if (bi >= NB || S.island_of[bi] < 0) continue;
+    for (int bi = L0; bi < NB; bi += LN) {
+        if (S.island_of[bi] < 0) continue;
         Body &b = Wd.b[bi];
         Cd.sweep_c0[bi] = b.c; Cd.sweep_a0[bi] = b.a;   // b2Island::Solve: "store positions for continuous collision"
         float fx = 0.0f;
         if (is_hull(bi)) fx = Wd.push_x[(bi - 1) / 5];
-        const float im = own_q[kb].mB;
+        const float im = S.sh_im[shape_of_body(bi)];
         b.v.x += h * (GRAVITY_Y * 0.0f + im * fx);
         b.v.y += h * (GRAVITY_Y + im * 0.0f);
         // linear / angular damping are 0: v *= 1 / (1 + h * 0)
     }
     par.sync();
     for (int w = L0; w < NW; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces (at the end of Step; nothing reads it in between)
-    MW_STAT(steps, 1); MW_STAT(sub_a, n_cl); MW_STAT(sub_b, n_jl); MW_STAT(manifolds, S.nm);
-    // One contact sweep: level by level, every lane walks the (ascending-level) lists of the bodies it owns.  F_ is a statement
-    // over the manifold `m_`, its mass data `q_` and the owning body `bi`.
-#define MW_CONTACT_SWEEP(F_)                                                                                  \
-    {                                                                                                         \
-        int ptr_[Par::BODIES];                                                                                \
-        MW_UNROLL                                                                                             \
-        for (int kb = 0; kb < Par::BODIES; ++kb) ptr_[kb] = 0;                                                \
-        for (int lv_ = 0; lv_ < n_cl; ++lv_) {                                                                \
-            MW_UNROLL                                                                                         \
-            for (int kb = 0; kb < Par::BODIES; ++kb) {                                                        \
-                const int bi = L0 + kb * LN;                                                                  \
-                if (bi >= NB || ptr_[kb] >= S.bm_cnt[bi]) continue;                                           \
-                const int k_ = S.bm_idx[own_lb[kb] + ptr_[kb]];                                               \
-                if (S.m_level[k_] != lv_) continue;                                                           \
-                ++ptr_[kb];                                                                                   \
-                Manifold &m_ = S.m[k_];                                                                       \
-                MassAB q_ = own_q[kb];                                                                        \
-                if (m_.bA >= 0) { const int sa_ = shape_of_body(m_.bA); q_.mA = S.sh_im[sa_]; q_.iA = S.sh_ii[sa_]; q_.lcA = S.sh_lc[sa_]; } \
-                F_;                                                                                           \
-            }                                                                                                 \
-            par.sync();                                                                                       \
-        }                                                                                                     \
+    MW_STAT(steps, 1); MW_STAT(sub_a, n_rounds); MW_STAT(sub_b, max_cnt); MW_STAT(manifolds, S.nm);
+    MW_STAT(cnt_hist[max_cnt < 23 ? max_cnt : 23], 1); MW_STAT(rounds_hist[n_rounds < 11 ? n_rounds : 11], 1);
+    constexpr int NREG = Par::MREG > 0 ? Par::MREG : 1;
+    SolveLane<NREG> LS[Par::SOLVE_EMU];
+#define MW_LANES for (int li_ = 0; li_ < Par::SOLVE_EMU; ++li_)
+#define MW_LANE const int sl_ = par.solve_lane(li_); SolveLane<NREG> &ls = LS[Par::SOLVE_EMU == 1 ? 0 : sl_]; (void)sl_;
+    MW_LANES { MW_LANE
+        ls.cnt = S.lane_cnt[sl_];
+        MW_UNROLL
+        for (int r = 0; r < NREG; ++r) {
+            ls.mrd[r] = -1; ls.mix[r] = -1;
+            if (r < Par::MREG && r < ls.cnt) {
+                const int k = S.lane_list[sl_][r];
+                ls.mix[r] = k; ls.mrd[r] = S.m_round[k]; ls.mc[r] = MP[k];
+                ls.mq[r] = mass_of_pair(S, ls.mc[r].bA, ls.mc[r].bB);
+            }
+        }
+        ls.jn = sl_ < NW ? S.jn[sl_] : 0;
+        MW_UNROLL
+        for (int q = 0; q < 4; ++q) ls.ji[q] = q < ls.jn ? S.jorder[sl_][q] : 0;
+        // the lane's manifolds past its private copies: slots of MO in lane order, then (no room) in place
+        ls.mo_base = 0;
+        for (int l2 = 0; l2 < sl_; ++l2) { const int c2 = S.lane_cnt[l2]; if (c2 > Par::MREG) ls.mo_base += c2 - Par::MREG; }
+        for (int r = Par::MREG; r < ls.cnt; ++r) { const int o = ls.mo_base + r - Par::MREG; if (o < mo_cap) MO[o] = MP[S.lane_list[sl_][r]]; }
+    }
+#define MW_POOL_MANIFOLD(r_) (ls.mo_base + (r_) - Par::MREG < mo_cap ? MO[ls.mo_base + (r_) - Par::MREG] : MP[S.lane_list[sl_][r_]])
+    // One contact sweep: round by round, inside a round position by position of the lanes' lists, all lanes at once (build_islands made
+    // sure two constraints of one (round, position) never share a body, and that the order of any two that do is the island's).  F_ is
+    // a statement over the manifold `m_` and its mass data `q_`.
+#define MW_CONTACT_SWEEP(F_)                                                                                              \
+    for (int rd_ = 0; rd_ < n_rounds; ++rd_) {                                                                            \
+        MW_UNROLL                                                                                                         \
+        for (int r_ = 0; r_ < NREG; ++r_) {                                                                               \
+            if (r_ >= Par::MREG || r_ >= max_cnt) continue;                                                               \
+            MW_LANES { MW_LANE if (ls.mrd[r_] == rd_) { Manifold &m_ = ls.mc[r_]; const MassAB &q_ = ls.mq[r_]; F_; } }    \
+            par.sync();                                                                                                   \
+        }                                                                                                                 \
+        for (int r_ = Par::MREG; r_ < max_cnt; ++r_) {   /* past the lane-private copies: in place in the pool */         \
+            MW_LANES { MW_LANE                                                                                            \
+                if (r_ >= ls.cnt) continue;                                                                               \
+                const int k_ = S.lane_list[sl_][r_];                                                                      \
+                if (S.m_round[k_] != rd_) continue;                                                                       \
+                Manifold &m_ = MW_POOL_MANIFOLD(r_);                                                                      \
+                const MassAB q_ = mass_of_pair(S, m_.bA, m_.bB);                                                          \
+                F_;                                                                                                       \
+            }                                                                                                             \
+            par.sync();                                                                                                   \
+        }                                                                                                                 \
     }
     // ---- contact constraints: b2ContactSolver::InitializeVelocityConstraints + WarmStart, in the island's order
     MW_CONTACT_SWEEP(contact_init_warm(Wd, m_, q_))
-    // ---- joints: InitVelocityConstraints (+ warm start), one lane per joint, level by level
-    JointCache JC[Par::JOINTS];
-    int jlv[Par::JOINTS];
-    MW_UNROLL
-    for (int kq = 0; kq < Par::JOINTS; ++kq) { const int ji = L0 + kq * LN; jlv[kq] = (ji < 4 * NW && S.j_level[ji] != 255) ? S.j_level[ji] : -1; }
-    for (int t = 0; t < n_jl; ++t) {
+    // ---- joints: InitVelocityConstraints (+ warm start)
+    MW_LANES { MW_LANE
         MW_UNROLL
-        for (int kq = 0; kq < Par::JOINTS; ++kq)
-            if (jlv[kq] == t) joint_init_warm(M, Wd, Cd, S, L0 + kq * LN, h, JC[kq]);
-        par.sync();
+        for (int q = 0; q < 4; ++q) if (q < ls.jn) joint_init_warm(M, Wd, Cd, S, ls.ji[q], h, ls.jc[q]);
     }
-    // ---- velocity iterations: all joints of an island, then all its contacts (islands are disjoint, so iterating them together
-    // changes nothing)
+    par.sync();
+    // ---- velocity iterations: all joints, then all contacts
     for (int it = 0; it < VEL_ITERS; ++it) {
-        for (int t = 0; t < n_jl; ++t) {
+        MW_LANES { MW_LANE
             MW_UNROLL
-            for (int kq = 0; kq < Par::JOINTS; ++kq)
-                if (jlv[kq] == t) joint_solve_velocity(Wd, JC[kq]);
-            par.sync();
+            for (int q = 0; q < 4; ++q) if (q < ls.jn) joint_solve_velocity(Wd, ls.jc[q]);
         }
+        par.sync();
         MW_CONTACT_SWEEP(contact_solve_velocity(Wd, m_, q_))
     }
     // the accumulated joint impulses and limit states go back to the world (warm start of the next step)
-    MW_UNROLL
-    for (int kq = 0; kq < Par::JOINTS; ++kq) {
-        if (jlv[kq] < 0) continue;
-        Joint &j = Cd.j[L0 + kq * LN];
-        j.ix = JC[kq].ix; j.iy = JC[kq].iy; j.iz = JC[kq].iz; j.motor_impulse = JC[kq].motor_impulse; j.limit_state = JC[kq].limit_state;
+    MW_LANES { MW_LANE
+        MW_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            if (q >= ls.jn) continue;
+            Joint &j = Cd.j[ls.ji[q]];
+            const JointCache &c = ls.jc[q];
+            j.ix = c.ix; j.iy = c.iy; j.iz = c.iz; j.motor_impulse = c.motor_impulse; j.limit_state = c.limit_state;
+        }
+    }
+    // b2ContactSolver::StoreImpulses -> the contacts (warm start of the next step); every lane stores its own
+    MW_LANES { MW_LANE
+        MW_UNROLL
+        for (int r = 0; r < NREG; ++r) {
+            if (r >= Par::MREG || ls.mix[r] < 0) continue;
+            const Manifold &m = ls.mc[r];
+            Slot &sl = Cd.slot[m.slot];
+            MW_UNROLL
+            for (int i = 0; i < 2; ++i) if (i < m.npts) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }   // (constant indices: mc stays in registers)
+        }
+        for (int r = Par::MREG; r < ls.cnt; ++r) {
+            const Manifold &m = MW_POOL_MANIFOLD(r);
+            Slot &sl = Cd.slot[m.slot];
+            for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
+        }
+    }
+    // The position iterations need the other half of every constraint (the b2Manifold in local coordinates, the joints' local anchors and
+    // limits), the velocity iterations above did not: it is fetched again here instead of being carried through them in registers.
+    MW_LANES { MW_LANE
+        MW_UNROLL
+        for (int r = 0; r < NREG; ++r) if (r < Par::MREG && ls.mix[r] >= 0) manifold_position_part(ls.mc[r], MP[ls.mix[r]]);
+        MW_UNROLL
+        for (int q = 0; q < 4; ++q) if (q < ls.jn) joint_position_part(M, S, ls.ji[q], ls.jc[q]);
     }
     // ---- integrate positions
     for (int bi = L0; bi < NB; bi += LN) {
@@ -1773,17 +1860,17 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
         for (int bi = L0; bi < NB; bi += LN) S.body_minsep[bi] = 0.0f;
         for (int j = L0; j < 4 * NW; j += LN) S.joint_ok[j] = 1;
         par.sync();
-        MW_CONTACT_SWEEP(if (!S.isl_done[m_.island]) S.body_minsep[bi] = mnf(S.body_minsep[bi], contact_solve_position(Wd, m_, q_)))
-        for (int t = 0; t < n_jl; ++t) {
+        MW_CONTACT_SWEEP(if (!S.isl_done[m_.island]) { const int ob_ = m_.bB; S.body_minsep[ob_] = mnf(S.body_minsep[ob_], contact_solve_position(Wd, m_, q_)); })
+        MW_LANES { MW_LANE
             MW_UNROLL
-            for (int kq = 0; kq < Par::JOINTS; ++kq) {
-                if (jlv[kq] != t) continue;
-                const int ji = L0 + kq * LN;
+            for (int q = 0; q < 4; ++q) {
+                if (q >= ls.jn) continue;
+                const int ji = ls.ji[q];
                 if (S.isl_done[S.j_island[ji]]) continue;
-                if (!joint_solve_position(Wd, JC[kq])) S.joint_ok[ji] = 0;
+                if (!joint_solve_position(Wd, ls.jc[q])) S.joint_ok[ji] = 0;
             }
-            par.sync();
         }
+        par.sync();
         if (L0 == 0) {
             bool all_done = true;
             for (int c = 0; c < n_isl; ++c) {
@@ -1801,13 +1888,10 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
         if (S.all_done) break;
     }
     par.sync();
-    // b2ContactSolver::StoreImpulses -> the contacts (warm start of the next step)
-    const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
-    for (int k = L0; k < nm; k += LN) {
-        const Manifold &m = S.m[k];
-        Slot &sl = Cd.slot[m.slot];
-        for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
-    }
+#undef MW_CONTACT_SWEEP
+#undef MW_POOL_MANIFOLD
+#undef MW_LANES
+#undef MW_LANE
     // ---- sleeping (b2Island::Solve, allowSleep): an island whose slowest-to-rest body has been below the tolerances for half a
     // second, and whose position constraints were solved, goes to sleep: velocities zeroed, awake flags cleared
     if (L0 == 0) {
@@ -1830,10 +1914,15 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
                     Wd.b[bi].v = v2(0, 0); Wd.b[bi].w = 0.0f;
                 }
         }
-        Wd.batch += 1;   // this step's FindNewContacts call
+        Wd.batch += 1;   // this step's FindNewContacts call (step_post)
     }
     par.sync();
-    // ---- SynchronizeFixtures of the simulated bodies, then FindNewContacts for the proxies that moved
+}
+
+// The tail of b2World::Solve: SynchronizeFixtures of the simulated bodies, then FindNewContacts for the proxies that moved
+template <class Par>
+MW_HD_INLINE void step_post(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+    const int L0 = par.lane(), LN = par.n(), NB = M.NB;
     {
         uint32_t mv = 0;
         for (int bi = L0; bi < NB; bi += LN)
@@ -1844,14 +1933,14 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
     if (L0 == 0 && S.moved) find_new_pair_contacts(M, Cd, S.moved, Wd.batch);
     par.sync();
 }
-#undef MW_CONTACT_SWEEP
 
 template <class Par>
 MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
     step_collide(M, Wd, Cd, S, par);
-    step_solve(M, Wd, Cd, S, par);
+    step_solve(M, Wd, Cd, S, S.m, par.solve_overflow(), Par::SOLVE_OVERFLOW, par);
+    step_post(M, Wd, Cd, S, par);
     // ---- continuous pass (b2World::Step: "if (m_continuousPhysics && step.dt > 0) SolveTOI(step)")
-    if (M.continuous) solve_toi(M, Wd, Cd, S, par, 1.0f / FPS);
+    if (M.continuous) { ToiWork T; solve_toi(M, Wd, Cd, S, T, par, 1.0f / FPS); }
 }
 
 

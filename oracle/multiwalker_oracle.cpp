@@ -20,6 +20,8 @@ struct MwOracle {
     mw::Model M;
     mw::EnvCfg C;
     int64_t n_envs, env_id_base;
+    bool rev = false;   /* run the emulated solver lanes in descending order (the schedule must not care) */
+    mw::SerialPar par() const { mw::SerialPar p; p.rev = rev; return p; }
     std::vector<mw::World> worlds;
 };
 
@@ -27,6 +29,7 @@ extern "C" {
 
 int mwo_obs_dim(const MwOracle *o) { return mw::obs_dim_of(o->C); }
 void mwo_set_one_hot(MwOracle *o, int one_hot) { o->C.one_hot = one_hot ? 1 : 0; }
+void mwo_set_lane_order(MwOracle *o, int descending) { o->rev = descending != 0; }
 void mwo_set_continuous(MwOracle *o, int on) { o->M.continuous = on ? 1 : 0; }  /* b2World continuousPhysics: experiments only */
 int mwo_world_bytes(void) { return (int)sizeof(mw::World); }
 
@@ -56,7 +59,7 @@ void mwo_reset(MwOracle *o, const uint8_t *mask, float *obs) {
         float zero[4 * mw::MAX_WALKERS] = {0};
         const uint32_t gid = (uint32_t)(o->env_id_base + n);
         mw::env_reset_world(o->M, o->C, o->worlds[n].h, o->worlds[n].c, gid);
-        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, mw::SerialPar(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
+        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, o->par(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
         o->worlds[n].h.t = 0;
     }
 }
@@ -71,7 +74,7 @@ void mwo_reset_with(MwOracle *o, const uint8_t *mask, const double *terrain, con
         float zero[4 * mw::MAX_WALKERS] = {0};
         const uint32_t gid = (uint32_t)(o->env_id_base + n);
         mw::env_reset_world(o->M, o->C, o->worlds[n].h, o->worlds[n].c, gid, terrain ? terrain + n * NT : nullptr, push ? push + n * W : nullptr);
-        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, mw::SerialPar(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
+        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, o->par(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
         o->worlds[n].h.t = 0;
     }
 }
@@ -81,7 +84,7 @@ void mwo_step(MwOracle *o, const float *actions, float *obs, float *rew, uint8_t
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < o->n_envs; ++n) {
         mw::Scratch S;
-        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, mw::SerialPar(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
+        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, o->par(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
                      obs + n * W * mw::obs_dim_of(o->C), rew + n * W, done + n);
     }
 }

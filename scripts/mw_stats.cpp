@@ -34,6 +34,10 @@ int main() {
         for (int i = 0; i < 10; ++i) printf("%ld ", g_stats.toi_hist[i]);
         printf(" | island manifolds 0..5+: ");
         for (int i = 0; i < 6; ++i) printf("%ld ", g_stats.toi_nisl[i]);
+        printf("\n    largest lane list (0..23+): ");
+        for (int i = 0; i < 24; ++i) printf("%ld ", g_stats.cnt_hist[i]);
+        printf("\n    rounds (0..11+): ");
+        for (int i = 0; i < 12; ++i) printf("%ld ", g_stats.rounds_hist[i]);
         printf("\n");
     }
 }

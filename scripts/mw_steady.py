@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madrl_amd.multiwalker import BatchedMultiWalkerEnv
-dev = torch.device("cuda:0"); N, W = 16384, 3
+dev = torch.device("cuda:0"); N, W = int(os.environ.get("MW_N", 16384)), 3
 import itertools
 combos = [(True, True)] if '--one' in sys.argv else [(True, True), (False, True)] if '--quick' in sys.argv else list(itertools.product((True, False), (True, False)))
 for cont, tof in combos:

@@ -194,15 +194,18 @@ def _contacts_equal(a, b):
     return len(ai) == len(bi) and np.array_equal(ai, bi) and np.array_equal(af, bf)
 
 
-@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local")])
-def test_product_source_matches_the_independent_oracle_bit_for_bit(n_walkers, reward_mech):
-    """Teacher-forced on the bodies (the product takes the oracle's poses and velocities at the start of every step; contacts,
+@pytest.mark.parametrize("n_walkers,reward_mech,descending", [(3, "local", False), (3, "local", True), (2, "global", False), (4, "local", True),
+                                                              (4, "local", False), (1, "local", False)])
+def test_product_source_matches_the_independent_oracle_bit_for_bit(n_walkers, reward_mech, descending):
+    """The product's solver runs on four lanes per env (lane w: walker w's joints and contacts), scheduled so that constraints which share
+    a body keep the island's order; the CPU build runs the lanes one after the other, in ascending or descending order -- the schedule
+    must make that irrelevant.  Teacher-forced on the bodies (the product takes the oracle's poses and velocities at the start of every step; contacts,
     joint impulses, fat AABBs and sleep times are each side's own), random actions with stretches of zero actions (limp walkers
     collapse: hull contacts, game over, resets), auto-reset on done.  Both sides use the same sin / cos polynomial here."""
     from oracle import multiwalker_ref as mwr
     W, N, T = n_walkers, 24, 160
     ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=5, env_id_base=3, position_noise=0, angle_noise=0, reward_mech=reward_mech, poly=True)
-    core = _mk(N, n_walkers=W, seed=5, env_id_base=3, reward_mech=reward_mech)
+    core = _mk(N, n_walkers=W, seed=5, env_id_base=3, reward_mech=reward_mech, lanes_descending=descending)
     ro, co = ref.reset(), core.reset()
     assert np.array_equal(ref.terrain(), core.terrain())
     # mass, inertia (the product stores the reciprocals: compare those)
@@ -238,7 +241,7 @@ def test_product_source_matches_the_independent_oracle_free_running():
     from oracle import multiwalker_ref as mwr
     W, N = 3, 16
     ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=8, position_noise=0, angle_noise=0, poly=True)
-    core = _mk(N, n_walkers=W, seed=8)
+    core = _mk(N, n_walkers=W, seed=8, lanes_descending=True)
     ref.reset(); core.reset()
     rng = np.random.RandomState(4)
     for t in range(250):
