@@ -35,6 +35,7 @@ struct MwDev {
     int32_t env_lds_bytes; // LDS per env outside the solver launch, first part: Hot | Scratch | actions, rewards, done
     int32_t env_lds_bytes_staged;  // ... all of it: | the used part of mw::Cold | mw::ToiWork
     int32_t env_lds_bytes_solve;   // LDS per env in the solver launch: Hot | the solver's part of Scratch
+    int32_t toi_lane0_bytes;       // time-of-impact cache of lane 0 (the package's contact slots)
     int32_t cold_dw;       // dwords of mw::Cold in use (up to the last slot of this walker count)
     int64_t n_envs;
     const mw::Model *model;
@@ -61,6 +62,8 @@ constexpr int SOLVE_HDR_BYTES = (int)((offsetof(mw::Scratch, dyn_midx) + 15) / 1
 #ifndef MADRL_MW_SOLVE_OVERFLOW
 #define MADRL_MW_SOLVE_OVERFLOW 8   // manifolds per env the solver launch can hold in LDS on top of the lanes' register copies
 #endif
+constexpr int TOI_WORK_BYTES = (int)((sizeof(mw::ToiWork) + 15) / 16 * 16);
+constexpr int TOI_LANE_BYTES = (mw::EDGE_SLOTS_HULL * 5 + 15) / 16 * 16;   // time-of-impact cache of a walker's body: 4 + 1 bytes per contact slot
 constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
 constexpr int IO_BYTES = (4 * mw::MAX_WALKERS + mw::MAX_WALKERS + 4) * 4;  // s_act | s_rew | s_done
 
@@ -105,6 +108,7 @@ template <int PHASE> struct PhaseStage { static constexpr bool value = true; };
 template <> struct PhaseStage<PH_SOLVE> { static constexpr bool value = false; };
 template <int PHASE> struct PhaseOcc { static constexpr int value = 2; };
 template <> struct PhaseOcc<PH_SOLVE> { static constexpr int value = MADRL_MW_SOLVE_WAVES; };
+template <> struct PhaseOcc<PH_TOI> { static constexpr int value = 1; };   // (LDS allows one wavefront per SIMD anyway; a mini island's manifolds live in registers)
 
 template <int PHASE, int EPW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PhaseOcc<PHASE>::value, PhaseOcc<PHASE>::value)))
@@ -167,7 +171,22 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
                                reinterpret_cast<mw::Manifold *>(base + HOT_BYTES + SOLVE_HDR_BYTES), MADRL_MW_SOLVE_OVERFLOW, par);
             } else {
                 mw::step_post(M, Wd, Cd, S, par);
-                if (M.continuous) mw::solve_toi(M, Wd, Cd, S, *reinterpret_cast<mw::ToiWork *>(base + d.env_lds_bytes + d.cold_dw * 4), par, 1.0f / mw::FPS);
+                if (M.continuous) {
+                    // per lane: the time-of-impact cache of the body it works on (lane 0 may hold the package: the largest contact cache) and
+                    // room for the manifolds of a mini island past the four in registers -- in the manifold pool of the state buffer,
+                    // free during this launch: most of it for lane 0, a few entries for every other lane
+                    unsigned char *tw = base + d.env_lds_bytes + d.cold_dw * 4;
+                    mw::ToiLaneWork TL;
+                    unsigned char *lc = tw + TOI_WORK_BYTES + (lane == 0 ? 0 : d.toi_lane0_bytes + (lane - 1) * TOI_LANE_BYTES);
+                    const int lcap = lane == 0 ? d.toi_lane0_bytes / 5 : TOI_LANE_BYTES / 5;
+                    TL.alpha = reinterpret_cast<float *>(lc); TL.meta = lc + 4 * lcap;
+                    mw::Manifold *pool = reinterpret_cast<mw::Manifold *>(scr + SCR_HDR_DW);
+                    constexpr int CO = NL <= 4 ? 4 : 1;
+                    const int c0 = M.max_manifolds - CO * ((NL < M.NB ? NL : M.NB) - 1);   // (lanes past the last body own nothing)
+                    TL.ovf = lane == 0 ? pool : pool + c0 + CO * (lane - 1);
+                    TL.ovf_cap = lane == 0 ? c0 : CO;
+                    mw::solve_toi(M, Wd, Cd, S, *reinterpret_cast<mw::ToiWork *>(tw), TL, par, 1.0f / mw::FPS);
+                }
                 float *obs_row = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM
                 if (lane == 0) {
                     *s_done = 0;
@@ -396,7 +415,8 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     d.env_lds_bytes_solve = HOT_BYTES + SOLVE_HDR_BYTES + MADRL_MW_SOLVE_OVERFLOW * (int32_t)sizeof(mw::Manifold);
     d.env_lds_bytes_solve = (d.env_lds_bytes_solve + 255 - 16) / 256 * 256 + 16;   // env g's block starts 4 LDS banks after env g-1's: the lanes
                                                                                     // of a wavefront (16 envs) then hit disjoint banks with 16-byte accesses
-    d.env_lds_bytes_staged = d.env_lds_bytes + d.cold_dw * 4 + (int32_t)align_up(sizeof(mw::ToiWork), 16);
+    d.toi_lane0_bytes = (int32_t)align_up((size_t)(M.slot_cap[0] > mw::EDGE_SLOTS_HULL ? M.slot_cap[0] : mw::EDGE_SLOTS_HULL) * 5, 16);
+    d.env_lds_bytes_staged = d.env_lds_bytes + d.cold_dw * 4 + TOI_WORK_BYTES + d.toi_lane0_bytes + (mw::MAXB - 1) * TOI_LANE_BYTES;
     // 8 resident wavefronts per CU (two per SIMD) need 4 envs x env_lds_bytes <= 20 KB; three walkers: 5 040 bytes per env
     h->epw_staged = 2;
     if (const char *e = getenv("MADRL_MW_EPW_STAGED")) { const int v = atoi(e); if (v == 2 || v == 4) h->epw_staged = v; }

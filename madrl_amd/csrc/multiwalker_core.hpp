@@ -54,7 +54,7 @@ namespace mw {
 
 // optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
 #ifdef MW_STATS
-struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], pairs_hist[40], posit_hist[8]; };
+struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], toi_multi, toi_ties, toi_pairs, toi_hullpkg; };
 extern Stats g_stats;
 #define MW_STAT(f, v) (g_stats.f += (v))
 #else
@@ -417,15 +417,6 @@ struct Scratch {  // per-step workspace (LDS on the GPU)
     int8_t dyn_midx[NDYN];     // manifold of pair p, or -1
     uint8_t slot_m[MAXSLOT];   // manifold of the (touching) contact in slot s this step, 255: did not fit the pool
     Manifold m[MAXM];  // LAST member: the HIP kernels allocate only Model::max_manifolds of them
-};
-
-// workspace of one SolveTOI (LDS in the HIP kernel of the continuous pass): per contact its cached time of impact and bit 0 e_toiFlag,
-// bit 1 NOT e_enabledFlag, bits 2.. m_toiCount; per body the box its vertices sweep this step; the lanes' candidates of the event selection
-struct ToiWork {
-    uint64_t red_key[64]; float red_alpha[64]; int32_t red_slot[64];   // one entry per lane of the largest group (one env per wavefront)
-    float toi_alpha[MAXSLOT];
-    float sbox[MAXB][4];
-    uint8_t toi_meta[MAXSLOT];
 };
 
 MW_HD Xf body_xf(const Model &M, const Body &b, int bi) {
@@ -854,7 +845,7 @@ MW_HD bool sync_fixture(const Model &M, const Hot &Wd, Cold &Cd, int b) {
 }
 // b2ContactManager::FindNewContacts for body b's moved proxy against the terrain: a contact is created (e_enabledFlag set, no
 // points) for every edge whose fat AABB overlaps and that has none yet
-MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, uint32_t batch) {
+MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, uint32_t batch, uint16_t tag = 0) {
     const AABB fatb = body_fat(Cd, b);
     int e0, e1;
     edge_range(M, fatb.lx, fatb.hx, e0, e1);
@@ -871,7 +862,7 @@ MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, u
             if (!sl.touching && !aabb_overlap(edge_fat_aabb(M, Cd, sl.edge), fatb)) Wd.overflow |= 2;
             else { Wd.overflow |= 1; continue; }
         }
-        sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch;
+        sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.reserved_ = tag;
     }
 }
 MW_HD void find_new_pair_contacts(const Model &M, Cold &Cd, uint32_t moved, uint32_t batch) {
@@ -1469,64 +1460,76 @@ MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl,
     return sl.touching != 0;
 }
 
-// b2World::SolveTOI.  Box2D's loop -- find the contact with the smallest time of impact, handle it, repeat -- with its two halves
-// mapped differently on the lanes of `par`: the SEARCH (time-of-impact root finder for every contact whose cached value is invalid,
-// minimum over all contacts) is shared by all lanes, contact by contact; the EVENT (a body arriving at the terrain within this step:
-// about one per three env-steps) is handled by lane 0.  Results do not depend on the mapping: the minimum is taken over (time, place in
-// the world's contact list), the same total order Box2D's serial walk realises.
+// b2World::SolveTOI.  Box2D's loop -- find the contact with the smallest time of impact over the whole world, handle it, repeat -- only
+// ever tests a dynamic body against the static terrain here (two dynamic non-bullet bodies are skipped), and handling an event changes
+// nothing but that one body, its own contacts and their cached times.  So the events of one body form a chain that does not depend on
+// the other bodies' chains, and the chains run side by side, one body per lane at a time.  What the world-wide ORDER of the events
+// decides is only the number of the FindNewContacts call that follows each of them (contact_key: the place of the contacts it creates
+// in Box2D's lists) and which box of the other body a new package / hull pair is tested against.  Every chain therefore logs its events
+// (time, contact), numbers the contacts it creates provisionally, and afterwards one lane merges the logs into Box2D's order -- smallest
+// time first, among equal times the contact nearest the front of the world's list -- hands out the final numbers and creates the pairs.
+constexpr int TOI_MAX_EVENTS = 32;   // events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7)
+constexpr int TOI_MAX_PAIR_EVENTS = 8;
+struct ToiEvent { float alpha; uint16_t slot, batch; uint8_t body, idx, moved, fat_i; };
+struct ToiWork {            // shared by the lanes of an env (LDS in the HIP kernel)
+    int n_ev, n_fat;
+    uint32_t batch_base;    // Hot::batch when the pass began
+    uint32_t overflow;      // bits for Hot::overflow, gathered by the lanes
+    ToiEvent ev[TOI_MAX_EVENTS];
+    float fat_log[TOI_MAX_PAIR_EVENTS][4];       // the fat AABB after an event that moved the proxy of the package or a hull
+    float fat0[1 + MAX_WALKERS][4];              // ... and their boxes when the pass began (package, hull 0, hull 1, ...)
+};
+struct ToiLaneWork {        // per lane: the cached times of impact of the contacts of the body it is working on
+    float *alpha;           // [Model::slot_cap of the body]
+    uint8_t *meta;          // bit 0 e_toiFlag (the cached time is valid), bit 1 NOT e_enabledFlag, bits 2.. m_toiCount
+    Manifold *ovf;          // room for the mini island's manifolds past the lane-private ones
+    int ovf_cap;
+};
+constexpr int TOI_MREG = 4;           // manifolds of a mini island held in lane-private storage (registers in the HIP kernel)
+MW_HD int pair_body_index(int b) { return b == 0 ? 0 : 1 + (b - 1) / 5; }   // package / hull -> row of ToiWork::fat0
+
+// the final number of the FindNewContacts call after event `idx` of body b's chain (valid once the merge has reached it)
+MW_HD uint32_t toi_final_batch(const ToiWork &T, int n, int b, int idx) {
+    for (int i = 0; i < n; ++i) if (T.ev[i].body == b && T.ev[i].idx == idx) return T.batch_base + 1u + T.ev[i].batch;
+    return T.batch_base;
+}
+
+// one body's chain of events
 template <class Par>
-MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, Par par, float h) {
-    const int L0 = par.lane(), LN = par.n();
-    const int NB = M.NB, NDP = M.n_dyn_pairs, NTS = M.dyn_slot_base;
-    // ---- "if (m_stepComplete)": alpha0 = 0 for every body, every contact's cached TOI invalid, its sub-step count 0, enabled (Collide
-    // has updated every contact in this step); per body the box it sweeps
-    for (int bi = L0; bi < NB; bi += LN) {
-        Cd.sweep_alpha0[bi] = 0.0f;
-        const SweptBox box = swept_box(M.shape[shape_of_body(bi)], sweep_of_body(M, Wd, Cd, bi));
-        T.sbox[bi][0] = box.xmin; T.sbox[bi][1] = box.xmax; T.sbox[bi][2] = box.ymin; T.sbox[bi][3] = box.ymax;
-    }
-    for (int s = L0; s < M.n_slots; s += LN) T.toi_meta[s] = 0;
-    par.sync();
-    if (M.continuous == 3) return;   // timing experiments only: 3 = set-up, 2 = set-up and one search without events
-    for (int guard = 0; guard < 8 * MAX_TOI_CONTACTS; ++guard) {
-        // ---- the contact with the smallest time of impact; among equal times the first of the world's contact list (largest key).  Two
-        // dynamic non-bullet bodies are never tested (the pairs), a sleeping body against static terrain has no active body.
-        float my_alpha = 1.0f;
-        uint64_t my_key = 0;
-        int my_slot = -1;
-        for (int s = L0; s < NTS; s += LN) {
-            const Slot &sl = Cd.slot[s];
-            if (sl.edge < 0) continue;
-            const int bi = M.slot_body[s];
-            if (!((Wd.awake >> bi) & 1u)) continue;
-            uint8_t meta = T.toi_meta[s];
-            if ((meta & 2) || (meta >> 2) > MAX_SUB_STEPS) continue;
-            if (!(meta & 1)) {   // no valid cached TOI: compute it on the body's current sweep
-                SweptBox box; box.xmin = T.sbox[bi][0]; box.xmax = T.sbox[bi][1]; box.ymin = T.sbox[bi][2]; box.ymax = T.sbox[bi][3];
-                T.toi_alpha[s] = toi_alpha_terrain(M, Cd, bi, sl.edge, sweep_of_body(M, Wd, Cd, bi), box);
-                T.toi_meta[s] = (uint8_t)(meta | 1);
-            }
-            const float alpha = T.toi_alpha[s];
-            if (alpha > my_alpha) continue;
-            const uint64_t key = bi == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(bi, M.NT));
-            if (alpha < my_alpha || (my_slot >= 0 && key > my_key)) { my_alpha = alpha; my_slot = s; my_key = key; }
-        }
-        T.red_alpha[L0] = my_alpha; T.red_key[L0] = my_key; T.red_slot[L0] = my_slot;
-        par.sync();
-        int min_slot = -1;
+MW_HD void toi_body_chain(const Model &M, Hot &Wd, Cold &Cd, const Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, int mover, float h) {
+    const int base = M.slot_base[mover], cap = M.slot_cap[mover];
+    const Shape &msh = M.shape[shape_of_body(mover)];
+    Cd.sweep_alpha0[mover] = 0.0f;   // "if (m_stepComplete)": alpha0 = 0, every contact's cached TOI invalid, its sub-step count 0, enabled
+    if (!((Wd.awake >> mover) & 1u)) return;   // a sleeping body against static terrain: no active body
+    bool any = false;
+    for (int k = 0; k < cap; ++k) { TL.meta[k] = 0; any = any || Cd.slot[base + k].edge >= 0; }
+    if (!any) return;
+    const float fr = sqrtf(FRICTION * msh.friction);
+    const MassAB qm = mass_of_pair(S, -1, mover);
+    const int pb = proxy_of_body(mover, M.NT);
+    SweptBox box = swept_box(msh, sweep_of_body(M, Wd, Cd, mover));
+    int n_events = 0;   // events of this chain that reached FindNewContacts
+    for (int guard = 0; guard < (MAX_SUB_STEPS + 2) * cap; ++guard) {
+        // ---- this body's contact with the smallest time of impact; among equal times the first of the contact list (largest key)
         float min_alpha = 1.0f;
         uint64_t min_key = 0;
-        for (int l = 0; l < LN; ++l) {   // every lane reduces the LN candidates: the same result everywhere
-            const int sl_ = T.red_slot[l];
-            if (sl_ < 0) continue;
-            const float a_ = T.red_alpha[l];
-            const uint64_t k_ = T.red_key[l];
-            if (a_ < min_alpha || (a_ == min_alpha && min_slot >= 0 && k_ > min_key)) { min_alpha = a_; min_slot = sl_; min_key = k_; }
+        int min_k = -1;
+        for (int k = 0; k < cap; ++k) {
+            const Slot &sl = Cd.slot[base + k];
+            if (sl.edge < 0) continue;
+            const uint8_t meta = TL.meta[k];
+            if ((meta & 2) || (meta >> 2) > MAX_SUB_STEPS) continue;
+            if (!(meta & 1)) {   // no valid cached TOI: compute it on the body's current sweep
+                TL.alpha[k] = toi_alpha_terrain(M, Cd, mover, sl.edge, sweep_of_body(M, Wd, Cd, mover), box);
+                TL.meta[k] = (uint8_t)(meta | 1);
+            }
+            const float alpha = TL.alpha[k];
+            if (alpha > min_alpha) continue;
+            const uint64_t key = mover == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), pb);
+            if (alpha < min_alpha || (min_k >= 0 && key > min_key)) { min_alpha = alpha; min_k = k; min_key = key; }
         }
-        par.sync();
-        if (min_slot < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha || M.continuous == 2) break;   // no more TOI events
-        if (L0 != 0) { par.sync(); continue; }   // the event itself: lane 0
-        const int mover = M.slot_body[min_slot];
+        if (min_k < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha || M.continuous == 2) break;   // no more TOI events
+        const int min_slot = base + min_k;
         // ---- advance the body to the time of impact (b2Body::Advance); the static edge does not move
         const V2 bk_c0 = Cd.sweep_c0[mover], bk_c = Wd.b[mover].c;
         const float bk_a0 = Cd.sweep_a0[mover], bk_a = Wd.b[mover].a, bk_alpha0 = Cd.sweep_alpha0[mover];
@@ -1536,32 +1539,36 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, 
             Cd.sweep_c0[mover] = sw.c0; Cd.sweep_a0[mover] = sw.a0; Cd.sweep_alpha0[mover] = sw.alpha0;
             Wd.b[mover].c = sw.c0; Wd.b[mover].a = sw.a0;
         }
-        Slot &ms = Cd.slot[min_slot];
         ManifoldOut mo;
-        const bool touching = toi_update_contact(M, Wd, Cd, ms, mover, mo);   // the TOI contact likely has some new contact points
-        T.toi_meta[min_slot] = (uint8_t)((T.toi_meta[min_slot] & ~1u) + 4u);   // e_toiFlag cleared, ++m_toiCount
+        const bool touching = toi_update_contact(M, Wd, Cd, Cd.slot[min_slot], mover, mo);   // the TOI contact likely has some new contact points
+        TL.meta[min_k] = (uint8_t)((TL.meta[min_k] & ~1u) + 4u);   // e_toiFlag cleared, ++m_toiCount
         MW_STAT(toi_events, 1);
         if (!touching) {  // not solid after all: disable the contact, restore the sweep
             MW_STAT(toi_undone, 1);
-            T.toi_meta[min_slot] |= 2;
+            TL.meta[min_k] |= 2;
             Cd.sweep_c0[mover] = bk_c0; Cd.sweep_a0[mover] = bk_a0; Cd.sweep_alpha0[mover] = bk_alpha0;
             Wd.b[mover].c = bk_c; Wd.b[mover].a = bk_a;
-            par.sync();
             continue;
         }
         // ---- mini island: the event's contact, then the body's other contacts with static bodies in its contact-edge order, each
         // updated at the time-of-impact pose and added when it touches
+        Manifold mm[TOI_MREG];
         int n_isl = 0;
-        const Shape &msh = M.shape[shape_of_body(mover)];
-        const float fr = sqrtf(FRICTION * msh.friction);
         auto add_manifold = [&](const ManifoldOut &o, int slot_index) {
             if (n_isl >= MAX_TOI_CONTACTS) return;
-            if (n_isl >= M.max_manifolds) { Wd.overflow |= 1; return; }
-            Manifold &m = S.m[n_isl++];
-            m.bA = -1; m.bB = (int8_t)mover; m.slot = (int16_t)slot_index; m.npts = (uint8_t)o.npts; m.type = (uint8_t)(o.type | (o.npts << 1)); m.island = 0;
+            if (n_isl >= TOI_MREG + TL.ovf_cap) { par.or_bits(&T.overflow, 1u); return; }
+            Manifold m;
+            m.bA = -1; m.bB = (int8_t)mover; m.slot = (int16_t)slot_index; m.npts = (uint8_t)o.npts; m.type = (uint8_t)(o.type | (o.npts << 1)); m.island = 0; m.block = 0;
             m.local_normal = o.local_normal; m.local_point = o.local_point;
+            MW_UNROLL
             for (int i = 0; i < 2; ++i) { m.lp[i] = i < o.npts ? o.lp[i] : v2(0, 0); m.ni[i] = 0.0f; m.ti[i] = 0.0f; }  // subStep.warmStarting = false
             m.friction = fr;
+            m.normal = v2(0, 0); m.rA[0] = m.rA[1] = m.rB[0] = m.rB[1] = v2(0, 0); m.nm[0] = m.nm[1] = m.tm[0] = m.tm[1] = 0.0f;
+            m.k11 = m.k12 = m.k22 = m.im11 = m.im12 = m.im22 = 0.0f;
+            MW_UNROLL
+            for (int q = 0; q < TOI_MREG; ++q) if (n_isl == q) mm[q] = m;
+            if (n_isl >= TOI_MREG) TL.ovf[n_isl - TOI_MREG] = m;
+            ++n_isl;
         };
         add_manifold(mo, min_slot);
         {
@@ -1574,17 +1581,23 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, 
                 if (toi_update_contact(M, Wd, Cd, Cd.slot[si], mover, o2)) add_manifold(o2, si);
             }
         }
+        // F_ over every manifold of the island, in its order
+#define MW_ISLAND_SWEEP(F_)                                                                                       \
+        {                                                                                                         \
+            MW_UNROLL                                                                                             \
+            for (int q_ = 0; q_ < TOI_MREG; ++q_) if (q_ < n_isl) { Manifold &m_ = mm[q_]; F_; }                   \
+            for (int q_ = TOI_MREG; q_ < n_isl; ++q_) { Manifold &m_ = TL.ovf[q_ - TOI_MREG]; F_; }                \
+        }
         // ---- b2Island::SolveTOI
-        const MassAB qm = mass_of_pair(S, -1, mover);
         for (int it = 0; it < 20; ++it) {   // subStep.positionIterations = 20
             float ms_min = 0.0f;
-            for (int k = 0; k < n_isl; ++k) ms_min = mnf(ms_min, contact_solve_toi_position(Wd, S.m[k], qm));
+            MW_ISLAND_SWEEP(ms_min = mnf(ms_min, contact_solve_toi_position(Wd, m_, qm)))
             if (ms_min >= -1.5f * LINEAR_SLOP) break;
         }
         Cd.sweep_c0[mover] = Wd.b[mover].c; Cd.sweep_a0[mover] = Wd.b[mover].a;  // "leap of faith to new safe state"
         {   // InitializeVelocityConstraints on velocities that stay untouched (impulses are zero: nothing to warm start)
             const V2 v_keep = Wd.b[mover].v; const float w_keep = Wd.b[mover].w;
-            for (int k = 0; k < n_isl; ++k) contact_init_warm(Wd, S.m[k], qm);
+            MW_ISLAND_SWEEP(contact_init_warm(Wd, m_, qm))
             Wd.b[mover].v = v_keep; Wd.b[mover].w = w_keep;
         }
         {
@@ -1598,27 +1611,32 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, 
             // the VEL_ITERS sweeps is known without running them.  History kept for islands of at most two manifolds.
             constexpr int NST = 3 + 4 * 2;
             float h1[NST], h2[NST], h3[NST], h4[NST];  // states after sweeps i - 1 .. i - 4
+            MW_UNROLL
             for (int q = 0; q < NST; ++q) { h1[q] = 0.0f; h2[q] = 0.0f; h3[q] = 0.0f; h4[q] = 0.0f; }
             const bool track = n_isl <= 2;
+            static_assert(TOI_MREG >= 2, "the cycle detector reads the first two manifolds from the lane-private copies");
             auto snapshot = [&](float *st) {
                 st[0] = vB.x; st[1] = vB.y; st[2] = wB;
+                MW_UNROLL
                 for (int k = 0; k < 2; ++k) {
                     const bool on = k < n_isl;
-                    st[3 + 4 * k] = on ? S.m[k].ni[0] : 0.0f; st[4 + 4 * k] = on ? S.m[k].ni[1] : 0.0f;
-                    st[5 + 4 * k] = on ? S.m[k].ti[0] : 0.0f; st[6 + 4 * k] = on ? S.m[k].ti[1] : 0.0f;
+                    st[3 + 4 * k] = on ? mm[k].ni[0] : 0.0f; st[4 + 4 * k] = on ? mm[k].ni[1] : 0.0f;
+                    st[5 + 4 * k] = on ? mm[k].ti[0] : 0.0f; st[6 + 4 * k] = on ? mm[k].ti[1] : 0.0f;
                 }
             };
             auto restore = [&](const float *st) {
                 vB.x = st[0]; vB.y = st[1]; wB = st[2];
-                for (int k = 0; k < 2; ++k) if (k < n_isl) { S.m[k].ni[0] = st[3 + 4 * k]; S.m[k].ni[1] = st[4 + 4 * k]; S.m[k].ti[0] = st[5 + 4 * k]; S.m[k].ti[1] = st[6 + 4 * k]; }
+                MW_UNROLL
+                for (int k = 0; k < 2; ++k) if (k < n_isl) { mm[k].ni[0] = st[3 + 4 * k]; mm[k].ni[1] = st[4 + 4 * k]; mm[k].ti[0] = st[5 + 4 * k]; mm[k].ti[1] = st[6 + 4 * k]; }
             };
             for (int it = 0; it < VEL_ITERS; ++it) {
                 MW_STAT(toi_vel_iters, 1);
-                for (int k = 0; k < n_isl; ++k) contact_solve_velocity_on(S.m[k], qm, vA, wA, vB, wB);
+                MW_ISLAND_SWEEP(contact_solve_velocity_on(m_, qm, vA, wA, vB, wB))
                 if (!track) { if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1); continue; }
                 float cur[NST];
                 snapshot(cur);
                 bool same1 = it >= 1, same2 = it >= 2, same3 = it >= 3, same4 = it >= 4;
+                MW_UNROLL
                 for (int q = 0; q < NST; ++q) {
                     same1 = same1 && cur[q] == h1[q]; same2 = same2 && cur[q] == h2[q]; same3 = same3 && cur[q] == h3[q]; same4 = same4 && cur[q] == h4[q];
                 }
@@ -1632,11 +1650,13 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, 
                     break;
                 }
                 if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1);
+                MW_UNROLL
                 for (int q = 0; q < NST; ++q) { h4[q] = h3[q]; h3[q] = h2[q]; h2[q] = h1[q]; h1[q] = cur[q]; }
             }
             MW_STAT(toi_nisl[n_isl < 5 ? n_isl : 5], 1);
             Wd.b[mover].v = vB; Wd.b[mover].w = wB;
         }
+#undef MW_ISLAND_SWEEP
         {   // integrate the rest of the step
             const float hs = (1.0f - min_alpha) * h;
             Body &b = Wd.b[mover];
@@ -1647,23 +1667,101 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, 
             b.c = b.c + hs * b.v;
             b.a += hs * b.w;
         }
-        // ---- the displaced body: SynchronizeFixtures, every one of its contacts loses its cached time of impact, FindNewContacts
+        // ---- the displaced body: SynchronizeFixtures, every one of its contacts loses its cached time of impact, FindNewContacts.  The
+        // call's number is not known yet: the new contacts carry this chain's running count (enough to order this body's own contact
+        // list) and Slot::reserved_ = 1 + the event's index in the chain until the merge below.
         {
             const bool moved = sync_fixture(M, Wd, Cd, mover);
-            const int base = M.slot_base[mover], cap = M.slot_cap[mover];
-            for (int k = 0; k < cap; ++k) T.toi_meta[base + k] &= (uint8_t)~1u;
-            Wd.batch += 1;
-            if (moved) {
-                find_new_terrain_contacts(M, Wd, Cd, mover, Wd.batch);
-                find_new_pair_contacts(M, Cd, 1u << mover, Wd.batch);
-            }
-            const SweptBox box = swept_box(msh, sweep_of_body(M, Wd, Cd, mover));   // its new sweep: from the safe pose to the end of the sub-step
-            T.sbox[mover][0] = box.xmin; T.sbox[mover][1] = box.xmax; T.sbox[mover][2] = box.ymin; T.sbox[mover][3] = box.ymax;
+            for (int k = 0; k < cap; ++k) TL.meta[k] &= (uint8_t)~1u;
+            const int li = par.alloc(&T.n_ev);
+            if (li < TOI_MAX_EVENTS) {
+                ToiEvent &e = T.ev[li];
+                e.alpha = min_alpha; e.slot = (uint16_t)min_slot; e.batch = 0; e.body = (uint8_t)mover; e.idx = (uint8_t)n_events; e.moved = moved ? 1 : 0; e.fat_i = 255;
+                if (moved && (mover == 0 || is_hull(mover))) {
+                    const int fi = par.alloc(&T.n_fat);
+                    if (fi < TOI_MAX_PAIR_EVENTS) { e.fat_i = (uint8_t)fi; for (int q = 0; q < 4; ++q) T.fat_log[fi][q] = Cd.fat[mover][q]; }
+                    else par.or_bits(&T.overflow, 4u);
+                }
+            } else par.or_bits(&T.overflow, 4u);
+            if (moved) find_new_terrain_contacts(M, Wd, Cd, mover, T.batch_base + 1u + (uint32_t)n_events, (uint16_t)(1 + n_events));
+            ++n_events;
+            box = swept_box(msh, sweep_of_body(M, Wd, Cd, mover));   // its new sweep: from the safe pose to the end of the sub-step
         }
-        par.sync();
+    }
+}
+
+template <class Par>
+MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, float h) {
+    const int L0 = par.lane(), LN = par.n();
+    const int NB = M.NB;
+    if (L0 == 0) {
+        T.n_ev = 0; T.n_fat = 0; T.overflow = 0; T.batch_base = Wd.batch;
+        for (int q = 0; q < 4; ++q) T.fat0[0][q] = Cd.fat[0][q];
+        for (int w = 0; w < M.W; ++w) for (int q = 0; q < 4; ++q) T.fat0[1 + w][q] = Cd.fat[hull_of(w)][q];
     }
     par.sync();
-    (void)NDP;
+    if (M.continuous == 3) return;   // timing experiments only: 3 = set-up, 2 = set-up and one search without events
+    // ---- the chains, one body per lane at a time
+    for (int bi = L0; bi < NB; bi += LN) toi_body_chain(M, Wd, Cd, S, T, TL, par, bi, h);
+    par.sync();
+    const int n = T.n_ev < TOI_MAX_EVENTS ? T.n_ev : TOI_MAX_EVENTS;
+    if (n == 0 && T.overflow == 0) return;
+    // ---- merge: Box2D's order of the events; event number r is followed by FindNewContacts call batch_base + 1 + r
+    if (L0 == 0) {
+        uint8_t next_idx[MAXB];
+        for (int b = 0; b < NB; ++b) next_idx[b] = 0;
+        float cur_fat[1 + MAX_WALKERS][4];
+        for (int p = 0; p <= M.W; ++p) for (int q = 0; q < 4; ++q) cur_fat[p][q] = T.fat0[p][q];
+        for (int r = 0; r < n; ++r) {
+            int best = -1;
+            float best_alpha = 0.0f;
+            uint64_t best_key = 0;
+            for (int i = 0; i < n; ++i) {
+                const ToiEvent &e = T.ev[i];
+                if (e.idx != next_idx[e.body]) continue;   // not the head of its chain (or already merged)
+                const Slot &sl = Cd.slot[e.slot];
+                const uint32_t batch = sl.reserved_ ? toi_final_batch(T, n, e.body, sl.reserved_ - 1) : (uint32_t)sl.batch;
+                const uint64_t key = e.body == 0 ? contact_key(batch, 0, proxy_of_edge(sl.edge)) : contact_key(batch, proxy_of_edge(sl.edge), proxy_of_body(e.body, M.NT));
+                if (best < 0 || e.alpha < best_alpha || (e.alpha == best_alpha && key > best_key)) { best = i; best_alpha = e.alpha; best_key = key; }
+            }
+            ToiEvent &e = T.ev[best];
+#ifdef MW_STATS
+            for (int i = 0; i < n; ++i) if (i != best && T.ev[i].idx == next_idx[T.ev[i].body] && T.ev[i].body != e.body && T.ev[i].alpha == e.alpha) { MW_STAT(toi_ties, 1); break; }
+            if (r == 0) { bool multi = false; for (int i = 1; i < n; ++i) multi = multi || T.ev[i].body != T.ev[0].body; if (multi) MW_STAT(toi_multi, 1); }
+            if (e.body == 0 || is_hull(e.body)) MW_STAT(toi_hullpkg, 1);
+#endif
+            e.batch = (uint16_t)r;
+            next_idx[e.body] += 1;
+            if (e.moved && (e.body == 0 || is_hull(e.body))) {   // FindNewContacts for the pairs of the moved proxy, against the boxes as they were then
+                if (e.fat_i != 255) for (int q = 0; q < 4; ++q) cur_fat[pair_body_index(e.body)][q] = T.fat_log[e.fat_i][q];
+                for (int p = 0; p < M.n_dyn_pairs; ++p) {
+                    const int bA = M.dyn_a[p], bB = M.dyn_b[p];
+                    if (bA != e.body && bB != e.body) continue;
+                    Slot &ps = Cd.slot[M.dyn_slot_base + p];
+                    if (ps.edge >= 0) continue;
+                    const float *fa = cur_fat[pair_body_index(bA)], *fb = cur_fat[pair_body_index(bB)];
+                    AABB A, B; A.lx = fa[0]; A.ly = fa[1]; A.hx = fa[2]; A.hy = fa[3]; B.lx = fb[0]; B.ly = fb[1]; B.hx = fb[2]; B.hy = fb[3];
+                    if (!aabb_overlap(A, B)) continue;
+                    ps.edge = 0; ps.npts = 0; ps.touching = 0; ps.batch = (uint16_t)(T.batch_base + 1u + (uint32_t)r);
+                    MW_STAT(toi_pairs, 1);
+                }
+            }
+        }
+        Wd.batch = T.batch_base + (uint32_t)n;
+        if (T.overflow) Wd.overflow |= (uint8_t)T.overflow;
+    }
+    par.sync();
+    // ---- the contacts created in this pass get the final number of their FindNewContacts call
+    for (int bi = L0; bi < NB; bi += LN) {
+        const int base = M.slot_base[bi], cap = M.slot_cap[bi];
+        for (int k = 0; k < cap; ++k) {
+            Slot &sl = Cd.slot[base + k];
+            if (sl.reserved_ == 0) continue;
+            if (sl.edge >= 0) sl.batch = (uint16_t)toi_final_batch(T, n, bi, sl.reserved_ - 1);
+            sl.reserved_ = 0;
+        }
+    }
+    par.sync();
 }
 
 // b2World::Step(1/50, 180, 60) for the lanes of `par`, in three phases -- the HIP build runs them as three kernels (the registers of
@@ -1940,7 +2038,12 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
     step_solve(M, Wd, Cd, S, S.m, par.solve_overflow(), Par::SOLVE_OVERFLOW, par);
     step_post(M, Wd, Cd, S, par);
     // ---- continuous pass (b2World::Step: "if (m_continuousPhysics && step.dt > 0) SolveTOI(step)")
-    if (M.continuous) { ToiWork T; solve_toi(M, Wd, Cd, S, T, par, 1.0f / FPS); }
+    if (M.continuous) {
+        ToiWork T;
+        float toi_alpha[EDGE_SLOTS_PKG_MAX]; uint8_t toi_meta[EDGE_SLOTS_PKG_MAX];
+        ToiLaneWork TL; TL.alpha = toi_alpha; TL.meta = toi_meta; TL.ovf = S.m; TL.ovf_cap = M.max_manifolds;
+        solve_toi(M, Wd, Cd, S, T, TL, par, 1.0f / FPS);
+    }
 }
 
 

@@ -36,6 +36,7 @@ int main() {
         for (int i = 0; i < 6; ++i) printf("%ld ", g_stats.toi_nisl[i]);
         printf("\n    largest lane list (0..23+): ");
         for (int i = 0; i < 24; ++i) printf("%ld ", g_stats.cnt_hist[i]);
+        printf("\n    continuous pass: merges with several bodies %ld, ties between bodies %ld, package / hull events %ld, pairs created by the merge %ld", g_stats.toi_multi, g_stats.toi_ties, g_stats.toi_hullpkg, g_stats.toi_pairs);
         printf("\n    rounds (0..11+): ");
         for (int i = 0; i < 12; ++i) printf("%ld ", g_stats.rounds_hist[i]);
         printf("\n");
