@@ -1,17 +1,17 @@
 // multiwalker.hip -- batched MultiWalkerEnv for MI355X (gfx950 / CDNA4), float32.
 //
-// FOUR ENVS PER WAVEFRONT: a group of 16 lanes owns one env (multiwalker_core.hpp `Par`: bodies and their terrain
-// contacts by lane, one lane per leg for the revolute joints, the package / hull contacts one at a time), the four groups
-// of a wavefront advance their envs through the same instruction stream.  The step is bound by instruction issue (about
-// 1 MFLOP of dependent FP32 work per env-step in 180 + 60 Gauss-Seidel sweeps against ~12 KB of HBM traffic), so sharing
-// the stream between four envs is worth almost 4x per wavefront.
+// SIXTEEN ENVS PER WAVEFRONT, FOUR LANES PER ENV.  A b2World::Step of this env is a long chain of short, dependent float32 updates
+// (180 + 60 Gauss-Seidel sweeps over 12 joints and a handful of contacts, then the continuous pass): there is no data parallelism
+// inside an env beyond its walkers, so the lanes of a wavefront are filled with ENVS.  Lane w of an env's group owns walker w: its four
+// joints live in that lane's registers for the whole solve; contacts are dealt out to the four lanes by a list schedule; in the
+// continuous pass every body's chain of time-of-impact events runs on its own lane.  16 384 envs are 1 024 wavefronts -- one per SIMD of
+// the chip, all resident at once.
 //
-// Per env, LDS holds only what the sweeps touch: mw::Hot (bodies, joints, flags: 1 KB) and mw::Scratch (active manifolds
-// + schedule, sized by n_walkers: 5.3 KB at three walkers); the joint constants and accumulated impulses of a leg sit in
-// the registers of the lane that owns it for the whole step.  mw::Cold (manifold cache with the warm-start impulses,
-// terrain) is touched once per step by Collide / StoreImpulses / lidar and is read and written in place in HBM (L2).
-// Lanes of a group that work concurrently never share a body and every pair of constraints that shares a body keeps its
-// serial order, so the result equals the serial sweep of the CPU build bit for bit.
+// One API call is a sequence of launches (collide | solve | continuous pass + observe, see below) over the per-env records in the
+// caller's state buffer: mw::Hot (bodies, flags: 0.6 KB) is in LDS for the duration of a launch, the terrain heights too; the contact
+// cache with its warm-start impulses (mw::Cold::slot, 7 KB) and the step's manifold pool stay in HBM / L2 and are read and written in
+// place, by the one lane that owns the body.  Constraints that share a body keep their serial order on every path, so the result equals
+// the serial CPU build of the same source bit for bit.
 //
 // PARITY UNPINNED (Box2D is not available to pin against) -- see multiwalker_core.hpp.
 #include "common.hpp"
@@ -32,11 +32,9 @@ struct MwDev {
     int32_t scratch_off_dw; // where the Scratch starts inside an env's block
     uint8_t *pending;      // [n_envs] at the end of the state buffer: this env runs the trailing step of a reset in pass 1
     int32_t scratch_bytes; // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
-    int32_t env_lds_bytes; // LDS per env outside the solver launch, first part: Hot | Scratch | actions, rewards, done
-    int32_t env_lds_bytes_staged;  // ... all of it: | the used part of mw::Cold | mw::ToiWork
-    int32_t env_lds_bytes_solve;   // LDS per env in the solver launch: Hot | the solver's part of Scratch
+    int32_t ty_bytes;      // the terrain heights of one env, 16-byte aligned
     int32_t toi_lane0_bytes;       // time-of-impact cache of lane 0 (the package's contact slots)
-    int32_t cold_dw;       // dwords of mw::Cold in use (up to the last slot of this walker count)
+    int32_t lds_stride[4]; // LDS per env by phase (PH_*): Hot | terrain | that phase's part of Scratch | its work areas
     int64_t n_envs;
     const mw::Model *model;
     uint32_t *state;
@@ -52,20 +50,24 @@ struct MwIO {
 };
 
 #ifndef MADRL_MW_SOLVE_WAVES
-#define MADRL_MW_SOLVE_WAVES 1   // resident wavefronts per SIMD the solver launch's registers are allocated for
+#define MADRL_MW_SOLVE_WAVES 1   // resident wavefronts per SIMD the launches' registers are allocated for
 #endif
 #ifndef MADRL_MW_SOLVE_MREG
 #define MADRL_MW_SOLVE_MREG 3    // manifolds a solver lane holds in registers for the whole solve
 #endif
-constexpr int SOLVE_EPW = 64 / mw::SOLVE_LANES;   // envs per wavefront in the solver launch: one lane per walker
-constexpr int SOLVE_HDR_BYTES = (int)((offsetof(mw::Scratch, dyn_midx) + 15) / 16 * 16);   // the part of Scratch the solver works on
 #ifndef MADRL_MW_SOLVE_OVERFLOW
 #define MADRL_MW_SOLVE_OVERFLOW 8   // manifolds per env the solver launch can hold in LDS on top of the lanes' register copies
 #endif
+constexpr int EPW = 64 / mw::SOLVE_LANES;   // envs per wavefront: one lane per walker
+constexpr int NL = mw::SOLVE_LANES;
+constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
+constexpr int SCR_HDR_BYTES = (int)((offsetof(mw::Scratch, m) + 15) / 16 * 16);              // Scratch without the pool
+constexpr int SCR_HDR_DW = (int)(offsetof(mw::Scratch, m) / 4);                               // where the pool starts in the state buffer's copy
+static_assert(offsetof(mw::Scratch, m) % 16 == 0, "the manifold pool follows the header at a 16-byte boundary");
+constexpr int SOLVE_HDR_BYTES = (int)((offsetof(mw::Scratch, m_bA) + 15) / 16 * 16);         // the part of Scratch the solver and the continuous pass work on
+constexpr int IO_BYTES = (4 * mw::MAX_WALKERS + mw::MAX_WALKERS + 4) * 4;                     // s_act | s_rew | s_done
 constexpr int TOI_WORK_BYTES = (int)((sizeof(mw::ToiWork) + 15) / 16 * 16);
 constexpr int TOI_LANE_BYTES = (mw::EDGE_SLOTS_HULL * 5 + 15) / 16 * 16;   // time-of-impact cache of a walker's body: 4 + 1 bytes per contact slot
-constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
-constexpr int IO_BYTES = (4 * mw::MAX_WALKERS + mw::MAX_WALKERS + 4) * 4;  // s_act | s_rew | s_done
 
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -73,10 +75,8 @@ __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the cooperating lanes of multiwalker_core.hpp's `Par` = one group of 64 / EPW lanes of the wavefront
-template <int EPW>
+// the cooperating lanes of multiwalker_core.hpp's `Par` = one group of four lanes of the wavefront
 struct GroupPar {
-    static constexpr int NL = 64 / EPW;
     static constexpr int SOLVE_EMU = 1;                    // mw::step_solve: this lane IS one solver lane
     static constexpr int MREG = MADRL_MW_SOLVE_MREG;
     int l;
@@ -88,46 +88,32 @@ struct GroupPar {
     __device__ __forceinline__ void or_bits(uint32_t *p, uint32_t v) const { atomicOr(p, v); }
 };
 
-// One API call is a SEQUENCE of launches over the same per-env records (Hot in LDS for the duration of a launch, Cold in place in
-// HBM, the step's Scratch -- manifolds and schedule -- handed from launch to launch through the caller's state buffer):
-//   PH_COLLIDE  apply_action, b2ContactManager::Collide, islands + level schedule        (mw::step_collide)
-//   PH_SOLVE    b2Island::Solve by levels, sleeping, SynchronizeFixtures, FindNewContacts (mw::step_solve)
-//   PH_TOI      b2World::SolveTOI, then the observation / reward / done of the step       (mw::solve_toi, mw::env_observe)
-//   PH_RESET    MultiWalkerEnv.reset (:330-357) without its trailing step                 (mw::env_reset_world)
-// Three kernels instead of one because a kernel's register allocation is the maximum over its phases: the narrow phase and the
-// time-of-impact root finder (GJK) need 250+ VGPRs, and in one kernel the 180-sweep solver loop ran at two wavefronts per SIMD with
-// its joint state spilled to scratch memory.
+// One API call is a SEQUENCE of launches over the same per-env records (the step's Scratch -- schedule and manifold pool -- handed from
+// launch to launch through the caller's state buffer):
+//   PH_COLLIDE  apply_action, b2ContactManager::Collide, islands + solver schedule                  (mw::step_collide)
+//   PH_SOLVE    b2Island::Solve, sleeping                                                          (mw::step_solve)
+//   PH_TOI      SynchronizeFixtures + FindNewContacts, b2World::SolveTOI, observation / reward / done (mw::step_post, solve_toi, env_observe)
+//   PH_RESET    MultiWalkerEnv.reset (:330-357) without its trailing step                           (mw::env_reset_world)
+// Separate kernels because a kernel's register allocation is the maximum over its phases: the narrow phase and the time-of-impact root
+// finder (GJK) want their registers for themselves, the 180-sweep solver loop wants every joint constant in a register.
 // pass 0 = the step proper (every env, the caller's actions, rewards / done written); pass 1 = the trailing zero-action step of a
 // reset (:357), only for the envs whose byte in `pending` is set -- by PH_RESET (reset(mask)) or by PH_TOI of pass 0 (auto-reset).
 enum { PH_RESET = 0, PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 3 };
 
-// Collide, the continuous pass and reset walk the contacts, the terrain and the broad phase's boxes with data-dependent, mostly
-// single-lane access chains: from HBM / L2 every link costs a memory round trip.  Those launches copy the env's Cold record into LDS
-// (coalesced), work there and copy it back; the solver launch touches Cold once per step and leaves it in HBM.
-template <int PHASE> struct PhaseStage { static constexpr bool value = true; };
-template <> struct PhaseStage<PH_SOLVE> { static constexpr bool value = false; };
-template <int PHASE> struct PhaseOcc { static constexpr int value = 2; };
-template <> struct PhaseOcc<PH_SOLVE> { static constexpr int value = MADRL_MW_SOLVE_WAVES; };
-template <> struct PhaseOcc<PH_TOI> { static constexpr int value = 1; };   // (LDS allows one wavefront per SIMD anyway; a mini island's manifolds live in registers)
-
-template <int PHASE, int EPW>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PhaseOcc<PHASE>::value, PhaseOcc<PHASE>::value)))
+template <int PHASE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_MW_SOLVE_WAVES, MADRL_MW_SOLVE_WAVES)))
 void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
     const mw::Model &M = *d.model;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NL = 64 / EPW;
     const int g = threadIdx.x / NL, lane = threadIdx.x % NL;
-    const GroupPar<EPW> par{lane};
-    constexpr bool STAGE = PhaseStage<PHASE>::value;
-    static_assert(PHASE != PH_SOLVE || NL == mw::SOLVE_LANES, "the solver launch runs one lane per walker");
-    unsigned char *base = smem + g * (STAGE ? d.env_lds_bytes_staged : d.env_lds_bytes_solve);
+    const GroupPar par{lane};
+    unsigned char *base = smem + g * d.lds_stride[PHASE];
     mw::Hot &Wd = *reinterpret_cast<mw::Hot *>(base);
-    mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES);
-    float *s_act = reinterpret_cast<float *>(base + HOT_BYTES + d.scratch_bytes);
-    float *s_rew = s_act + 4 * mw::MAX_WALKERS;
-    uint32_t *s_done = reinterpret_cast<uint32_t *>(s_rew + mw::MAX_WALKERS);
+    float *ty_l = reinterpret_cast<float *>(base + HOT_BYTES);
+    const int tyb = (PHASE == PH_COLLIDE || PHASE == PH_TOI) ? d.ty_bytes : 0;
+    mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES + tyb);   // (only the phase's part of it is there)
+    unsigned char *work = base + HOT_BYTES + tyb + (PHASE == PH_COLLIDE ? SCR_HDR_BYTES : SOLVE_HDR_BYTES);
     const int W = M.W;
-    constexpr int SCR_HDR_DW = (int)(offsetof(mw::Scratch, m) / 4);
     for (int64_t e0 = (int64_t)blockIdx.x * EPW; e0 < d.n_envs; e0 += (int64_t)gridDim.x * EPW) {
         const int64_t env = e0 + g;
         bool active = env < d.n_envs;
@@ -137,17 +123,20 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
         }
         if (active) {
             uint32_t *rec = d.state + env * (int64_t)d.world_dw;
-            uint32_t *cold_g = rec + sizeof(mw::Hot) / 4;
-            uint32_t *cold_l = reinterpret_cast<uint32_t *>(base + d.env_lds_bytes);   // staged copy (launches with STAGE)
-            mw::Cold &Cd = *reinterpret_cast<mw::Cold *>(STAGE ? cold_l : cold_g);
+            mw::Cold *cold_g = reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
+            mw::ColdView Cd = mw::cold_view(*cold_g);
             uint32_t *scr = rec + d.scratch_off_dw;   // the step's Scratch between launches
+            mw::Manifold *pool = reinterpret_cast<mw::Manifold *>(scr + SCR_HDR_DW);
             {
                 uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
                 for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = rec[k];
-                if (STAGE) for (int k = lane; k < d.cold_dw; k += NL) cold_l[k] = cold_g[k];
-                if (PHASE == PH_SOLVE || PHASE == PH_TOI) {   // the schedule the collide launch built (the solver: only its part)
+                if (PHASE == PH_COLLIDE || PHASE == PH_TOI) {   // the terrain: read over and over by the narrow phase, the root finder, the lidar
+                    for (int k = lane; k < M.NT; k += NL) ty_l[k] = cold_g->ty[k];
+                    Cd.ty = ty_l;
+                }
+                if (PHASE == PH_SOLVE || PHASE == PH_TOI) {   // the schedule the collide launch built
                     uint32_t *sd = reinterpret_cast<uint32_t *>(&S);
-                    for (int k = lane; k < (PHASE == PH_SOLVE ? SOLVE_HDR_BYTES / 4 : SCR_HDR_DW); k += NL) sd[k] = scr[k];
+                    for (int k = lane; k < SOLVE_HDR_BYTES / 4; k += NL) sd[k] = scr[k];
                 }
             }
             lds_sync();
@@ -158,30 +147,30 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
                     d.pending[env] = 1;
                 }
             } else if (PHASE == PH_COLLIDE) {
+                float *s_act = reinterpret_cast<float *>(work);
                 for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (pass == 0 && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
                 lds_sync();
                 mw::env_apply_actions(M, Wd, Cd, par, s_act);
-                mw::step_collide(M, Wd, Cd, S, par);
-                const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
+                mw::step_collide(M, Wd, Cd, S, pool, par);
                 const uint32_t *sd = reinterpret_cast<const uint32_t *>(&S);
-                for (int k = lane; k < SCR_HDR_DW + nm * (int)(sizeof(mw::Manifold) / 4); k += NL) scr[k] = sd[k];
+                for (int k = lane; k < SCR_HDR_DW; k += NL) scr[k] = sd[k];
             } else if (PHASE == PH_SOLVE) {
                 // the manifolds the collide launch emitted stay in the state buffer: every lane copies the ones it owns into registers
-                mw::step_solve(M, Wd, Cd, S, reinterpret_cast<mw::Manifold *>(scr + SCR_HDR_DW),
-                               reinterpret_cast<mw::Manifold *>(base + HOT_BYTES + SOLVE_HDR_BYTES), MADRL_MW_SOLVE_OVERFLOW, par);
+                mw::step_solve(M, Wd, Cd, S, pool, reinterpret_cast<mw::Manifold *>(work), MADRL_MW_SOLVE_OVERFLOW, par);
             } else {
+                float *s_rew = reinterpret_cast<float *>(work);
+                uint32_t *s_done = reinterpret_cast<uint32_t *>(s_rew + mw::MAX_WALKERS);
                 mw::step_post(M, Wd, Cd, S, par);
                 if (M.continuous) {
                     // per lane: the time-of-impact cache of the body it works on (lane 0 may hold the package: the largest contact cache) and
                     // room for the manifolds of a mini island past the four in registers -- in the manifold pool of the state buffer,
                     // free during this launch: most of it for lane 0, a few entries for every other lane
-                    unsigned char *tw = base + d.env_lds_bytes + d.cold_dw * 4;
+                    unsigned char *tw = work + 32;
                     mw::ToiLaneWork TL;
                     unsigned char *lc = tw + TOI_WORK_BYTES + (lane == 0 ? 0 : d.toi_lane0_bytes + (lane - 1) * TOI_LANE_BYTES);
                     const int lcap = lane == 0 ? d.toi_lane0_bytes / 5 : TOI_LANE_BYTES / 5;
                     TL.alpha = reinterpret_cast<float *>(lc); TL.meta = lc + 4 * lcap;
-                    mw::Manifold *pool = reinterpret_cast<mw::Manifold *>(scr + SCR_HDR_DW);
-                    constexpr int CO = NL <= 4 ? 4 : 1;
+                    constexpr int CO = 4;
                     const int c0 = M.max_manifolds - CO * ((NL < M.NB ? NL : M.NB) - 1);   // (lanes past the last body own nothing)
                     TL.ovf = lane == 0 ? pool : pool + c0 + CO * (lane - 1);
                     TL.ovf_cap = lane == 0 ? c0 : CO;
@@ -211,10 +200,9 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
             {
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
                 for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
-                if (STAGE) for (int k = lane; k < d.cold_dw; k += NL) cold_g[k] = cold_l[k];
             }
         }
-        // the next env of this group reuses the LDS block; its Cold part is other memory, nothing to wait for
+        // the next env of this group reuses the LDS block
         lds_sync();
     }
 }
@@ -295,7 +283,6 @@ struct madrl_multiwalker {
     madrl_multiwalker_config cfg;
     MwDev dev;
     int device;
-    int epw_staged;  // envs per wavefront in the launches that stage Cold in LDS: 2 (default) or 4 (MADRL_MW_EPW_STAGED at create: experiments)
     int64_t max_blocks;
     void *model_dev;
     int NB, NT;
@@ -317,33 +304,28 @@ int mw_validate(const madrl_multiwalker_config *c) {
     return MADRL_OK;
 }
 
-template <int PH, int EPW>
+template <int PH>
 void mw_launch_phase(const madrl_multiwalker *h, const MwIO &io, int pass, hipStream_t s) {
     int64_t blocks = (h->dev.n_envs + EPW - 1) / EPW;   // default: every group of EPW envs gets its own wavefront
     if (h->max_blocks > 0 && blocks > h->max_blocks) blocks = h->max_blocks;
-    const size_t lds = (size_t)EPW * (PhaseStage<PH>::value ? h->dev.env_lds_bytes_staged : h->dev.env_lds_bytes_solve);
-    hipLaunchKernelGGL((mw_phase_kernel<PH, EPW>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io, pass);
+    const size_t lds = (size_t)EPW * h->dev.lds_stride[PH];
+    hipLaunchKernelGGL((mw_phase_kernel<PH>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io, pass);
 }
-// EPW envs per wavefront in the solver launch (16 lanes per env: one per joint / body), ES in the launches that stage Cold in LDS
-template <int EPW, int ES>
-void mw_launch_epw(const madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
-#define MW_PHASE(PH, PASS) mw_launch_phase<PH, (PH == PH_SOLVE ? EPW : ES)>(h, io, PASS, s)
+void mw_launch_all(const madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
     if (mode == 1) {   // MultiWalkerEnv.step
-        MW_PHASE(PH_COLLIDE, 0); MW_PHASE(PH_SOLVE, 0); MW_PHASE(PH_TOI, 0);
+        mw_launch_phase<PH_COLLIDE>(h, io, 0, s); mw_launch_phase<PH_SOLVE>(h, io, 0, s); mw_launch_phase<PH_TOI>(h, io, 0, s);
         if (!h->cfg.auto_reset) return;
     }
     // MultiWalkerEnv.reset(mask), or the fused auto-reset of the envs whose step just ended their episode: reset, then step(zeros)
     MwIO r = io;
     if (mode == 1) { r.mask = nullptr; r.inj_terrain = nullptr; r.inj_push = nullptr; }
-    mw_launch_phase<PH_RESET, ES>(h, r, mode == 1 ? 1 : 0, s);
-    MW_PHASE(PH_COLLIDE, 1); MW_PHASE(PH_SOLVE, 1); MW_PHASE(PH_TOI, 1);
-#undef MW_PHASE
+    mw_launch_phase<PH_RESET>(h, r, mode == 1 ? 1 : 0, s);
+    mw_launch_phase<PH_COLLIDE>(h, io, 1, s); mw_launch_phase<PH_SOLVE>(h, io, 1, s); mw_launch_phase<PH_TOI>(h, io, 1, s);
 }
 
 int mw_launch(const madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (h->epw_staged == 4) mw_launch_epw<SOLVE_EPW, 4>(h, io, mode, s);
-    else mw_launch_epw<SOLVE_EPW, 2>(h, io, mode, s);
+    mw_launch_all(h, io, mode, s);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }
@@ -410,16 +392,14 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     d.scratch_off_dw = (int32_t)(align_up(sizeof(mw::World), 16) / 4);
     d.world_dw = d.scratch_off_dw + d.scratch_bytes / 4;
     d.pending = (uint8_t *)state_dev + (size_t)d.world_dw * 4 * (size_t)n_envs;
-    d.env_lds_bytes = HOT_BYTES + d.scratch_bytes + (int32_t)align_up(IO_BYTES, 16);
-    d.cold_dw = (int32_t)(align_up(offsetof(mw::Cold, slot) + (size_t)M.n_slots * sizeof(mw::Slot), 16) / 4);
-    d.env_lds_bytes_solve = HOT_BYTES + SOLVE_HDR_BYTES + MADRL_MW_SOLVE_OVERFLOW * (int32_t)sizeof(mw::Manifold);
-    d.env_lds_bytes_solve = (d.env_lds_bytes_solve + 255 - 16) / 256 * 256 + 16;   // env g's block starts 4 LDS banks after env g-1's: the lanes
-                                                                                    // of a wavefront (16 envs) then hit disjoint banks with 16-byte accesses
+    d.ty_bytes = (int32_t)align_up((size_t)M.NT * 4, 16);
     d.toi_lane0_bytes = (int32_t)align_up((size_t)(M.slot_cap[0] > mw::EDGE_SLOTS_HULL ? M.slot_cap[0] : mw::EDGE_SLOTS_HULL) * 5, 16);
-    d.env_lds_bytes_staged = d.env_lds_bytes + d.cold_dw * 4 + TOI_WORK_BYTES + d.toi_lane0_bytes + (mw::MAXB - 1) * TOI_LANE_BYTES;
-    // 8 resident wavefronts per CU (two per SIMD) need 4 envs x env_lds_bytes <= 20 KB; three walkers: 5 040 bytes per env
-    h->epw_staged = 2;
-    if (const char *e = getenv("MADRL_MW_EPW_STAGED")) { const int v = atoi(e); if (v == 2 || v == 4) h->epw_staged = v; }
+    d.lds_stride[PH_RESET] = HOT_BYTES + SOLVE_HDR_BYTES;
+    d.lds_stride[PH_COLLIDE] = HOT_BYTES + d.ty_bytes + SCR_HDR_BYTES + (int32_t)align_up(IO_BYTES, 16);
+    d.lds_stride[PH_SOLVE] = HOT_BYTES + SOLVE_HDR_BYTES + MADRL_MW_SOLVE_OVERFLOW * (int32_t)sizeof(mw::Manifold);
+    d.lds_stride[PH_TOI] = HOT_BYTES + d.ty_bytes + SOLVE_HDR_BYTES + 32 + TOI_WORK_BYTES + d.toi_lane0_bytes + (NL - 1) * TOI_LANE_BYTES;
+    // env g's block starts 4 LDS banks after env g-1's: the 16 envs of a wavefront then hit disjoint banks with 16-byte accesses
+    for (int ph = 0; ph < 4; ++ph) d.lds_stride[ph] = (d.lds_stride[ph] + 255 - 16) / 256 * 256 + 16;
     d.n_envs = n_envs;
     d.model = (const mw::Model *)h->model_dev;
     d.state = (uint32_t *)state_dev;

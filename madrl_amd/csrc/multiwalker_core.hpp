@@ -389,6 +389,22 @@ struct Cold {
                                   // this struct in LDS copy only that much)
 };
 struct World { Hot h; Cold c; };  // the packed per-env record in HBM
+// How the code below sees a Cold record: one pointer per member, so that a kernel can keep some members in LDS and leave the others in HBM
+// (the CPU build and the tests point all of them into one Cold).  The pointers are what is const in a `const ColdView &`, not the record.
+struct ColdView {
+    Joint *j;
+    float (*fat)[4];
+    float *sleep_time;
+    V2 *sweep_c0;
+    float *sweep_a0, *sweep_alpha0;
+    float *ty;
+    Slot *slot;
+};
+MW_HD ColdView cold_view(Cold &c) {
+    ColdView v;
+    v.j = c.j; v.fat = c.fat; v.sleep_time = c.sleep_time; v.sweep_c0 = c.sweep_c0; v.sweep_a0 = c.sweep_a0; v.sweep_alpha0 = c.sweep_alpha0; v.ty = c.ty; v.slot = c.slot;
+    return v;
+}
 
 constexpr int NDYN = MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
 constexpr int MAXISL = MAX_WALKERS + 1;
@@ -396,7 +412,7 @@ constexpr int MAXISL = MAX_WALKERS + 1;
 // the lanes by build_islands.  (The CPU build executes the lanes one after the other.)
 constexpr int SOLVE_LANES = MAX_WALKERS;
 struct Scratch {  // per-step workspace (LDS on the GPU)
-    // ---- what the solver launch keeps in LDS (up to `dyn_midx`)
+    // ---- what the solver launch keeps in LDS (up to `m_bA`)
     int nm;
     int8_t n_isl, n_rounds, max_cnt, all_done;
     uint32_t moved;            // bit b: body b's proxy is in the broad phase's move buffer
@@ -414,9 +430,10 @@ struct Scratch {  // per-step workspace (LDS on the GPU)
     uint8_t isl_done[MAXISL], isl_pos_solved[MAXISL], joint_ok[MAXJ];
     float body_minsep[MAXB];
     // ---- the other launches
-    int8_t dyn_midx[NDYN];     // manifold of pair p, or -1
-    uint8_t slot_m[MAXSLOT];   // manifold of the (touching) contact in slot s this step, 255: did not fit the pool
-    Manifold m[MAXM];  // LAST member: the HIP kernels allocate only Model::max_manifolds of them
+    // what the island construction needs of manifold k without going to the pool: its bodies and its place in Box2D's lists
+    int8_t m_bA[MAXM], m_bB[MAXM];
+    uint64_t m_key[MAXM];
+    alignas(16) Manifold m[MAXM];  // LAST member.  The CPU build's pool; the HIP kernels leave the pool in the state buffer (Model::max_manifolds entries)
 };
 
 MW_HD Xf body_xf(const Model &M, const Body &b, int bi) {
@@ -672,7 +689,7 @@ MW_HD AABB poly_aabb(const Shape &s, Xf t) {   // b2PolygonShape::ComputeAABB
 }
 MW_HD AABB fatten(AABB a) { AABB f; f.lx = a.lx - AABB_EXTENSION; f.ly = a.ly - AABB_EXTENSION; f.hx = a.hx + AABB_EXTENSION; f.hy = a.hy + AABB_EXTENSION; return f; }
 // terrain edge e: b2EdgeShape::ComputeAABB at the identity transform, fattened at proxy creation; static, so it never changes
-MW_HD AABB edge_fat_aabb(const Model &M, const Cold &Cd, int e) {
+MW_HD AABB edge_fat_aabb(const Model &M, const ColdView &Cd, int e) {
     const float x1 = M.tx[e], x2 = M.tx[e + 1], y1 = Cd.ty[e], y2 = Cd.ty[e + 1];
     AABB a; a.lx = mnf(x1, x2) - POLY_RADIUS; a.ly = mnf(y1, y2) - POLY_RADIUS; a.hx = mxf(x1, x2) + POLY_RADIUS; a.hy = mxf(y1, y2) + POLY_RADIUS;
     return fatten(a);
@@ -683,8 +700,8 @@ MW_HD bool aabb_overlap(const AABB &a, const AABB &b) {   // b2TestOverlap
     return true;
 }
 MW_HD bool aabb_contains(const AABB &a, const AABB &b) { return a.lx <= b.lx && a.ly <= b.ly && b.hx <= a.hx && b.hy <= a.hy; }
-MW_HD AABB body_fat(const Cold &Cd, int b) { AABB f; f.lx = Cd.fat[b][0]; f.ly = Cd.fat[b][1]; f.hx = Cd.fat[b][2]; f.hy = Cd.fat[b][3]; return f; }
-MW_HD void set_body_fat(Cold &Cd, int b, const AABB &f) { Cd.fat[b][0] = f.lx; Cd.fat[b][1] = f.ly; Cd.fat[b][2] = f.hx; Cd.fat[b][3] = f.hy; }
+MW_HD AABB body_fat(const ColdView &Cd, int b) { AABB f; f.lx = Cd.fat[b][0]; f.ly = Cd.fat[b][1]; f.hx = Cd.fat[b][2]; f.hy = Cd.fat[b][3]; return f; }
+MW_HD void set_body_fat(const ColdView &Cd, int b, const AABB &f) { Cd.fat[b][0] = f.lx; Cd.fat[b][1] = f.ly; Cd.fat[b][2] = f.hx; Cd.fat[b][3] = f.hy; }
 // edges whose fat AABB can overlap [lx, hx] in x: a conservative index range, every candidate is then tested exactly
 MW_HD void edge_range(const Model &M, float lx, float hx, int &e0, int &e1) {
     e0 = (int)floorf((lx - 0.12f) / TERRAIN_STEP) - 1;
@@ -739,17 +756,18 @@ MW_HD int contact_update(Slot &sl, const ManifoldOut &mo) {
 }
 // a touching contact becomes a solver manifold (pool slot from par.alloc; the solver's order is decided later by build_islands)
 template <class Par>
-MW_HD int emit_manifold(Hot &Wd, Scratch &S, Par par, const Slot &sl, int slot_index, const ManifoldOut &mo, int bA, int bB, float friction, int max_manifolds) {
+MW_HD int emit_manifold(Hot &Wd, Scratch &S, Manifold *MP, Par par, const Slot &sl, int slot_index, uint64_t key, const ManifoldOut &mo, int bA, int bB, float friction, int max_manifolds) {
     const int idx = par.alloc(&S.nm);
     if (idx >= max_manifolds) { Wd.overflow |= 1; return -1; }  // pool exhausted: the pair is ignored this step (sticky flag)
-    Manifold &m = S.m[idx];
+    S.m_bA[idx] = (int8_t)bA; S.m_bB[idx] = (int8_t)bB; S.m_key[idx] = key;
+    Manifold &m = MP[idx];
     m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)(mo.type | (mo.npts << 1)); m.island = 0;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
     for (int i = 0; i < mo.npts; ++i) { m.lp[i] = mo.lp[i]; m.ni[i] = sl.ni[i]; m.ti[i] = sl.ti[i]; }
     m.friction = friction;
     return idx;
 }
-MW_HD void edge_polygon_manifold(const Model &M, const Cold &Cd, int e, const Shape &s, Xf xfB, ManifoldOut &mo) {
+MW_HD void edge_polygon_manifold(const Model &M, const ColdView &Cd, int e, const Shape &s, Xf xfB, ManifoldOut &mo) {
     const V2 p1 = v2(M.tx[e], Cd.ty[e]), p2 = v2(M.tx[e + 1], Cd.ty[e + 1]);
     collide_edge_polygon(mo, p1, p2, s, xfB, false, p1, false, p2);   // plain b2EdgeShape: no ghost vertices (:617-620)
 }
@@ -758,7 +776,7 @@ MW_HD void edge_polygon_manifold(const Model &M, const Cold &Cd, int e, const Sh
 // first); the only thing that order decides here is a lower leg's ground_contact when one pass holds both a Begin and an End
 // for it: the LAST event of the walk -- the one on the OLDEST contact -- wins.
 template <class Par>
-MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int bi, uint8_t *slot_m) {
+MW_HD void collide_body_terrain(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Manifold *MP, Par par, int bi) {
     const Shape &s = M.shape[shape_of_body(bi)];
     const AABB fatb = body_fat(Cd, bi);
     Slot *slots = Cd.slot + M.slot_base[bi];
@@ -787,10 +805,7 @@ MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, P
                 edge_polygon_manifold(M, Cd, e, s, xfB, mo);
             ev = contact_update(sl, mo);
             if (ev == 1) contact_begin_flags(Wd, -1, bi);
-            if (sl.touching) {
-                const int idx = emit_manifold(Wd, S, par, sl, M.slot_base[bi] + k, mo, -1, bi, fr, M.max_manifolds);
-                slot_m[M.slot_base[bi] + k] = (uint8_t)(idx < 0 ? 255 : idx);
-            }
+            if (sl.touching) emit_manifold(Wd, S, MP, par, sl, M.slot_base[bi] + k, key, mo, -1, bi, fr, M.max_manifolds);
         }
         if (ev != 0 && key < ev_key) { ev_key = key; ev_kind = ev; }
     }
@@ -799,10 +814,9 @@ MW_HD void collide_body_terrain(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, P
 
 // package - hull and hull - hull pair p (two dynamic bodies: filtered by b2ContactFilter, never jointed)
 template <class Par>
-MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par, int p, uint8_t *slot_m) {
+MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Manifold *MP, Par par, int p) {
     const int bA = M.dyn_a[p], bB = M.dyn_b[p];
     Slot &sl = Cd.slot[M.dyn_slot_base + p];
-    S.dyn_midx[p] = -1;
     if (sl.edge < 0) return;
     if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) {   // Destroy (an EndContact would only clear lower-leg flags: none here)
         sl.edge = -1; sl.npts = 0; sl.touching = 0;
@@ -820,17 +834,15 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par p
         for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; } }
     }
     (void)was;
-    if (sl.touching) {
-        const int idx = emit_manifold(Wd, S, par, sl, M.dyn_slot_base + p, mo, bA, bB, sqrtf(sA.friction * sB.friction), M.max_manifolds);
-        S.dyn_midx[p] = (int8_t)idx;
-        slot_m[M.dyn_slot_base + p] = (uint8_t)(idx < 0 ? 255 : idx);
-    }
+    if (sl.touching)
+        emit_manifold(Wd, S, MP, par, sl, M.dyn_slot_base + p, contact_key(sl.batch, proxy_of_body(bA, M.NT), proxy_of_body(bB, M.NT)), mo, bA, bB,
+                      sqrtf(sA.friction * sB.friction), M.max_manifolds);
 }
 
 // b2Body::SynchronizeFixtures -> b2Fixture::Synchronize -> b2BroadPhase::MoveProxy: the proxy's box is the union of the boxes at
 // the sweep's start pose (c0, a0) and at the current pose; it is re-fattened (extension + twice the displacement) and buffered as
 // moved only when it left its fat AABB.
-MW_HD bool sync_fixture(const Model &M, const Hot &Wd, Cold &Cd, int b) {
+MW_HD bool sync_fixture(const Model &M, const Hot &Wd, const ColdView &Cd, int b) {
     const Shape &s = M.shape[shape_of_body(b)];
     const Xf xf1 = xf_from(Cd.sweep_c0[b], Cd.sweep_a0[b], s.centroid), xf2 = body_xf(M, Wd.b[b], b);
     const AABB a1 = poly_aabb(s, xf1), a2 = poly_aabb(s, xf2);
@@ -845,7 +857,7 @@ MW_HD bool sync_fixture(const Model &M, const Hot &Wd, Cold &Cd, int b) {
 }
 // b2ContactManager::FindNewContacts for body b's moved proxy against the terrain: a contact is created (e_enabledFlag set, no
 // points) for every edge whose fat AABB overlaps and that has none yet
-MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, uint32_t batch, uint16_t tag = 0) {
+MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, const ColdView &Cd, int b, uint32_t batch, uint16_t tag = 0) {
     const AABB fatb = body_fat(Cd, b);
     int e0, e1;
     edge_range(M, fatb.lx, fatb.hx, e0, e1);
@@ -865,7 +877,7 @@ MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, Cold &Cd, int b, u
         sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.reserved_ = tag;
     }
 }
-MW_HD void find_new_pair_contacts(const Model &M, Cold &Cd, uint32_t moved, uint32_t batch) {
+MW_HD void find_new_pair_contacts(const Model &M, const ColdView &Cd, uint32_t moved, uint32_t batch) {
     for (int p = 0; p < M.n_dyn_pairs; ++p) {
         const int bA = M.dyn_a[p], bB = M.dyn_b[p];
         Slot &sl = Cd.slot[M.dyn_slot_base + p];
@@ -877,7 +889,7 @@ MW_HD void find_new_pair_contacts(const Model &M, Cold &Cd, uint32_t moved, uint
 
 // ---------------------------------------------------------------- islands (b2World::Solve) and the level schedule
 // The key of the contact in slot `si` seen from anywhere (its place in the world list and in both bodies' edge lists).
-MW_HD uint64_t slot_key(const Model &M, const Cold &Cd, int si) {
+MW_HD uint64_t slot_key(const Model &M, const ColdView &Cd, int si) {
     const Slot &sl = Cd.slot[si];
     if (si >= M.dyn_slot_base) { const int p = si - M.dyn_slot_base; return contact_key(sl.batch, proxy_of_body(M.dyn_a[p], M.NT), proxy_of_body(M.dyn_b[p], M.NT)); }
     int b = 0;
@@ -885,26 +897,16 @@ MW_HD uint64_t slot_key(const Model &M, const Cold &Cd, int si) {
     return b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
 }
 // The next entry of body b's contact-edge list after the one with key `below` (newest first = descending key), among the contacts
-// that are touching and have a manifold (every contact is enabled when Solve runs: Collide has just updated it); returns the slot index or -1.  (b2World::Solve: "for (b2ContactEdge* ce =
-// b->m_contactList; ce; ce = ce->next)".)
-MW_HD int next_contact_edge(const Model &M, const Cold &Cd, const uint8_t *slot_m, int b, uint64_t below, uint64_t &key_out) {
+// that are touching and have a manifold (every contact is enabled when Solve runs: Collide has just updated it); returns the manifold
+// or -1.  (b2World::Solve: "for (b2ContactEdge* ce = b->m_contactList; ce; ce = ce->next)".)
+MW_HD int next_contact_edge(const Scratch &S, int nm, int b, uint64_t below, uint64_t &key_out) {
     int best = -1;
     uint64_t bk = 0;
-    const int base = M.slot_base[b], cap = M.slot_cap[b];
-    for (int k = 0; k < cap; ++k) {
-        const Slot &sl = Cd.slot[base + k];
-        if (sl.edge < 0 || !sl.touching || slot_m[base + k] == 255) continue;
-        const uint64_t key = b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
-        if (key < below && (best < 0 || key > bk)) { best = base + k; bk = key; }
+    for (int k = 0; k < nm; ++k) {
+        if (S.m_bA[k] != b && S.m_bB[k] != b) continue;
+        const uint64_t key = S.m_key[k];
+        if (key < below && (best < 0 || key > bk)) { best = k; bk = key; }
     }
-    if (b == 0 || is_hull(b))
-        for (int p = 0; p < M.n_dyn_pairs; ++p) {
-            if (M.dyn_a[p] != b && M.dyn_b[p] != b) continue;
-            const Slot &sl = Cd.slot[M.dyn_slot_base + p];
-            if (sl.edge < 0 || !sl.touching || slot_m[M.dyn_slot_base + p] == 255) continue;
-            const uint64_t key = contact_key(sl.batch, proxy_of_body(M.dyn_a[p], M.NT), proxy_of_body(M.dyn_b[p], M.NT));
-            if (key < below && (best < 0 || key > bk)) { best = M.dyn_slot_base + p; bk = key; }
-        }
     key_out = bk;
     return best;
 }
@@ -912,8 +914,9 @@ MW_HD int next_contact_edge(const Model &M, const Cold &Cd, const uint8_t *slot_
 // b2World::Solve's island construction, run by ONE lane: seeds in body-list order (last created body first), depth-first search
 // over contact edges then joint edges; the islands' joint and contact sequences are cut into levels (file header) and every body
 // gets the list of the manifolds it owns in ascending level.  A sleeping seed is skipped; every body reached is woken.
-MW_HD void build_islands(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, const uint8_t *slot_m) {
+MW_HD void build_islands(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Manifold *MP) {
     const int NB = M.NB, NW = M.W;
+    const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
     // the last contact constraint scheduled on body b: its lane, position in that lane's list and round (lane -1: none yet)
     int8_t b_lane[MAXB], b_pos[MAXB], b_round[MAXB];
     int8_t lane_round[SOLVE_LANES];
@@ -940,13 +943,12 @@ MW_HD void build_islands(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, const ui
             S.island_of[b] = (int8_t)isl;
             if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; }   // "make sure the body is awake"
             uint64_t below = ~0ull, key;
-            for (int si = next_contact_edge(M, Cd, slot_m, b, below, key); si >= 0; si = next_contact_edge(M, Cd, slot_m, b, below, key)) {
+            for (int mi = next_contact_edge(S, nm, b, below, key); mi >= 0; mi = next_contact_edge(S, nm, b, below, key)) {
                 below = key;
-                const int mi = slot_m[si];
                 if ((cflag >> mi) & 1ull) continue;     // already in an island (reached from its other body)
                 cflag |= 1ull << mi;
-                Manifold &m = S.m[mi];
-                m.island = (uint8_t)isl;
+                struct { int bA, bB; } m = {S.m_bA[mi], S.m_bB[mi]};
+                MP[mi].island = (uint8_t)isl;
                 // schedule: a sweep runs round by round and inside a round position by position of the lanes' lists, all lanes at once.
                 // Any lane may hold any contact (the bodies live in shared memory): the contact goes to the lane that can run it earliest,
                 // where it must sit lexicographically after the last constraint of either body that another lane holds.
@@ -1121,7 +1123,7 @@ struct JointCache {
 };
 
 // b2RevoluteJoint::InitVelocityConstraints (+ warm start)
-MW_HD_INLINE void joint_init_warm(const Model &M, Hot &Wd, const Cold &Cd, Scratch &S, int ji, float h, JointCache &c) {
+MW_HD_INLINE void joint_init_warm(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, int ji, float h, JointCache &c) {
     const JointDef &jd = M.jd[ji];
     const Joint &j = Cd.j[ji];
     c.bA = jd.bA; c.bB = jd.bB;
@@ -1360,7 +1362,7 @@ MW_HD void proxy_of_shape(Proxy &p, const Shape &s) {
     MW_UNROLL
     for (int i = 0; i < TOI_MAX_VERTS; ++i) p.v[i] = i < s.n ? s.v[i] : s.v[0];
 }
-MW_HD Sweep sweep_of_body(const Model &M, const Hot &Wd, const Cold &Cd, int b) {
+MW_HD Sweep sweep_of_body(const Model &M, const Hot &Wd, const ColdView &Cd, int b) {
     Sweep s;
     s.lc = M.shape[shape_of_body(b)].centroid;
     s.c0 = Cd.sweep_c0[b]; s.a0 = Cd.sweep_a0[b]; s.alpha0 = Cd.sweep_alpha0[b];
@@ -1381,7 +1383,7 @@ MW_HD SweptBox swept_box(const Shape &sh, const Sweep &sB) {
     return q;
 }
 // time of impact of body `bi` with terrain edge e, as b2World::SolveTOI computes it for one contact
-MW_HD float toi_alpha_terrain(const Model &M, const Cold &Cd, int bi, int e, const Sweep &sB, const SweptBox &box) {
+MW_HD float toi_alpha_terrain(const Model &M, const ColdView &Cd, int bi, int e, const Sweep &sB, const SweptBox &box) {
     const V2 p1 = v2(M.tx[e], Cd.ty[e]), p2 = v2(M.tx[e + 1], Cd.ty[e + 1]);
     const float m = 4.0f * LINEAR_SLOP;   // what the root finder calls touching, with margin
     if (box.xmin - m > p2.x || box.xmax + m < p1.x || box.ymin - m > mxf(p1.y, p2.y) || box.ymax + m < mnf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
@@ -1437,7 +1439,7 @@ constexpr int MAX_TOI_CONTACTS = 32;  // b2_maxTOIContacts
 constexpr int MAX_SUB_STEPS = 8;      // b2_maxSubSteps
 
 // the next terrain contact of body b after the one with key `below` in its contact-edge list (descending key), touching or not
-MW_HD int next_terrain_slot(const Model &M, const Cold &Cd, int b, uint64_t below, uint64_t &key_out) {
+MW_HD int next_terrain_slot(const Model &M, const ColdView &Cd, int b, uint64_t below, uint64_t &key_out) {
     int best = -1;
     uint64_t bk = 0;
     const int base = M.slot_base[b], cap = M.slot_cap[b];
@@ -1451,7 +1453,7 @@ MW_HD int next_terrain_slot(const Model &M, const Cold &Cd, int b, uint64_t belo
     return best;
 }
 // b2Contact::Update inside the continuous pass: events take effect at once, in call order (ContactDetector, :50-84)
-MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl, int b, ManifoldOut &mo) {
+MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const ColdView &Cd, Slot &sl, int b, ManifoldOut &mo) {
     mo.npts = 0;
     edge_polygon_manifold(M, Cd, sl.edge, M.shape[shape_of_body(b)], body_xf(M, Wd.b[b], b), mo);
     const int ev = contact_update(sl, mo);
@@ -1468,7 +1470,7 @@ MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const Cold &Cd, Slot &sl,
 // in Box2D's lists) and which box of the other body a new package / hull pair is tested against.  Every chain therefore logs its events
 // (time, contact), numbers the contacts it creates provisionally, and afterwards one lane merges the logs into Box2D's order -- smallest
 // time first, among equal times the contact nearest the front of the world's list -- hands out the final numbers and creates the pairs.
-constexpr int TOI_MAX_EVENTS = 32;   // events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7)
+constexpr int TOI_MAX_EVENTS = 20;   // events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7)
 constexpr int TOI_MAX_PAIR_EVENTS = 8;
 struct ToiEvent { float alpha; uint16_t slot, batch; uint8_t body, idx, moved, fat_i; };
 struct ToiWork {            // shared by the lanes of an env (LDS in the HIP kernel)
@@ -1496,7 +1498,7 @@ MW_HD uint32_t toi_final_batch(const ToiWork &T, int n, int b, int idx) {
 
 // one body's chain of events
 template <class Par>
-MW_HD void toi_body_chain(const Model &M, Hot &Wd, Cold &Cd, const Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, int mover, float h) {
+MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, int mover, float h) {
     const int base = M.slot_base[mover], cap = M.slot_cap[mover];
     const Shape &msh = M.shape[shape_of_body(mover)];
     Cd.sweep_alpha0[mover] = 0.0f;   // "if (m_stepComplete)": alpha0 = 0, every contact's cached TOI invalid, its sub-step count 0, enabled
@@ -1691,7 +1693,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, Cold &Cd, const Scratch &S, T
 }
 
 template <class Par>
-MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, float h) {
+MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, float h) {
     const int L0 = par.lane(), LN = par.n();
     const int NB = M.NB;
     if (L0 == 0) {
@@ -1770,19 +1772,19 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, ToiWork &T, 
 //   step_solve     b2Island::Solve of every island (level by level), sleeping, SynchronizeFixtures, FindNewContacts
 //   solve_toi      b2World::SolveTOI
 template <class Par>
-MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Manifold *MP, Par par) {
     const int L0 = par.lane(), LN = par.n();
     const int NB = M.NB, NDP = M.n_dyn_pairs;
     for (int sh = L0; sh < N_SHAPES; sh += LN) { S.sh_im[sh] = M.shape[sh].inv_mass; S.sh_ii[sh] = M.shape[sh].inv_I; S.sh_lc[sh] = M.shape[sh].centroid; }
     if (L0 == 0) { S.nm = 0; S.moved = 0; }
     par.sync();
     // ---- b2ContactManager::Collide: every contact is updated (D4); Begin / EndContact -> ContactDetector flags
-    for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, par, bi, S.slot_m);
+    for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, MP, par, bi);
     par.sync();
-    if (L0 == 0) for (int p = 0; p < NDP; ++p) collide_dyn_pair(M, Wd, Cd, S, par, p, S.slot_m);   // may wake bodies: one lane
+    if (L0 == 0) for (int p = 0; p < NDP; ++p) collide_dyn_pair(M, Wd, Cd, S, MP, par, p);   // may wake bodies: one lane
     par.sync();
     // ---- b2World::Solve: islands, constraint order and levels (one lane)
-    if (L0 == 0) build_islands(M, Wd, Cd, S, S.slot_m);
+    if (L0 == 0) build_islands(M, Wd, Cd, S, MP);
     par.sync();
 }
 
@@ -1820,7 +1822,7 @@ struct SolveLane {
 // copies of the first Par::MREG manifolds of its list and on copies in MO -- LDS, room for `mo_cap` manifolds per env -- of the rest;
 // whatever does not fit there either is solved in place in MP.
 template <class Par>
-MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Manifold *MP, Manifold *MO, int mo_cap, Par par) {
+MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Manifold *MP, Manifold *MO, int mo_cap, Par par) {
     const float h = 1.0f / FPS;
     const int L0 = par.lane(), LN = par.n();
     const int NB = M.NB, NW = M.W;   // the model scalars are read once: the solver loops below must not go back to memory for them
@@ -2019,7 +2021,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Mani
 
 // The tail of b2World::Solve: SynchronizeFixtures of the simulated bodies, then FindNewContacts for the proxies that moved
 template <class Par>
-MW_HD_INLINE void step_post(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
+MW_HD_INLINE void step_post(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Par par) {
     const int L0 = par.lane(), LN = par.n(), NB = M.NB;
     {
         uint32_t mv = 0;
@@ -2033,8 +2035,8 @@ MW_HD_INLINE void step_post(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par p
 }
 
 template <class Par>
-MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par par) {
-    step_collide(M, Wd, Cd, S, par);
+MW_HD_INLINE void world_step(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Par par) {
+    step_collide(M, Wd, Cd, S, S.m, par);
     step_solve(M, Wd, Cd, S, S.m, par.solve_overflow(), Par::SOLVE_OVERFLOW, par);
     step_post(M, Wd, Cd, S, par);
     // ---- continuous pass (b2World::Step: "if (m_continuousPhysics && step.dt > 0) SolveTOI(step)")
@@ -2048,7 +2050,7 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, Cold &Cd, Scratch &S, Par 
 
 
 // ---------------------------------------------------------------- lidar: b2World::RayCast -> b2EdgeShape::RayCast over the terrain, closest hit (D2)
-MW_HD float lidar_fraction(const Model &M, const Cold &Cd, V2 p1, V2 p2) {
+MW_HD float lidar_fraction(const Model &M, const ColdView &Cd, V2 p1, V2 p2) {
     const V2 d = p2 - p1;
     float best = 1.0f;  // LidarCallback.fraction starts at 1.0 (:210)
     int e0 = (int)floorf(mnf(p1.x, p2.x) / TERRAIN_STEP) - 1, e1 = (int)floorf(mxf(p1.x, p2.x) / TERRAIN_STEP) + 1;
@@ -2095,11 +2097,11 @@ enum : uint32_t { TAG_MW_TERRAIN = 32, TAG_MW_PUSH = 33, TAG_MW_NOISE = 34 };
 MW_HD float u24f(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 MW_HD double u24d(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 
-MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done);
+MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done);
 
 // MultiWalkerEnv.reset (:330-357) without its trailing step: a fresh b2World (D1) with the package, the terrain edges and the
 // walkers created in the reference's order.  terrain_in (NT float64 heights) / push_in (W float64) replace the Philox draws (D3).
-MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, uint32_t gid, const double *terrain_in = nullptr, const double *push_in = nullptr) {
+MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, uint32_t gid, const double *terrain_in = nullptr, const double *push_in = nullptr) {
     const uint32_t tick = Wd.tick;
     Wd.game_over = 0; Wd.overflow = 0; Wd.prev_package_shaping = 0.0; Wd.t = 0;
     for (int w = 0; w < MAX_WALKERS; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
@@ -2175,7 +2177,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, u
 // MultiWalkerEnv.step (:359-428).  obs: [W][32], rew: [W]
 // apply_action (:194-203) for all walkers: the first thing MultiWalkerEnv.step does
 template <class Par>
-MW_HD_INLINE void env_apply_actions(const Model &M, Hot &Wd, Cold &Cd, Par par, const float *actions) {
+MW_HD_INLINE void env_apply_actions(const Model &M, Hot &Wd, const ColdView &Cd, Par par, const float *actions) {
     for (int w = par.lane(); w < M.W; w += par.n()) {
         for (int k = 0; k < 4; ++k) {
             const float a = actions[4 * w + k];
@@ -2191,7 +2193,7 @@ MW_HD_INLINE void env_apply_actions(const Model &M, Hot &Wd, Cold &Cd, Par par, 
     par.sync();
 }
 template <class Par>
-MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
+MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, Scratch &S, Par par, uint32_t gid, const float *actions, float *obs,
                     float *rew, uint8_t *done) {
     env_apply_actions(M, Wd, Cd, par, actions);
     world_step(M, Wd, Cd, S, par);  // :365
@@ -2203,7 +2205,7 @@ MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, Cold &Cd, S
     par.sync();
 }
 
-MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const Cold &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
+MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
     // the Python side of the reference computes in float64 on the float32 values Box2D hands it; so does this function
     const Body &pkg = Wd.b[0];
     const V2 pkg_pos = body_xf(M, pkg, 0).p;

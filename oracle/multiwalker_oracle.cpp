@@ -58,8 +58,8 @@ void mwo_reset(MwOracle *o, const uint8_t *mask, float *obs) {
         mw::Scratch S;
         float zero[4 * mw::MAX_WALKERS] = {0};
         const uint32_t gid = (uint32_t)(o->env_id_base + n);
-        mw::env_reset_world(o->M, o->C, o->worlds[n].h, o->worlds[n].c, gid);
-        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, o->par(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
+        mw::env_reset_world(o->M, o->C, o->worlds[n].h, mw::cold_view(o->worlds[n].c), gid);
+        mw::env_step(o->M, o->C, o->worlds[n].h, mw::cold_view(o->worlds[n].c), S, o->par(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
         o->worlds[n].h.t = 0;
     }
 }
@@ -73,8 +73,8 @@ void mwo_reset_with(MwOracle *o, const uint8_t *mask, const double *terrain, con
         mw::Scratch S;
         float zero[4 * mw::MAX_WALKERS] = {0};
         const uint32_t gid = (uint32_t)(o->env_id_base + n);
-        mw::env_reset_world(o->M, o->C, o->worlds[n].h, o->worlds[n].c, gid, terrain ? terrain + n * NT : nullptr, push ? push + n * W : nullptr);
-        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, o->par(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
+        mw::env_reset_world(o->M, o->C, o->worlds[n].h, mw::cold_view(o->worlds[n].c), gid, terrain ? terrain + n * NT : nullptr, push ? push + n * W : nullptr);
+        mw::env_step(o->M, o->C, o->worlds[n].h, mw::cold_view(o->worlds[n].c), S, o->par(), gid, zero, obs + n * W * mw::obs_dim_of(o->C), nullptr, nullptr);
         o->worlds[n].h.t = 0;
     }
 }
@@ -84,7 +84,7 @@ void mwo_step(MwOracle *o, const float *actions, float *obs, float *rew, uint8_t
 #pragma omp parallel for schedule(static)
     for (int64_t n = 0; n < o->n_envs; ++n) {
         mw::Scratch S;
-        mw::env_step(o->M, o->C, o->worlds[n].h, o->worlds[n].c, S, o->par(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
+        mw::env_step(o->M, o->C, o->worlds[n].h, mw::cold_view(o->worlds[n].c), S, o->par(), (uint32_t)(o->env_id_base + n), actions + n * W * 4,
                      obs + n * W * mw::obs_dim_of(o->C), rew + n * W, done + n);
     }
 }
@@ -141,7 +141,7 @@ void mwo_get_aux(const MwOracle *o, float *out) {
 /* the contacts of env n in WORLD LIST ORDER (descending key), same record as mwr_get_contacts of multiwalker_ref.c */
 int mwo_get_contacts(const MwOracle *o, int64_t n, int32_t *ints, float *flts, int max_contacts) {
     const mw::Model &M = o->M;
-    const mw::Cold &Cd = o->worlds[n].c;
+    const mw::ColdView Cd = mw::cold_view(const_cast<mw::Cold &>(o->worlds[n].c));
     int total = 0;
     for (int s = 0; s < M.dyn_slot_base + M.n_dyn_pairs; ++s) if (Cd.slot[s].edge >= 0 && (s >= M.dyn_slot_base || s < M.slot_base[M.NB - 1] + M.slot_cap[M.NB - 1])) ++total;
     uint64_t below = ~0ull;

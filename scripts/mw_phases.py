@@ -5,7 +5,7 @@ db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if 'kernel_dispatch' in t][0]; sym = [t for t in tabs if 'kernel_symbol' in t][0]
 rows = list(cur.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id where s.kernel_name like '%%mw_phase%%' order by d.start" % (kd, sym)))
-seq = [(int(re.search(r'ILi(\d)ELi', r[0]).group(1)), (r[2] - r[1]) / 1e3) for r in rows]
+seq = [(int(re.search(r'ILi(\d)E', r[0]).group(1)), (r[2] - r[1]) / 1e3) for r in rows]
 # a step = COLLIDE SOLVE TOI [RESET COLLIDE SOLVE TOI]; find steps by scanning
 names = {0: "reset", 1: "collide", 2: "solve", 3: "toi"}
 steps, i = [], 0

@@ -17,13 +17,13 @@ int main() {
         uint32_t lcg = 12345;
         for (int n = 0; n < 64; ++n) {
             Scratch S; uint8_t done = 0; float zero[16] = {0};
-            env_reset_world(M, C, worlds[n].h, worlds[n].c, n);
-            env_step(M, C, worlds[n].h, worlds[n].c, S, SerialPar(), n, zero, obs.data(), nullptr, nullptr);
+            env_reset_world(M, C, worlds[n].h, cold_view(worlds[n].c), n);
+            env_step(M, C, worlds[n].h, cold_view(worlds[n].c), S, SerialPar(), n, zero, obs.data(), nullptr, nullptr);
             memset(&g_stats, 0, 0);
             for (int t = 0; t < 300; ++t) {
                 for (auto &a : act) { lcg = lcg * 1664525u + 1013904223u; a = (float)(lcg >> 8) / 8388608.0f - 1.0f; }
-                env_step(M, C, worlds[n].h, worlds[n].c, S, SerialPar(), n, act.data(), obs.data(), rew.data(), &done);
-                if (done) { env_reset_world(M, C, worlds[n].h, worlds[n].c, n); env_step(M, C, worlds[n].h, worlds[n].c, S, SerialPar(), n, zero, obs.data(), nullptr, nullptr); }
+                env_step(M, C, worlds[n].h, cold_view(worlds[n].c), S, SerialPar(), n, act.data(), obs.data(), rew.data(), &done);
+                if (done) { env_reset_world(M, C, worlds[n].h, cold_view(worlds[n].c), n); env_step(M, C, worlds[n].h, cold_view(worlds[n].c), S, SerialPar(), n, zero, obs.data(), nullptr, nullptr); }
             }
         }
         const double s = (double)g_stats.steps;
