@@ -34,10 +34,17 @@ struct MwDev {
     int32_t scratch_bytes; // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
     int32_t ty_bytes;      // the terrain heights of one env, 16-byte aligned
     int32_t toi_lane0_bytes;       // time-of-impact cache of lane 0 (the package's contact slots)
+    int32_t cold_q;        // 16-byte words of mw::Cold in use (up to the last contact slot of this walker count)
     int32_t lds_stride[4]; // LDS per env by phase (PH_*): Hot | terrain | that phase's part of Scratch | its work areas
     int64_t n_envs;
     const mw::Model *model;
     uint32_t *state;
+    // the NEXT episode of every env, prepared ahead of time (see the launch sequence below)
+    uint32_t *spare_state; // [n_envs] records like `state`
+    float *spare_obs;      // [n_envs][W][D]: the observation MultiWalkerEnv.reset returns for that episode
+    uint32_t *ready_step;  // [n_envs] 0: the spare is stale / consumed, SPARE_BUSY: being prepared, else the step() call that finished it
+    uint32_t step_id;      // this step() call (starts at 1)
+    int32_t spare_blocks;  // leading blocks of a pass-0 launch that work on spares
 };
 struct MwIO {
     const double *inj_terrain;  // reset only, parity hook: [N][NT] terrain heights instead of the Philox walk (or NULL)
@@ -99,6 +106,15 @@ struct GroupPar {
 // pass 0 = the step proper (every env, the caller's actions, rewards / done written); pass 1 = the trailing zero-action step of a
 // reset (:357), only for the envs whose byte in `pending` is set -- by PH_RESET (reset(mask)) or by PH_TOI of pass 0 (auto-reset).
 enum { PH_RESET = 0, PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 3 };
+//
+// AUTO-RESET WITHOUT A SECOND PASS.  With the Philox contract a reset's world depends on the env and on how many episodes it has had,
+// not on when the previous episode ended -- so it can be built BEFORE it is needed.  Every env has a spare record holding its next
+// episode (world after reset + the trailing step, and the observation reset returns).  When a step ends an env's episode, the
+// continuous-pass launch copies the spare over the live record and hands out its observation; the spare is then rebuilt by the NEXT
+// step() call, inside that call's own three launches (its blocks come first in the grid): pass 2.  Only an env whose spare is not ready
+// (two episodes ending within two steps, or the very first episode) goes through pass 1.  A spare finished by the current call is not
+// taken (ready_step == step_id): which launch order the hardware picks must not decide which path an env takes.
+constexpr uint32_t SPARE_BUSY = 0xFFFFFFFFu;
 
 template <int PHASE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_MW_SOLVE_WAVES, MADRL_MW_SOLVE_WAVES)))
@@ -114,15 +130,18 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
     mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES + tyb);   // (only the phase's part of it is there)
     unsigned char *work = base + HOT_BYTES + tyb + (PHASE == PH_COLLIDE ? SCR_HDR_BYTES : SOLVE_HDR_BYTES);
     const int W = M.W;
-    for (int64_t e0 = (int64_t)blockIdx.x * EPW; e0 < d.n_envs; e0 += (int64_t)gridDim.x * EPW) {
-        const int64_t env = e0 + g;
+    {
+        // pass 0: the blocks below d.spare_blocks work on the spares (= pass 2), the others on the live records
+        const bool spare = pass == 2 || (pass == 0 && (int)blockIdx.x < d.spare_blocks);
+        const int64_t env = ((int64_t)blockIdx.x - ((pass == 0 && !spare) ? d.spare_blocks : 0)) * EPW + g;
         bool active = env < d.n_envs;
         if (active) {
-            if (PHASE == PH_RESET) active = io.mask ? io.mask[env] != 0 : (pass == 0 || d.pending[env] != 0);   // reset(mask) / auto-reset
+            if (spare) active = PHASE == PH_RESET ? d.ready_step[env] == 0 : d.ready_step[env] == SPARE_BUSY;
+            else if (PHASE == PH_RESET) active = io.mask ? io.mask[env] != 0 : (pass == 0 || d.pending[env] != 0);   // reset(mask) / auto-reset
             else if (pass == 1) active = d.pending[env] != 0;
         }
         if (active) {
-            uint32_t *rec = d.state + env * (int64_t)d.world_dw;
+            uint32_t *rec = (spare ? d.spare_state : d.state) + env * (int64_t)d.world_dw;
             mw::Cold *cold_g = reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
             mw::ColdView Cd = mw::cold_view(*cold_g);
             uint32_t *scr = rec + d.scratch_off_dw;   // the step's Scratch between launches
@@ -143,12 +162,19 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
             const uint32_t gid = d.gid_base + (uint32_t)env;
             if (PHASE == PH_RESET) {
                 if (lane == 0) {
-                    mw::env_reset_world(M, d.cfg, Wd, Cd, gid, io.inj_terrain ? io.inj_terrain + env * M.NT : nullptr, io.inj_push ? io.inj_push + env * W : nullptr);
-                    d.pending[env] = 1;
+                    if (spare) {   // the episode the live env will start next
+                        Wd.episode = reinterpret_cast<const mw::Hot *>(d.state + env * (int64_t)d.world_dw)->episode;
+                        mw::env_reset_world(M, d.cfg, Wd, Cd, gid);
+                        d.ready_step[env] = SPARE_BUSY;
+                    } else {
+                        mw::env_reset_world(M, d.cfg, Wd, Cd, gid, io.inj_terrain ? io.inj_terrain + env * M.NT : nullptr, io.inj_push ? io.inj_push + env * W : nullptr);
+                        d.pending[env] = 1;
+                        d.ready_step[env] = 0;   // the spare held this episode (or an older one)
+                    }
                 }
             } else if (PHASE == PH_COLLIDE) {
                 float *s_act = reinterpret_cast<float *>(work);
-                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (pass == 0 && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
+                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (pass == 0 && !spare && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
                 lds_sync();
                 mw::env_apply_actions(M, Wd, Cd, par, s_act);
                 mw::step_collide(M, Wd, Cd, S, pool, par);
@@ -176,24 +202,44 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
                     TL.ovf_cap = lane == 0 ? c0 : CO;
                     mw::solve_toi(M, Wd, Cd, S, *reinterpret_cast<mw::ToiWork *>(tw), TL, par, 1.0f / mw::FPS);
                 }
-                float *obs_row = io.obs + env * W * mw::obs_dim_of(d.cfg);  // observation rows go straight to HBM
+                const int OD = W * mw::obs_dim_of(d.cfg);
+                float *obs_row = (spare ? d.spare_obs : io.obs) + env * OD;  // observation rows go straight to HBM
+                const bool real = pass == 0 && !spare;   // the step proper: rewards and done go out
                 if (lane == 0) {
                     *s_done = 0;
-                    mw::env_observe(M, d.cfg, Wd, Cd, gid, obs_row, pass == 0 ? s_rew : (float *)nullptr, pass == 0 ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
+                    mw::env_observe(M, d.cfg, Wd, Cd, gid, obs_row, real ? s_rew : (float *)nullptr, real ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
                     Wd.t += 1;
                     Wd.tick += 1;
-                    if (pass == 0) {
+                    if (real) {
                         if (d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2;
-                        d.pending[env] = (d.cfg.auto_reset && *s_done != 0) ? 1 : 0;
+                        uint32_t take = 0;
+                        if (d.cfg.auto_reset && *s_done != 0) {
+                            const uint32_t rs = d.ready_step[env];
+                            take = (rs != 0 && rs != SPARE_BUSY && rs != d.step_id) ? 1u : 2u;   // 1: the spare is ready, 2: pass 1
+                        }
+                        d.pending[env] = take == 2 ? 1 : 0;
+                        *s_done |= take << 8;
                     } else {
                         Wd.t = 0;   // the reset's trailing step does not count (:357)
-                        d.pending[env] = 0;
+                        if (spare) d.ready_step[env] = d.step_id;
+                        else d.pending[env] = 0;
                     }
                 }
                 lds_sync();
-                if (pass == 0) {
+                if (real) {
                     if (lane < W) io.rew[env * W + lane] = s_rew[lane];
                     if (lane == 0) io.done[env] = (uint8_t)*s_done;
+                    if ((*s_done >> 8) == 1) {   // the episode ended and the next one is ready: it becomes the live record
+                        const uint32_t *sp = d.spare_state + env * (int64_t)d.world_dw;
+                        uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
+                        for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = sp[k];   // (written back to the live record below)
+                        const uint4 *cs = reinterpret_cast<const uint4 *>(sp + sizeof(mw::Hot) / 4);
+                        uint4 *cdst = reinterpret_cast<uint4 *>(rec + sizeof(mw::Hot) / 4);
+                        for (int k = lane; k < d.cold_q; k += NL) cdst[k] = cs[k];
+                        const float *so = d.spare_obs + env * OD;
+                        for (int k = lane; k < OD; k += NL) obs_row[k] = so[k];
+                        if (lane == 0) d.ready_step[env] = 0;
+                    }
                 }
             }
             lds_sync();
@@ -202,8 +248,6 @@ void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
                 for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
             }
         }
-        // the next env of this group reuses the LDS block
-        lds_sync();
     }
 }
 
@@ -284,6 +328,8 @@ struct madrl_multiwalker {
     MwDev dev;
     int device;
     int64_t max_blocks;
+    uint32_t step_id;
+    int use_spares;
     void *model_dev;
     int NB, NT;
 };
@@ -305,25 +351,31 @@ int mw_validate(const madrl_multiwalker_config *c) {
 }
 
 template <int PH>
-void mw_launch_phase(const madrl_multiwalker *h, const MwIO &io, int pass, hipStream_t s) {
-    int64_t blocks = (h->dev.n_envs + EPW - 1) / EPW;   // default: every group of EPW envs gets its own wavefront
-    if (h->max_blocks > 0 && blocks > h->max_blocks) blocks = h->max_blocks;
-    const size_t lds = (size_t)EPW * h->dev.lds_stride[PH];
-    hipLaunchKernelGGL((mw_phase_kernel<PH>), dim3((unsigned)blocks), dim3(64), lds, s, h->dev, io, pass);
+void mw_launch_phase(const madrl_multiwalker *h, const MwDev &d, const MwIO &io, int pass, hipStream_t s) {
+    const int64_t blocks = (d.n_envs + EPW - 1) / EPW + (pass == 0 ? d.spare_blocks : 0);   // every group of EPW envs gets its own wavefront
+    const size_t lds = (size_t)EPW * d.lds_stride[PH];
+    hipLaunchKernelGGL((mw_phase_kernel<PH>), dim3((unsigned)blocks), dim3(64), lds, s, d, io, pass);
 }
-void mw_launch_all(const madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
+void mw_launch_all(madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
+    MwDev d = h->dev;
+    d.spare_blocks = 0;
     if (mode == 1) {   // MultiWalkerEnv.step
-        mw_launch_phase<PH_COLLIDE>(h, io, 0, s); mw_launch_phase<PH_SOLVE>(h, io, 0, s); mw_launch_phase<PH_TOI>(h, io, 0, s);
+        d.step_id = ++h->step_id;
+        if (h->cfg.auto_reset && h->use_spares) {   // stale spares are rebuilt inside this call's launches
+            mw_launch_phase<PH_RESET>(h, d, io, 2, s);
+            d.spare_blocks = (int32_t)((d.n_envs + EPW - 1) / EPW);
+        }
+        mw_launch_phase<PH_COLLIDE>(h, d, io, 0, s); mw_launch_phase<PH_SOLVE>(h, d, io, 0, s); mw_launch_phase<PH_TOI>(h, d, io, 0, s);
         if (!h->cfg.auto_reset) return;
     }
-    // MultiWalkerEnv.reset(mask), or the fused auto-reset of the envs whose step just ended their episode: reset, then step(zeros)
+    // MultiWalkerEnv.reset(mask), or the auto-reset of the envs whose episode just ended without a ready spare: reset, then step(zeros)
     MwIO r = io;
     if (mode == 1) { r.mask = nullptr; r.inj_terrain = nullptr; r.inj_push = nullptr; }
-    mw_launch_phase<PH_RESET>(h, r, mode == 1 ? 1 : 0, s);
-    mw_launch_phase<PH_COLLIDE>(h, io, 1, s); mw_launch_phase<PH_SOLVE>(h, io, 1, s); mw_launch_phase<PH_TOI>(h, io, 1, s);
+    mw_launch_phase<PH_RESET>(h, d, r, mode == 1 ? 1 : 0, s);
+    mw_launch_phase<PH_COLLIDE>(h, d, io, 1, s); mw_launch_phase<PH_SOLVE>(h, d, io, 1, s); mw_launch_phase<PH_TOI>(h, d, io, 1, s);
 }
 
-int mw_launch(const madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
+int mw_launch(madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     mw_launch_all(h, io, mode, s);
     MADRL_HIP_TRY(hipGetLastError());
@@ -349,8 +401,11 @@ int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n
     mw::Model M;
     memset(&M, 0, sizeof(M));
     mw::build_model(M, cfg->n_walkers);
-    // per env: the world record, then the step's Scratch (manifolds + schedule handed from launch to launch); then one byte per env
-    *out_bytes = (uint64_t)(align_up(sizeof(mw::World), 16) + mw_scratch_bytes(M)) * (uint64_t)n_envs + align_up((uint64_t)n_envs, 16);
+    // per env: the world record, then the step's Scratch (manifolds + schedule handed from launch to launch); one byte per env; then the
+    // spares: a second record per env, its observation, one dword per env
+    const uint64_t rec = (uint64_t)(align_up(sizeof(mw::World), 16) + mw_scratch_bytes(M));
+    const uint64_t od = (uint64_t)cfg->n_walkers * (uint64_t)(mw::OBS_DIM - 1 + (cfg->one_hot ? mw::MAX_AGENTS_ID : 1));
+    *out_bytes = rec * (uint64_t)n_envs + align_up((uint64_t)n_envs, 16) + rec * (uint64_t)n_envs + align_up(od * 4 * (uint64_t)n_envs, 16) + 4 * (uint64_t)n_envs;
     return MADRL_OK;
 }
 
@@ -392,6 +447,17 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     d.scratch_off_dw = (int32_t)(align_up(sizeof(mw::World), 16) / 4);
     d.world_dw = d.scratch_off_dw + d.scratch_bytes / 4;
     d.pending = (uint8_t *)state_dev + (size_t)d.world_dw * 4 * (size_t)n_envs;
+    {
+        unsigned char *p = d.pending + align_up((size_t)n_envs, 16);
+        d.spare_state = (uint32_t *)p; p += (size_t)d.world_dw * 4 * (size_t)n_envs;
+        d.spare_obs = (float *)p; p += align_up((size_t)cfg->n_walkers * (size_t)mw::obs_dim_of(d.cfg) * 4 * (size_t)n_envs, 16);
+        d.ready_step = (uint32_t *)p;
+        if (hipMemset(d.ready_step, 0, 4 * (size_t)n_envs) != hipSuccess) { (void)hipFree(h->model_dev); delete h; return fail(MADRL_EHIP, "state buffer too small or not device memory"); }
+    }
+    d.cold_q = (int32_t)(align_up(offsetof(mw::Cold, slot) + (size_t)M.n_slots * sizeof(mw::Slot), 16) / 16);
+    h->step_id = 0;
+    h->use_spares = 1;
+    if (const char *e = getenv("MADRL_MW_SPARES")) h->use_spares = atoi(e) != 0;   // experiments: 0 = every auto-reset through pass 1
     d.ty_bytes = (int32_t)align_up((size_t)M.NT * 4, 16);
     d.toi_lane0_bytes = (int32_t)align_up((size_t)(M.slot_cap[0] > mw::EDGE_SLOTS_HULL ? M.slot_cap[0] : mw::EDGE_SLOTS_HULL) * 5, 16);
     d.lds_stride[PH_RESET] = HOT_BYTES + SOLVE_HDR_BYTES;

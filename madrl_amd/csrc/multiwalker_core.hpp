@@ -371,7 +371,9 @@ struct Hot {
     double prev_shaping[MAX_WALKERS], prev_package_shaping;   // float64 like the reference's Python side (:403-411)
     uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, overflow;   // overflow: sticky, a contact did not fit its cache / the pool
     uint8_t pending_reset, pad_;  // HIP build: this env runs the reset's trailing step in the current launch sequence (multiwalker.hip)
-    uint32_t tick;
+    uint32_t tick;                // observations of the current episode so far (noise draws)
+    uint32_t episode;             // resets of this env so far (a reset's draws)
+    uint32_t pad2_;
     int32_t t;
     uint32_t awake;               // bit b: body b is awake (b2Body::e_awakeFlag)
     uint32_t batch;               // FindNewContacts calls so far in this world (contact_key)
@@ -2102,7 +2104,9 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView 
 // MultiWalkerEnv.reset (:330-357) without its trailing step: a fresh b2World (D1) with the package, the terrain edges and the
 // walkers created in the reference's order.  terrain_in (NT float64 heights) / push_in (W float64) replace the Philox draws (D3).
 MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, uint32_t gid, const double *terrain_in = nullptr, const double *push_in = nullptr) {
-    const uint32_t tick = Wd.tick;
+    // D3: the draws of a reset are keyed by (env, episode) -- the world an env gets is a function of how many episodes it has had, not of
+    // when the previous one ended; that is what lets the HIP build prepare the next episode's world ahead of time
+    const uint32_t tick = Wd.episode;
     Wd.game_over = 0; Wd.overflow = 0; Wd.prev_package_shaping = 0.0; Wd.t = 0;
     for (int w = 0; w < MAX_WALKERS; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
     for (int k = 0; k < M.n_slots; ++k) { Slot &sl = Cd.slot[k]; sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.batch = 0; sl.reserved_ = 0; }
@@ -2171,7 +2175,8 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, const ColdV
     }
     for (int b = 0; b < M.NB; ++b) find_new_terrain_contacts(M, Wd, Cd, b, 0);
     find_new_pair_contacts(M, Cd, (1u << M.NB) - 1u, 0);
-    Wd.tick = tick + 1;
+    Wd.episode = tick + 1;
+    Wd.tick = 0;
 }
 
 // MultiWalkerEnv.step (:359-428).  obs: [W][32], rew: [W]
@@ -2239,7 +2244,7 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView 
         if (C.position_noise != 0.0f || C.angle_noise != 0.0f) {
             for (int q = 0; q < 4; ++q) {
                 uint32_t r[4];
-                philox10(gid, Wd.tick, (uint32_t)(w * 4 + q), TAG_MW_NOISE, C.k0, C.k1, r);
+                philox10(gid, Wd.episode, (Wd.tick << 4) | (uint32_t)(w * 4 + q), TAG_MW_NOISE, C.k0, C.k1, r);
                 const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u24f(r[1]);
                 const float rad = sqrtf(-2.0f * logf(u1));
                 float bs, bc;

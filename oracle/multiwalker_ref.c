@@ -1938,7 +1938,7 @@ typedef struct {
     double start_x[MW_MAX_WALKERS], package_scale, package_length;
     int game_over, fallen[MW_MAX_WALKERS];
     double prev_shaping[MW_MAX_WALKERS], prev_package_shaping;
-    uint32_t tick;                            /* RNG draw counter (D3): +1 per reset and per step */
+    uint32_t episode, tick;                   /* RNG counters (D3): resets of this env so far; observations of the current episode so far */
     int32_t t;
 } MwEnv;
 
@@ -1948,7 +1948,9 @@ typedef struct {
     MwEnv *envs;
 } mwr_handle;
 
-/* Philox4x32-10 (Salmon et al., SC'11), restated from the paper; counter (env id, tick, index, tag), key = seed */
+/* Philox4x32-10 (Salmon et al., SC'11), restated from the paper; key = seed; counter = (env id, episode, index, tag) for the draws of a
+ * reset and (env id, episode, observation << 4 | index, tag) for the observation noise: a reset's world is a function of the env and of
+ * how many episodes it has had, not of when the previous episode ended */
 static void mwr_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -1987,7 +1989,7 @@ static void mw_contact_listener(void *user, World *w, int ci, int begin) {
 static void mw_reset_world(const mwr_config *cfg, MwEnv *e, uint32_t gid, const double *terrain_in, const double *push_in) {
     const int W = cfg->n_walkers;
     const uint32_t k0 = (uint32_t)cfg->seed, k1 = (uint32_t)(cfg->seed >> 32);
-    const uint32_t tick = e->tick;
+    const uint32_t tick = e->episode;
     World *w = &e->world;
     world_init(w, V(0.0f, -10.0f));           /* Box2D.b2World(): gravity (0, -10), doSleep True (:280); a fresh world, see D1 */
     w->continuousPhysics = cfg->continuous_physics;
@@ -2071,7 +2073,8 @@ static void mw_reset_world(const mwr_config *cfg, MwEnv *e, uint32_t gid, const 
                                                                 (float)MW_MOTORS_TORQUE, 1.0f);
         }
     }
-    e->tick = tick + 1;
+    e->episode = tick + 1;
+    e->tick = 0;
 }
 
 static void joint_set_motor(World *w, int ji, float speed, float torque) {   /* b2RevoluteJoint::SetMotorSpeed / SetMaxMotorTorque */
@@ -2144,7 +2147,7 @@ static void mw_step(const mwr_config *cfg, MwEnv *e, uint32_t gid, const float *
         if (cfg->position_noise != 0.0 || cfg->angle_noise != 0.0) {
             for (int q = 0; q < 4; ++q) {
                 uint32_t r[4];
-                mwr_philox(gid, e->tick, (uint32_t)(i * 4 + q), MWR_TAG_NOISE, k0, k1, r);
+                mwr_philox(gid, e->episode, (e->tick << 4) | (uint32_t)(i * 4 + q), MWR_TAG_NOISE, k0, k1, r);
                 const double u1 = (double)((r[0] >> 8) + 1u) / 16777216.0, u2 = u24(r[1]);
                 const double rad = sqrt(-2.0 * log(u1));
                 nz[2 * q] = rad * cos(2.0 * 3.14159265358979323846 * u2);
