@@ -18,6 +18,7 @@
 #include "multiwalker_core.hpp"
 
 #include <new>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,14 +29,14 @@ using namespace madrl;
 struct MwDev {
     mw::EnvCfg cfg;
     uint32_t gid_base;
-    int32_t world_dw;      // dwords per env in the state buffer: mw::World, then the step's Scratch
-    int32_t scratch_off_dw; // where the Scratch starts inside an env's block
+    int32_t world_dw;      // dwords per env in the state buffer: mw::World, then the step's manifold pool
+    int32_t scratch_off_dw; // where the pool starts inside an env's block
     uint8_t *pending;      // [n_envs] at the end of the state buffer: this env runs the trailing step of a reset in pass 1
-    int32_t scratch_bytes; // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
+    int32_t scratch_bytes; // the pool: Model::max_manifolds manifolds, 16-byte aligned
     int32_t ty_bytes;      // the terrain heights of one env, 16-byte aligned
     int32_t toi_lane0_bytes;       // time-of-impact cache of lane 0 (the package's contact slots)
     int32_t cold_q;        // 16-byte words of mw::Cold in use (up to the last contact slot of this walker count)
-    int32_t lds_stride[4]; // LDS per env by phase (PH_*): Hot | terrain | that phase's part of Scratch | its work areas
+    int32_t lds_stride[4]; // LDS per env: Hot | terrain | the solver's part of Scratch | work area of the phase; [0] all phases in one launch, [1..3] collide, solve, continuous pass
     int64_t n_envs;
     const mw::Model *model;
     uint32_t *state;
@@ -43,8 +44,10 @@ struct MwDev {
     uint32_t *spare_state; // [n_envs] records like `state`
     float *spare_obs;      // [n_envs][W][D]: the observation MultiWalkerEnv.reset returns for that episode
     uint32_t *ready_step;  // [n_envs] 0: the spare is stale / consumed, SPARE_BUSY: being prepared, else the step() call that finished it
-    uint32_t step_id;      // this step() call (starts at 1)
-    int32_t spare_blocks;  // leading blocks of a pass-0 launch that work on spares
+    uint32_t *dirty_list;  // [2][n_envs] envs whose spare is stale: list (step_id & 1) is rebuilt by step() call step_id, which appends to the other
+    uint32_t *n_dirty;     // [2]
+    uint32_t step_id;      // this step() call (starts at 1; reset calls carry the last one)
+    int32_t spare_blocks;  // leading blocks of a step launch that work on spares
 };
 struct MwIO {
     const double *inj_terrain;  // reset only, parity hook: [N][NT] terrain heights instead of the Philox walk (or NULL)
@@ -63,16 +66,14 @@ struct MwIO {
 #define MADRL_MW_SOLVE_MREG 3    // manifolds a solver lane holds in registers for the whole solve
 #endif
 #ifndef MADRL_MW_SOLVE_OVERFLOW
-#define MADRL_MW_SOLVE_OVERFLOW 8   // manifolds per env the solver launch can hold in LDS on top of the lanes' register copies
+#define MADRL_MW_SOLVE_OVERFLOW 5   // manifolds per env the solver launch can hold in LDS on top of the lanes' register copies
 #endif
 constexpr int EPW = 64 / mw::SOLVE_LANES;   // envs per wavefront: one lane per walker
 constexpr int NL = mw::SOLVE_LANES;
 constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
 constexpr int SCR_HDR_BYTES = (int)((offsetof(mw::Scratch, m) + 15) / 16 * 16);              // Scratch without the pool
-constexpr int SCR_HDR_DW = (int)(offsetof(mw::Scratch, m) / 4);                               // where the pool starts in the state buffer's copy
 static_assert(offsetof(mw::Scratch, m) % 16 == 0, "the manifold pool follows the header at a 16-byte boundary");
 constexpr int SOLVE_HDR_BYTES = (int)((offsetof(mw::Scratch, m_bA) + 15) / 16 * 16);         // the part of Scratch the solver and the continuous pass work on
-constexpr int IO_BYTES = (4 * mw::MAX_WALKERS + mw::MAX_WALKERS + 4) * 4;                     // s_act | s_rew | s_done
 constexpr int TOI_WORK_BYTES = (int)((sizeof(mw::ToiWork) + 15) / 16 * 16);
 constexpr int TOI_LANE_BYTES = (mw::EDGE_SLOTS_HULL * 5 + 15) / 16 * 16;   // time-of-impact cache of a walker's body: 4 + 1 bytes per contact slot
 
@@ -95,160 +96,183 @@ struct GroupPar {
     __device__ __forceinline__ void or_bits(uint32_t *p, uint32_t v) const { atomicOr(p, v); }
 };
 
-// One API call is a SEQUENCE of launches over the same per-env records (the step's Scratch -- schedule and manifold pool -- handed from
-// launch to launch through the caller's state buffer):
-//   PH_COLLIDE  apply_action, b2ContactManager::Collide, islands + solver schedule                  (mw::step_collide)
-//   PH_SOLVE    b2Island::Solve, sleeping                                                          (mw::step_solve)
-//   PH_TOI      SynchronizeFixtures + FindNewContacts, b2World::SolveTOI, observation / reward / done (mw::step_post, solve_toi, env_observe)
-//   PH_RESET    MultiWalkerEnv.reset (:330-357) without its trailing step                           (mw::env_reset_world)
-// Separate kernels because a kernel's register allocation is the maximum over its phases: the narrow phase and the time-of-impact root
-// finder (GJK) want their registers for themselves, the 180-sweep solver loop wants every joint constant in a register.
-// pass 0 = the step proper (every env, the caller's actions, rewards / done written); pass 1 = the trailing zero-action step of a
-// reset (:357), only for the envs whose byte in `pending` is set -- by PH_RESET (reset(mask)) or by PH_TOI of pass 0 (auto-reset).
-enum { PH_RESET = 0, PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 3 };
+// ONE LAUNCH PER b2World::Step.  A wavefront takes its 16 envs through the whole step:
+//   apply_action, b2ContactManager::Collide, islands + solver schedule                                (mw::step_collide)
+//   b2Island::Solve, sleeping                                                                        (mw::step_solve)
+//   SynchronizeFixtures + FindNewContacts, b2World::SolveTOI, observation / reward / done             (mw::step_post, solve_toi, env_observe)
+// with mw::Hot, the terrain heights and the step's schedule in LDS from beginning to end (the manifold pool of the step lives in the
+// state buffer next to the env's record).  How long a phase takes varies a lot between envs -- a lying package, a leg arriving at the
+// ground -- and a launch ends with its slowest wavefront: one launch pays that tail once, three launches paid it three times.
 //
 // AUTO-RESET WITHOUT A SECOND PASS.  With the Philox contract a reset's world depends on the env and on how many episodes it has had,
 // not on when the previous episode ended -- so it can be built BEFORE it is needed.  Every env has a spare record holding its next
-// episode (world after reset + the trailing step, and the observation reset returns).  When a step ends an env's episode, the
-// continuous-pass launch copies the spare over the live record and hands out its observation; the spare is then rebuilt by the NEXT
-// step() call, inside that call's own three launches (its blocks come first in the grid): pass 2.  Only an env whose spare is not ready
-// (two episodes ending within two steps, or the very first episode) goes through pass 1.  A spare finished by the current call is not
-// taken (ready_step == step_id): which launch order the hardware picks must not decide which path an env takes.
+// episode (world after reset + the trailing step, and the observation reset returns).  When a step ends an env's episode, the end of
+// the launch copies the spare over the live record and hands out its observation; the env goes on a list, and the NEXT step() call
+// rebuilds the listed spares in the leading blocks of its own launch (16 per wavefront).  Only an env whose spare is not ready (two
+// episodes ending within two steps) takes the second launch: reset + trailing step for the envs marked `pending`, which is also what
+// reset(mask) runs.  A spare finished by the current call is never taken (ready_step == step_id): which order the hardware runs the
+// blocks in must not decide which path an env takes.
 constexpr uint32_t SPARE_BUSY = 0xFFFFFFFFu;
 
-template <int PHASE>
+// mode 0: step() -- blocks [0, spare_blocks) rebuild spares (reset + trailing step), the others step the live envs;
+// mode 1: reset + trailing step of the live envs selected by io.mask (reset(mask)) or, without a mask, by `pending` (auto-reset)
+// PH: which phases this launch runs (all of them, or one: the step as three launches -- every wavefront of a launch then runs the same
+// loops, which is what the instruction caches, shared by the eight wavefronts of two CUs, are sized for).  Between the launches of a
+// split step the schedule (the solver's part of mw::Scratch) waits in front of the manifold pool in the state buffer.
+enum { PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 4, PH_ALL = 7 };
+template <int PH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_MW_SOLVE_WAVES, MADRL_MW_SOLVE_WAVES)))
-void mw_phase_kernel(const MwDev d, const MwIO io, const int pass) {
+void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pending_only) {
     const mw::Model &M = *d.model;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int g = threadIdx.x / NL, lane = threadIdx.x % NL;
     const GroupPar par{lane};
-    unsigned char *base = smem + g * d.lds_stride[PHASE];
+    constexpr int PHI = PH == PH_ALL ? 0 : (PH == PH_COLLIDE ? 1 : (PH == PH_SOLVE ? 2 : 3));
+    constexpr bool TERRAIN = PH != PH_SOLVE;   // the solver never looks at the terrain
+    const int tyb = TERRAIN ? d.ty_bytes : 0;
+    unsigned char *base = smem + g * d.lds_stride[PHI];
     mw::Hot &Wd = *reinterpret_cast<mw::Hot *>(base);
     float *ty_l = reinterpret_cast<float *>(base + HOT_BYTES);
-    const int tyb = (PHASE == PH_COLLIDE || PHASE == PH_TOI) ? d.ty_bytes : 0;
-    mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES + tyb);   // (only the phase's part of it is there)
-    unsigned char *work = base + HOT_BYTES + tyb + (PHASE == PH_COLLIDE ? SCR_HDR_BYTES : SOLVE_HDR_BYTES);
+    mw::Scratch &S = *reinterpret_cast<mw::Scratch *>(base + HOT_BYTES + tyb);   // its header; the pool stays in the state buffer
+    // after the solver's part of the header: the collide phase's manifold summaries and the actions | the solver's LDS copies of
+    // manifolds | the continuous pass's work areas -- one after the other in the same bytes
+    unsigned char *work = base + HOT_BYTES + tyb + SOLVE_HDR_BYTES;
+    float *s_rew = reinterpret_cast<float *>(work);   // (written after the continuous pass is done with the work area)
+    uint32_t *s_done = reinterpret_cast<uint32_t *>(s_rew + mw::MAX_WALKERS);
     const int W = M.W;
+    const uint32_t cur = d.step_id & 1u, nxt = cur ^ 1u;
+    const bool spare = mode == 0 && (int)blockIdx.x < d.spare_blocks;
+    int64_t env = ((int64_t)blockIdx.x - (mode == 0 && !spare ? d.spare_blocks : 0)) * EPW + g;
+    bool active;
+    if (spare) {   // slot -> the env whose spare is to be rebuilt
+        active = env < (int64_t)d.n_dirty[cur];
+        if (active) env = d.dirty_list[cur * d.n_envs + env];
+    } else {
+        active = env < d.n_envs;
+        if (active && mode == 1) active = pending_only ? d.pending[env] != 0 : (io.mask ? io.mask[env] != 0 : true);
+    }
+    if (!active) return;   // (a whole group: the lanes that stay only ever synchronise inside their wavefront)
+    const bool fresh = spare || mode == 1;   // reset first, then the trailing zero-action step (:357)
+    uint32_t *rec = (spare ? d.spare_state : d.state) + env * (int64_t)d.world_dw;
+    mw::Cold *cold_g = reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
+    mw::ColdView Cd = mw::cold_view(*cold_g);
+    uint32_t *sched_g = rec + d.scratch_off_dw;   // the schedule between the launches of a split step
+    mw::Manifold *pool = reinterpret_cast<mw::Manifold *>(sched_g + SOLVE_HDR_BYTES / 4);
+    const uint32_t gid = d.gid_base + (uint32_t)env;
     {
-        // pass 0: the blocks below d.spare_blocks work on the spares (= pass 2), the others on the live records
-        const bool spare = pass == 2 || (pass == 0 && (int)blockIdx.x < d.spare_blocks);
-        const int64_t env = ((int64_t)blockIdx.x - ((pass == 0 && !spare) ? d.spare_blocks : 0)) * EPW + g;
-        bool active = env < d.n_envs;
-        if (active) {
-            if (spare) active = PHASE == PH_RESET ? d.ready_step[env] == 0 : d.ready_step[env] == SPARE_BUSY;
-            else if (PHASE == PH_RESET) active = io.mask ? io.mask[env] != 0 : (pass == 0 || d.pending[env] != 0);   // reset(mask) / auto-reset
-            else if (pass == 1) active = d.pending[env] != 0;
-        }
-        if (active) {
-            uint32_t *rec = (spare ? d.spare_state : d.state) + env * (int64_t)d.world_dw;
-            mw::Cold *cold_g = reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
-            mw::ColdView Cd = mw::cold_view(*cold_g);
-            uint32_t *scr = rec + d.scratch_off_dw;   // the step's Scratch between launches
-            mw::Manifold *pool = reinterpret_cast<mw::Manifold *>(scr + SCR_HDR_DW);
-            {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
-                for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = rec[k];
-                if (PHASE == PH_COLLIDE || PHASE == PH_TOI) {   // the terrain: read over and over by the narrow phase, the root finder, the lidar
-                    for (int k = lane; k < M.NT; k += NL) ty_l[k] = cold_g->ty[k];
-                    Cd.ty = ty_l;
-                }
-                if (PHASE == PH_SOLVE || PHASE == PH_TOI) {   // the schedule the collide launch built
-                    uint32_t *sd = reinterpret_cast<uint32_t *>(&S);
-                    for (int k = lane; k < SOLVE_HDR_BYTES / 4; k += NL) sd[k] = scr[k];
-                }
-            }
-            lds_sync();
-            const uint32_t gid = d.gid_base + (uint32_t)env;
-            if (PHASE == PH_RESET) {
-                if (lane == 0) {
-                    if (spare) {   // the episode the live env will start next
-                        Wd.episode = reinterpret_cast<const mw::Hot *>(d.state + env * (int64_t)d.world_dw)->episode;
-                        mw::env_reset_world(M, d.cfg, Wd, Cd, gid);
-                        d.ready_step[env] = SPARE_BUSY;
-                    } else {
-                        mw::env_reset_world(M, d.cfg, Wd, Cd, gid, io.inj_terrain ? io.inj_terrain + env * M.NT : nullptr, io.inj_push ? io.inj_push + env * W : nullptr);
-                        d.pending[env] = 1;
-                        d.ready_step[env] = 0;   // the spare held this episode (or an older one)
-                    }
-                }
-            } else if (PHASE == PH_COLLIDE) {
-                float *s_act = reinterpret_cast<float *>(work);
-                for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (pass == 0 && !spare && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
-                lds_sync();
-                mw::env_apply_actions(M, Wd, Cd, par, s_act);
-                mw::step_collide(M, Wd, Cd, S, pool, par);
-                const uint32_t *sd = reinterpret_cast<const uint32_t *>(&S);
-                for (int k = lane; k < SCR_HDR_DW; k += NL) scr[k] = sd[k];
-            } else if (PHASE == PH_SOLVE) {
-                // the manifolds the collide launch emitted stay in the state buffer: every lane copies the ones it owns into registers
-                mw::step_solve(M, Wd, Cd, S, pool, reinterpret_cast<mw::Manifold *>(work), MADRL_MW_SOLVE_OVERFLOW, par);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
+        for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = rec[k];
+    }
+    if (!(PH & PH_COLLIDE)) {
+        uint32_t *sd = reinterpret_cast<uint32_t *>(&S);
+        for (int k = lane; k < SOLVE_HDR_BYTES / 4; k += NL) sd[k] = sched_g[k];
+    }
+    lds_sync();
+    if ((PH & PH_COLLIDE) && fresh) {
+        if (lane == 0) {
+            if (spare) {   // the episode the live env will start next
+                Wd.episode = reinterpret_cast<const mw::Hot *>(d.state + env * (int64_t)d.world_dw)->episode;
+                mw::env_reset_world(M, d.cfg, Wd, Cd, gid);
+                d.ready_step[env] = SPARE_BUSY;
             } else {
-                float *s_rew = reinterpret_cast<float *>(work);
-                uint32_t *s_done = reinterpret_cast<uint32_t *>(s_rew + mw::MAX_WALKERS);
-                mw::step_post(M, Wd, Cd, S, par);
-                if (M.continuous) {
-                    // per lane: the time-of-impact cache of the body it works on (lane 0 may hold the package: the largest contact cache) and
-                    // room for the manifolds of a mini island past the four in registers -- in the manifold pool of the state buffer,
-                    // free during this launch: most of it for lane 0, a few entries for every other lane
-                    unsigned char *tw = work + 32;
-                    mw::ToiLaneWork TL;
-                    unsigned char *lc = tw + TOI_WORK_BYTES + (lane == 0 ? 0 : d.toi_lane0_bytes + (lane - 1) * TOI_LANE_BYTES);
-                    const int lcap = lane == 0 ? d.toi_lane0_bytes / 5 : TOI_LANE_BYTES / 5;
-                    TL.alpha = reinterpret_cast<float *>(lc); TL.meta = lc + 4 * lcap;
-                    constexpr int CO = 4;
-                    const int c0 = M.max_manifolds - CO * ((NL < M.NB ? NL : M.NB) - 1);   // (lanes past the last body own nothing)
-                    TL.ovf = lane == 0 ? pool : pool + c0 + CO * (lane - 1);
-                    TL.ovf_cap = lane == 0 ? c0 : CO;
-                    mw::solve_toi(M, Wd, Cd, S, *reinterpret_cast<mw::ToiWork *>(tw), TL, par, 1.0f / mw::FPS);
-                }
-                const int OD = W * mw::obs_dim_of(d.cfg);
-                float *obs_row = (spare ? d.spare_obs : io.obs) + env * OD;  // observation rows go straight to HBM
-                const bool real = pass == 0 && !spare;   // the step proper: rewards and done go out
-                if (lane == 0) {
-                    *s_done = 0;
-                    mw::env_observe(M, d.cfg, Wd, Cd, gid, obs_row, real ? s_rew : (float *)nullptr, real ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
-                    Wd.t += 1;
-                    Wd.tick += 1;
-                    if (real) {
-                        if (d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2;
-                        uint32_t take = 0;
-                        if (d.cfg.auto_reset && *s_done != 0) {
-                            const uint32_t rs = d.ready_step[env];
-                            take = (rs != 0 && rs != SPARE_BUSY && rs != d.step_id) ? 1u : 2u;   // 1: the spare is ready, 2: pass 1
-                        }
-                        d.pending[env] = take == 2 ? 1 : 0;
-                        *s_done |= take << 8;
-                    } else {
-                        Wd.t = 0;   // the reset's trailing step does not count (:357)
-                        if (spare) d.ready_step[env] = d.step_id;
-                        else d.pending[env] = 0;
-                    }
-                }
-                lds_sync();
-                if (real) {
-                    if (lane < W) io.rew[env * W + lane] = s_rew[lane];
-                    if (lane == 0) io.done[env] = (uint8_t)*s_done;
-                    if ((*s_done >> 8) == 1) {   // the episode ended and the next one is ready: it becomes the live record
-                        const uint32_t *sp = d.spare_state + env * (int64_t)d.world_dw;
-                        uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
-                        for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = sp[k];   // (written back to the live record below)
-                        const uint4 *cs = reinterpret_cast<const uint4 *>(sp + sizeof(mw::Hot) / 4);
-                        uint4 *cdst = reinterpret_cast<uint4 *>(rec + sizeof(mw::Hot) / 4);
-                        for (int k = lane; k < d.cold_q; k += NL) cdst[k] = cs[k];
-                        const float *so = d.spare_obs + env * OD;
-                        for (int k = lane; k < OD; k += NL) obs_row[k] = so[k];
-                        if (lane == 0) d.ready_step[env] = 0;
-                    }
+                mw::env_reset_world(M, d.cfg, Wd, Cd, gid, io.inj_terrain ? io.inj_terrain + env * M.NT : nullptr, io.inj_push ? io.inj_push + env * W : nullptr);
+                if (d.ready_step[env] != 0) {   // the spare held this episode: stale now, to be rebuilt by the next step() call
+                    d.ready_step[env] = 0;
+                    d.dirty_list[nxt * d.n_envs + atomicAdd(&d.n_dirty[nxt], 1u)] = (uint32_t)env;
                 }
             }
-            lds_sync();
-            {
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
-                for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
+        }
+        lds_sync();
+    }
+    if (TERRAIN) {   // read over and over by the narrow phase, the root finder, the lidar
+        for (int k = lane; k < M.NT; k += NL) ty_l[k] = cold_g->ty[k];
+        Cd.ty = ty_l;
+    }
+    if (PH & PH_COLLIDE) {
+        float *s_act = reinterpret_cast<float *>(work + SCR_HDR_BYTES - SOLVE_HDR_BYTES);
+        for (int k = lane; k < 4 * mw::MAX_WALKERS; k += NL) s_act[k] = (!fresh && k < 4 * W) ? io.actions[env * 4 * W + k] : 0.0f;
+        lds_sync();
+        mw::env_apply_actions(M, Wd, Cd, par, s_act);
+        mw::step_collide(M, Wd, Cd, S, pool, par);
+        lds_sync();
+    }
+    // every lane copies the manifolds it owns from the pool into registers (and LDS: the bytes the collide phase's summaries were in)
+    if (PH & PH_SOLVE) { mw::step_solve(M, Wd, Cd, S, pool, reinterpret_cast<mw::Manifold *>(work), MADRL_MW_SOLVE_OVERFLOW, par); lds_sync(); }
+    if (PH != PH_ALL && !(PH & PH_TOI)) {   // hand the step on to the next launch
+        if (PH & PH_COLLIDE) { const uint32_t *sd = reinterpret_cast<const uint32_t *>(&S); for (int k = lane; k < SOLVE_HDR_BYTES / 4; k += NL) sched_g[k] = sd[k]; }
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
+        for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
+        return;
+    }
+    mw::step_post(M, Wd, Cd, S, par);
+    if (M.continuous) {
+        // per lane: the time-of-impact cache of the body it works on (lane 0 may hold the package: the largest contact cache) and room
+        // for the manifolds of a mini island past the four in registers -- in the manifold pool, free by now: most of it for lane 0,
+        // a few entries for every other lane
+        mw::ToiLaneWork TL;
+        unsigned char *lc = work + TOI_WORK_BYTES + (lane == 0 ? 0 : d.toi_lane0_bytes + (lane - 1) * TOI_LANE_BYTES);
+        const int lcap = lane == 0 ? d.toi_lane0_bytes / 5 : TOI_LANE_BYTES / 5;
+        TL.alpha = reinterpret_cast<float *>(lc); TL.meta = lc + 4 * lcap;
+        constexpr int CO = 4;
+        const int c0 = M.max_manifolds - CO * ((NL < M.NB ? NL : M.NB) - 1);   // (lanes past the last body own nothing)
+        TL.ovf = lane == 0 ? pool : pool + c0 + CO * (lane - 1);
+        TL.ovf_cap = lane == 0 ? c0 : CO;
+        mw::solve_toi(M, Wd, Cd, S, *reinterpret_cast<mw::ToiWork *>(work), TL, par, 1.0f / mw::FPS);
+    }
+    const int OD = W * mw::obs_dim_of(d.cfg);
+    float *obs_row = (spare ? d.spare_obs : io.obs) + env * OD;  // observation rows go straight to HBM
+    if (lane == 0) {
+        *s_done = 0;
+        mw::env_observe(M, d.cfg, Wd, Cd, gid, obs_row, !fresh ? s_rew : (float *)nullptr, !fresh ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
+        Wd.t += 1;
+        Wd.tick += 1;
+        if (!fresh) {
+            if (d.cfg.max_steps > 0 && Wd.t >= d.cfg.max_steps) *s_done |= 2;
+            uint32_t take = 0;
+            if (d.cfg.auto_reset && *s_done != 0) {
+                const uint32_t rs = d.ready_step[env];
+                take = (rs != 0 && rs != SPARE_BUSY && rs != d.step_id) ? 1u : 2u;   // 1: the spare is ready, 2: the second launch
+            }
+            d.pending[env] = take == 2 ? 1 : 0;
+            *s_done |= take << 8;
+        } else {
+            Wd.t = 0;   // the reset's trailing step does not count (:357)
+            if (spare) d.ready_step[env] = d.step_id;
+            else d.pending[env] = 0;
+        }
+    }
+    lds_sync();
+    if (!fresh) {
+        if (lane < W) io.rew[env * W + lane] = s_rew[lane];
+        if (lane == 0) io.done[env] = (uint8_t)*s_done;
+        if ((*s_done >> 8) == 1) {   // the episode ended and the next one is ready: it becomes the live record
+            const uint32_t *sp = d.spare_state + env * (int64_t)d.world_dw;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);
+            for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) dst[k] = sp[k];   // (written back to the live record below)
+            const uint4 *cs = reinterpret_cast<const uint4 *>(sp + sizeof(mw::Hot) / 4);
+            uint4 *cdst = reinterpret_cast<uint4 *>(rec + sizeof(mw::Hot) / 4);
+            for (int k = lane; k < d.cold_q; k += NL) cdst[k] = cs[k];
+            const float *so = d.spare_obs + env * OD;
+            for (int k = lane; k < OD; k += NL) obs_row[k] = so[k];
+            if (lane == 0) {
+                d.ready_step[env] = 0;
+                d.dirty_list[nxt * d.n_envs + atomicAdd(&d.n_dirty[nxt], 1u)] = (uint32_t)env;
             }
         }
     }
+    lds_sync();
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
+        for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
+    }
+}
+
+// first thing in a step() call: the list the call's own launch will append to starts empty
+__global__ void mw_begin_step_kernel(const MwDev d) { if (threadIdx.x == 0 && blockIdx.x == 0) d.n_dirty[(d.step_id & 1u) ^ 1u] = 0; }
+__global__ void mw_init_spares_kernel(const MwDev d) {   // every spare is stale: all envs on the list of the first step() call (step_id 1)
+    const int64_t env = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (env < d.n_envs) { d.ready_step[env] = 0; d.dirty_list[d.n_envs + env] = (uint32_t)env; }
+    if (env == 0) { d.n_dirty[0] = 0; d.n_dirty[1] = (uint32_t)d.n_envs; }
 }
 
 __global__ void mw_get_bodies_kernel(const MwDev d, float *bodies, uint8_t *flags, float *terrain) {
@@ -329,15 +353,15 @@ struct madrl_multiwalker {
     int device;
     int64_t max_blocks;
     uint32_t step_id;
-    int use_spares;
+    int use_spares, fused;
     void *model_dev;
     int NB, NT;
 };
 
 namespace {
 
-size_t mw_scratch_bytes(const mw::Model &M) {   // mw::Scratch truncated to Model::max_manifolds manifolds, 16-byte aligned
-    return align_up(sizeof(mw::Scratch) - (size_t)(mw::MAXM - M.max_manifolds) * sizeof(mw::Manifold), 16);
+size_t mw_scratch_bytes(const mw::Model &M) {   // the schedule between launches, then the manifold pool of a step (Model::max_manifolds entries)
+    return (size_t)SOLVE_HDR_BYTES + align_up((size_t)M.max_manifolds * sizeof(mw::Manifold), 16);
 }
 
 int mw_validate(const madrl_multiwalker_config *c) {
@@ -350,29 +374,33 @@ int mw_validate(const madrl_multiwalker_config *c) {
     return MADRL_OK;
 }
 
-template <int PH>
-void mw_launch_phase(const madrl_multiwalker *h, const MwDev &d, const MwIO &io, int pass, hipStream_t s) {
-    const int64_t blocks = (d.n_envs + EPW - 1) / EPW + (pass == 0 ? d.spare_blocks : 0);   // every group of EPW envs gets its own wavefront
-    const size_t lds = (size_t)EPW * d.lds_stride[PH];
-    hipLaunchKernelGGL((mw_phase_kernel<PH>), dim3((unsigned)blocks), dim3(64), lds, s, d, io, pass);
+void mw_launch_step(const madrl_multiwalker *h, const MwDev &d, const MwIO &io, int mode, int pending_only, hipStream_t s) {
+    const unsigned blocks = (unsigned)((d.n_envs + EPW - 1) / EPW + d.spare_blocks);   // every group of EPW envs gets its own wavefront
+    if (h->fused) {
+        hipLaunchKernelGGL(mw_step_kernel<PH_ALL>, dim3(blocks), dim3(64), (size_t)EPW * d.lds_stride[0], s, d, io, mode, pending_only);
+    } else {
+        hipLaunchKernelGGL(mw_step_kernel<PH_COLLIDE>, dim3(blocks), dim3(64), (size_t)EPW * d.lds_stride[1], s, d, io, mode, pending_only);
+        hipLaunchKernelGGL(mw_step_kernel<PH_SOLVE>, dim3(blocks), dim3(64), (size_t)EPW * d.lds_stride[2], s, d, io, mode, pending_only);
+        hipLaunchKernelGGL(mw_step_kernel<PH_TOI>, dim3(blocks), dim3(64), (size_t)EPW * d.lds_stride[3], s, d, io, mode, pending_only);
+    }
 }
 void mw_launch_all(madrl_multiwalker *h, const MwIO &io, int mode, hipStream_t s) {
     MwDev d = h->dev;
     d.spare_blocks = 0;
+    d.step_id = h->step_id;
     if (mode == 1) {   // MultiWalkerEnv.step
         d.step_id = ++h->step_id;
-        if (h->cfg.auto_reset && h->use_spares) {   // stale spares are rebuilt inside this call's launches
-            mw_launch_phase<PH_RESET>(h, d, io, 2, s);
-            d.spare_blocks = (int32_t)((d.n_envs + EPW - 1) / EPW);
+        if (h->cfg.auto_reset && h->use_spares) {
+            hipLaunchKernelGGL(mw_begin_step_kernel, dim3(1), dim3(64), 0, s, d);
+            d.spare_blocks = (int32_t)((d.n_envs + EPW - 1) / EPW);   // room for every spare (a common horizon ends all episodes at once); mostly a handful do something
         }
-        mw_launch_phase<PH_COLLIDE>(h, d, io, 0, s); mw_launch_phase<PH_SOLVE>(h, d, io, 0, s); mw_launch_phase<PH_TOI>(h, d, io, 0, s);
+        mw_launch_step(h, d, io, 0, 0, s);
         if (!h->cfg.auto_reset) return;
+        d.spare_blocks = 0;
+        mw_launch_step(h, d, io, 1, 1, s);   // envs without a ready spare
+        return;
     }
-    // MultiWalkerEnv.reset(mask), or the auto-reset of the envs whose episode just ended without a ready spare: reset, then step(zeros)
-    MwIO r = io;
-    if (mode == 1) { r.mask = nullptr; r.inj_terrain = nullptr; r.inj_push = nullptr; }
-    mw_launch_phase<PH_RESET>(h, d, r, mode == 1 ? 1 : 0, s);
-    mw_launch_phase<PH_COLLIDE>(h, d, io, 1, s); mw_launch_phase<PH_SOLVE>(h, d, io, 1, s); mw_launch_phase<PH_TOI>(h, d, io, 1, s);
+    mw_launch_step(h, d, io, 1, 0, s);
 }
 
 int mw_launch(madrl_multiwalker *h, const MwIO &io, int mode, void *stream) {
@@ -402,10 +430,10 @@ int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n
     memset(&M, 0, sizeof(M));
     mw::build_model(M, cfg->n_walkers);
     // per env: the world record, then the step's Scratch (manifolds + schedule handed from launch to launch); one byte per env; then the
-    // spares: a second record per env, its observation, one dword per env
+    // spares: a second record per env, its observation, three dwords per env (state, two lists), the lists' lengths
     const uint64_t rec = (uint64_t)(align_up(sizeof(mw::World), 16) + mw_scratch_bytes(M));
     const uint64_t od = (uint64_t)cfg->n_walkers * (uint64_t)(mw::OBS_DIM - 1 + (cfg->one_hot ? mw::MAX_AGENTS_ID : 1));
-    *out_bytes = rec * (uint64_t)n_envs + align_up((uint64_t)n_envs, 16) + rec * (uint64_t)n_envs + align_up(od * 4 * (uint64_t)n_envs, 16) + 4 * (uint64_t)n_envs;
+    *out_bytes = rec * (uint64_t)n_envs + align_up((uint64_t)n_envs, 16) + rec * (uint64_t)n_envs + align_up(od * 4 * (uint64_t)n_envs, 16) + 12 * (uint64_t)n_envs + 16;
     return MADRL_OK;
 }
 
@@ -451,24 +479,38 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
         unsigned char *p = d.pending + align_up((size_t)n_envs, 16);
         d.spare_state = (uint32_t *)p; p += (size_t)d.world_dw * 4 * (size_t)n_envs;
         d.spare_obs = (float *)p; p += align_up((size_t)cfg->n_walkers * (size_t)mw::obs_dim_of(d.cfg) * 4 * (size_t)n_envs, 16);
-        d.ready_step = (uint32_t *)p;
-        if (hipMemset(d.ready_step, 0, 4 * (size_t)n_envs) != hipSuccess) { (void)hipFree(h->model_dev); delete h; return fail(MADRL_EHIP, "state buffer too small or not device memory"); }
+        d.ready_step = (uint32_t *)p; p += 4 * (size_t)n_envs;
+        d.dirty_list = (uint32_t *)p; p += 8 * (size_t)n_envs;
+        d.n_dirty = (uint32_t *)p;
     }
     d.cold_q = (int32_t)(align_up(offsetof(mw::Cold, slot) + (size_t)M.n_slots * sizeof(mw::Slot), 16) / 16);
     h->step_id = 0;
     h->use_spares = 1;
+    h->fused = 0;
+    if (const char *e = getenv("MADRL_MW_FUSED")) h->fused = atoi(e) != 0;         // experiments: the whole step in one launch
     if (const char *e = getenv("MADRL_MW_SPARES")) h->use_spares = atoi(e) != 0;   // experiments: 0 = every auto-reset through pass 1
     d.ty_bytes = (int32_t)align_up((size_t)M.NT * 4, 16);
     d.toi_lane0_bytes = (int32_t)align_up((size_t)(M.slot_cap[0] > mw::EDGE_SLOTS_HULL ? M.slot_cap[0] : mw::EDGE_SLOTS_HULL) * 5, 16);
-    d.lds_stride[PH_RESET] = HOT_BYTES + SOLVE_HDR_BYTES;
-    d.lds_stride[PH_COLLIDE] = HOT_BYTES + d.ty_bytes + SCR_HDR_BYTES + (int32_t)align_up(IO_BYTES, 16);
-    d.lds_stride[PH_SOLVE] = HOT_BYTES + SOLVE_HDR_BYTES + MADRL_MW_SOLVE_OVERFLOW * (int32_t)sizeof(mw::Manifold);
-    d.lds_stride[PH_TOI] = HOT_BYTES + d.ty_bytes + SOLVE_HDR_BYTES + 32 + TOI_WORK_BYTES + d.toi_lane0_bytes + (NL - 1) * TOI_LANE_BYTES;
-    // env g's block starts 4 LDS banks after env g-1's: the 16 envs of a wavefront then hit disjoint banks with 16-byte accesses
-    for (int ph = 0; ph < 4; ++ph) d.lds_stride[ph] = (d.lds_stride[ph] + 255 - 16) / 256 * 256 + 16;
+    {
+        const int wc = SCR_HDR_BYTES - SOLVE_HDR_BYTES + (int32_t)align_up(4 * 4 * mw::MAX_WALKERS, 16);            // collide
+        const int ws = MADRL_MW_SOLVE_OVERFLOW * (int32_t)sizeof(mw::Manifold);                                       // solve
+        const int wt = TOI_WORK_BYTES + d.toi_lane0_bytes + (NL - 1) * TOI_LANE_BYTES;                                // continuous pass
+        const int wa = wc > ws ? (wc > wt ? wc : wt) : (ws > wt ? ws : wt);
+        const int common = HOT_BYTES + SOLVE_HDR_BYTES;
+        d.lds_stride[0] = common + d.ty_bytes + (int32_t)align_up((size_t)wa, 16);
+        d.lds_stride[1] = common + d.ty_bytes + (int32_t)align_up((size_t)wc, 16);
+        d.lds_stride[2] = common + (int32_t)align_up((size_t)ws, 16);
+        d.lds_stride[3] = common + d.ty_bytes + (int32_t)align_up((size_t)wt, 16);
+        // env g's block starts 4 LDS banks after env g-1's (mod 32 banks): neighbouring envs of a wavefront hit different banks
+        for (int k = 0; k < 4; ++k) d.lds_stride[k] = (d.lds_stride[k] + 127 - 16) / 128 * 128 + 16;
+        if (getenv("MADRL_MW_LDS_EXTRA")) for (int k = 0; k < 4; ++k) d.lds_stride[k] += atoi(getenv("MADRL_MW_LDS_EXTRA"));   // experiments: occupancy vs LDS
+    }
     d.n_envs = n_envs;
     d.model = (const mw::Model *)h->model_dev;
     d.state = (uint32_t *)state_dev;
+    if (getenv("MADRL_MW_VERBOSE")) fprintf(stderr, "multiwalker: LDS per env %d (one launch) | %d %d %d (collide, solve, continuous pass)\n", d.lds_stride[0], d.lds_stride[1], d.lds_stride[2], d.lds_stride[3]);
+    hipLaunchKernelGGL(mw_init_spares_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, 0, d);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(h->model_dev); delete h; return fail(MADRL_EHIP, "state buffer too small or not device memory"); }
     *out = h;
     return MADRL_OK;
 }

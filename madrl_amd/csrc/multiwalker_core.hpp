@@ -38,6 +38,7 @@
 #pragma once
 
 #include <math.h>
+#include <string.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -54,9 +55,10 @@ namespace mw {
 
 // optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
 #ifdef MW_STATS
-struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], toi_multi, toi_ties, toi_pairs, toi_hullpkg; };
+struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], toi_multi, toi_ties, toi_pairs, toi_hullpkg, lane_cost[4], cur_lane, pos_iters_step, maxcnt_step; };
 extern Stats g_stats;
 #define MW_STAT(f, v) (g_stats.f += (v))
+inline int g_stats_lane();
 #else
 #define MW_STAT(f, v) ((void)0)
 #endif
@@ -1213,8 +1215,10 @@ MW_HD_INLINE void joint_solve_velocity(Hot &Wd, JointCache &c) {
 
 // b2ContactSolver::SolveVelocityConstraints for manifold k
 // ... on velocities the caller holds (the continuous pass keeps its one moving body in registers over all sweeps)
-MW_HD_INLINE void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float &wA, V2 &vB, float &wB) {
+// `changed` is set when an accumulated impulse ends the call with another value than it began with
+MW_HD_INLINE void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float &wA, V2 &vB, float &wB, bool &changed) {
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
+    const float o_n0 = m.ni[0], o_n1 = m.ni[1], o_t0 = m.ti[0], o_t1 = m.ti[1];
     const V2 normal = m.normal, tangent = cross(normal, 1.0f);
     MW_UNROLL
     for (int i = 0; i < 2; ++i) if (i < m.npts) {  // friction first
@@ -1263,6 +1267,11 @@ MW_HD_INLINE void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA
             m.ni[0] = x1; m.ni[1] = x2;
         }
     }
+    changed = changed || m.ni[0] != o_n0 || m.ni[1] != o_n1 || m.ti[0] != o_t0 || m.ti[1] != o_t1;
+}
+MW_HD_INLINE void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float &wA, V2 &vB, float &wB) {
+    bool changed = false;
+    contact_solve_velocity_on(m, q, vA, wA, vB, wB, changed);
 }
 MW_HD_INLINE void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) {
     V2 vA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].v, vB = Wd.b[m.bB].v;
@@ -1389,7 +1398,7 @@ MW_HD float toi_alpha_terrain(const Model &M, const ColdView &Cd, int bi, int e,
     const V2 p1 = v2(M.tx[e], Cd.ty[e]), p2 = v2(M.tx[e + 1], Cd.ty[e + 1]);
     const float m = 4.0f * LINEAR_SLOP;   // what the root finder calls touching, with margin
     if (box.xmin - m > p2.x || box.xmax + m < p1.x || box.ymin - m > mxf(p1.y, p2.y) || box.ymax + m < mnf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
-    MW_STAT(toi_full, 1);
+    MW_STAT(toi_full, 1); MW_STAT(lane_cost[g_stats_lane()], 6000);
     Proxy pA, pB;
     pA.n = 2; pA.v[0] = p1; pA.v[1] = p2;
     MW_UNROLL
@@ -1472,8 +1481,8 @@ MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const ColdView &Cd, Slot 
 // in Box2D's lists) and which box of the other body a new package / hull pair is tested against.  Every chain therefore logs its events
 // (time, contact), numbers the contacts it creates provisionally, and afterwards one lane merges the logs into Box2D's order -- smallest
 // time first, among equal times the contact nearest the front of the world's list -- hands out the final numbers and creates the pairs.
-constexpr int TOI_MAX_EVENTS = 20;   // events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7)
-constexpr int TOI_MAX_PAIR_EVENTS = 8;
+constexpr int TOI_MAX_EVENTS = 16;   // events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7)
+constexpr int TOI_MAX_PAIR_EVENTS = 4;
 struct ToiEvent { float alpha; uint16_t slot, batch; uint8_t body, idx, moved, fat_i; };
 struct ToiWork {            // shared by the lanes of an env (LDS in the HIP kernel)
     int n_ev, n_fat;
@@ -1499,10 +1508,16 @@ MW_HD uint32_t toi_final_batch(const ToiWork &T, int n, int b, int idx) {
 }
 
 // one body's chain of events
+#ifdef MW_STATS
+inline int g_stats_lane() { return (int)(g_stats.cur_lane & 3); }
+#endif
 template <class Par>
 MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, int mover, float h) {
     const int base = M.slot_base[mover], cap = M.slot_cap[mover];
     const Shape &msh = M.shape[shape_of_body(mover)];
+#ifdef MW_STATS
+    g_stats.cur_lane = mover;
+#endif
     Cd.sweep_alpha0[mover] = 0.0f;   // "if (m_stepComplete)": alpha0 = 0, every contact's cached TOI invalid, its sub-step count 0, enabled
     if (!((Wd.awake >> mover) & 1u)) return;   // a sleeping body against static terrain: no active body
     bool any = false;
@@ -1611,51 +1626,48 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             V2 vB = Wd.b[mover].v, vA = v2(0, 0);
             float wB = Wd.b[mover].w, wA = 0.0f;
             // The sweep is a deterministic map of (velocity, accumulated impulses).  Besides the exact fixed point it often ends in a
-            // short cycle (impulses flipping in their last bits): once state(i) == state(i - p), p <= 4, the state after the last of
-            // the VEL_ITERS sweeps is known without running them.  History kept for islands of at most two manifolds.
-            constexpr int NST = 3 + 4 * 2;
-            float h1[NST], h2[NST], h3[NST], h4[NST];  // states after sweeps i - 1 .. i - 4
-            MW_UNROLL
-            for (int q = 0; q < NST; ++q) { h1[q] = 0.0f; h2[q] = 0.0f; h3[q] = 0.0f; h4[q] = 0.0f; }
-            const bool track = n_isl <= 2;
-            static_assert(TOI_MREG >= 2, "the cycle detector reads the first two manifolds from the lane-private copies");
-            auto snapshot = [&](float *st) {
-                st[0] = vB.x; st[1] = vB.y; st[2] = wB;
+            // cycle (impulses flipping in their last bits, with a period of 2 .. a few dozen sweeps): once the state equals, bit for bit,
+            // the state saved after an earlier sweep -- saved at sweeps 1, 2, 4, 8, ... (Brent) -- everything from here on repeats with
+            // that period, and the state after the last of the VEL_ITERS sweeps is reached by running only the remainder.
+            constexpr int NST = 3 + 4 * TOI_MREG;
+            uint32_t anchor[NST];
+            int anchor_it = -1, next_anchor = 1;
+            const bool track = n_isl <= TOI_MREG;
+            auto state_bits = [&](int q) -> uint32_t {   // q: compile-time after unrolling
+                float f = q == 0 ? vB.x : (q == 1 ? vB.y : (q == 2 ? wB : 0.0f));
                 MW_UNROLL
-                for (int k = 0; k < 2; ++k) {
-                    const bool on = k < n_isl;
-                    st[3 + 4 * k] = on ? mm[k].ni[0] : 0.0f; st[4 + 4 * k] = on ? mm[k].ni[1] : 0.0f;
-                    st[5 + 4 * k] = on ? mm[k].ti[0] : 0.0f; st[6 + 4 * k] = on ? mm[k].ti[1] : 0.0f;
+                for (int k = 0; k < TOI_MREG; ++k) {
+                    if (q == 3 + 4 * k) f = mm[k].ni[0];
+                    if (q == 4 + 4 * k) f = mm[k].ni[1];
+                    if (q == 5 + 4 * k) f = mm[k].ti[0];
+                    if (q == 6 + 4 * k) f = mm[k].ti[1];
                 }
+                uint32_t u; memcpy(&u, &f, 4); return u;
             };
-            auto restore = [&](const float *st) {
-                vB.x = st[0]; vB.y = st[1]; wB = st[2];
-                MW_UNROLL
-                for (int k = 0; k < 2; ++k) if (k < n_isl) { mm[k].ni[0] = st[3 + 4 * k]; mm[k].ni[1] = st[4 + 4 * k]; mm[k].ti[0] = st[5 + 4 * k]; mm[k].ti[1] = st[6 + 4 * k]; }
-            };
-            for (int it = 0; it < VEL_ITERS; ++it) {
-                MW_STAT(toi_vel_iters, 1);
-                MW_ISLAND_SWEEP(contact_solve_velocity_on(m_, qm, vA, wA, vB, wB))
-                if (!track) { if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1); continue; }
-                float cur[NST];
-                snapshot(cur);
-                bool same1 = it >= 1, same2 = it >= 2, same3 = it >= 3, same4 = it >= 4;
-                MW_UNROLL
-                for (int q = 0; q < NST; ++q) {
-                    same1 = same1 && cur[q] == h1[q]; same2 = same2 && cur[q] == h2[q]; same3 = same3 && cur[q] == h3[q]; same4 = same4 && cur[q] == h4[q];
+            int stop_at = VEL_ITERS;   // sweeps [0, stop_at) are run
+            for (int it = 0; it < stop_at; ++it) {
+                MW_STAT(toi_vel_iters, 1); MW_STAT(lane_cost[mover & 3], 300 * n_isl + 60);
+                bool changed = false;
+                MW_ISLAND_SWEEP(contact_solve_velocity_on(m_, qm, vA, wA, vB, wB, changed))
+                if (!changed) { MW_STAT(toi_hist[it / 20], 1); break; }   // no impulse moved: the velocity did not either, and every further sweep is this one
+                if (!track || stop_at != VEL_ITERS) { if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1); continue; }
+                if (anchor_it >= 0) {
+                    bool same = true;
+                    MW_UNROLL
+                    for (int q = 0; q < NST; ++q) if (q < 3 + 4 * n_isl) same = same && state_bits(q) == anchor[q];
+                    if (same) {   // state(it) == state(anchor_it): period it - anchor_it; the last sweep's state = state(it + left)
+                        MW_STAT(toi_hist[8], 1);
+                        const int period = it - anchor_it;
+                        stop_at = it + 1 + (VEL_ITERS - 1 - it) % period;
+                        continue;
+                    }
                 }
-                if (same1) { MW_STAT(toi_hist[it / 20], 1); break; }   // fixed point: every further sweep is a no-op
-                const int period = same2 ? 2 : (same3 ? 3 : (same4 ? 4 : 0));
-                if (period != 0) {  // state(j + period) = state(j) from here on; `left` sweeps remain: state(last) = state(it - period + left % period)
-                    MW_STAT(toi_hist[8], 1);
-                    const int left = (VEL_ITERS - 1 - it) % period;   // 0: cur
-                    const int back = left == 0 ? 0 : period - left;    // the wanted state lies `back` sweeps before cur
-                    if (back == 1) restore(h1); else if (back == 2) restore(h2); else if (back == 3) restore(h3);
-                    break;
+                if (it + 1 == next_anchor) {
+                    MW_UNROLL
+                    for (int q = 0; q < NST; ++q) anchor[q] = state_bits(q);
+                    anchor_it = it; next_anchor *= 2;
                 }
                 if (it == VEL_ITERS - 1) MW_STAT(toi_hist[9], 1);
-                MW_UNROLL
-                for (int q = 0; q < NST; ++q) { h4[q] = h3[q]; h3[q] = h2[q]; h2[q] = h1[q]; h1[q] = cur[q]; }
             }
             MW_STAT(toi_nisl[n_isl < 5 ? n_isl : 5], 1);
             Wd.b[mover].v = vB; Wd.b[mover].w = wB;
@@ -1844,7 +1856,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
     par.sync();
     for (int w = L0; w < NW; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces (at the end of Step; nothing reads it in between)
     MW_STAT(steps, 1); MW_STAT(sub_a, n_rounds); MW_STAT(sub_b, max_cnt); MW_STAT(manifolds, S.nm);
-    MW_STAT(cnt_hist[max_cnt < 23 ? max_cnt : 23], 1); MW_STAT(rounds_hist[n_rounds < 11 ? n_rounds : 11], 1);
+    MW_STAT(maxcnt_step, max_cnt); MW_STAT(cnt_hist[max_cnt < 23 ? max_cnt : 23], 1); MW_STAT(rounds_hist[n_rounds < 11 ? n_rounds : 11], 1);
     constexpr int NREG = Par::MREG > 0 ? Par::MREG : 1;
     SolveLane<NREG> LS[Par::SOLVE_EMU];
 #define MW_LANES for (int li_ = 0; li_ < Par::SOLVE_EMU; ++li_)
@@ -1958,7 +1970,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
     // ---- position iterations: contacts then joints; each island stops on its own (b2Island::Solve early exit)
     const int n_isl = S.n_isl;
     for (int it = 0; it < POS_ITERS; ++it) {
-        MW_STAT(pos_iters, 1);
+        MW_STAT(pos_iters, 1); MW_STAT(pos_iters_step, 1);
         for (int bi = L0; bi < NB; bi += LN) S.body_minsep[bi] = 0.0f;
         for (int j = L0; j < 4 * NW; j += LN) S.joint_ok[j] = 1;
         par.sync();
