@@ -1,0 +1,109 @@
+#!/usr/bin/env python
+"""Generate tests/golden/multiwalker_box2d_*.npz from the UNMODIFIED reference MultiWalkerEnv (multi_walker.py) -- wherever pybox2d
+can be imported.  TEST INFRASTRUCTURE ONLY.
+
+The build image has no Box2D (neither the Python package nor a C++ tree to compile), so in this repository the script has never
+produced a file and the MultiWalker oracles stay PARITY UNPINNED.  It is committed so that anybody with `pip install
+box2d-py` and the reference checkout can pin them:
+
+    MADRL_REFERENCE_ROOT=/path/to/MADRL python oracle/make_golden_multiwalker.py
+    python -m pytest tests/test_oracle_multiwalker_golden.py        # skips while tests/golden/multiwalker_box2d_*.npz do not exist
+
+Exit status 0 and a message when Box2D is missing (nothing written).
+
+What is recorded, per episode of n_walkers walkers under seeded random actions with stretches of zero actions (walkers collapse:
+hull contacts, dropped package, resets):
+  terrain_y [NT] float64        env.terrain_y after reset (multi_walker.py:516-612)            -> reset_with(terrain=)
+  push      [W]  float64        the initial hull pushes: np_random.uniform(-5, 5) per walker (:130-131), captured from the RNG
+  actions   [T, W, 4] float32
+  bodies    [T + 1, NB, 6] float32   every body's (worldCenter.x, .y, angle, linearVelocity.x, .y, angularVelocity) BEFORE step t
+                                (row 0: after reset) in the order package, then per walker hull, leg0 upper, leg0 lower, leg1 upper,
+                                leg1 lower -- what the oracles are teacher-forced on
+  obs       [T + 1, W, 32] float32   reset() / step() observations (position / angle noise set to 0)
+  rew       [T, W] float64 ; done [T] uint8
+  flags     [T + 1, 1 + 3W] uint8    game_over, fallen[W], ground_contact[W][2] (ContactDetector :50-84)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def bodies_of(env):
+    rows = []
+    def rec(b):
+        c = b.worldCenter
+        rows.append([c[0], c[1], b.angle, b.linearVelocity[0], b.linearVelocity[1], b.angularVelocity])
+    rec(env.package)
+    for w in env.walkers:
+        rec(w.hull)
+        for leg in w.legs:      # [upper0, lower0, upper1, lower1] (:136-179)
+            rec(leg)
+    return np.asarray(rows, np.float32)
+
+
+def flags_of(env):
+    f = [int(bool(env.game_over))] + [int(bool(x)) for x in env.fallen_walkers]
+    for w in env.walkers:
+        f += [int(bool(w.legs[1].ground_contact)), int(bool(w.legs[3].ground_contact))]
+    return np.asarray(f, np.uint8)
+
+
+def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for ep in range(episodes):
+        env = MultiWalkerEnv(n_walkers=n_walkers, position_noise=0.0, angle_noise=0.0, reward_mech=reward_mech)
+        env.seed(int(rng.randint(2 ** 31 - 1)))
+        pushes = []
+        real_uniform = env.np_random.uniform
+        def spy(lo, hi, *a, **k):
+            v = real_uniform(lo, hi, *a, **k)
+            if np.isscalar(v) and (lo, hi) == (-5.0, 5.0):     # INITIAL_RANDOM (:130)
+                pushes.append(float(v))
+            return v
+        env.np_random.uniform = spy
+        obs0 = env.reset()
+        env.np_random.uniform = real_uniform
+        rec = dict(terrain_y=np.asarray(env.terrain_y, np.float64), push=np.asarray(pushes[-n_walkers:], np.float64), actions=[], bodies=[bodies_of(env)],
+                   obs=[np.asarray(obs0, np.float32)], rew=[], done=[], flags=[flags_of(env)])
+        for t in range(steps):
+            a = rng.uniform(-1, 1, (n_walkers, 4)).astype(np.float32)
+            if t % 60 > 44:
+                a[:] = 0
+            o, r, d, _ = env.step(a)
+            rec["actions"].append(a); rec["obs"].append(np.asarray(o, np.float32)); rec["rew"].append(np.asarray(r, np.float64).reshape(-1) * np.ones(n_walkers))
+            rec["done"].append(int(bool(d))); rec["bodies"].append(bodies_of(env)); rec["flags"].append(flags_of(env))
+            if d:
+                break
+        out.append({k: np.asarray(v) for k, v in rec.items()})
+    path = os.path.join(OUT, "multiwalker_box2d_%s.npz" % name)
+    flat = {"n_episodes": np.int64(len(out)), "n_walkers": np.int64(n_walkers), "reward_global": np.int64(reward_mech == "global")}
+    for i, r in enumerate(out):
+        for k, v in r.items():
+            flat["ep%d_%s" % (i, k)] = v
+    np.savez_compressed(path, **flat)
+    print("%s: %d episodes, %d steps, %.1f KB" % (path, len(out), sum(len(r["done"]) for r in out), os.path.getsize(path) / 1024.0))
+
+
+def main():
+    try:
+        import Box2D  # noqa: F401
+    except Exception as e:  # pragma: no cover
+        print("Box2D cannot be imported here (%s): no MultiWalker goldens written; the MultiWalker oracles stay PARITY UNPINNED." % e)
+        return 0
+    root = os.environ.get("MADRL_REFERENCE_ROOT", "/root/reference")
+    for p in (root, os.path.join(HERE, "shims")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from madrl_environments.walker.multi_walker import MultiWalkerEnv
+    run(MultiWalkerEnv, "w3_local", 3, "local", episodes=6, steps=200, seed=31)
+    run(MultiWalkerEnv, "w2_global", 2, "global", episodes=4, steps=200, seed=32)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

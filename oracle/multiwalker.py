@@ -87,6 +87,13 @@ class MultiWalkerOracle(object):
         self.L.mwo_get_bodies(self.h, _p(out), _p(flags))
         return out, flags
 
+    def overflow(self):
+        """sticky per-env overflow bits of the contact storage (0: every contact Box2D would have had was simulated)"""
+        out = np.zeros(self.N, np.uint8)
+        self.L.mwo_get_overflow.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.mwo_get_overflow(self.h, _p(out))
+        return out
+
     def terrain(self):
         out = np.zeros((self.N, self.NT), np.float32)
         self.L.mwo_get_terrain(self.h, _p(out))

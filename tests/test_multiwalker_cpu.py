@@ -234,6 +234,7 @@ def test_product_source_matches_the_independent_oracle_bit_for_bit(n_walkers, re
         if rd.any():
             ref.reset(mask=rd); core.reset(mask=rd)
     assert n_done > 0 and n_touch > 0 and ref.stats()["toi_events"] > 50
+    assert not core.overflow().any(), "a contact did not fit the product's fixed-size contact storage (sticky Hot::overflow)"
 
 
 def test_product_source_matches_the_independent_oracle_free_running():
@@ -251,6 +252,7 @@ def test_product_source_matches_the_independent_oracle_free_running():
         assert np.array_equal(ref.bodies(), core.bodies()[0]) and np.array_equal(rd, cd), t
         if rd.any():
             ref.reset(mask=rd); core.reset(mask=rd)
+    assert not core.overflow().any()
 
 
 def test_injected_terrain_and_push_and_libm_sensitivity():

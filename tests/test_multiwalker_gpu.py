@@ -23,8 +23,8 @@ def _mk(n_envs, **kw):
 
 @pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local"), (3, "one_hot")])
 def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
-    """The GPU execution (16 lanes per env, level-scheduled sweeps, LDS staging) against the CPU build of the same source (one
-    lane, same schedule): the WHOLE per-env world record -- bodies, joints, every contact with its list position and impulses,
+    """The GPU execution (four lanes per env, sixteen envs per wavefront, the step in three launches, contact cache in HBM) against the
+    CPU build of the same source (the lanes one after the other): the WHOLE per-env world record -- bodies, joints, every contact with its list position and impulses,
     fat AABBs, sleep times, flags -- must come out identical in every byte, every step.  (This checks the port; the algorithm is
     checked against the independent oracle below and, without a GPU, in tests/test_multiwalker_cpu.py.)"""
     from oracle import multiwalker as mwo
@@ -55,6 +55,42 @@ def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
         if odone.any():
             orc.reset(mask=odone)
             env.reset(mask=odone)
+
+
+@pytest.mark.parametrize("horizon,fused", [(0, False), (9, False), (0, True)])
+def test_auto_reset_through_spares_matches_mask_resets(horizon, fused, monkeypatch):
+    """auto_reset=True: an env whose episode ends gets its next episode from the spare record prepared ahead of time (multiwalker.hip), or,
+    when the spare is not ready, from the second launch -- either way exactly what reset(mask) + the next steps give on the CPU build.  With
+    a horizon every env ends its episode in the same call, and again `horizon` calls later: all spares consumed and rebuilt at once."""
+    from oracle import multiwalker as mwo
+    if fused:
+        monkeypatch.setenv("MADRL_MW_FUSED", "1")   # the whole step in one launch: same results
+    N, W, T = 80, 3, 90
+    env = _mk(N, n_walkers=W, seed=21, env_id_base=5, auto_reset=True, max_steps=horizon)
+    orc = mwo.MultiWalkerOracle(n_walkers=W, position_noise=0.0, angle_noise=0.0, n_envs=N, seed=21, env_id_base=5)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    rng = np.random.RandomState(6)
+    tstep = np.zeros(N, np.int64)
+    n_resets = n_back_to_back = 0
+    last = np.zeros(N, bool)
+    for t in range(T):
+        act = rng.uniform(-1, 1, (N, W, 4)).astype(np.float32)
+        if t % 25 > 17:
+            act[:] = 0
+        obs, rew, done, info = env.step(act)
+        oobs, orew, odone = orc.step(act)
+        tstep += 1
+        ends = odone.astype(bool) | ((tstep >= horizon) if horizon else False)
+        assert np.array_equal(info["done_bits"].cpu().numpy() != 0, ends), "step %d: which episodes ended" % t
+        assert np.array_equal(rew.cpu().numpy(), orew), "step %d: rewards" % t
+        if ends.any():
+            orc.reset(mask=ends.astype(np.uint8))
+            tstep[ends] = 0
+        n_resets += int(ends.sum()); n_back_to_back += int((ends & last).sum()); last = ends
+        assert np.array_equal(obs.cpu().numpy(), orc.obs), "step %d: observations (the next episode's first one where an episode ended)" % t
+        same = (env.state_buffer.cpu().numpy()[:, :orc.world_bytes] == orc.worlds()).all(axis=1)
+        assert same.all(), "step %d: %d world records differ" % (t, int((~same).sum()))
+    assert n_resets > N // 2 and (horizon == 0 or n_resets >= N * (T // horizon))
 
 
 @pytest.mark.parametrize("n_walkers", [3, 2])
