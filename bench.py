@@ -359,10 +359,12 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu):
         # algorithmic HBM bytes per env-step: actions in, observation / reward / done rows out, the per-env record (bodies, joints,
         # contact cache, terrain) read and written once
         bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * env.world_bytes
-        kernel = "multiwalker_kernel"
+        kernel = "mw_step_kernel<collide> + <solve> + <continuous pass> (three launches per step; kernel_ms is their sum)"
         # this path is not HBM-bound -- dependent FP32 work of 180 velocity + up to 60 position Gauss-Seidel sweeps
-        # over 12 joints and the active manifolds against ~15 KB; the binding resource is VALU issue / dependent-op latency
-        binding = "FP32 VALU instruction issue / dependent-op latency of the Gauss-Seidel sweeps (not HBM); see profiles/*_multiwalker/pmc_mix.txt"
+        # over 12 joints and the active manifolds, and the serial sub-steps of the continuous pass, against ~25 KB; a launch ends with
+        # its slowest wavefront (16 envs in lockstep), so the binding resource is the latency of the longest per-env chain
+        binding = ("latency of the longest per-env chain of dependent FP32 operations (180 + 60 Gauss-Seidel sweeps, time-of-impact sub-steps): "
+                   "one wavefront per SIMD, 16 envs per wavefront; neither HBM nor VALU throughput (DESIGN.md 4c)")
         flop_per_env_step, flop_src = env.flops_per_env_step()
         extra = {"flop_per_env_step": flop_per_env_step, "flop_source": flop_src}
         workload_s = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % N

@@ -55,13 +55,15 @@ namespace mw {
 
 // optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
 #ifdef MW_STATS
-struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], toi_multi, toi_ties, toi_pairs, toi_hullpkg, lane_cost[4], cur_lane, pos_iters_step, maxcnt_step; };
+struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], toi_multi, toi_ties, toi_pairs, toi_hullpkg, lane_cost[4], cur_lane, pos_iters_step, maxcnt_step;
+               long flops; };   // float32 / float64 additions, multiplications, divisions, square roots: hand-counted per primitive (MW_FLOPS below)
 extern Stats g_stats;
 #define MW_STAT(f, v) (g_stats.f += (v))
 inline int g_stats_lane();
 #else
 #define MW_STAT(f, v) ((void)0)
 #endif
+#define MW_FLOPS(n) MW_STAT(flops, (n))   // the arithmetic of the primitive this sits in, counted by hand from its source
 
 // World::Step parameters of the env (multi_walker.py:365).  Overridable ONLY by the known-answer harness of the test
 // infrastructure, which replays the published Box2D HelloWorld scene (1/60 s, 6 velocity / 2 position iterations)
@@ -511,6 +513,7 @@ MW_HD float find_max_separation(int *edge_index, const Shape &p1, Xf xf1, const 
 
 // b2CollidePolygons (2.3.0: reference face chosen with the 0.98 / 0.001 hysteresis)
 MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shape &pB, Xf xfB) {
+    MW_FLOPS(420);   // b2CollidePolygons: two b2FindMaxSeparation searches, incident edge, two clips
     mo.npts = 0;
     const float total_radius = 2.0f * POLY_RADIUS;
     int edgeA = 0, edgeB = 0;
@@ -772,6 +775,7 @@ MW_HD int emit_manifold(Hot &Wd, Scratch &S, Manifold *MP, Par par, const Slot &
     return idx;
 }
 MW_HD void edge_polygon_manifold(const Model &M, const ColdView &Cd, int e, const Shape &s, Xf xfB, ManifoldOut &mo) {
+    MW_FLOPS(260);   // b2CollideEdgeAndPolygon: polygon into the edge's frame, edge and polygon separations, reference face, two clips
     const V2 p1 = v2(M.tx[e], Cd.ty[e]), p2 = v2(M.tx[e + 1], Cd.ty[e + 1]);
     collide_edge_polygon(mo, p1, p2, s, xfB, false, p1, false, p2);   // plain b2EdgeShape: no ghost vertices (:617-620)
 }
@@ -847,6 +851,7 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, const ColdView &Cd, Scratch
 // the sweep's start pose (c0, a0) and at the current pose; it is re-fattened (extension + twice the displacement) and buffered as
 // moved only when it left its fat AABB.
 MW_HD bool sync_fixture(const Model &M, const Hot &Wd, const ColdView &Cd, int b) {
+    MW_FLOPS(150);
     const Shape &s = M.shape[shape_of_body(b)];
     const Xf xf1 = xf_from(Cd.sweep_c0[b], Cd.sweep_a0[b], s.centroid), xf2 = body_xf(M, Wd.b[b], b);
     const AABB a1 = poly_aabb(s, xf1), a2 = poly_aabb(s, xf2);
@@ -1047,6 +1052,7 @@ MW_HD void solve22(const float *k, float det, float bx, float by, float &x, floa
 
 // b2ContactSolver::InitializeVelocityConstraints + WarmStart for manifold k
 MW_HD_INLINE void contact_init_warm(Hot &Wd, Manifold &m, const MassAB &q) {
+    MW_FLOPS(m.npts == 2 ? 230 : 120);   // two transforms (sin / cos), world manifold, rA / rB, normal and tangent masses, block K and inverse, warm start
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     const V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
     Xf xfA; if (m.bA < 0) { xfA.p = v2(0, 0); xfA.q.s = 0; xfA.q.c = 1; } else xfA = xf_from(Wd.b[m.bA].c, Wd.b[m.bA].a, q.lcA);
@@ -1130,6 +1136,7 @@ struct JointCache {
 MW_HD_INLINE void joint_init_warm(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, int ji, float h, JointCache &c) {
     const JointDef &jd = M.jd[ji];
     const Joint &j = Cd.j[ji];
+    MW_FLOPS(140);   // two sin / cos pairs, rA / rB, the 3x3 K, its Cramer terms, warm start
     c.bA = jd.bA; c.bB = jd.bB;
     Body &A = Wd.b[jd.bA], &B = Wd.b[jd.bB];
     const MassAB q = mass_of_pair(S, jd.bA, jd.bB);
@@ -1171,6 +1178,7 @@ MW_HD_INLINE void joint_solve_velocity(Hot &Wd, JointCache &c) {
     const float mA = c.mA, iA = c.iA, mB = c.mB, iB = c.iB;
     const V2 rA = c.rA, rB = c.rB;
     V2 vA = A.v, vB = B.v; float wA = A.w, wB = B.w;
+    MW_FLOPS((c.limit_state != 3 ? 9 : 0) + (c.limit_state != 0 ? 73 : 38));
     if (c.limit_state != 3) {  // motor (enableMotor is always true)
         const float Cdot = wB - wA - c.motor_speed;
         float imp = -c.motor_mass * Cdot;
@@ -1219,6 +1227,7 @@ MW_HD_INLINE void joint_solve_velocity(Hot &Wd, JointCache &c) {
 MW_HD_INLINE void contact_solve_velocity_on(Manifold &m, const MassAB &q, V2 &vA, float &wA, V2 &vB, float &wB, bool &changed) {
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     const float o_n0 = m.ni[0], o_n1 = m.ni[1], o_t0 = m.ti[0], o_t1 = m.ti[1];
+    MW_FLOPS(m.npts == 2 ? 152 : 73);
     const V2 normal = m.normal, tangent = cross(normal, 1.0f);
     MW_UNROLL
     for (int i = 0; i < 2; ++i) if (i < m.npts) {  // friction first
@@ -1284,6 +1293,7 @@ MW_HD_INLINE void contact_solve_velocity(Hot &Wd, Manifold &m, const MassAB &q) 
 // b2ContactSolver::SolvePositionConstraints for manifold k; returns its minimum separation
 MW_HD_INLINE float contact_solve_position(Hot &Wd, const Manifold &m, const MassAB &q) {
     float min_sep = 0.0f;
+    MW_FLOPS(137 * (m.type >> 1));   // per point: two transforms (sin / cos), separation, K, impulse
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     V2 cA = m.bA < 0 ? v2(0, 0) : Wd.b[m.bA].c, cB = Wd.b[m.bB].c;
     float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a, aB = Wd.b[m.bB].a;
@@ -1320,6 +1330,7 @@ MW_HD_INLINE float contact_solve_position(Hot &Wd, const Manifold &m, const Mass
 
 // b2RevoluteJoint::SolvePositionConstraints; returns whether the joint is within tolerance
 MW_HD_INLINE bool joint_solve_position(Hot &Wd, const JointCache &c) {
+    MW_FLOPS(c.limit_state != 0 ? 145 : 135);
     Body &A = Wd.b[c.bA], &B = Wd.b[c.bB];
     const float mA = c.mA, iA = c.iA, mB = c.mB, iB = c.iB;
     float ang_err = 0.0f;
@@ -1384,6 +1395,7 @@ MW_HD Sweep sweep_of_body(const Model &M, const Hot &Wd, const ColdView &Cd, int
 // report an event (never changes a result)
 struct SweptBox { float xmin, xmax, ymin, ymax; };
 MW_HD SweptBox swept_box(const Shape &sh, const Sweep &sB) {
+    MW_FLOPS(170);
     SweptBox q; q.xmin = 3.0e38f; q.xmax = -3.0e38f; q.ymin = 3.0e38f; q.ymax = -3.0e38f;
     poly_aabb_at(sh, sB.c0, sB.a0, q.xmin, q.xmax, q.ymin, q.ymax);
     poly_aabb_at(sh, sB.c, sB.a, q.xmin, q.xmax, q.ymin, q.ymax);
@@ -1414,6 +1426,7 @@ MW_HD float toi_alpha_terrain(const Model &M, const ColdView &Cd, int bi, int e,
 // b2ContactSolver::SolveTOIPositionConstraints for one manifold: only the TOI body (B; A is static) moves
 MW_HD float contact_solve_toi_position(Hot &Wd, const Manifold &m, const MassAB &q) {
     float min_sep = 0.0f;
+    MW_FLOPS(95 * (m.type >> 1));
     const float mB = q.mB, iB = q.iB;
     V2 cB = Wd.b[m.bB].c;
     float aB = Wd.b[m.bB].a;
@@ -1855,6 +1868,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
     }
     par.sync();
     for (int w = L0; w < NW; w += LN) Wd.push_x[w] = 0.0f;  // ClearForces (at the end of Step; nothing reads it in between)
+    MW_FLOPS(16 * NB);   // integrate velocities, integrate positions, sleep test
     MW_STAT(steps, 1); MW_STAT(sub_a, n_rounds); MW_STAT(sub_b, max_cnt); MW_STAT(manifolds, S.nm);
     MW_STAT(maxcnt_step, max_cnt); MW_STAT(cnt_hist[max_cnt < 23 ? max_cnt : 23], 1); MW_STAT(rounds_hist[n_rounds < 11 ? n_rounds : 11], 1);
     constexpr int NREG = Par::MREG > 0 ? Par::MREG : 1;
@@ -2065,12 +2079,14 @@ MW_HD_INLINE void world_step(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
 
 // ---------------------------------------------------------------- lidar: b2World::RayCast -> b2EdgeShape::RayCast over the terrain, closest hit (D2)
 MW_HD float lidar_fraction(const Model &M, const ColdView &Cd, V2 p1, V2 p2) {
+    MW_FLOPS(12);
     const V2 d = p2 - p1;
     float best = 1.0f;  // LidarCallback.fraction starts at 1.0 (:210)
     int e0 = (int)floorf(mnf(p1.x, p2.x) / TERRAIN_STEP) - 1, e1 = (int)floorf(mxf(p1.x, p2.x) / TERRAIN_STEP) + 1;
     if (e0 < 0) e0 = 0;
     if (e1 > M.NT - 2) e1 = M.NT - 2;
     for (int e = e0; e <= e1; ++e) {
+        MW_FLOPS(30);   // b2EdgeShape::RayCast
         const V2 v1 = v2(M.tx[e], Cd.ty[e]), v2e = v2(M.tx[e + 1], Cd.ty[e + 1]);
         const V2 ee = v2e - v1;
         V2 normal = v2(ee.y, -ee.x);
@@ -2223,6 +2239,7 @@ MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, const ColdV
 }
 
 MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
+    MW_FLOPS(90 * M.W + 40);   // besides the lidar: transforms of the hulls and the package, the 14 + 8 state entries, shaping, rewards
     // the Python side of the reference computes in float64 on the float32 values Box2D hands it; so does this function
     const Body &pkg = Wd.b[0];
     const V2 pkg_pos = body_xf(M, pkg, 0).p;

@@ -103,7 +103,9 @@ MW_HD float gjk_distance(SimplexCache &cache, const Proxy &pA, Xf xfA, const Pro
     if (s.count == 0) { simplex_set(s.v1, 0, 0, pA, xfA, pB, xfB); s.v1.a = 1.0f; s.count = 1; }
     int saveA[3] = {0, 0, 0}, saveB[3] = {0, 0, 0};
     int iter = 0;
+    MW_FLOPS(60);   // cache read-back / metric, witness points and distance at the end
     while (iter < 20) {
+        MW_FLOPS(70);   // simplex solve, search direction, two support searches (rotations, dot products over the vertices)
         const int save_count = s.count;
         saveA[0] = s.v1.ia; saveB[0] = s.v1.ib; saveA[1] = s.v2.ia; saveB[1] = s.v2.ib; saveA[2] = s.v3.ia; saveB[2] = s.v3.ib;
         if (s.count == 2) simplex_solve2(s);
@@ -171,6 +173,7 @@ MW_HD void sep_init(SepFn &f, const SimplexCache &cache, const Proxy &pA, const 
 }
 // FindMinSeparation (find = true: picks the witness indices) / Evaluate (find = false: uses the given ones)
 MW_HD float sep_eval(const SepFn &f, const Proxy &pA, const Sweep &sA, const Proxy &pB, const Sweep &sB, int &ia, int &ib, float t, bool find) {
+    MW_FLOPS(find ? 110 : 90);   // two sweep transforms (sin / cos), the axis in world space, support search or two points
     const Xf xfA = sweep_xf(sA, t), xfB = sweep_xf(sB, t);
     if (f.type == 0) {
         if (find) { ia = proxy_support(pA, mulT(xfA.q, f.axis)); ib = proxy_support(pB, mulT(xfB.q, -f.axis)); }

@@ -195,9 +195,16 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
                                                            _lib.current_stream(self.device)))
         return self._obs
 
+    # float32 / float64 additions, multiplications, divisions and square roots per env-step under uniform random actions with
+    # terminate_on_fall (the bench workload), by n_walkers: every primitive of the step (joint / contact velocity and position solves,
+    # sub-step sweeps, GJK and root-finder iterations, narrow phase, lidar, ...) carries a hand count of its arithmetic, and the CPU build
+    # of the kernel source counts how often each runs (scripts/mw_stats.cpp, 19 500 env-steps per entry)
+    COUNTED_FLOPS = {1: 88998.0, 2: 188102.0, 3: 262265.0, 4: 341100.0}
+
     def flops_per_env_step(self):
-        """(FP32 operations per env-step, how the figure was obtained) for the roofline line of bench.py"""
-        return 1.0e6, "estimate: ~180 velocity + up to 60 position sweeps over 12 joints and ~10 manifolds (not counted)"
+        """(floating-point operations per env-step, how the figure was obtained) for the roofline line of bench.py"""
+        return self.COUNTED_FLOPS[int(self.n_walkers)], ("counted: hand counts of the arithmetic of every primitive x how often the CPU build of the "
+                                                         "kernel source runs it under the bench's action distribution (scripts/mw_stats.cpp)")
 
     @property
     def state_buffer(self):
