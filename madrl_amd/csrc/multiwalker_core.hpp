@@ -2137,7 +2137,9 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, const ColdV
     const uint32_t tick = Wd.episode;
     Wd.game_over = 0; Wd.overflow = 0; Wd.prev_package_shaping = 0.0; Wd.t = 0;
     for (int w = 0; w < MAX_WALKERS; ++w) { Wd.fallen[w] = 0; Wd.prev_shaping[w] = 0.0; Wd.ground[w][0] = Wd.ground[w][1] = 0; }
-    for (int k = 0; k < M.n_slots; ++k) { Slot &sl = Cd.slot[k]; sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.batch = 0; sl.reserved_ = 0; }
+    // every field, also of the empty entries: a record after reset is a function of (env, episode) alone, whatever was in its bytes before
+    // (the HIP build prepares it in a spare record and copies it over the live one)
+    for (int k = 0; k < M.n_slots; ++k) { Slot &sl = Cd.slot[k]; sl.edge = -1; sl.npts = 0; sl.touching = 0; sl.id[0] = sl.id[1] = 0; sl.ni[0] = sl.ni[1] = sl.ti[0] = sl.ti[1] = 0.0f; sl.batch = 0; sl.reserved_ = 0; }
     // _generate_terrain, non-hardcore branch (:516-612): float64 like the reference's Python loop, float32 when it enters Box2D
     {
         double velocity = 0.0, y = TERRAIN_HEIGHT64;
