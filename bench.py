@@ -368,7 +368,9 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu):
         flop_per_env_step, flop_src = env.flops_per_env_step()
         extra = {"flop_per_env_step": flop_per_env_step, "flop_source": flop_src}
         workload_s = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % N
-        K, W = min(K, 20), max(W, 60)   # 60 warm-up steps: the walkers have landed and the first falls / resets have happened
+        # 200 warm-up steps: episodes last ~60 steps under random actions and all start together, so the first 100 steps see waves of
+        # simultaneous falls; after 200 the episode phases of the envs are mixed (the steady state of a rollout)
+        K, W = min(K, 50), max(W, 200)
 
         def age():
             pass   # episodes end by falling long before the horizon; the warm-up above reaches that steady state
@@ -459,7 +461,7 @@ def main():
     # The same driver run times every other BASELINE config (N = 1, default workload, default batch): bounded steps each
     if args.workload == "pursuit" and world == 1 and not args.no_workloads and not args.envs:
         wl = {}
-        for name, k, w in (("waterworld", min(K, 200), min(W, 20)), ("multiwalker", min(K, 20), W), ("pursuit_c5", min(K, 200), min(W, 20))):
+        for name, k, w in (("waterworld", min(K, 200), min(W, 20)), ("multiwalker", min(K, 50), W), ("pursuit_c5", min(K, 200), min(W, 20))):
             try:
                 r = bench_pursuit(args, True, k, w, rank, world, dev, False) if name == "pursuit_c5" else \
                     bench_other(args, name, k, w, rank, world, dev, False)

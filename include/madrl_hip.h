@@ -316,21 +316,26 @@ typedef struct madrl_multiwalker_config {
 typedef struct madrl_multiwalker madrl_multiwalker; /* opaque */
 
 int madrl_multiwalker_obs_dim(const madrl_multiwalker_config *cfg, int32_t *out_dim);        /* 32 (:243) */
-/* one world record + step scratch per env (see madrl_multiwalker_record_bytes) plus one byte per env; caller allocates + zeroes */
+/* two records per env (the live world + the next episode prepared ahead of time, each followed by the step's scratch: see
+ * madrl_multiwalker_record_bytes), the prepared episode's first observation, and a few bytes of bookkeeping per env; caller
+ * allocates + zeroes, create() initialises the bookkeeping */
 int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n_envs, uint64_t *out_bytes);
 int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device, void *state_dev,
                              madrl_multiwalker **out);
 void madrl_multiwalker_destroy(madrl_multiwalker *h);
-int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks);
+int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks);  /* kept for ABI compatibility: every 16 envs get their own wavefront */
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain);
-/* layout of the state buffer: n_envs blocks of stride_bytes each -- the world record (world_bytes: bodies, flags, joints, contacts,
- * broad phase, terrain) followed by the step's scratch (manifolds and solver schedule, handed from launch to launch: one step is a
- * sequence of kernel launches) -- then one byte per env (pending trailing step of a reset) */
+/* layout of the state buffer: first n_envs blocks of stride_bytes each -- the world record (world_bytes: bodies, flags, joints,
+ * contacts, broad phase, terrain) followed by the step's scratch (solver schedule and manifolds, handed from launch to launch: one
+ * step is a sequence of kernel launches); behind them the library's own part (pending flags, the spare records of the auto-reset,
+ * their observations and bookkeeping) */
 int madrl_multiwalker_record_bytes(const madrl_multiwalker *h, int32_t *stride_bytes, int32_t *world_bytes);
 /* MultiWalkerEnv.reset (:330-357) incl. its trailing zero-action step; obs float32 [N][W][obs_dim] (32, or 71 with one_hot) */
 int madrl_multiwalker_reset(madrl_multiwalker *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
 /* MultiWalkerEnv.step (:359-428): actions float32 [N][W][4]; rew float32 [N][W]; done uint8 [N]
- * (bit0 = the reference's done, bit1 = max_steps reached) */
+ * (bit0 = the reference's done, bit1 = max_steps reached).  With auto_reset an env whose episode ended continues with its next
+ * episode (reset + trailing step, :330-357) and obs holds that episode's first observation; the result is the same as
+ * reset(mask = done) after the call, whichever way the library gets there (a prepared spare record or a second pass) */
 int madrl_multiwalker_step(madrl_multiwalker *h, const float *actions_dev, float *obs_dev, float *rew_dev,
                            uint8_t *done_dev, void *stream);
 /* inspection: bodies float32 [N][NB][6] = centre x, y, angle, vx, vy, w (body 0 = package, then per walker hull,
