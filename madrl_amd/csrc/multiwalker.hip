@@ -221,9 +221,10 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
     }
     const int OD = W * mw::obs_dim_of(d.cfg);
     float *obs_row = (spare ? d.spare_obs : io.obs) + env * OD;  // observation rows go straight to HBM
+    if (lane == 0) *s_done = 0;
+    mw::env_observe(M, d.cfg, Wd, Cd, par, gid, obs_row, !fresh ? s_rew : (float *)nullptr, !fresh ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr,
+                    reinterpret_cast<double *>(work + 32));   // walker w's row by lane w
     if (lane == 0) {
-        *s_done = 0;
-        mw::env_observe(M, d.cfg, Wd, Cd, gid, obs_row, !fresh ? s_rew : (float *)nullptr, !fresh ? reinterpret_cast<uint8_t *>(s_done) : (uint8_t *)nullptr);
         Wd.t += 1;
         Wd.tick += 1;
         if (!fresh) {

@@ -455,20 +455,22 @@ struct ClipV { V2 v; uint32_t id; };
 MW_HD uint32_t mk_id(int ia, int ib, int ta, int tb) { return (uint32_t)ia | ((uint32_t)ib << 8) | ((uint32_t)ta << 16) | ((uint32_t)tb << 24); }
 MW_HD uint32_t swap_id(uint32_t id) { return ((id >> 8) & 0xFF) | ((id & 0xFF) << 8) | (((id >> 24) & 0xFF) << 16) | (((id >> 16) & 0xFF) << 24); }
 
+// (written without a running output index: the small arrays of the narrow phase stay in registers on the GPU)
 MW_HD int clip_segment(ClipV out[2], const ClipV in[2], V2 normal, float offset, int vertexIndexA) {
-    int n = 0;
     const float d0 = dot(normal, in[0].v) - offset, d1 = dot(normal, in[1].v) - offset;
-    if (d0 <= 0.0f) out[n++] = in[0];
-    if (d1 <= 0.0f) out[n++] = in[1];
-    if (d0 * d1 < 0.0f) {
+    const bool k0 = d0 <= 0.0f, k1 = d1 <= 0.0f, kx = d0 * d1 < 0.0f;   // k0 && k1 && kx cannot all hold
+    ClipV x; x.v = v2(0, 0); x.id = 0;
+    if (kx) {
         const float interp = d0 / (d0 - d1);
-        out[n].v = in[0].v + interp * (in[1].v - in[0].v);
-        out[n].id = mk_id(vertexIndexA, (in[0].id >> 8) & 0xFF, 0, 1);
-        ++n;
+        x.v = in[0].v + interp * (in[1].v - in[0].v);
+        x.id = mk_id(vertexIndexA, (in[0].id >> 8) & 0xFF, 0, 1);
     }
-    return n;
+    // the kept points in the order in[0], in[1], intersection (field-wise selects on values, see sel())
+    const ClipV a = in[0], b = in[1];
+    out[0].v = sel(k0, a.v, sel(k1, b.v, x.v)); out[0].id = k0 ? a.id : (k1 ? b.id : x.id);
+    out[1].v = sel(k0 && k1, b.v, x.v); out[1].id = (k0 && k1) ? b.id : x.id;
+    return (k0 ? 1 : 0) + (k1 ? 1 : 0) + (kx ? 1 : 0);
 }
-
 struct ManifoldOut { int npts, type; V2 local_normal, local_point, lp[2]; uint32_t id[2]; };
 
 
@@ -547,16 +549,17 @@ MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shap
     if (clip_segment(c1, inc, -tangent, side1, iv1) < 2) return;
     if (clip_segment(c2, c1, tangent, side2, iv2) < 2) return;
     mo.local_normal = local_normal; mo.local_point = plane_point;
-    int n = 0;
+    V2 cand[2]; uint32_t cid[2]; bool keep[2];   // the kept clip points, packed to the front without a running index
+    MW_UNROLL
     for (int i = 0; i < 2; ++i) {
         const float sep = dot(normal, c2[i].v) - front_offset;
-        if (sep <= total_radius) {
-            mo.lp[n] = mulT(xf2, c2[i].v);
-            mo.id[n] = flip ? swap_id(c2[i].id) : c2[i].id;
-            ++n;
-        }
+        keep[i] = sep <= total_radius;
+        cand[i] = mulT(xf2, c2[i].v);
+        cid[i] = flip ? swap_id(c2[i].id) : c2[i].id;
     }
-    mo.npts = n;
+    if (keep[0]) { mo.lp[0] = cand[0]; mo.id[0] = cid[0]; if (keep[1]) { mo.lp[1] = cand[1]; mo.id[1] = cid[1]; } }
+    else if (keep[1]) { mo.lp[0] = cand[1]; mo.id[0] = cid[1]; }
+    mo.npts = (keep[0] ? 1 : 0) + (keep[1] ? 1 : 0);
 }
 
 
@@ -623,24 +626,36 @@ MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB,
         front = offset1 >= 0.0f;
         if (front) { m_normal = normal1; lower = -normal1; upper = -normal1; } else { m_normal = -normal1; lower = normal1; upper = normal1; }
     }
-    V2 bv[5], bn[5];
-    for (int i = 0; i < pB.n; ++i) { bv[i] = mul(xf, pB.v[i]); bn[i] = mul(xf.q, pB.nrm[i]); }
+    V2x5 bv, bn;   // (named members, see V2x5)
+    const int nB = pB.n;
+#define MW_E5(F_) F_(0, e0) F_(1, e1) F_(2, e2) F_(3, e3) F_(4, e4)
+#define MW_XF_(i, e) bv.e = v2(0, 0); bn.e = v2(0, 0); if (i < nB) { bv.e = mul(xf, pB.v[i]); bn.e = mul(xf.q, pB.nrm[i]); }
+    MW_E5(MW_XF_)
+#undef MW_XF_
     const float radius = 2.0f * POLY_RADIUS;
     // edge axis
     float edge_sep = 3.0e38f;
-    for (int i = 0; i < pB.n; ++i) { const float s = dot(m_normal, bv[i] - v1); if (s < edge_sep) edge_sep = s; }
+#define MW_ES_(i, e) if (i < nB) { const float s = dot(m_normal, bv.e - v1); if (s < edge_sep) edge_sep = s; }
+    MW_E5(MW_ES_)
+#undef MW_ES_
     if (edge_sep > radius) return;
     // polygon axis
     int poly_type = 0, poly_index = -1; float poly_sep = -3.0e38f;
     const V2 perp = v2(-m_normal.y, m_normal.x);
-    for (int i = 0; i < pB.n; ++i) {
-        const V2 n = -bn[i];
-        const float s1 = dot(n, bv[i] - v1), s2 = dot(n, bv[i] - v2e), s = mnf(s1, s2);
-        if (s > radius) { poly_type = 2; poly_index = i; poly_sep = s; break; }
-        if (dot(n, perp) >= 0.0f) { if (dot(n - upper, m_normal) < -ANGULAR_SLOP) continue; }
-        else { if (dot(n - lower, m_normal) < -ANGULAR_SLOP) continue; }
-        if (s > poly_sep) { poly_type = 2; poly_index = i; poly_sep = s; }
+    bool stop = false;   // Box2D leaves the loop at the first separating axis
+#define MW_PA_(i, e) if (i < nB && !stop) {                                                                     \
+        const V2 n = -bn.e;                                                                                    \
+        const float s1 = dot(n, bv.e - v1), s2 = dot(n, bv.e - v2e), s = mnf(s1, s2);                          \
+        if (s > radius) { poly_type = 2; poly_index = i; poly_sep = s; stop = true; }                          \
+        else {                                                                                                 \
+            bool skip;                                                                                         \
+            if (dot(n, perp) >= 0.0f) skip = dot(n - upper, m_normal) < -ANGULAR_SLOP;                         \
+            else skip = dot(n - lower, m_normal) < -ANGULAR_SLOP;                                              \
+            if (!skip && s > poly_sep) { poly_type = 2; poly_index = i; poly_sep = s; }                        \
+        }                                                                                                      \
     }
+    MW_E5(MW_PA_)
+#undef MW_PA_
     if (poly_type != 0 && poly_sep > radius) return;
     const float k_rel = 0.98f, k_abs = 0.001f;
     const bool primary_edge = (poly_type == 0) || !(poly_sep > k_rel * edge_sep + k_abs);
@@ -648,19 +663,22 @@ MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB,
     int rf_i1, rf_i2; V2 rf_v1, rf_v2, rf_normal;
     if (primary_edge) {
         mo.type = 0;
-        int best = 0; float bestv = dot(m_normal, bn[0]);
-        for (int i = 1; i < pB.n; ++i) { const float val = dot(m_normal, bn[i]); if (val < bestv) { bestv = val; best = i; } }
-        const int i1 = best, i2 = (i1 + 1 < pB.n) ? i1 + 1 : 0;
-        ie[0].v = bv[i1]; ie[0].id = mk_id(0, i1, 1, 0);
-        ie[1].v = bv[i2]; ie[1].id = mk_id(0, i2, 1, 0);
+        int best = 0; float bestv = dot(m_normal, bn.e0);
+#define MW_BI_(i, e) if (i >= 1 && i < nB) { const float val = dot(m_normal, bn.e); if (val < bestv) { bestv = val; best = i; } }
+        MW_E5(MW_BI_)
+#undef MW_BI_
+#undef MW_E5
+        const int i1 = best, i2 = (i1 + 1 < nB) ? i1 + 1 : 0;
+        ie[0].v = pick(bv, i1); ie[0].id = mk_id(0, i1, 1, 0);
+        ie[1].v = pick(bv, i2); ie[1].id = mk_id(0, i2, 1, 0);
         if (front) { rf_i1 = 0; rf_i2 = 1; rf_v1 = v1; rf_v2 = v2e; rf_normal = normal1; }
         else { rf_i1 = 1; rf_i2 = 0; rf_v1 = v2e; rf_v2 = v1; rf_normal = -normal1; }
     } else {
         mo.type = 1;
         ie[0].v = v1; ie[0].id = mk_id(0, poly_index, 0, 1);
         ie[1].v = v2e; ie[1].id = mk_id(0, poly_index, 0, 1);
-        rf_i1 = poly_index; rf_i2 = (rf_i1 + 1 < pB.n) ? rf_i1 + 1 : 0;
-        rf_v1 = bv[rf_i1]; rf_v2 = bv[rf_i2]; rf_normal = bn[rf_i1];
+        rf_i1 = poly_index; rf_i2 = (rf_i1 + 1 < nB) ? rf_i1 + 1 : 0;
+        rf_v1 = pick(bv, rf_i1); rf_v2 = pick(bv, rf_i2); rf_normal = pick(bn, rf_i1);
     }
     const V2 side_n1 = v2(rf_normal.y, -rf_normal.x), side_n2 = -side_n1;
     const float so1 = dot(side_n1, rf_v1), so2 = dot(side_n2, rf_v2);
@@ -669,16 +687,18 @@ MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB,
     if (clip_segment(c2, c1, side_n2, so2, rf_i2) < 2) return;
     if (primary_edge) { mo.local_normal = rf_normal; mo.local_point = rf_v1; }
     else { mo.local_normal = pB.nrm[rf_i1]; mo.local_point = pB.v[rf_i1]; }
-    int n = 0;
+    // the kept clip points, packed to the front (no running index: ManifoldOut stays in registers)
+    V2 cand[2]; uint32_t cid[2]; bool keep[2];
+    MW_UNROLL
     for (int i = 0; i < 2; ++i) {
         const float sep = dot(rf_normal, c2[i].v - rf_v1);
-        if (sep <= radius) {
-            if (primary_edge) { mo.lp[n] = mulT(xf, c2[i].v); mo.id[n] = c2[i].id; }
-            else { mo.lp[n] = c2[i].v; mo.id[n] = swap_id(c2[i].id); }
-            ++n;
-        }
+        keep[i] = sep <= radius;
+        if (primary_edge) { cand[i] = mulT(xf, c2[i].v); cid[i] = c2[i].id; }
+        else { cand[i] = c2[i].v; cid[i] = swap_id(c2[i].id); }
     }
-    mo.npts = n;
+    if (keep[0]) { mo.lp[0] = cand[0]; mo.id[0] = cid[0]; if (keep[1]) { mo.lp[1] = cand[1]; mo.id[1] = cid[1]; } }
+    else if (keep[1]) { mo.lp[0] = cand[1]; mo.id[0] = cid[1]; }
+    mo.npts = (keep[0] ? 1 : 0) + (keep[1] ? 1 : 0);
 }
 
 
@@ -752,13 +772,18 @@ struct SerialPar {
 // b2Contact::Update of one contact whose new manifold is `mo`: impulses carried over by feature id, touching state, e_enabledFlag
 // set again.  Returns 0: no event, 1: BeginContact, 2: EndContact.
 MW_HD int contact_update(Slot &sl, const ManifoldOut &mo) {
-    float ni[2] = {0, 0}, ti[2] = {0, 0};
-    for (int i = 0; i < mo.npts; ++i)
-        for (int k = 0; k < sl.npts; ++k)
-            if (sl.id[k] == mo.id[i]) { ni[i] = sl.ni[k]; ti[i] = sl.ti[k]; break; }
-    const bool touching = mo.npts > 0, was = sl.touching != 0;
-    sl.touching = touching ? 1 : 0; sl.npts = (uint8_t)mo.npts;
-    for (int i = 0; i < mo.npts; ++i) { sl.id[i] = mo.id[i]; sl.ni[i] = ni[i]; sl.ti[i] = ti[i]; }
+    // new point i takes the impulses of the FIRST old point with its feature id (two points at most on either side: written out, so that
+    // nothing here is an indexed array on the GPU)
+    const int on = sl.npts, nn = mo.npts;
+    const uint32_t o0 = sl.id[0], o1 = sl.id[1];
+    const float sn0 = sl.ni[0], sn1 = sl.ni[1], st0 = sl.ti[0], st1 = sl.ti[1];
+    float ni0 = 0.0f, ni1 = 0.0f, ti0 = 0.0f, ti1 = 0.0f;
+    if (nn > 0) { if (on > 0 && o0 == mo.id[0]) { ni0 = sn0; ti0 = st0; } else if (on > 1 && o1 == mo.id[0]) { ni0 = sn1; ti0 = st1; } }
+    if (nn > 1) { if (on > 0 && o0 == mo.id[1]) { ni1 = sn0; ti1 = st0; } else if (on > 1 && o1 == mo.id[1]) { ni1 = sn1; ti1 = st1; } }
+    const bool touching = nn > 0, was = sl.touching != 0;
+    sl.touching = touching ? 1 : 0; sl.npts = (uint8_t)nn;
+    if (nn > 0) { sl.id[0] = mo.id[0]; sl.ni[0] = ni0; sl.ti[0] = ti0; }
+    if (nn > 1) { sl.id[1] = mo.id[1]; sl.ni[1] = ni1; sl.ti[1] = ti1; }
     return touching == was ? 0 : (touching ? 1 : 2);
 }
 // a touching contact becomes a solver manifold (pool slot from par.alloc; the solver's order is decided later by build_islands)
@@ -770,7 +795,9 @@ MW_HD int emit_manifold(Hot &Wd, Scratch &S, Manifold *MP, Par par, const Slot &
     Manifold &m = MP[idx];
     m.bA = (int8_t)bA; m.bB = (int8_t)bB; m.slot = (int16_t)slot_index; m.npts = (uint8_t)mo.npts; m.type = (uint8_t)(mo.type | (mo.npts << 1)); m.island = 0;
     m.local_normal = mo.local_normal; m.local_point = mo.local_point;
-    for (int i = 0; i < mo.npts; ++i) { m.lp[i] = mo.lp[i]; m.ni[i] = sl.ni[i]; m.ti[i] = sl.ti[i]; }
+    // (component by component: a struct copy out of a conditionally written local is done with integer loads, and those keep it in memory)
+    if (mo.npts > 0) { m.lp[0].x = mo.lp[0].x; m.lp[0].y = mo.lp[0].y; m.ni[0] = sl.ni[0]; m.ti[0] = sl.ti[0]; }
+    if (mo.npts > 1) { m.lp[1].x = mo.lp[1].x; m.lp[1].y = mo.lp[1].y; m.ni[1] = sl.ni[1]; m.ti[1] = sl.ti[1]; }
     m.friction = friction;
     return idx;
 }
@@ -1381,8 +1408,7 @@ MW_HD void poly_aabb_at(const Shape &s, V2 c, float a, float &xmin, float &xmax,
 }
 MW_HD void proxy_of_shape(Proxy &p, const Shape &s) {
     p.n = s.n;
-    MW_UNROLL
-    for (int i = 0; i < TOI_MAX_VERTS; ++i) p.v[i] = i < s.n ? s.v[i] : s.v[0];
+    p.v.e0 = s.v[0]; p.v.e1 = 1 < s.n ? s.v[1] : s.v[0]; p.v.e2 = 2 < s.n ? s.v[2] : s.v[0]; p.v.e3 = 3 < s.n ? s.v[3] : s.v[0]; p.v.e4 = 4 < s.n ? s.v[4] : s.v[0];
 }
 MW_HD Sweep sweep_of_body(const Model &M, const Hot &Wd, const ColdView &Cd, int b) {
     Sweep s;
@@ -1412,9 +1438,7 @@ MW_HD float toi_alpha_terrain(const Model &M, const ColdView &Cd, int bi, int e,
     if (box.xmin - m > p2.x || box.xmax + m < p1.x || box.ymin - m > mxf(p1.y, p2.y) || box.ymax + m < mnf(p1.y, p2.y)) { MW_STAT(toi_culled, 1); return 1.0f; }
     MW_STAT(toi_full, 1); MW_STAT(lane_cost[g_stats_lane()], 6000);
     Proxy pA, pB;
-    pA.n = 2; pA.v[0] = p1; pA.v[1] = p2;
-    MW_UNROLL
-    for (int i = 2; i < TOI_MAX_VERTS; ++i) pA.v[i] = p1;
+    pA.n = 2; pA.v.e0 = p1; pA.v.e1 = p2; pA.v.e2 = p1; pA.v.e3 = p1; pA.v.e4 = p1;
     proxy_of_shape(pB, M.shape[shape_of_body(bi)]);
     Sweep sA;
     sA.lc = v2(0, 0); sA.c0 = v2(0, 0); sA.c = v2(0, 0); sA.a0 = 0.0f; sA.a = 0.0f; sA.alpha0 = 0.0f;
@@ -1593,7 +1617,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             m.bA = -1; m.bB = (int8_t)mover; m.slot = (int16_t)slot_index; m.npts = (uint8_t)o.npts; m.type = (uint8_t)(o.type | (o.npts << 1)); m.island = 0; m.block = 0;
             m.local_normal = o.local_normal; m.local_point = o.local_point;
             MW_UNROLL
-            for (int i = 0; i < 2; ++i) { m.lp[i] = i < o.npts ? o.lp[i] : v2(0, 0); m.ni[i] = 0.0f; m.ti[i] = 0.0f; }  // subStep.warmStarting = false
+            for (int i = 0; i < 2; ++i) { m.lp[i].x = i < o.npts ? o.lp[i].x : 0.0f; m.lp[i].y = i < o.npts ? o.lp[i].y : 0.0f; m.ni[i] = 0.0f; m.ti[i] = 0.0f; }  // subStep.warmStarting = false
             m.friction = fr;
             m.normal = v2(0, 0); m.rA[0] = m.rA[1] = m.rB[0] = m.rB[1] = v2(0, 0); m.nm[0] = m.nm[1] = m.tm[0] = m.tm[1] = 0.0f;
             m.k11 = m.k12 = m.k22 = m.im11 = m.im12 = m.im22 = 0.0f;
@@ -2127,7 +2151,8 @@ enum : uint32_t { TAG_MW_TERRAIN = 32, TAG_MW_PUSH = 33, TAG_MW_NOISE = 34 };
 MW_HD float u24f(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 MW_HD double u24d(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 
-MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done);
+template <class Par>
+MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, Par par, uint32_t gid, float *obs, float *rew, uint8_t *done, double *rw);
 
 // MultiWalkerEnv.reset (:330-357) without its trailing step: a fresh b2World (D1) with the package, the terrain edges and the
 // walkers created in the reference's order.  terrain_in (NT float64 heights) / push_in (W float64) replace the Philox draws (D3).
@@ -2232,26 +2257,29 @@ MW_HD_INLINE void env_step(const Model &M, const EnvCfg &C, Hot &Wd, const ColdV
                     float *rew, uint8_t *done) {
     env_apply_actions(M, Wd, Cd, par, actions);
     world_step(M, Wd, Cd, S, par);  // :365
+    double rw[MAX_WALKERS];
+    env_observe(M, C, Wd, Cd, par, gid, obs, rew, done, rw);
     if (par.lane() == 0) {
-        env_observe(M, C, Wd, Cd, gid, obs, rew, done);
         Wd.t += 1;
         Wd.tick += 1;
     }
     par.sync();
 }
 
-MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, uint32_t gid, float *obs, float *rew, uint8_t *done) {
-    MW_FLOPS(90 * M.W + 40);   // besides the lidar: transforms of the hulls and the package, the 14 + 8 state entries, shaping, rewards
+// get_observation + the reward / done logic of MultiWalkerEnv.step: the walkers' rows by lane (walker w on lane w % n), then one lane
+// for what couples them.  rw: MAX_WALKERS doubles the lanes share (LDS in the HIP kernel).  No indexed local arrays (they would live
+// in scratch memory on the GPU): hull positions and noise pairs are recomputed where they are needed.
+template <class Par>
+MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView &Cd, Par par, uint32_t gid, float *obs, float *rew, uint8_t *done, double *rw) {
     // the Python side of the reference computes in float64 on the float32 values Box2D hands it; so does this function
     const Body &pkg = Wd.b[0];
     const V2 pkg_pos = body_xf(M, pkg, 0).p;
-    double rewards[MAX_WALKERS];
-    V2 hull_pos[MAX_WALKERS];
     const double package_length = 240.0 / 30.0 * (M.W / 1.75);   // :293-294
-    for (int w = 0; w < M.W; ++w) hull_pos[w] = body_xf(M, Wd.b[hull_of(w)], hull_of(w)).p;
-    for (int w = 0; w < M.W; ++w) {
+    const bool noisy = C.position_noise != 0.0f || C.angle_noise != 0.0f;
+    for (int w = par.lane(); w < M.W; w += par.n()) {
+        MW_FLOPS(90 + 40 / M.W);   // besides the lidar: transforms of the hulls and the package, the 14 + 8 state entries, shaping, rewards
         const Body &hull = Wd.b[hull_of(w)];
-        const V2 pos = hull_pos[w];
+        const V2 pos = body_xf(M, hull, hull_of(w)).p;
         float *o = obs + w * obs_dim_of(C);
         // get_observation (:205-237)
         o[0] = hull.a;
@@ -2270,54 +2298,60 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView 
             const V2 p2 = v2((float)((double)pos.x + M.lidar_dx[i]), (float)((double)pos.y - M.lidar_dy[i]));
             o[14 + i] = lidar_fraction(M, Cd, pos, p2);
         }
-        // neighbours and package (:380-400), gaussian noise via Box-Muller on keyed uniforms
-        float nz[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (C.position_noise != 0.0f || C.angle_noise != 0.0f) {
-            for (int q = 0; q < 4; ++q) {
-                uint32_t r[4];
-                philox10(gid, Wd.episode, (Wd.tick << 4) | (uint32_t)(w * 4 + q), TAG_MW_NOISE, C.k0, C.k1, r);
-                const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u24f(r[1]);
-                const float rad = sqrtf(-2.0f * logf(u1));
-                float bs, bc;
-                sincos_det(2.0f * B2_PI * u2, bs, bc);
-                nz[2 * q] = rad * bc;
-                if (2 * q + 1 < 7) nz[2 * q + 1] = rad * bs;
-            }
-        }
+        // neighbours and package (:380-400), gaussian noise via Box-Muller on keyed uniforms: draw q gives the values 2q and 2q + 1 of the
+        // walker's seven normals (:389-395 consumes them in order: left neighbour, right neighbour, package x, y, angle)
+        auto normal_pair = [&](int q, float &a, float &b) {
+            a = 0.0f; b = 0.0f;
+            if (!noisy) return;
+            uint32_t r[4];
+            philox10(gid, Wd.episode, (Wd.tick << 4) | (uint32_t)(w * 4 + q), TAG_MW_NOISE, C.k0, C.k1, r);
+            const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u24f(r[1]);
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float bs, bc;
+            sincos_det(2.0f * B2_PI * u2, bs, bc);
+            a = rad * bc; b = rad * bs;
+        };
         int n = 24, zi = 0;
         for (int dj = -1; dj <= 1; dj += 2) {
             const int j = w + dj;
             if (j < 0 || j == M.W) { o[n++] = 0.0f; o[n++] = 0.0f; }
             else {
-                const double xm = ((double)hull_pos[j].x - (double)pos.x) / package_length, ym = ((double)hull_pos[j].y - (double)pos.y) / package_length;
-                o[n++] = (float)(xm + (double)C.position_noise * (double)nz[zi++]);
-                o[n++] = (float)(ym + (double)C.position_noise * (double)nz[zi++]);
+                float za, zb;
+                normal_pair(zi, za, zb); ++zi;
+                const V2 hj = body_xf(M, Wd.b[hull_of(j)], hull_of(j)).p;
+                const double xm = ((double)hj.x - (double)pos.x) / package_length, ym = ((double)hj.y - (double)pos.y) / package_length;
+                o[n++] = (float)(xm + (double)C.position_noise * (double)za);
+                o[n++] = (float)(ym + (double)C.position_noise * (double)zb);
             }
         }
+        float z4, z5, z6, z7;
+        normal_pair(2, z4, z5); normal_pair(3, z6, z7);
         const double xd = ((double)pkg_pos.x - (double)pos.x) / package_length, yd = ((double)pkg_pos.y - (double)pos.y) / package_length;
-        o[n++] = (float)(xd + (double)C.position_noise * (double)nz[4]);
-        o[n++] = (float)(yd + (double)C.position_noise * (double)nz[5]);
-        o[n++] = (float)((double)pkg.a + (double)C.angle_noise * (double)nz[6]);
+        o[n++] = (float)(xd + (double)C.position_noise * (double)z4);
+        o[n++] = (float)(yd + (double)C.position_noise * (double)z5);
+        o[n++] = (float)((double)pkg.a + (double)C.angle_noise * (double)z6);
         if (C.one_hot) { for (int k = 0; k < MAX_AGENTS_ID; ++k) o[n++] = (k == w) ? 1.0f : 0.0f; }  // np.eye(MAX_AGENTS)[i] :397-398
         else o[n++] = (float)((double)w / (double)M.W);  // :400
         // shaping (:403-407)
         const double shaping = 0.0 - 5.0 * fabs((double)hull.a);
-        rewards[w] = shaping - Wd.prev_shaping[w];
+        rw[w] = shaping - Wd.prev_shaping[w];
         Wd.prev_shaping[w] = shaping;
     }
+    par.sync();
+    if (par.lane() != 0) return;
     const double package_shaping = (double)C.forward_reward * 130 * (double)pkg_pos.x / 30.0;  // :409-411
-    for (int w = 0; w < M.W; ++w) rewards[w] += (package_shaping - Wd.prev_package_shaping);
+    for (int w = 0; w < M.W; ++w) rw[w] += (package_shaping - Wd.prev_package_shaping);
     Wd.prev_package_shaping = package_shaping;
     bool dn = false;
-    const double last_x = (double)hull_pos[M.W - 1].x;  // `pos` leaks out of the loop: the LAST walker (:417, :420)
-    if (Wd.game_over || last_x < 0.0) { for (int w = 0; w < M.W; ++w) rewards[w] += (double)C.drop_reward; dn = true; }
+    const double last_x = (double)body_xf(M, Wd.b[hull_of(M.W - 1)], hull_of(M.W - 1)).p.x;  // `pos` leaks out of the loop: the LAST walker (:417, :420)
+    if (Wd.game_over || last_x < 0.0) { for (int w = 0; w < M.W; ++w) rw[w] += (double)C.drop_reward; dn = true; }
     if (last_x > (M.NT - TERRAIN_GRASS) * (14.0 / 30.0)) dn = true;
     int nfallen = 0;
-    for (int w = 0; w < M.W; ++w) { rewards[w] += (double)C.fall_reward * (Wd.fallen[w] ? 1.0 : 0.0); nfallen += Wd.fallen[w]; }
+    for (int w = 0; w < M.W; ++w) { rw[w] += (double)C.fall_reward * (Wd.fallen[w] ? 1.0 : 0.0); nfallen += Wd.fallen[w]; }
     if (C.terminate_on_fall && nfallen > 0) dn = true;
     if (rew) {
-        if (C.reward_global) { double s = 0.0; for (int w = 0; w < M.W; ++w) s += rewards[w]; s /= (double)M.W; for (int w = 0; w < M.W; ++w) rew[w] = (float)s; }
-        else for (int w = 0; w < M.W; ++w) rew[w] = (float)rewards[w];
+        if (C.reward_global) { double s = 0.0; for (int w = 0; w < M.W; ++w) s += rw[w]; s /= (double)M.W; for (int w = 0; w < M.W; ++w) rew[w] = (float)s; }
+        else for (int w = 0; w < M.W; ++w) rew[w] = (float)rw[w];
     }
     if (done) *done = dn ? 1 : 0;
 }

@@ -10,23 +10,28 @@ namespace mw {
 constexpr float B2_EPSILON = 1.1920928955078125e-7f;  // FLT_EPSILON
 constexpr int TOI_MAX_VERTS = 5;
 
+// Five points with NAMED members: an array, even one only ever indexed by unrolled loops and select chains, is turned back into an
+// indexed object in scratch memory by the optimizer (it folds a select of two loads into one load from a selected address before the
+// array is promoted to registers); members cannot be.
+struct V2x5 { V2 e0, e1, e2, e3, e4; };
+static_assert(TOI_MAX_VERTS == 5, "V2x5");
+// (selects on the float components, operands by value: `c ? a : b` on two struct lvalues is a select between their ADDRESSES)
+MW_HD V2 sel(bool c, V2 a, V2 b) { V2 r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; return r; }
+MW_HD V2 pick(const V2x5 &a, int i) { return sel(i == 4, a.e4, sel(i == 3, a.e3, sel(i == 2, a.e2, sel(i == 1, a.e1, a.e0)))); }
 struct Proxy {        // b2DistanceProxy: a convex vertex set (edge: 2 vertices, polygon: its vertices); radius is not used (useRadii = false)
-    V2 v[TOI_MAX_VERTS];
+    V2x5 v;
     int n;
 };
 MW_HD int proxy_support(const Proxy &p, V2 d) {
     int best = 0;
-    float bv = dot(p.v[0], d);
-    for (int i = 1; i < p.n; ++i) { const float val = dot(p.v[i], d); if (val > bv) { best = i; bv = val; } }
+    float bv = dot(p.v.e0, d);
+    if (1 < p.n) { const float val = dot(p.v.e1, d); if (val > bv) { best = 1; bv = val; } }
+    if (2 < p.n) { const float val = dot(p.v.e2, d); if (val > bv) { best = 2; bv = val; } }
+    if (3 < p.n) { const float val = dot(p.v.e3, d); if (val > bv) { best = 3; bv = val; } }
+    if (4 < p.n) { const float val = dot(p.v.e4, d); if (val > bv) { best = 4; bv = val; } }
     return best;
 }
-// select vertex i of a proxy without dynamic register indexing
-MW_HD V2 proxy_vertex(const Proxy &p, int i) {
-    V2 r = p.v[0];
-    MW_UNROLL
-    for (int k = 1; k < TOI_MAX_VERTS; ++k) if (i == k) r = p.v[k];
-    return r;
-}
+MW_HD V2 proxy_vertex(const Proxy &p, int i) { return pick(p.v, i); }
 
 struct Sweep { V2 lc, c0, c; float a0, a, alpha0; };  // b2Sweep
 MW_HD Xf sweep_xf(const Sweep &s, float beta) {       // b2Sweep::GetTransform

@@ -14,7 +14,7 @@ for cont, tof in combos:
         acts = [(torch.rand((N, W, 4), device=dev) * 2 - 1).contiguous() for _ in range(4)]
         env.reset()
         line = []
-        for win in range(16):
+        for win in range(int(os.environ.get("MW_WINDOWS", 16))):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             nd = 0

@@ -30,7 +30,17 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     names = {}
     for k, v in acc:
         names.setdefault(k, []).append(v)
-    if names:
+    if names and wl == "multiwalker":
+        # one step = several launches of the phase kernels (plus the near-empty second pass): everything they move, per step() call
+        grids = []
+        for f in glob.glob(os.path.join(out, "pmc_" + c, "**", "*counter_collection*.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if ksub in row["Kernel_Name"] and row["Counter_Name"] == c and "ILi1E" in row["Kernel_Name"]:
+                    grids.append(int(row["Grid_Size"]))
+        n_steps = sum(1 for g in grids if g == max(grids))   # the collide launch of the main pass: once per step() call
+        kname = "mw_step_kernel<collide | solve | continuous pass>, all launches of a step() call"
+        vals[c] = sum(v for _, v in acc) / max(n_steps, 1)
+    elif names:
         kname = max(names, key=lambda k: len(names[k]))
         vals[c] = sum(names[kname]) / len(names[kname])
 if len(vals) == 2:
