@@ -557,8 +557,9 @@ MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shap
         cand[i] = mulT(xf2, c2[i].v);
         cid[i] = flip ? swap_id(c2[i].id) : c2[i].id;
     }
-    if (keep[0]) { mo.lp[0] = cand[0]; mo.id[0] = cid[0]; if (keep[1]) { mo.lp[1] = cand[1]; mo.id[1] = cid[1]; } }
-    else if (keep[1]) { mo.lp[0] = cand[1]; mo.id[0] = cid[1]; }
+    // fixed destinations, selected VALUES (entries past npts are never read)
+    mo.lp[0] = sel(keep[0], cand[0], cand[1]); mo.id[0] = keep[0] ? cid[0] : cid[1];
+    mo.lp[1] = cand[1]; mo.id[1] = cid[1];
     mo.npts = (keep[0] ? 1 : 0) + (keep[1] ? 1 : 0);
 }
 
@@ -696,8 +697,9 @@ MW_HD void collide_edge_polygon(ManifoldOut &mo, V2 v1, V2 v2e, const Shape &pB,
         if (primary_edge) { cand[i] = mulT(xf, c2[i].v); cid[i] = c2[i].id; }
         else { cand[i] = c2[i].v; cid[i] = swap_id(c2[i].id); }
     }
-    if (keep[0]) { mo.lp[0] = cand[0]; mo.id[0] = cid[0]; if (keep[1]) { mo.lp[1] = cand[1]; mo.id[1] = cid[1]; } }
-    else if (keep[1]) { mo.lp[0] = cand[1]; mo.id[0] = cid[1]; }
+    // fixed destinations, selected VALUES (entries past npts are never read)
+    mo.lp[0] = sel(keep[0], cand[0], cand[1]); mo.id[0] = keep[0] ? cid[0] : cid[1];
+    mo.lp[1] = cand[1]; mo.id[1] = cid[1];
     mo.npts = (keep[0] ? 1 : 0) + (keep[1] ? 1 : 0);
 }
 

@@ -71,12 +71,13 @@ def test_specialised_particle_kernels_do_not_spill():
         assert k["scratch"] == 0 and k["vgpr_spills"] == 0, (n, k)
 
 
-def test_multiwalker_solver_launch_has_no_scratch():
-    """The 180 + 60 sweep loops of the MultiWalker island solver keep every joint constant and three manifolds per lane in registers
-    (512 unified VGPRs at one wavefront per SIMD): the solver launch must not touch scratch memory at all, and the other two launches of
-    the step only for their small dynamically indexed work arrays (GJK simplex, merge tables) -- never several hundred bytes of spills."""
+def test_multiwalker_launches_have_no_scratch():
+    """No MultiWalker kernel touches scratch memory.  The 180 + 60 sweep loops of the island solver keep every joint constant and three
+    manifolds per lane in registers (512 unified VGPRs at one wavefront per SIMD); the narrow phase, the GJK proxies and the observation use
+    named members and value-wise selects instead of indexed local arrays (multiwalker_toi.hpp V2x5).  Besides the latency of scratch
+    accesses inside GJK, a kernel with a few hundred bytes of scratch per lane made the runtime re-allocate scratch around every other
+    kernel on the stream: +3 ms per step next to a policy's torch kernels."""
     ks = {n: k for n, k in _kernels().items() if "mw_step_kernel" in n}
-    solve = [k for n, k in ks.items() if "ILi2E" in n]
-    assert len(solve) == 1 and solve[0]["scratch"] == 0 and solve[0]["vgpr_spills"] == 0, solve
+    assert len(ks) == 4, sorted(ks)
     for n, k in ks.items():
-        assert k["scratch"] <= 320 and k["vgpr_spills"] == 0, (n, k)
+        assert k["scratch"] == 0 and k["vgpr_spills"] == 0, (n, k)
