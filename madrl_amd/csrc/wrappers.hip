@@ -58,6 +58,19 @@ __global__ void obsbuffer_kernel(const float *obs, float *buf, int64_t n, int64_
     }
 }
 
+// k == 4: an element's history is one 16-byte word
+__global__ void obsbuffer4_kernel(const float *obs, float4 *buf, int64_t n, int64_t per_env, const uint8_t *reset_mask,
+                                  const uint8_t *active_mask) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (active_mask != nullptr && active_mask[i / per_env] == 0) continue;
+        const float x = obs[i];
+        float4 b;
+        if (reset_mask != nullptr && reset_mask[i / per_env] != 0) { b.x = x; b.y = x; b.z = x; b.w = x; }   // reset :190-192
+        else { const float4 o = buf[i]; b.x = o.y; b.y = o.z; b.z = o.w; b.w = x; }                           // step :179-181
+        buf[i] = b;
+    }
+}
+
 __global__ void diagnostics_kernel(const float *rew, const uint8_t *done, double *ep_reward, int32_t *ep_len, double *disc_ret,
                                    double *disc_pow, int64_t N, int A, double discount, int max_traj_len, double *out_ep_reward,
                                    double *out_disc, int32_t *out_len, uint8_t *out_finished) {
@@ -122,6 +135,7 @@ extern "C" {
 int madrl_wrap_obsnorm(const float *obs_in, double *mean, double *var, float *obs_out, int64_t n_elems, int64_t elems_per_env,
                        const uint8_t *mask, double alpha, double eps, void *stream) {
     if (!obs_in || !mean || !var || !obs_out || n_elems < 1 || elems_per_env < 1) return fail(MADRL_EINVAL, "obsnorm: bad argument");
+    // (two elements per lane with 16-byte accesses to the statistics were measured: 650-730 us against 645 us at 65 536 x 8 x 148 -- no gain)
     hipLaunchKernelGGL(obsnorm_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, obs_in, mean, var, obs_out,
                        n_elems, elems_per_env, mask, alpha, eps);
     MADRL_HIP_TRY(hipGetLastError());
@@ -140,8 +154,12 @@ int madrl_wrap_rewnorm(const float *rew_in, double *mean, double *var, float *re
 int madrl_wrap_obsbuffer(const float *obs, float *buf, int64_t n_elems, int64_t elems_per_env, int32_t k, const uint8_t *reset_mask,
                          const uint8_t *active_mask, void *stream) {
     if (!obs || !buf || n_elems < 1 || elems_per_env < 1 || k < 1) return fail(MADRL_EINVAL, "obsbuffer: bad argument");
-    hipLaunchKernelGGL(obsbuffer_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, obs, buf, n_elems,
-                       elems_per_env, (int)k, reset_mask, active_mask);
+    if (k == 4 && (uintptr_t)buf % 16 == 0)
+        hipLaunchKernelGGL(obsbuffer4_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, obs, (float4 *)buf, n_elems,
+                           elems_per_env, reset_mask, active_mask);
+    else
+        hipLaunchKernelGGL(obsbuffer_kernel, dim3(grid_for(n_elems)), dim3(256), 0, (hipStream_t)stream, obs, buf, n_elems,
+                           elems_per_env, (int)k, reset_mask, active_mask);
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }

@@ -29,7 +29,7 @@ mean = torch.zeros(N, A, D, dtype=torch.float64, device=dev); var = torch.ones_l
 n = obs.numel()
 report("obsnorm (f32 in/out, f64 stats rw)", timeit(lambda: _lib.check(L.madrl_wrap_obsnorm(P(obs), P(mean), P(var), P(out), n, n // N, None, 0.001, 1e-8, st))), n * (4 + 4 + 32))
 buf = torch.zeros(N, A, D, K, device=dev)
-report("obsbuffer k=4 (shift + append)", timeit(lambda: _lib.check(L.madrl_wrap_obsbuffer(P(obs), P(buf), n, n // N, K, None, st))), n * (4 + 2 * 4 * K))
+report("obsbuffer k=4 (shift + append)", timeit(lambda: _lib.check(L.madrl_wrap_obsbuffer(P(obs), P(buf), n, n // N, K, None, None, st))), n * (4 + 2 * 4 * K))
 rew = torch.rand(N, A, device=dev); rout = torch.empty_like(rew); rm = torch.zeros(N, A, dtype=torch.float64, device=dev); rv = torch.ones_like(rm)
 report("rewnorm", timeit(lambda: _lib.check(L.madrl_wrap_rewnorm(P(rew), P(rm), P(rv), P(rout), N * A, A, None, 0.001, 1e-8, 1.0, 1, st))), N * A * 40)
 T = 100

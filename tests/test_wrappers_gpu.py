@@ -134,3 +134,25 @@ def test_fused_standardized_waterworld_matches_unfused_and_oracle():
         want = so.rew(rr.cpu().numpy())
         assert np.abs(rf.cpu().numpy() - want).max() < 1e-5 * max(1.0, np.abs(want).max()), t
     assert torch.equal(fused._obs_mean, plain._obs_mean) and torch.equal(fused._rew_var, plain._rew_var)
+
+
+def test_vectorised_observation_buffer_equals_the_scalar_kernel():
+    """The k = 4 observation buffer moves one 16-byte word per element whenever the buffer is 16-byte aligned (643 -> 551 us at
+    65 536 x 8 x 148), the scalar kernel otherwise: identical results (a buffer shifted by one float forces the scalar path)."""
+    import torch
+    from madrl_amd import _lib
+    L, P = _lib.lib(), _lib.ptr
+    dev = torch.device(DEV)
+    st = _lib.current_stream(dev)
+    N, E = 257, 30
+    g = torch.Generator(device="cpu").manual_seed(5)
+    obs = torch.randn((5, N * E), generator=g).to(dev)
+    rm = (torch.rand(N, generator=g) < 0.3).to(torch.uint8).to(dev)
+    am = (torch.rand(N, generator=g) < 0.9).to(torch.uint8).to(dev)
+    def runbuf(off):
+        buf = torch.zeros(N * E * 4 + 4, device=dev)
+        for t in range(5):
+            _lib.check(L.madrl_wrap_obsbuffer(P(obs[t]), P(buf[off:]), N * E, E, 4, P(rm) if t in (0, 3) else None, P(am) if t == 3 else None, st))
+        return buf[off:off + N * E * 4].clone()
+    a, b = runbuf(0), runbuf(1)
+    assert torch.equal(a, b) and float(a.abs().sum()) > 0
