@@ -2,8 +2,15 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" 
-tail -5 gpurun_out/smoke.log
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -30 gpurun_out/pytest_gpu.log
-timeout 300 python bench.py --steps 200 --warmup 20 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"
-tail -5 gpurun_out/bench.log
+tail -3 gpurun_out/smoke.log
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+tail -8 gpurun_out/pytest_gpu.log
+timeout 400 python bench.py > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"
+tail -1 gpurun_out/bench.log | python -c "
+import json,sys
+j=json.loads(sys.stdin.read())
+print('headline %.4g %s  ms/step %.4f  frac %.3f' % (j['value'], j['unit'], j['ms_per_step'], j['roofline']['frac']))
+for k,v in j.get('workloads',{}).items():
+    print(' ', k, ('%.4g ms/step %.4f frac %.3f' % (v['value'], v['ms_per_step'], v['roofline']['frac'])) if 'value' in v else v)
+print('cpu_baseline', j.get('cpu_baseline',{}).get('value'))
+"

@@ -35,7 +35,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         grids = []
         for f in glob.glob(os.path.join(out, "pmc_" + c, "**", "*counter_collection*.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if ksub in row["Kernel_Name"] and row["Counter_Name"] == c and "ILi1E" in row["Kernel_Name"]:
+                if ksub in row["Kernel_Name"] and row["Counter_Name"] == c and ("mw_step_kernel<1>" in row["Kernel_Name"] or "ILi1E" in row["Kernel_Name"]):
                     grids.append(int(row["Grid_Size"]))
         n_steps = sum(1 for g in grids if g == max(grids))   # the collide launch of the main pass: once per step() call
         kname = "mw_step_kernel<collide | solve | continuous pass>, all launches of a step() call"
