@@ -38,6 +38,8 @@ int main() {
         for (int i = 0; i < 24; ++i) printf("%ld ", g_stats.cnt_hist[i]);
         printf("\n    continuous pass: merges with several bodies %ld, ties between bodies %ld, package / hull events %ld, pairs created by the merge %ld", g_stats.toi_multi, g_stats.toi_ties, g_stats.toi_hullpkg, g_stats.toi_pairs);
         printf("\n    counted arithmetic: %.0f float operations per env-step (hand counts per primitive x measured calls: 180 + up to 60 solver sweeps, sub-step sweeps, GJK / root finder, narrow phase, lidar)", g_stats.flops / s);
+        printf("\n      by phase: collide %.0f | solve %.0f | broad phase %.0f | time-of-impact search %.0f | sub-steps %.0f | observation %.0f", g_stats.flops_by[0] / s, g_stats.flops_by[1] / s,
+               g_stats.flops_by[2] / s, g_stats.flops_by[3] / s, g_stats.flops_by[4] / s, g_stats.flops_by[5] / s);
         printf("\n    rounds (0..11+): ");
         for (int i = 0; i < 12; ++i) printf("%ld ", g_stats.rounds_hist[i]);
         printf("\n");
