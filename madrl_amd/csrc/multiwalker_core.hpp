@@ -826,6 +826,22 @@ MW_HD void edge_polygon_manifold(const Model &M, const ColdView &Cd, int e, cons
     collide_edge_polygon(mo, p1, p2, s, xfB, false, p1, false, p2);   // plain b2EdgeShape: no ghost vertices (:617-620)
 }
 
+// Which entries of a body's contact cache hold a contact (bit k: slots[k].edge >= 0).  The cache lives in HBM in the HIP kernels: the
+// loads of one group of eight are independent, so a scan costs a few memory round trips instead of one per entry, and the callers then
+// touch only the occupied entries (a handful out of 12 - 44).
+MW_HD uint64_t occupied_slots(const Slot *slots, int cap) {
+    uint64_t m = 0;
+    for (int k = 0; k < cap; k += 8) {
+        int e[8];
+        MW_UNROLL
+        for (int q = 0; q < 8; ++q) e[q] = k + q < cap ? (int)slots[k + q].edge : -1;
+        MW_UNROLL
+        for (int q = 0; q < 8; ++q) if (e[q] >= 0) m |= 1ull << (k + q);
+    }
+    return m;
+}
+MW_HD int pop_lowest(uint64_t &m) { const int k = __builtin_ctzll(m); m &= m - 1; return k; }
+
 // b2ContactManager::Collide for the contacts of body `bi` with terrain edges.  Box2D walks the world's contact list (newest
 // first); the only thing that order decides here is a lower leg's ground_contact when one pass holds both a Begin and an End
 // for it: the LAST event of the walk -- the one on the OLDEST contact -- wins.
@@ -841,10 +857,10 @@ MW_HD void collide_body_terrain(const Model &M, Hot &Wd, const ColdView &Cd, Scr
     uint64_t ev_key = ~0ull;
     int ev_kind = 0;
     const float fr = sqrtf(FRICTION * s.friction);   // b2MixFriction
-    for (int k = 0; k < cap; ++k) {
+    for (uint64_t occ = occupied_slots(slots, cap); occ != 0;) {
+        const int k = pop_lowest(occ);
         Slot &sl = slots[k];
         const int e = sl.edge;
-        if (e < 0) continue;
         // (0, edge) for the package, (edge, body) for a walker's body: b2Contact::Create stores the edge as fixture A either way
         const uint64_t key = bi == 0 ? contact_key(sl.batch, 0, proxy_of_edge(e)) : contact_key(sl.batch, proxy_of_edge(e), pb);
         int ev;
@@ -1513,13 +1529,13 @@ constexpr int MAX_TOI_CONTACTS = 32;  // b2_maxTOIContacts
 constexpr int MAX_SUB_STEPS = 8;      // b2_maxSubSteps
 
 // the next terrain contact of body b after the one with key `below` in its contact-edge list (descending key), touching or not
-MW_HD int next_terrain_slot(const Model &M, const ColdView &Cd, int b, uint64_t below, uint64_t &key_out) {
+MW_HD int next_terrain_slot(const Model &M, const ColdView &Cd, int b, uint64_t occ, uint64_t below, uint64_t &key_out) {
     int best = -1;
     uint64_t bk = 0;
-    const int base = M.slot_base[b], cap = M.slot_cap[b];
-    for (int k = 0; k < cap; ++k) {
+    const int base = M.slot_base[b];
+    while (occ != 0) {   // occ: occupied_slots of the body's cache
+        const int k = pop_lowest(occ);
         const Slot &sl = Cd.slot[base + k];
-        if (sl.edge < 0) continue;
         const uint64_t key = b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
         if (key < below && (best < 0 || key > bk)) { best = base + k; bk = key; }
     }
@@ -1583,9 +1599,9 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
 #endif
     Cd.sweep_alpha0[mover] = 0.0f;   // "if (m_stepComplete)": alpha0 = 0, every contact's cached TOI invalid, its sub-step count 0, enabled
     if (!((Wd.awake >> mover) & 1u)) return;   // a sleeping body against static terrain: no active body
-    bool any = false;
-    for (int k = 0; k < cap; ++k) { TL.meta[k] = 0; any = any || Cd.slot[base + k].edge >= 0; }
-    if (!any) return;
+    uint64_t occ = occupied_slots(Cd.slot + base, cap);
+    if (occ == 0) return;
+    for (int k = 0; k < cap; ++k) TL.meta[k] = 0;
     const float fr = sqrtf(FRICTION * msh.friction);
     const MassAB qm = mass_of_pair(S, -1, mover);
     const int pb = proxy_of_body(mover, M.NT);
@@ -1596,9 +1612,9 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
         float min_alpha = 1.0f;
         uint64_t min_key = 0;
         int min_k = -1;
-        for (int k = 0; k < cap; ++k) {
+        for (uint64_t o2 = occ; o2 != 0;) {
+            const int k = pop_lowest(o2);
             const Slot &sl = Cd.slot[base + k];
-            if (sl.edge < 0) continue;
             const uint8_t meta = TL.meta[k];
             if ((meta & 2) || (meta >> 2) > MAX_SUB_STEPS) continue;
             if (!(meta & 1)) {   // no valid cached TOI: compute it on the body's current sweep
@@ -1656,7 +1672,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
         add_manifold(mo, min_slot);
         {
             uint64_t below = ~0ull, key;
-            for (int si = next_terrain_slot(M, Cd, mover, below, key); si >= 0; si = next_terrain_slot(M, Cd, mover, below, key)) {
+            for (int si = next_terrain_slot(M, Cd, mover, occ, below, key); si >= 0; si = next_terrain_slot(M, Cd, mover, occ, below, key)) {
                 below = key;
                 if (si == min_slot) continue;
                 if (n_isl >= MAX_TOI_CONTACTS) break;
@@ -1763,7 +1779,10 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
                     else par.or_bits(&T.overflow, 4u);
                 }
             } else par.or_bits(&T.overflow, 4u);
-            if (moved) find_new_terrain_contacts(M, Wd, Cd, mover, T.batch_base + 1u + (uint32_t)n_events, (uint16_t)(1 + n_events));
+            if (moved) {
+                find_new_terrain_contacts(M, Wd, Cd, mover, T.batch_base + 1u + (uint32_t)n_events, (uint16_t)(1 + n_events));
+                occ = occupied_slots(Cd.slot + base, cap);
+            }
             ++n_events;
             box = swept_box(msh, sweep_of_body(M, Wd, Cd, mover));   // its new sweep: from the safe pose to the end of the sub-step
             MW_PHASE(3);
