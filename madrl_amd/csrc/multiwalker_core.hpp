@@ -1,8 +1,8 @@
 // multiwalker_core.hpp -- MultiWalkerEnv dynamics: a from-scratch float32 restatement of the
 // subset of Box2D 2.3.0 that madrl_environments/walker/multi_walker.py drives
 // (`self.world.Step(1.0 / FPS, 6 * 30, 2 * 30)`, multi_walker.py:365), plus the env logic
-// around it.  Written once as host/device code: the HIP kernel (multiwalker.hip) runs it with the
-// world resident in LDS.
+// around it.  Written once as host/device code: the HIP kernels (multiwalker.hip) run it with the bodies,
+// the terrain and the step's schedule in LDS and the contact cache in HBM.
 //
 // PARITY UNPINNED: the arithmetic lives in third-party Box2D (pybox2d /
 // box2d-py, Box2D 2.3.0 inside; no version pin anywhere in the reference tree, the module is not
@@ -21,10 +21,12 @@
 //   reference builds edgeShape(vertices=[p1, p2]): no ghost vertices); b2EdgeShape::RayCast.
 // The independent check of all of this is the test infrastructure's multiwalker_ref.c (plain C, Box2D's own data
 // structures, no code shared with this file): tests/test_multiwalker_*.py compare the two step by step.
-// Lane-parallel execution keeps Box2D's results: the island's constraint sequence is cut into LEVELS by list
-// scheduling (a constraint's level = 1 + the highest level among earlier constraints that share a body with
-// it); constraints of one level touch disjoint bodies and commute exactly, so solving level by level -- on one
-// lane (CPU build) or on 16 (HIP kernel) -- gives the bits of the serial sweep.
+// Lane-parallel execution keeps Box2D's results: two constraints without a common body commute exactly, so any
+// schedule that keeps, for every body, the island's order of the constraints touching it gives the bits of the
+// serial sweep.  The solver runs on four lanes per env (build_islands: a walker's joints on its lane, the contacts
+// dealt out by a list schedule of rounds x positions); the continuous pass runs every body's chain of events on
+// its own lane and restores Box2D's world-wide event order afterwards (solve_toi).  The CPU build executes the
+// solver lanes one after the other, in either order.
 // Stated differences from the real library (same list as the oracle's header): D1 linear scan over
 // fat AABBs instead of b2DynamicTree, proxy ids in creation order as in a fresh b2World; D2 lidar = closest hit;
 // D3 Philox instead of numpy's Mersenne Twister; D4 a contact between two sleeping bodies is updated like any
@@ -391,7 +393,7 @@ struct Hot {
     float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
     double prev_shaping[MAX_WALKERS], prev_package_shaping;   // float64 like the reference's Python side (:403-411)
     uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, overflow;   // overflow: sticky, a contact did not fit its cache / the pool
-    uint8_t pending_reset, pad_;  // HIP build: this env runs the reset's trailing step in the current launch sequence (multiwalker.hip)
+    uint8_t pad_[2];
     uint32_t tick;                // observations of the current episode so far (noise draws)
     uint32_t episode;             // resets of this env so far (a reset's draws)
     uint32_t pad2_;
@@ -768,11 +770,10 @@ MW_HD bool is_lower_leg(int b) { return b >= 1 && ((b - 1) % 5 == 2 || (b - 1) %
 MW_HD void set_ground_flag(Hot &Wd, int b, bool on) { Wd.ground[(b - 1) / 5][(b - 1) % 5 == 2 ? 0 : 1] = on ? 1 : 0; }
 
 // ---------------------------------------------------------------- lane parallelism
-// The step is written once for a group of cooperating lanes (`Par`): SerialPar (CPU build: one lane that owns
-// everything, no-op sync) or a 16-lane group of a wavefront in the HIP kernel (four envs per wavefront).  Bodies and the
-// manifolds they own (their terrain contacts, and the pairs whose body B they are) by lane, one lane per revolute joint.
-// Constraints of one LEVEL of the schedule never share a body, so the lane-parallel sweep produces the bits of Box2D's
-// serial one (see the file header).
+// The step is written once for a group of cooperating lanes (`Par`): SerialPar (CPU build: one lane that owns every body,
+// no-op sync, and executes the four solver lanes one after the other) or a group of four lanes of a wavefront in the HIP
+// kernels (16 envs per wavefront).  Bodies by lane (body b on lane b % n) wherever the work is per body; the solver's and
+// the continuous pass's own mappings are described where they are built (build_islands, Model::toi_body).
 struct SerialPar {
     static constexpr int SOLVE_EMU = SOLVE_LANES;   // solver lanes this thread executes, one after the other
     static constexpr int MREG = 2;                  // manifolds a solver lane keeps in lane-private storage (the rest: the pool)
@@ -958,7 +959,7 @@ MW_HD void find_new_pair_contacts(const Model &M, const ColdView &Cd, uint32_t m
     }
 }
 
-// ---------------------------------------------------------------- islands (b2World::Solve) and the level schedule
+// ---------------------------------------------------------------- islands (b2World::Solve) and the solver schedule
 // The key of the contact in slot `si` seen from anywhere (its place in the world list and in both bodies' edge lists).
 MW_HD uint64_t slot_key(const Model &M, const ColdView &Cd, int si) {
     const Slot &sl = Cd.slot[si];
@@ -983,8 +984,8 @@ MW_HD int next_contact_edge(const Scratch &S, int nm, int b, uint64_t below, uin
 }
 
 // b2World::Solve's island construction, run by ONE lane: seeds in body-list order (last created body first), depth-first search
-// over contact edges then joint edges; the islands' joint and contact sequences are cut into levels (file header) and every body
-// gets the list of the manifolds it owns in ascending level.  A sleeping seed is skipped; every body reached is woken.
+// over contact edges then joint edges.  In that order the constraints get their place in the solver's schedule: a walker's joints on its
+// lane, every contact on the lane that can run it earliest (rounds x positions).  A sleeping seed is skipped; every body reached is woken.
 MW_HD void build_islands(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Manifold *MP) {
     const int NB = M.NB, NW = M.W;
     const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
@@ -1866,8 +1867,8 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
 
 // b2World::Step(1/50, 180, 60) for the lanes of `par`, in three phases -- the HIP build runs them as three kernels (the registers of
 // the narrow phase and of the time-of-impact root finder would otherwise be charged to the 180-sweep solver loop):
-//   step_collide   b2ContactManager::Collide + the island construction and level schedule of b2World::Solve
-//   step_solve     b2Island::Solve of every island (level by level), sleeping, SynchronizeFixtures, FindNewContacts
+//   step_collide   b2ContactManager::Collide + the island construction and solver schedule of b2World::Solve
+//   step_solve     b2Island::Solve of every island, sleeping;  step_post: SynchronizeFixtures, FindNewContacts
 //   solve_toi      b2World::SolveTOI
 template <class Par>
 MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Manifold *MP, Par par) {
@@ -1881,7 +1882,7 @@ MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, const ColdView &Cd, Scra
     par.sync();
     if (L0 == 0) for (int p = 0; p < NDP; ++p) collide_dyn_pair(M, Wd, Cd, S, MP, par, p);   // may wake bodies: one lane
     par.sync();
-    // ---- b2World::Solve: islands, constraint order and levels (one lane)
+    // ---- b2World::Solve: islands, constraint order and schedule (one lane)
     if (L0 == 0) build_islands(M, Wd, Cd, S, MP);
     par.sync();
 }

@@ -6,8 +6,8 @@
  * reference holds no golden vectors.  This file is NOT the independent restatement
  * (that is oracle/multiwalker_ref.c, which also replays Box2D's published HelloWorld output): it
  * compiles the same solver source the HIP kernel uses (madrl_amd/csrc/multiwalker_core.hpp,
- * host/device code) with g++ for the CPU.  It serves two checks: the GPU *port* (LDS staging, lane
- * mapping, level schedule) bit for bit against this build, and the ALGORITHM of that source against
+ * host/device code) with g++ for the CPU.  It serves two checks: the GPU *port* (LDS, lane
+ * mapping, launch sequence, spare records) bit for bit against this build, and the ALGORITHM of that source against
  * multiwalker_ref.c step by step (tests/test_multiwalker_cpu.py, no GPU needed).
  */
 #include <stdlib.h>
