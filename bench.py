@@ -2,19 +2,27 @@
 """bench.py -- env-steps/sec of the batched rollout engine (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --gpus 8 --workload pursuit_c5        # BASELINE configs[4]: 32x32, 16 v 60, 262 144 envs over 8 GPUs
 
 One "step" = one pass of the hot path over one batch: a single launch of the fused step kernel (pre-move reward, moves,
 catch resolution, observations, fused auto-reset) over `--envs` env instances per GPU (default 65 536 = BASELINE
 configs[1], PursuitEvade 16x16, 8 pursuers / 30 evaders, obs_range 7, surround).  Inputs (the pursuer action tensors) are
 resident in HBM before the timed region starts; evader actions are drawn in-kernel (Philox).  The env instances start the
 timed region at episode ages spread uniformly over [0, horizon), so EVERY launch carries its N / horizon share of fused
-auto-resets (the two-observation-pass path), as in a steady rollout.  N > 1: launched by torch.distributed.run, one rank
-per GPU, env index ranges sharded by rank (weak scaling), the compact trajectory (actions, rewards, dones) of the timed
-region is all-gathered over RCCL at the end, inside the timed region.
+auto-resets (the two-observation-pass path), as in a steady rollout.
+
+N > 1: one rank per GPU -- started by torch.distributed.run (the driver's command line), or by this script itself when it is
+invoked as plain `python bench.py --gpus N` (it re-executes itself under torch.distributed.run on 127.0.0.1).  Env index
+ranges are sharded by rank (weak scaling), the compact trajectory (actions, rewards, dones) of the timed region is
+all-gathered over RCCL at the end, inside the timed region.
+
+Timing: W untimed warm-up steps, then REPEATS regions of EXACTLY K steps, each bracketed by barrier + synchronize on both
+sides, max over ranks; `value` / `ms_per_step` are the MEDIAN region, `config.region_ms_per_step` lists all of them.
 
 Rank 0 prints ONE JSON line (contract in the task description) with `roofline` and `cpu_baseline`; at N = 1 the same line
 carries `workloads`: the other BASELINE configs (Waterworld configs[2], MultiWalker configs[3], the per-GPU shard of
-configs[4]) timed the same way for a bounded number of steps, each with its own roofline.
+configs[4]), the survey's secondary Pursuit mode and Waterworld under StandardizedEnv, timed the same way for a bounded
+number of steps, each with its own roofline and its own bounded cpu_baseline.
 
 cpu_baseline = the C restatement of the reference algorithm (oracle/, kind "port") timed LIVE on this box's host cores;
 when MADRL_REFERENCE_ROOT names a checkout of the reference (never the case on the GPU box, where the tree does not
@@ -32,7 +40,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0  # the same guide's measured copy rate (MI355X_MICROARCH.md:34-35): what a pure streaming kernel reaches
 VALU_PEAK_TFLOPS = 157.3  # FP32 vector peak, same guide
+REPEATS = 3             # timed K-step regions per workload (each bracketed by barrier + synchronize); the line reports the median
 
 
 def algorithmic_bytes_per_env_step(P, E, D, rec_bytes):
@@ -98,7 +108,7 @@ def cpu_reference_live(which, budget_steps=1200):
                        "OMP_NUM_THREADS=1, timed live on %s" % (which, r["processes"], r["steps_per_process"], r["cpu_model"]))
 
 
-def cpu_baseline_port(maps, kw, budget_s=12.0):
+def cpu_baseline_port(maps, kw, budget_s=10.0):
     """The C oracle (a port of the reference's algorithm) on the host cores, OpenMP over envs.
     Bounded sample of the same workload: 4096 envs, free-running, ~budget_s seconds."""
     import numpy as np
@@ -151,10 +161,8 @@ class Timer(object):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(self, step, K, W, tail=None):
+    def region(self, step, K, tail=None):
         import torch
-        for i in range(W):
-            step(i, False)
         self.barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -174,18 +182,58 @@ class Timer(object):
             dt = float(tmax.item())
         return dt, kernel_ms
 
+    def run(self, step, K, W, tail=None, prepare=None, repeats=REPEATS):
+        """-> (dt, kernel_ms) of the MEDIAN region (by wall time) and the list of all regions' ms per step.  `prepare` runs
+        before every region, outside it (receive buffers of the trajectory gather)."""
+        for i in range(W):
+            step(i, False)
+        regions = []
+        for _ in range(max(1, repeats)):
+            if prepare is not None:
+                prepare()
+            regions.append(self.region(step, K, tail))
+        order = sorted(range(len(regions)), key=lambda r: regions[r][0])
+        dt, kernel_ms = regions[order[len(order) // 2]]
+        return dt, kernel_ms, [r[0] / K * 1e3 for r in regions]
 
-def bench_pursuit(args, c5, K, W, rank, world, dev, cpu):
+
+def region_stats(region_ms):
+    s = sorted(region_ms)
+    return {"timed_regions": len(s), "region_ms_per_step": [round(x, 6) for x in region_ms], "region_ms_per_step_min": s[0],
+            "region_ms_per_step_median": s[len(s) // 2], "value_is": "median region"}
+
+
+def roofline(bytes_per, N, kernel_ms, traffic, kernel, **more):
+    achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+           "frac_vs_measured_copy": achieved / HBM_COPY_GBPS, "measured_copy_peak": HBM_COPY_GBPS,
+           "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
+           "algorithmic_bytes_per_launch": bytes_per * N, "kernel": kernel, "kernel_ms": kernel_ms,
+           "algorithmic_bytes_per_env_step": bytes_per}
+    out.update(more)
+    return out
+
+
+PURSUIT_VARIANTS = {
+    # name: (map side, pursuers, evaders, default envs per GPU, env kwargs)
+    "pursuit": (16, 8, 30, 65536, dict(n_catch=2, surround=True, flatten=True)),              # BASELINE configs[1]
+    "pursuit_c5": (32, 16, 60, 32768, dict(n_catch=2, surround=True, flatten=True)),          # configs[4], one GPU's shard
+    # SURVEY 8 preamble's secondary mode: heuristics/pursuit.py:66-67 (co-location catch, (R, R, 4) observations)
+    "pursuit_colocate": (16, 8, 30, 65536, dict(n_catch=4, surround=False, flatten=False)),
+}
+
+
+def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget):
     import numpy as np
     import torch
     from madrl_amd.maps import rectangle_map
     from madrl_amd.pursuit import BatchedPursuitEvade
     from madrl_amd import _lib
-    N, P, E, R = (args.envs or (32768 if c5 else 65536)), (16 if c5 else 8), (60 if c5 else 30), 7
-    MS = 32 if c5 else 16
+    MS, P, E, N0, mode = PURSUIT_VARIANTS[variant]
+    N, R = (args.envs or N0), 7
     H = args.horizon
     maps = [rectangle_map(MS, MS)]
-    kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, n_catch=2, surround=True, flatten=True, reward_mech="local")
+    kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, reward_mech="local", **mode)
     env = BatchedPursuitEvade(maps, n_envs=N, device=dev, seed=0, env_id_base=rank * N, max_steps=H,
                               auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw)
     D = env.obs_dim
@@ -212,7 +260,10 @@ def bench_pursuit(args, c5, K, W, rank, world, dev, cpu):
     if world > 1:
         from madrl_amd.dist import ChunkedTrajectoryGather
         gatherer = ChunkedTrajectoryGather()
-        gatherer.reserve(traj)   # receive buffers + RCCL channel setup stay out of the timed region
+
+    def prepare():
+        if gatherer is not None:
+            gatherer.reserve(traj)   # receive buffers + RCCL channel setup stay out of the timed region
 
     def one_step(i, record):
         rp, dp = slot_p[i] if (record and world > 1) else (rew_p, done_p)
@@ -233,13 +284,13 @@ def bench_pursuit(args, c5, K, W, rank, world, dev, cpu):
     env.reset()
     # steady state: episode ages uniform over [0, H) -- env n reaches the horizon (and runs the fused reset) at step H - age
     env.set_state(dict(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H))
-    dt, kernel_ms = Timer(world, dev).run(one_step, K, W, tail)
+    dt, kernel_ms, region_ms = Timer(world, dev).run(one_step, K, W, tail, prepare)
     if rank != 0:
         return None
     bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
-    achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
-    name = "pursuit_c5" if c5 else "pursuit"
-    traffic = measured_traffic(N, name)
+    fast = ("pursuit_group_kernel<%d,%d,%d,%d,%d,%d,2>" if P + E > 64 else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))
+    kname = fast if env.kernel_kind == "wave" else "pursuit_kernel<NT>"
+    catch = "surround, n_catch 2" if mode["surround"] else "co-location catch, n_catch %d" % mode["n_catch"]
     out = {
         "metric": "env-steps/sec at fixed batch (PursuitEvade %dx%d, %dv%d)" % (MS, MS, P, E),
         "value": world * N * K / dt,
@@ -254,46 +305,57 @@ def bench_pursuit(args, c5, K, W, rank, world, dev, cpu):
         "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
         "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset; episode ages "
                 "start uniform over [0, %d): every launch resets ~%d of its %d envs through the two-observation-pass path)" % (H, N // H, N),
-        "config": {"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, surround, "
-                               "n_catch 2, flatten, local reward, %d envs per GPU, horizon %d" % (MS, MS, P, E, N, H),
-                   "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world,
-                   "horizon_resets_per_env_in_timed_region": K / float(H),
-                   "horizon_resets_per_launch": N / float(H)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": traffic[0] if traffic else None,
-                     "traffic_source": traffic[1] if traffic else None,
-                     "algorithmic_bytes_per_launch": bytes_per * N,
-                     "kernel": ("pursuit_group_kernel<32,32,16,60,7,1,2>" if c5 else "pursuit_wave_kernel<16,16,8,30,7,1>") if env.kernel_kind == "wave" else "pursuit_kernel<NT>",
-                     "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_env_step": bytes_per},
+        "config": dict({"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, %s, %s, local reward, "
+                                    "%d envs per GPU, horizon %d" % (MS, MS, P, E, catch, "flatten" if mode["flatten"] else "(R,R,4) observations", N, H),
+                        "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world,
+                        "rccl_ranks": world, "collective_backend": (os.environ.get("MADRL_BENCH_BACKEND", "nccl") if world > 1 else None),
+                        "horizon_resets_per_env_in_timed_region": K / float(H),
+                        "horizon_resets_per_launch": N / float(H)}, **region_stats(region_ms)),
+        "roofline": roofline(bytes_per, N, kernel_ms, measured_traffic(N, variant), kname),
     }
-    if cpu:
-        attach_cpu_baselines(out, None if c5 else "pursuit", None if c5 else "pursuit_c1", lambda: cpu_baseline_port(maps, kw))
+    if cpu_budget:
+        c2 = variant == "pursuit"
+        attach_cpu_baselines(out, "pursuit" if c2 else None, "pursuit_c1" if c2 else None, lambda: cpu_baseline_port(maps, kw, cpu_budget))
     del env
     return out
 
 
-def bench_other(args, workload, K, W, rank, world, dev, cpu):
-    """Waterworld (BASELINE configs[2]), MultiWalker (configs[3]) and the hostage world on the same contract."""
+def bench_other(args, workload, K, W, rank, world, dev, cpu_budget):
+    """Waterworld (BASELINE configs[2]; `waterworld_std` = the same env under StandardizedEnv, which is how every reference run
+    wraps it, runners/run_waterworld.py / run_pursuit.py:57-58), MultiWalker (configs[3]) and the hostage world on the same contract."""
     import numpy as np
     import torch
     from madrl_amd import _lib
     L = _lib.lib()
     extra, flop_per_env_step, live_key, rec_key = {}, None, None, None
-    if workload == "waterworld":
+    if workload in ("waterworld", "waterworld_std"):
         from madrl_amd.waterworld import BatchedMAWaterWorld
         N = args.envs or 32768
         env = BatchedMAWaterWorld(5, 10, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
                                   max_blocks=args.max_blocks)
         acts = [(torch.rand((N, 5, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)]
-        outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
-        step = lambda i, rec: _lib.check(L.madrl_waterworld_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
-        bytes_per = 40 + 4 * 5 * env.obs_dim + 20 + 1 + 8 + 2 * (env._state.numel() // N)
-        kernel, binding = "waterworld_kernel<1,5,10,10,30>", "VALU / scalar-pipe issue of the sensing loop (profiles/*_waterworld/pmc_mix.txt), not HBM"
+        rec = env._state.numel() // N
+        sim_bytes = 40 + 20 + 1 + 8 + 2 * rec                 # actions, rewards, done, info, state record in + out
+        n_el = 5 * env.obs_dim
         workload_s = "MAWaterWorld 5 pursuers / 10 evaders / 10 poison / 30 sensors, n_coop 2, %d envs per GPU, timestep_limit 1000" % N
         H = 1000
-        live_key, rec_key = "waterworld", "waterworld_c3_single_env"
+        if workload == "waterworld":
+            outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
+            step = lambda i, rec: _lib.check(L.madrl_waterworld_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
+            bytes_per = sim_bytes + 4 * n_el
+            kernel, binding = "waterworld_kernel<1,5,10,10,30>", "VALU / scalar-pipe issue of the sensing loop (profiles/*_waterworld/pmc_mix.txt), not HBM"
+            live_key, rec_key = "waterworld", "waterworld_c3_single_env"
+        else:
+            from madrl_amd.wrappers import StandardizedEnv
+            wenv = StandardizedEnv(env, scale_reward=0.5, enable_obsnorm=True, enable_rewnorm=True)
+            assert wenv._fused, "the Waterworld engine fuses StandardizedEnv into its step kernel"
+            step = lambda i, rec: wenv.step(acts[i % 8])
+            # per observation element: float64 mean + var read and written (32 B) + the normalised float32 out (4 B); the raw row never
+            # reaches HBM.  Per agent: the reward statistics (32 B) + normalised reward (4 B).  DESIGN.md 4e
+            bytes_per = sim_bytes + 36 * n_el + 36 * 5
+            kernel = "waterworld_kernel<1,5,10,10,30> with the StandardizedEnv epilogue (madrl_waterworld_set_standardize)"
+            binding = "HBM: 32 of every 36 bytes are the per-env float64 running mean / variance (madrl_environments/__init__.py:242-257)"
+            workload_s = "StandardizedEnv(obsnorm, rewnorm) around " + workload_s
 
         def age():  # steady state: episode ages uniform over [0, 1000)
             env.set_state(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H)
@@ -306,11 +368,11 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu):
             o.reset()
             a = np.random.RandomState(0).uniform(-1, 1, (n, 5, 2)).astype(np.float32)
             t0 = time.time(); k = 0
-            while time.time() - t0 < 10:
+            while time.time() - t0 < cpu_budget:
                 o.step(a); k += 1
             dt = time.time() - t0
             return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
-                        sample="float32 C oracle (oracle/waterworld_oracle.c, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
+                        sample="float32 C oracle (oracle/waterworld_oracle.c, OpenMP; the simulation only, no wrapper), %d envs x %d steps, %.1f s" % (n, k, dt))
     elif workload == "hostage":
         from madrl_amd.hostage import BatchedContinuousHostageWorld
         N = args.envs or 32768
@@ -335,7 +397,7 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu):
             o.reset()
             a = np.random.RandomState(0).uniform(-1, 1, (n, 3, 2)).astype(np.float32)
             t0 = time.time(); k = 0
-            while time.time() - t0 < 10:
+            while time.time() - t0 < cpu_budget:
                 _, _, dn, _ = o.step(a); k += 1
                 if dn.any():
                     o.reset(mask=dn)
@@ -363,7 +425,7 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu):
         # over 12 joints and the active manifolds, and the serial sub-steps of the continuous pass, against ~25 KB; a launch ends with
         # its slowest wavefront (16 envs in lockstep), so the binding resource is the latency of the longest per-env chain
         binding = ("latency of the longest per-env chain of dependent FP32 operations (180 + 60 Gauss-Seidel sweeps, time-of-impact sub-steps): "
-                   "one wavefront per SIMD, 16 envs per wavefront; neither HBM nor VALU throughput (DESIGN.md 4c)")
+                   "neither HBM nor VALU throughput (DESIGN.md 4c)")
         flop_per_env_step, flop_src = env.flops_per_env_step()
         extra = {"flop_per_env_step": flop_per_env_step, "flop_source": flop_src}
         workload_s = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % N
@@ -375,46 +437,61 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu):
             pass   # episodes end by falling long before the horizon; the warm-up above reaches that steady state
 
         def cpu_fn():
-            from oracle import multiwalker as mwo
-            from oracle import pursuit as po
+            # the INDEPENDENT plain-C restatement (oracle/multiwalker_ref.c), not the product source compiled for the host
+            from oracle import multiwalker_ref as mwr
             n = 1024
-            o = mwo.MultiWalkerOracle(n_walkers=3, n_envs=n, seed=0)
+            o = mwr.MultiWalkerRef(n_walkers=3, n_envs=n, seed=0, position_noise=0.0, angle_noise=0.0, poly=True)
             o.reset()
             a = np.random.RandomState(0).uniform(-1, 1, (n, 3, 4)).astype(np.float32)
             t0 = time.time(); k = 0
-            while time.time() - t0 < 10:
+            while time.time() - t0 < cpu_budget:
                 _, _, d = o.step(a); k += 1
                 if d.any():
                     o.reset(mask=d)
             dt = time.time() - t0
-            return dict(value=n * k / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
-                        sample="CPU build of the solver source (oracle/multiwalker_oracle.cpp, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
+            return dict(value=n * k / dt, unit="env-steps/s", cores=int(o.L.mwr_num_threads()), kind="port",
+                        sample="independent C restatement of MultiWalkerEnv over a Box2D-2.3.0-ordered solver (oracle/multiwalker_ref.c, OpenMP; "
+                               "PARITY UNPINNED like the kernel), %d envs x %d steps, %.1f s" % (n, k, dt))
     env.reset()
     age()
-    dt, kernel_ms = Timer(world, dev).run(step, K, W)
+    dt, kernel_ms, region_ms = Timer(world, dev).run(step, K, W)
     if rank != 0:
         return None
-    achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
-    traffic = measured_traffic(N, workload)
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None, "kernel": kernel,
-            "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per, "binding_resource": binding}
-    cfg = {"workload": workload_s, "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world}
+    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(N, workload), kernel, binding_resource=binding)
+    cfg = {"workload": workload_s, "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world, "rccl_ranks": world}
+    cfg.update(region_stats(region_ms))
     if workload == "multiwalker":
         tf = flop_per_env_step * N / (kernel_ms * 1e-3) / 1e12
         roof.update({"valu_flops_achieved_TFLOPs": tf, "valu_peak_TFLOPs": VALU_PEAK_TFLOPS, "valu_frac": tf / VALU_PEAK_TFLOPS, **extra})
-        cfg["episode_ends_per_env_in_timed_region"] = float((done_rows[:K] != 0).sum().item()) / N
+        cfg["episode_ends_per_env_in_last_region"] = float((done_rows[:K] != 0).sum().item()) / N
     else:
         cfg["horizon_resets_per_env_in_timed_region"] = K / float(H)
     out = {"metric": "env-steps/sec at fixed batch (%s)" % workload, "value": world * N * K / dt, "unit": "env-steps/s",
            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32" if workload != "waterworld_std" else "f32 simulation, f64 running statistics",
            "data": "synthetic (uniform random actions resident in HBM, in-kernel Philox, fused auto-reset, steady-state episode ages)",
            "config": cfg, "roofline": roof}
-    if cpu:
+    if cpu_budget:
         attach_cpu_baselines(out, live_key, rec_key, cpu_fn)
     del env
     return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver's own
+    command line does the same thing explicitly)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+WORKLOADS = ["pursuit", "pursuit_c5", "pursuit_colocate", "waterworld", "waterworld_std", "multiwalker", "hostage"]
 
 
 def main():
@@ -423,9 +500,10 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=0, help="env instances per GPU (0 = the BASELINE config's batch)")
-    ap.add_argument("--workload", default="pursuit", choices=["pursuit", "pursuit_c5", "waterworld", "multiwalker", "hostage"],
+    ap.add_argument("--workload", default="pursuit", choices=WORKLOADS,
                     help="pursuit = BASELINE.json's metric (default, configs[1]); pursuit_c5 = configs[4]'s per-GPU shard "
-                         "(32x32, 16 v 60, 32 768 envs); the others are the remaining north_star envs")
+                         "(32x32, 16 v 60, 32 768 envs: `--workload pursuit_c5 --gpus 8` IS configs[4], 262 144 envs); pursuit_colocate = the "
+                         "survey's secondary catch mode; waterworld_std = Waterworld under StandardizedEnv; the others are the remaining north_star envs")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -433,12 +511,14 @@ def main():
     ap.add_argument("--horizon", type=int, default=500, help="max_path_length (runners/__init__.py:88)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)   # does not return
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with WORLD_SIZE=%d (got %d)" % (args.gpus, args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     backend = os.environ.get("MADRL_BENCH_BACKEND", "nccl")  # "gloo": exercise the N > 1 path with all ranks on one GPU (tests only)
     if backend == "gloo":
         local_rank = 0
@@ -452,24 +532,29 @@ def main():
             dist.init_process_group(backend)
 
     K, W = args.steps, args.warmup
-    cpu = (not args.no_cpu_baseline) and world == 1   # the CPU baseline is reported with the 1-GPU line only
-    if args.workload in ("pursuit", "pursuit_c5"):
-        out = bench_pursuit(args, args.workload == "pursuit_c5", K, W, rank, world, dev, cpu)
+    cpu = (not args.no_cpu_baseline) and world == 1   # the CPU baselines are reported with the 1-GPU line only
+    scale = float(os.environ.get("MADRL_BENCH_CPU_BUDGET", "1"))   # tests shorten the CPU samples
+    head_cpu, side_cpu = (10.0 * scale, 3.0 * scale) if cpu else (0, 0)
+    if args.workload.startswith("pursuit"):
+        out = bench_pursuit(args, args.workload, K, W, rank, world, dev, head_cpu)
     else:
-        out = bench_other(args, args.workload, K, W, rank, world, dev, cpu)
-    # The same driver run times every other BASELINE config (N = 1, default workload, default batch): bounded steps each
+        out = bench_other(args, args.workload, K, W, rank, world, dev, head_cpu)
+    # The same driver run times every other BASELINE config (N = 1, default workload, default batch): bounded steps and a bounded
+    # CPU sample (3 s) each
     if args.workload == "pursuit" and world == 1 and not args.no_workloads and not args.envs:
         wl = {}
-        for name, k, w in (("waterworld", min(K, 200), min(W, 20)), ("multiwalker", min(K, 50), W), ("pursuit_c5", min(K, 200), min(W, 20))):
+        for name, k, w in (("waterworld", min(K, 200), min(W, 20)), ("multiwalker", min(K, 50), W), ("pursuit_c5", min(K, 200), min(W, 20)),
+                           ("pursuit_colocate", min(K, 200), min(W, 20)), ("waterworld_std", min(K, 100), min(W, 20))):
             try:
-                r = bench_pursuit(args, True, k, w, rank, world, dev, False) if name == "pursuit_c5" else \
-                    bench_other(args, name, k, w, rank, world, dev, False)
-                wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
+                r = bench_pursuit(args, name, k, w, rank, world, dev, side_cpu) if name.startswith("pursuit") else \
+                    bench_other(args, name, k, w, rank, world, dev, side_cpu)
+                wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline") if f in r}
             except Exception as e:  # a failing side workload must not take the headline down; it shows up as an error entry
                 wl[name] = {"error": repr(e)}
         out["workloads"] = wl
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MADRL_ABI_VERSION 3
+#define MADRL_ABI_VERSION 4
 
 #define MADRL_OK 0
 #define MADRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -63,7 +63,8 @@ typedef struct madrl_pursuit_config {
                               same launch and its obs row holds the new episode's first obs */
     int32_t max_opponents; /* 0: fixed n_evaders; > 0: random_opponents with train_pursuit (:177-181): every reset creates
                               randint(1, max_opponents) evaders (at most n_evaders), the other slots count as gone */
-    int32_t train_pursuit; /* :105; 1 (the reference's default): the actions drive the pursuers.  0: evader control (:204-207,
+    int32_t control_evaders; /* = not train_pursuit (:105).  0 (a zero-initialised struct keeps the reference's default,
+                              train_pursuit=True): the actions drive the pursuers.  1: evader control (:204-207,
                               :215-224) -- action k moves the k-th REMAINING evader (layer order; n_pursuers actions per env, as
                               many as env.agents has entries), every pursuer moves by one pursuer_controller.act() draw
                               (in-kernel Philox, or entry j of the injected array, then [n_envs][n_pursuers]); observation row
@@ -142,7 +143,7 @@ int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t
  *                else is treated as 4 (stay) -- the reference raises IndexError instead;
  *   inj_evader_actions_dev  int32 [n_envs][E] or NULL: entry k is the action of the k-th
  *                REMAINING evader in layer order (one RandomPolicy.act per remaining evader,
- *                pursuit_evade.py:238-241); NULL = in-kernel Philox draws.  (train_pursuit = 0: the
+ *                pursuit_evade.py:238-241); NULL = in-kernel Philox draws.  (control_evaders = 1: the
  *                opponents are the pursuers, the array is [n_envs][P], entry j = pursuer j.)
  *   obs_dev      as in reset (IN/OUT);
  *   rew_dev      float32 [n_envs][P]  (computed in float64 like the reference, then rounded);
@@ -323,7 +324,6 @@ int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n
 int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device, void *state_dev,
                              madrl_multiwalker **out);
 void madrl_multiwalker_destroy(madrl_multiwalker *h);
-int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks);  /* kept for ABI compatibility: every 16 envs get their own wavefront */
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain);
 /* layout of the state buffer: first n_envs blocks of stride_bytes each -- the world record (world_bytes: bodies, flags, joints,
  * contacts, broad phase, terrain) followed by the step's scratch (solver schedule and manifolds, handed from launch to launch: one

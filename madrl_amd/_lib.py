@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MADRL_HIP_LIB") or os.path.join(_HERE, "libmadrl_hip.so")  # override: profiling variants only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
 
@@ -31,7 +31,7 @@ class PursuitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "xs", "ys", "n_pursuers", "n_evaders", "obs_range", "n_catch", "surround",
         "flatten", "include_id", "reward_global", "sample_maps", "n_maps", "max_steps",
-        "auto_reset", "max_opponents", "train_pursuit", "reserved0")] + [(n, C.c_double) for n in (
+        "auto_reset", "max_opponents", "control_evaders", "reserved0")] + [(n, C.c_double) for n in (
             "catchr", "term_pursuit", "urgency_reward", "layer_norm", "constraint_window")] + [
                 ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 
@@ -119,7 +119,6 @@ SIGNATURES = {
     "madrl_multiwalker_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
     "madrl_multiwalker_create": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
     "madrl_multiwalker_destroy": (None, [_vp]),
-    "madrl_multiwalker_set_launch": (C.c_int, [_vp, C.c_int64]),
     "madrl_multiwalker_dims": (C.c_int, [_vp, _vp, _vp]),
     "madrl_multiwalker_record_bytes": (C.c_int, [_vp, _vp, _vp]),
     "madrl_multiwalker_reset": (C.c_int, [_vp] * 4),

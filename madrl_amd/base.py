@@ -65,23 +65,28 @@ class AbstractMAEnv(object):
         return None
 
     def animate(self, act_fn, nsteps, **kwargs):
-        """:72-107 without the video encoder: one policy function per agent (or one for all), reset, then up to nsteps
-        steps or until done; returns (summed rewards per agent, stacked info dicts) like the reference."""
-        if not isinstance(act_fn, list):
-            act_fn = [act_fn for _ in range(len(self.agents))]
-        assert len(act_fn) == len(self.agents)
-        obs = self.reset()
-        rew = np.zeros((len(self.agents)))
-        traj_info_list = []
-        for step in range(nsteps):
-            a = list(map(lambda afn, o: afn(o), act_fn, obs))
-            obs, r, done, info = self.step(a)
-            rew += r
+        """Contract of AbstractMAEnv.animate (madrl_environments/__init__.py:72-107) for headless use: `act_fn` is one policy
+        callable per controllable agent, or a single callable shared by all of them; the env is reset and stepped with
+        `[policy_i(observation_i)]` until it reports done or `nsteps` steps have run.  Returns (per-agent reward totals,
+        the non-empty info dicts of the episode stacked key by key).  Frame capture and video encoding are out of scope
+        (`vid=` / `fps=` are accepted and ignored)."""
+        n_agents = len(self.agents)
+        policies = list(act_fn) if isinstance(act_fn, (list, tuple)) else [act_fn] * n_agents
+        if len(policies) != n_agents:
+            raise AssertionError("animate: %d policy functions for %d agents" % (len(policies), n_agents))
+        totals = np.zeros(n_agents)
+        infos = []
+        observations = self.reset()
+        t = 0
+        finished = False
+        while t < nsteps and not finished:
+            actions = [policy(o) for policy, o in zip(policies, observations)]
+            observations, rewards, finished, info = self.step(actions)
+            totals += rewards
             if info:
-                traj_info_list.append(info)
-            if done:
-                break
-        return rew, stack_dict_list(traj_info_list)
+                infos.append(info)
+            t += 1
+        return totals, stack_dict_list(infos)
 
     @property
     def unwrapped(self):

@@ -522,12 +522,6 @@ void madrl_multiwalker_destroy(madrl_multiwalker *h) {
     delete h;
 }
 
-int madrl_multiwalker_set_launch(madrl_multiwalker *h, int64_t max_blocks) {
-    if (!h || max_blocks < 0) return fail(MADRL_EINVAL, "set_launch: bad argument");
-    h->max_blocks = max_blocks;
-    return MADRL_OK;
-}
-
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain) {
     if (!h) return fail(MADRL_EINVAL, "handle is NULL");
     if (n_bodies) *n_bodies = h->NB;

@@ -662,7 +662,7 @@ const WaveEntry WAVE_TABLE[] = {
 
 const WaveEntry *find_wave(const madrl_pursuit_config *c) {
     if (c->flatten && !c->include_id) return nullptr;
-    if (!c->train_pursuit) return nullptr;  // evader control runs on the generic kernel
+    if (c->control_evaders) return nullptr;  // evader control runs on the generic kernel
     for (const WaveEntry &e : WAVE_TABLE) {
         const WaveGeom &g = e.g;
         if (g.xs == c->xs && g.ys == c->ys && g.P == c->n_pursuers && g.E == c->n_evaders && g.R == c->obs_range &&
@@ -688,12 +688,12 @@ int validate(const madrl_pursuit_config *c) {
     if (!(c->layer_norm > 0.0)) return fail(MADRL_EINVAL, "layer_norm must be > 0");
     if (!(c->constraint_window > 0.0 && c->constraint_window <= 1.0))
         return fail(MADRL_EINVAL, "constraint_window must be in (0,1]");
-    if (c->train_pursuit != 0 && c->train_pursuit != 1) return fail(MADRL_EINVAL, "train_pursuit must be 0 or 1");
-    if (!c->train_pursuit && c->n_evaders < c->n_pursuers)
-        return fail(MADRL_EINVAL, "train_pursuit=0: collect_obs walks range(n_pursuers) over evaders_gone (pursuit_evade.py:418-428): n_evaders=%d must be >= n_pursuers=%d",
+    if (c->control_evaders != 0 && c->control_evaders != 1) return fail(MADRL_EINVAL, "control_evaders must be 0 or 1");
+    if (c->control_evaders && c->n_evaders < c->n_pursuers)
+        return fail(MADRL_EINVAL, "control_evaders=1 (train_pursuit=False): collect_obs walks range(n_pursuers) over evaders_gone (pursuit_evade.py:418-428): n_evaders=%d must be >= n_pursuers=%d",
                     c->n_evaders, c->n_pursuers);
-    if (!c->train_pursuit && c->max_opponents != 0)
-        return fail(MADRL_EINVAL, "train_pursuit=0 with random_opponents (a per-reset number of pursuers, :180-181) is not supported");
+    if (c->control_evaders && c->max_opponents != 0)
+        return fail(MADRL_EINVAL, "control_evaders=1 (train_pursuit=False) with random_opponents (a per-reset number of pursuers, :180-181) is not supported");
     if (c->max_opponents != 0 && c->max_opponents < 2) return fail(MADRL_EINVAL, "max_opponents=%d: random_opponents draws randint(1, max_opponents)", c->max_opponents);
     return MADRL_OK;
 }
@@ -715,7 +715,7 @@ void layout(const madrl_pursuit_config *c, PursuitDev *d) {
     d->sample_maps = c->sample_maps; d->n_maps = c->n_maps; d->max_steps = c->max_steps;
     d->auto_reset = c->auto_reset;
     d->max_opponents = c->max_opponents;
-    d->train_pursuit = c->train_pursuit;
+    d->train_pursuit = !c->control_evaders;
     d->ngw = (d->E + 31) / 32; if (d->ngw < 1) d->ngw = 1;
     d->ntw = (d->A + 31) / 32;
     d->off_gone = (int)align_up(HDR_BYTES + 2 * (size_t)d->A, 4);

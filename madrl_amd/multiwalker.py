@@ -87,8 +87,6 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         _lib.check(L.madrl_multiwalker_create(C.byref(cfg), N, dev_index, _lib.ptr(self._state), C.byref(h)))
         self._handle = h
-        if self._max_blocks:
-            _lib.check(L.madrl_multiwalker_set_launch(h, self._max_blocks))
         nb, nt = C.c_int32(), C.c_int32()
         _lib.check(L.madrl_multiwalker_dims(h, C.byref(nb), C.byref(nt)))
         self.n_bodies, self.n_terrain = nb.value, nt.value
@@ -99,10 +97,6 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         self.package_scale = W / 1.75
         self.package_length = 240 / 30.0 * self.package_scale
         self.total_agents = W
-
-    def set_launch(self, max_blocks=0):
-        self._max_blocks = int(max_blocks)
-        _lib.check(_lib.lib().madrl_multiwalker_set_launch(self._handle, self._max_blocks))
 
     def _destroy(self):
         if getattr(self, "_handle", None):

@@ -107,7 +107,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
         c.max_steps, c.auto_reset = self.max_steps, int(self.auto_reset)
         # :177-181 (train_pursuit): every reset creates randint(1, max_opponents) evaders, at most the n_evaders slots
         c.max_opponents = int(self.max_opponents) if self.random_opponents else 0
-        c.train_pursuit = int(bool(self.train_pursuit))
+        c.control_evaders = int(not self.train_pursuit)
         c.catchr, c.term_pursuit = float(self.catchr), float(self.term_pursuit)
         c.urgency_reward, c.layer_norm = float(self.urgency_reward), float(self.layer_norm)
         c.constraint_window = float(self.constraint_window)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libmadrl_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "madrl_amd/_lib.py has no signature for %s" % n
-    assert L.madrl_abi_version() == _lib.ABI_VERSION == 3
+    assert L.madrl_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_host_philox_matches_published_vectors():
@@ -43,7 +43,7 @@ def _cfg(**over):
     c.struct_size = C.sizeof(_lib.PursuitConfig)
     c.xs = c.ys = 16
     c.n_pursuers, c.n_evaders, c.obs_range, c.n_catch = 8, 30, 7, 2
-    c.surround = c.flatten = c.include_id = c.train_pursuit = 1
+    c.surround = c.flatten = c.include_id = 1
     c.n_maps = 1
     c.layer_norm, c.constraint_window = 10.0, 1.0
     for k, v in over.items():
@@ -65,7 +65,7 @@ def test_obs_dim_and_state_bytes():
     assert r.value == 112  # 16 B header + 76 B positions + masks, 16-B aligned
     assert b.value == 65536 * (112 + 256)  # records, then the fast path's stale-zero masks (256 B per env): all caller-owned
     assert L.madrl_pursuit_state_bytes(C.byref(_cfg(n_pursuers=7)), 65536, C.byref(b)) == 0 and b.value == 65536 * 112  # no fast path
-    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(train_pursuit=0)), 1000, C.byref(b)) == 0 and b.value == 112128  # evader control: generic kernel only, records padded to 256 B
+    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(control_evaders=1)), 1000, C.byref(b)) == 0 and b.value == 112128  # evader control: generic kernel only, records padded to 256 B
 
 
 def test_invalid_configs_are_rejected_with_a_message():

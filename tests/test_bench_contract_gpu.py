@@ -38,20 +38,41 @@ def test_two_ranks_gather_path():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 70 and j["config"]["parallelism"] == "env-sharded x2" and "cpu_baseline" not in j
+    assert j["config"]["rccl_ranks"] == 2 and j["config"]["envs_total"] == 4096 and j["config"]["timed_regions"] == 3
+
+
+def test_plain_python_gpus_2_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no launcher around it (how the driver invokes the 1-GPU bench) must start its own two
+    ranks instead of exiting: the same code path the RCCL run takes, here over gloo on the one visible GPU"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MADRL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--envs", "2048", "--steps", "70", "--warmup", "5"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _last_json(r.stdout)
+    assert KEYS <= set(j) and j["n_gpus"] == 2 and j["steps"] == 70 and j["config"]["rccl_ranks"] == 2
+    assert j["config"]["collective_backend"] == "gloo" and j["value"] > 1e6
 
 
 def test_default_batch_line_carries_every_baseline_config():
     """the default invocation (BASELINE batch sizes) times Waterworld, MultiWalker and the configs[4] shard in the same run and
     reports them under `workloads`; every launch of the headline carries fused resets (steady-state episode ages)"""
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT,
+    env = dict(os.environ, MADRL_BENCH_CPU_BUDGET="0.5")   # every workload still runs its CPU sample, just a short one
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     assert KEYS <= set(j) and j["config"]["envs_per_gpu"] == 65536
     assert 0 < j["config"]["horizon_resets_per_env_in_timed_region"] < 1 and j["config"]["horizon_resets_per_launch"] > 100
     wl = j["workloads"]
-    assert set(wl) == {"waterworld", "multiwalker", "pursuit_c5"}
+    assert set(wl) == {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std"}
+    assert j["cpu_baseline"]["value"] > 0 and j["roofline"]["frac_vs_measured_copy"] > j["roofline"]["frac"]
+    assert len(j["config"]["region_ms_per_step"]) == 3 and j["config"]["region_ms_per_step_min"] <= j["ms_per_step"] + 1e-9
     for name, w in wl.items():
         assert "error" not in w, (name, w)
         assert w["value"] > 1e5 and w["roofline"]["frac"] > 0 and "workload" in w["config"], name
+        cb = w["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"], name
+    assert "multiwalker_ref.c" in wl["multiwalker"]["cpu_baseline"]["sample"]     # the independent restatement, not the product source
+    assert wl["pursuit_colocate"]["roofline"]["kernel"].startswith("pursuit_wave_kernel")
     assert wl["multiwalker"]["roofline"]["valu_frac"] > 0 and wl["multiwalker"]["config"]["envs_per_gpu"] == 16384
