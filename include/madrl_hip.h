@@ -118,6 +118,10 @@ int madrl_pursuit_kernel_kind(const madrl_pursuit *h, int32_t *out_kind);
  * and the maximum number of workgroups (0 = default: one per env for GENERIC, 5120 persistent
  * workgroups for WAVE); workgroups stride over envs. */
 int madrl_pursuit_set_launch(madrl_pursuit *h, int32_t threads, int64_t max_blocks);
+/* Order in which successive step launches of the fast path walk the env range: 0 = automatic (forward; alternating directions
+ * once a launch moves more than ~375 MB, so that the rows written last are the first ones touched again while they are still in
+ * the memory-side cache), 1 = always alternate, 2 = always forward.  Results do not depend on it. */
+int madrl_pursuit_set_walk(madrl_pursuit *h, int32_t mode);
 
 /* Replaces PursuitEvade.reset (pursuit_evade.py:173-207) for every env with mask[n] != 0
  * (mask_dev NULL = all).
@@ -324,6 +328,10 @@ int madrl_multiwalker_state_bytes(const madrl_multiwalker_config *cfg, int64_t n
 int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device, void *state_dev,
                              madrl_multiwalker **out);
 void madrl_multiwalker_destroy(madrl_multiwalker *h);
+/* How a step is issued.  fused: 0 (default) = three launches per b2World::Step (collide | solve | continuous pass + observe), 1 = one
+ * launch.  use_spares: 1 (default) = an env whose episode ends takes the next episode prepared ahead of time, 0 = every auto-reset
+ * runs the reset + trailing step in a second pass.  Results do not depend on either (tests/test_multiwalker_gpu.py). */
+int madrl_multiwalker_set_mode(madrl_multiwalker *h, int32_t fused, int32_t use_spares);
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain);
 /* layout of the state buffer: first n_envs blocks of stride_bytes each -- the world record (world_bytes: bodies, flags, joints,
  * contacts, broad phase, terrain) followed by the step's scratch (solver schedule and manifolds, handed from launch to launch: one

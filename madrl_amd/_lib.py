@@ -119,6 +119,8 @@ SIGNATURES = {
     "madrl_multiwalker_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
     "madrl_multiwalker_create": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
     "madrl_multiwalker_destroy": (None, [_vp]),
+    "madrl_multiwalker_set_mode": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "madrl_pursuit_set_walk": (C.c_int, [_vp, C.c_int32]),
     "madrl_multiwalker_dims": (C.c_int, [_vp, _vp, _vp]),
     "madrl_multiwalker_record_bytes": (C.c_int, [_vp, _vp, _vp]),
     "madrl_multiwalker_reset": (C.c_int, [_vp] * 4),

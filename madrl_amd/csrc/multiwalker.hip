@@ -232,7 +232,10 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
             uint32_t take = 0;
             if (d.cfg.auto_reset && *s_done != 0) {
                 const uint32_t rs = d.ready_step[env];
-                take = (rs != 0 && rs != SPARE_BUSY && rs != d.step_id) ? 1u : 2u;   // 1: the spare is ready, 2: the second launch
+                // the spare must hold THIS record's next episode: a caller that restored or teacher-forced the live records through
+                // state_buffer (Hot::episode included) leaves spares built for another episode behind -- those take the second launch
+                const uint32_t sp_episode = reinterpret_cast<const mw::Hot *>(d.spare_state + env * (int64_t)d.world_dw)->episode;
+                take = (rs != 0 && rs != SPARE_BUSY && rs != d.step_id && sp_episode == Wd.episode + 1u) ? 1u : 2u;   // 1: the spare is ready, 2: the second launch
             }
             d.pending[env] = take == 2 ? 1 : 0;
             *s_done |= take << 8;
@@ -454,7 +457,9 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     memset(&M, 0, sizeof(M));
     mw::build_model(M, cfg->n_walkers);
     M.continuous = cfg->discrete_only ? 0 : 1;
-    if (const char *e = getenv("MADRL_MW_TOI")) M.continuous = atoi(e);  // experiments: 0 = no continuous pass, 2 = candidates only
+#ifdef MADRL_EXPERIMENTS   // measurement builds only (scripts/variants.sh): the production library takes nothing from the process environment
+    if (const char *e = getenv("MADRL_MW_TOI")) M.continuous = atoi(e);  // 0 = no continuous pass, 2 = candidates only
+#endif
     h->NB = M.NB; h->NT = M.NT;
     hipError_t e = hipMalloc(&h->model_dev, sizeof(M));
     if (e == hipSuccess) e = hipMemcpy(h->model_dev, &M, sizeof(M), hipMemcpyHostToDevice);
@@ -488,8 +493,6 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
     h->step_id = 0;
     h->use_spares = 1;
     h->fused = 0;
-    if (const char *e = getenv("MADRL_MW_FUSED")) h->fused = atoi(e) != 0;         // experiments: the whole step in one launch
-    if (const char *e = getenv("MADRL_MW_SPARES")) h->use_spares = atoi(e) != 0;   // experiments: 0 = every auto-reset through pass 1
     d.ty_bytes = (int32_t)align_up((size_t)M.NT * 4, 16);
     d.toi_lane0_bytes = (int32_t)align_up((size_t)(M.slot_cap[0] > mw::EDGE_SLOTS_HULL ? M.slot_cap[0] : mw::EDGE_SLOTS_HULL) * 5, 16);
     {
@@ -504,12 +507,16 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
         d.lds_stride[3] = common + d.ty_bytes + (int32_t)align_up((size_t)wt, 16);
         // env g's block starts 4 LDS banks after env g-1's (mod 32 banks): neighbouring envs of a wavefront hit different banks
         for (int k = 0; k < 4; ++k) d.lds_stride[k] = (d.lds_stride[k] + 127 - 16) / 128 * 128 + 16;
-        if (getenv("MADRL_MW_LDS_EXTRA")) for (int k = 0; k < 4; ++k) d.lds_stride[k] += atoi(getenv("MADRL_MW_LDS_EXTRA"));   // experiments: occupancy vs LDS
+#ifdef MADRL_EXPERIMENTS
+        if (const char *e = getenv("MADRL_MW_LDS_EXTRA")) { const int x = atoi(e); if (x > 0 && x <= 32768) for (int k = 0; k < 4; ++k) d.lds_stride[k] += x / 16 * 16; }   // occupancy vs LDS
+#endif
     }
     d.n_envs = n_envs;
     d.model = (const mw::Model *)h->model_dev;
     d.state = (uint32_t *)state_dev;
+#ifdef MADRL_EXPERIMENTS
     if (getenv("MADRL_MW_VERBOSE")) fprintf(stderr, "multiwalker: LDS per env %d (one launch) | %d %d %d (collide, solve, continuous pass)\n", d.lds_stride[0], d.lds_stride[1], d.lds_stride[2], d.lds_stride[3]);
+#endif
     hipLaunchKernelGGL(mw_init_spares_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, 0, d);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(h->model_dev); delete h; return fail(MADRL_EHIP, "state buffer too small or not device memory"); }
     *out = h;
@@ -520,6 +527,13 @@ void madrl_multiwalker_destroy(madrl_multiwalker *h) {
     if (!h) return;
     if (h->model_dev) (void)hipFree(h->model_dev);
     delete h;
+}
+
+int madrl_multiwalker_set_mode(madrl_multiwalker *h, int32_t fused, int32_t use_spares) {
+    if (!h || (fused & ~1) || (use_spares & ~1)) return fail(MADRL_EINVAL, "set_mode: handle is NULL or a flag is not 0 / 1");
+    h->fused = fused;
+    h->use_spares = use_spares;
+    return MADRL_OK;
 }
 
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain) {

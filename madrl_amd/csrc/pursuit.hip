@@ -1056,8 +1056,7 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         }
     }
 
-    if (const char *e = getenv("MADRL_PURSUIT_WALK"))  // "alternate" / "forward": experiments and tests; read once, here
-        h->walk_mode = (e[0] == 'a') ? 1 : (e[0] == 'f') ? 2 : 0;
+    h->walk_mode = 0;
     h->max_blocks = 0;
     rc = madrl_pursuit_set_launch(h, 0, 0);
     if (rc) {
@@ -1067,6 +1066,12 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         return rc;
     }
     *out = h;
+    return MADRL_OK;
+}
+
+int madrl_pursuit_set_walk(madrl_pursuit *h, int32_t mode) {
+    if (!h || mode < 0 || mode > 2) return fail(MADRL_EINVAL, "set_walk: mode must be 0 (auto), 1 (alternate) or 2 (forward)");
+    h->walk_mode = mode;
     return MADRL_OK;
 }
 

@@ -87,6 +87,8 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         _lib.check(L.madrl_multiwalker_create(C.byref(cfg), N, dev_index, _lib.ptr(self._state), C.byref(h)))
         self._handle = h
+        if getattr(self, "_mode", (0, 1)) != (0, 1):
+            _lib.check(L.madrl_multiwalker_set_mode(h, *self._mode))
         nb, nt = C.c_int32(), C.c_int32()
         _lib.check(L.madrl_multiwalker_dims(h, C.byref(nb), C.byref(nt)))
         self.n_bodies, self.n_terrain = nb.value, nt.value
@@ -97,6 +99,12 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         self.package_scale = W / 1.75
         self.package_length = 240 / 30.0 * self.package_scale
         self.total_agents = W
+
+    def set_mode(self, fused=False, use_spares=True):
+        """How a step is issued (same results either way): `fused` = one launch per b2World::Step instead of three; `use_spares` =
+        auto-reset through the episodes prepared ahead of time (False: every auto-reset takes the second pass)."""
+        self._mode = (int(bool(fused)), int(bool(use_spares)))
+        _lib.check(_lib.lib().madrl_multiwalker_set_mode(self._handle, *self._mode))
 
     def _destroy(self):
         if getattr(self, "_handle", None):

@@ -157,6 +157,8 @@ class BatchedPursuitEvade(AbstractMAEnv):
             _lib.check(L.madrl_pursuit_set_launch(h, self._threads, self._max_blocks))
         if getattr(self, "_kernel", "auto") != "auto":
             self.set_kernel(self._kernel)
+        if getattr(self, "_walk", "auto") != "auto":
+            self.set_walk(self._walk)
         obs_shape = (D,) if self.flatten else (self.obs_range, self.obs_range, 4)
         self.pursuers = [PursuitAgent(obs_shape) for _ in range(P)]
         self.act_dims = [5] * P
@@ -172,6 +174,12 @@ class BatchedPursuitEvade(AbstractMAEnv):
         out = C.c_int32()
         _lib.check(_lib.lib().madrl_pursuit_kernel_kind(self._handle, C.byref(out)))
         return {_lib.KERNEL_GENERIC: "generic", _lib.KERNEL_WAVE: "wave"}[out.value]
+
+    def set_walk(self, mode):
+        """'auto' | 'alternate' | 'forward': the order in which successive launches of the fast path walk the env range (a
+        memory-side cache matter for large batches; results do not depend on it)"""
+        _lib.check(_lib.lib().madrl_pursuit_set_walk(self._handle, {"auto": 0, "alternate": 1, "forward": 2}[mode]))
+        self._walk = mode
 
     def set_launch(self, threads=0, max_blocks=0):
         self._threads, self._max_blocks = int(threads), int(max_blocks)
@@ -238,8 +246,11 @@ class BatchedPursuitEvade(AbstractMAEnv):
             mask = torch.as_tensor(mask, device=self.device).reshape(N).to(torch.uint8).contiguous()
         pos = self._i32(positions, (N, A, 2), "positions")
         mid = self._i32(map_ids, (N,), "map_ids")
+        if mask is not None and getattr(self, "_needs_reset", False):
+            raise RuntimeError("the agent counts changed (update_curriculum / set_param_values): the whole batch must be reset() once")
         _lib.check(_lib.lib().madrl_pursuit_reset(self._handle, _lib.ptr(mask), _lib.ptr(pos), _lib.ptr(mid),
                                                   _lib.ptr(self._obs), self._stream()))
+        self._was_reset, self._needs_reset = True, False
         return self._obs_view()
 
     def step(self, actions, evader_actions=None, rew_out=None, done_out=None):
@@ -248,6 +259,9 @@ class BatchedPursuitEvade(AbstractMAEnv):
         rew_out float32 [N, P] / done_out uint8 [N]: optional contiguous destinations (e.g. a slot of a trajectory tensor) the
         kernel writes instead of the env's own buffers -- the C ABI takes any device pointer, no copy afterwards."""
         N, P, E = self.n_envs, int(self.n_pursuers), int(self.n_evaders)
+        if getattr(self, "_needs_reset", False):
+            raise RuntimeError("update_curriculum / set_param_values changed the agent counts: the running episodes cannot continue "
+                               "(the reference applies new counts at the next reset(), pursuit_evade.py:173-199) -- call reset() first")
         act = self._i32(actions, (N, P), "actions")
         # evader control (train_pursuit=False): the opponents are the pursuers, one injected action per pursuer
         eact = self._i32(evader_actions, (N, E if self.train_pursuit else P), "evader_actions")
@@ -297,7 +311,16 @@ class BatchedPursuitEvade(AbstractMAEnv):
         if self._handle is not None and self._create_key() == getattr(self, "_handle_key", None):
             _lib.check(_lib.lib().madrl_pursuit_set_params(self._handle, float(self.catchr), float(self.constraint_window)))
         else:
+            # Something the handle bakes in changed (agent counts, map, observation shape): the handle is re-created, and when the
+            # state layout changed with it the state starts from the constructor's (every agent at (0, 0)).  In the reference the
+            # running episode goes on with the old agents and the new counts take effect at the next reset() (:173-199); here the
+            # running episodes cannot continue, so step() refuses until reset() has been called.
+            had_episode, key = getattr(self, "_was_reset", False), getattr(self, "_shape_key", None)
             self.setup()
+            if had_episode and key != self._shape_key:
+                self._needs_reset = True
+            if self._cw_env is not None:   # the per-env curriculum arrays belong to the env object, not to the handle
+                _lib.check(_lib.lib().madrl_pursuit_set_curriculum(self._handle, _lib.ptr(self._cw_env), _lib.ptr(self._catchr_env)))
 
     @staticmethod
     def curriculum_next(itr, constraint_window, n_evaders, n_pursuers, catchr, constrain_rate, remove_every, turn_off_shaping):
@@ -411,13 +434,18 @@ class BatchedPursuitEvade(AbstractMAEnv):
         # curriculum attributes travel with the pickle (pursuit_evade.py:397-411)
         d["curriculum"] = dict(constraint_window=self.constraint_window, n_evaders=self.n_evaders,
                                n_pursuers=self.n_pursuers, catchr=self.catchr)
+        if self._cw_env is not None:   # the per-env curriculum (update_curriculum(itr, mask=) / set_curriculum) travels too
+            d["curriculum_env"] = dict(constraint_window=self._cw_env.cpu().numpy(), catchr=self._catchr_env.cpu().numpy())
         return d
 
     def __setstate__(self, d):
         cur = d.pop("curriculum", {})
+        cur_env = d.pop("curriculum_env", None)
         kwargs = d.pop("kwargs")
         kwargs.update(cur)
         self.__init__(d.pop("map_pool"), **d, **kwargs)
+        if cur_env is not None:
+            self.set_curriculum(**cur_env)
 
 
 class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):

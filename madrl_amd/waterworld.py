@@ -118,8 +118,12 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         # fresh ones, so that the wrapper keeps receiving standardised rows.
         old, self._std = getattr(self, "_std", None), None
         if old is not None:
-            keep = old if tuple(old["obs_out"].shape) == (N, Np, D) else None
-            self.bind_standardize(tensors=keep, **self._std_kwargs)
+            if tuple(old["obs_out"].shape) == (N, Np, D):
+                self.bind_standardize(tensors=old, **self._std_kwargs)
+            else:   # new shapes: fresh statistics, handed to the wrapper through the SAME dict object it holds
+                fresh = self.bind_standardize(tensors=None, **self._std_kwargs)
+                old.clear(); old.update(fresh)
+                self._std = old
 
     def set_launch(self, max_blocks=0):
         self._max_blocks = int(max_blocks)

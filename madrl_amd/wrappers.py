@@ -177,16 +177,27 @@ class StandardizedEnv(_Wrapper):
         super().__init__(env)
         self._scale_reward, self._enable_obsnorm, self._enable_rewnorm = scale_reward, enable_obsnorm, enable_rewnorm
         self._obs_alpha, self._rew_alpha, self._eps = obs_alpha, rew_alpha, eps
-        self._obs_mean = self._obs_var = self._rew_mean = self._rew_var = None
+        self._own = dict(obs_mean=None, obs_var=None, rew_mean=None, rew_var=None)   # epilogue path: this wrapper's own statistics
+        self._fused_state = None
         self._obs_out = self._rew_out = None
         self._fused = False
         if fused is not False and not self._single and hasattr(self._unwrapped, "bind_standardize"):
             st = self._unwrapped.bind_standardize(scale_reward=scale_reward, enable_obsnorm=enable_obsnorm, enable_rewnorm=enable_rewnorm,
                                                   obs_alpha=obs_alpha, rew_alpha=rew_alpha, eps=eps)
-            self._obs_mean, self._obs_var, self._rew_mean, self._rew_var = st["obs_mean"], st["obs_var"], st["rew_mean"], st["rew_var"]
+            self._fused_state = st   # the env re-fills this same dict when a shape change makes it start new statistics
             self._fused = True
         elif fused:
             raise ValueError("fused=True needs an env with bind_standardize() directly below this wrapper")
+
+    def _stat(name):
+        def get(self):
+            return (self._fused_state if self._fused else self._own)[name]
+
+        def put(self, v):
+            (self._fused_state if self._fused else self._own)[name] = v
+        return property(get, put)
+    _obs_mean, _obs_var, _rew_mean, _rew_var = _stat("obs_mean"), _stat("obs_var"), _stat("rew_mean"), _stat("rew_var")
+    del _stat
 
     def _norm_obs(self, obs):
         if not self._enable_obsnorm:

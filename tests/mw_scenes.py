@@ -1,0 +1,393 @@
+"""Known-answer scenes for the MultiWalker dynamics (test infrastructure).
+
+PARITY STAYS UNPINNED: none of this is Box2D output.  Each scene drives the env into a situation whose outcome is known
+analytically or from Box2D's published constants, and runs through every restatement of the physics this repo has -- the
+independent plain-C world (oracle/multiwalker_ref.c), the product's solver source compiled for the host
+(oracle/multiwalker_oracle.cpp) and the HIP kernels (through the C ABI) -- to narrow what the "Hello Box2D" replay leaves open:
+
+  * motorised revolute joints running at their motor speed and stopping at their limits (multi_walker.py:145-179, :194-203;
+    b2RevoluteJoint motor, limit states, position correction to within b2_angularSlop), with momentum conserved in free fall;
+  * a box on a tilted chain of b2EdgeShapes (:617-620) with mixed friction sqrt(0.5 * 2.5): sticks below atan(mu), slides above it
+    with a = g (sin t - mu cos t) (b2CollideEdgeAndPolygon, two-point manifolds, friction clamped by the normal impulse);
+  * an island coming to rest and going to sleep exactly b2_timeToSleep after it dropped below the sleep tolerances;
+  * a thin box arriving at an edge faster than its own thickness per step: tunnels without the continuous pass, rests at
+    2 * polygonRadius - linearSlop with it (b2World::SolveTOI);
+  * the stateful gait gym's BipedalWalker demo uses (of which heuristics/multi_walker.py:16-86 is a copy whose state machine
+    restarts on every call) walking the package to the end of a flat terrain.
+"""
+import numpy as np
+
+SCALE = 30.0
+FPS = 50.0
+TERRAIN_STEP = 14 / SCALE
+TERRAIN_HEIGHT = 400 / SCALE / 4
+LINEAR_SLOP, ANGULAR_SLOP = 0.005, 2.0 / 180.0 * np.pi
+POLY_RADIUS = 2 * LINEAR_SLOP
+SPEED_HIP, SPEED_KNEE = 4.0, 6.0
+HIP_LIM, KNEE_LIM = (-0.8, 1.1), (-1.6, -0.1)
+G = 10.0
+MU_PACKAGE_TERRAIN = float(np.sqrt(np.float32(0.5) * np.float32(2.5)))   # b2MixFriction
+TIME_TO_SLEEP, LIN_SLEEP_TOL, ANG_SLEEP_TOL = 0.5, 0.01, 2.0 / 180.0 * np.pi
+PKG_HALF_H = 5 / SCALE
+
+
+class Backend(object):
+    """one interface over the three restatements; arrays are numpy on every side"""
+
+    def __init__(self, kind, n_envs, n_walkers=3, continuous=True, terminate_on_fall=True, seed=0):
+        self.kind, self.N, self.W = kind, n_envs, n_walkers
+        kw = dict(n_walkers=n_walkers, n_envs=n_envs, seed=seed, position_noise=0.0, angle_noise=0.0, terminate_on_fall=terminate_on_fall)
+        if kind == "ref":
+            from oracle import multiwalker_ref as mwr
+            self.o = mwr.MultiWalkerRef(poly=True, continuous_physics=continuous, **kw)
+        elif kind == "core":
+            from oracle import multiwalker as mwo
+            self.o = mwo.MultiWalkerOracle(**kw)
+            self.o.L.mwo_set_continuous.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]
+            self.o.L.mwo_set_continuous(self.o.h, int(continuous))
+        elif kind == "hip":
+            from madrl_amd.multiwalker import BatchedMultiWalkerEnv
+            self.o = BatchedMultiWalkerEnv(device="cuda:0", continuous_physics=continuous, **kw)
+        else:
+            raise ValueError(kind)
+        self.NT = int(200 * n_walkers / 8)
+
+    def reset(self, terrain=None, push=None):
+        if terrain is None and push is None:
+            obs = self.o.reset()
+        elif self.kind == "ref":
+            obs = self.o.reset(terrain=terrain, push=push)
+        else:
+            obs = self.o.reset_with(terrain=terrain, push=push)
+        return self._np(obs)
+
+    @staticmethod
+    def _np(a):
+        return a.detach().cpu().numpy().astype(np.float64) if hasattr(a, "detach") else np.asarray(a, np.float64).copy()
+
+    def step(self, actions):
+        if self.kind == "hip":
+            import torch
+            obs, rew, done, _ = self.o.step(torch.as_tensor(np.asarray(actions, np.float32), device="cuda:0"))
+            return self._np(obs), self._np(rew), done.cpu().numpy().astype(bool)
+        obs, rew, done = self.o.step(actions)
+        return self._np(obs), self._np(rew), np.asarray(done).astype(bool).copy()
+
+    def bodies(self):
+        if self.kind == "ref":
+            return self.o.bodies().astype(np.float64)
+        if self.kind == "core":
+            return self.o.bodies()[0].astype(np.float64)
+        return self._np(self.o.get_state()["bodies"])
+
+    def set_bodies(self, b):
+        if self.kind == "hip":
+            self.o.set_state(bodies=np.asarray(b, np.float32))
+        else:
+            self.o.set_bodies(np.asarray(b, np.float32))
+
+    def aux(self):
+        """[N, NB, 6]: fat AABB (4), sleep time, awake"""
+        if self.kind == "hip":
+            return self._np(self.o.get_state()["aux"])
+        return self.o.aux().astype(np.float64)
+
+    def flags(self):
+        """[N, 1 + 3W]: game_over, fallen[W], ground contact [W][2]"""
+        if self.kind == "ref":
+            return self.o.flags().copy()
+        if self.kind == "core":
+            return self.o.bodies()[1].copy()
+        return self.o.get_state()["flags"].cpu().numpy()[:, :1 + 3 * self.W]
+
+    def masses(self):
+        """(mass, rotational inertia) per body [NB, 2] from the shapes of multi_walker.py:17-47 (independent of every backend)"""
+        hull = np.array([(-30, 9), (6, 9), (34, 1), (34, -8), (-30, -8)], float) / SCALE
+        out = [_box_mass(240 / SCALE * self.W / 1.75 / 2, PKG_HALF_H, 1.0)]
+        for _ in range(self.W):
+            out.append(_poly_mass(hull, 5.0))
+            for k in range(2):
+                out.append(_box_mass(8 / SCALE / 2, 34 / SCALE / 2, 1.0))
+                out.append(_box_mass(0.8 * 8 / SCALE / 2, 34 / SCALE / 2, 1.0))
+        return np.array(out)
+
+
+def _box_mass(hx, hy, density):
+    m = density * 4 * hx * hy
+    return m, m * (4 * hx * hx + 4 * hy * hy) / 12.0
+
+
+def _poly_mass(v, density):
+    """b2PolygonShape::ComputeMass by the textbook formulas: area, centroid, inertia about the centroid"""
+    x, y = v[:, 0], v[:, 1]
+    xn, yn = np.roll(x, -1), np.roll(y, -1)
+    cr = x * yn - xn * y
+    area = 0.5 * cr.sum()
+    cx, cy = ((x + xn) * cr).sum() / (6 * area), ((y + yn) * cr).sum() / (6 * area)
+    ixx = ((y * y + y * yn + yn * yn) * cr).sum() / 12.0
+    iyy = ((x * x + x * xn + xn * xn) * cr).sum() / 12.0
+    m = density * abs(area)
+    return m, density * abs(ixx + iyy) - m * (cx * cx + cy * cy)
+
+
+def hull_centroid():
+    hull = np.array([(-30, 9), (6, 9), (34, 1), (34, -8), (-30, -8)], float) / SCALE
+    x, y = hull[:, 0], hull[:, 1]
+    xn, yn = np.roll(x, -1), np.roll(y, -1)
+    cr = x * yn - xn * y
+    a = 0.5 * cr.sum()
+    return np.array([((x + xn) * cr).sum() / (6 * a), ((y + yn) * cr).sum() / (6 * a)])
+
+
+# ------------------------------------------------------------------------------------------------ scene 1: motors and limits in free fall
+def scene_motor_limits(be, steps=40, lift=30.0):
+    """Every body lifted `lift` metres (nothing touches anything), all velocities zero; constant full actions: hips +1 / -1, knees -1 / +1.
+    Returns per step: joint angles [T, N, W, 4], joint speeds [T, N, W, 4], centre-of-mass height and vertical velocity of each walker
+    [T, N, W], angular momentum of each walker about its centre of mass [T, N, W]."""
+    be.reset()
+    b = be.bodies()
+    b[:, :, 1] += lift
+    b[:, 0, 1] += 10.0          # the package further up still: it must not land on the hulls within the scene
+    b[:, :, 3:] = 0.0
+    be.set_bodies(b)
+    act = np.tile(np.array([1.0, -1.0, -1.0, 1.0], np.float32), (be.N, be.W, 1))
+    ms = be.masses()
+    m, inertia = ms[:, 0], ms[:, 1]
+    ang, spd, comy, comvy, L = [], [], [], [], []
+    for t in range(steps):
+        be.step(act)
+        q = be.bodies()
+        a_t, s_t, cy_t, cv_t, L_t = [], [], [], [], []
+        for w in range(be.W):
+            h, ul, ll, ur, lr = (1 + 5 * w + k for k in range(5))
+            pairs = ((h, ul), (ul, ll), (h, ur), (ur, lr))
+            a_t.append(np.stack([q[:, bb, 2] - q[:, aa, 2] for aa, bb in pairs], -1))
+            s_t.append(np.stack([q[:, bb, 5] - q[:, aa, 5] for aa, bb in pairs], -1))
+            ids = [h, ul, ll, ur, lr]
+            mw = m[ids]
+            c = (q[:, ids, 0:2] * mw[None, :, None]).sum(1) / mw.sum()
+            v = (q[:, ids, 3:5] * mw[None, :, None]).sum(1) / mw.sum()
+            cy_t.append(c[:, 1]); cv_t.append(v[:, 1])
+            r = q[:, ids, 0:2] - c[:, None]
+            dv = q[:, ids, 3:5] - v[:, None]
+            L_t.append((inertia[ids][None] * q[:, ids, 5] + mw[None] * (r[..., 0] * dv[..., 1] - r[..., 1] * dv[..., 0])).sum(1))
+        ang.append(np.stack(a_t, 1)); spd.append(np.stack(s_t, 1)); comy.append(np.stack(cy_t, 1)); comvy.append(np.stack(cv_t, 1)); L.append(np.stack(L_t, 1))
+    return dict(angle=np.array(ang), speed=np.array(spd), com_y=np.array(comy), com_vy=np.array(comvy), L=np.array(L))
+
+
+def check_motor_limits(r):
+    T = r["angle"].shape[0]
+    h = 1.0 / FPS
+    # free fall: joint impulses are internal -- the centre of mass of a walker follows semi-implicit Euler exactly, its angular
+    # momentum stays what it was (zero)
+    n = np.arange(1, T + 1)
+    assert np.abs(r["com_vy"] + G * h * n[:, None, None]).max() < 2e-3, "centre-of-mass velocity of a walker in free fall"
+    dy = r["com_y"] - r["com_y"][0]
+    assert np.abs(dy + G * h * h * (n * (n + 1) / 2 - 1)[:, None, None]).max() < 5e-3, "centre-of-mass height of a walker in free fall"
+    # angular momentum about the centre of mass: the velocity solver's impulses are internal and conserve it; Box2D's position
+    # correction moves bodies without touching velocities, which shifts r x m v a little (0.04 at most here, against the ~0.5 kg m^2 / s
+    # the hull and the legs exchange while the motors run)
+    assert np.abs(r["L"]).max() < 6e-2, "angular momentum about the centre of mass (internal torques only): %g" % np.abs(r["L"]).max()
+    # (target speed, limit reached, the other limit) per joint under the scene's actions
+    spec = [(+SPEED_HIP, HIP_LIM[1], HIP_LIM[0]), (-SPEED_KNEE, KNEE_LIM[0], KNEE_LIM[1]), (-SPEED_HIP, HIP_LIM[0], HIP_LIM[1]), (+SPEED_KNEE, KNEE_LIM[1], KNEE_LIM[0])]
+    for j, (target, lim, _) in enumerate(spec):
+        a, s = r["angle"][..., j], r["speed"][..., j]
+        sign = np.sign(target)
+        inside = sign * (lim - a) > abs(target) * h + 0.02        # more than one step of travel away from the limit
+        moving = inside[1:] & inside[:-1]
+        if moving.any():   # the motor holds its speed: enough torque (80 N m against legs of < 0.2 kg m^2), b2RevoluteJoint motor constraint
+            assert np.abs(s[1:][moving] - target).max() < 0.05, "joint %d: motor speed %g, seen %s" % (j, target, s[1:][moving][:5])
+            da = np.diff(a, axis=0)[moving]
+            # (the position iterations rotate the light legs a little on top of that -- anchor corrections, and the neighbouring knee
+            # being pulled inside its limit: 5 - 6 % of a step on average for the knees, a quarter of a step at worst)
+            assert np.abs(da - target * h).max() < 0.3 * abs(target) * h and abs(da.mean() - target * h) < 0.1 * abs(target) * h, "joint %d: angle advances by speed * dt" % j
+        # at the limit: Box2D does not anticipate a limit, so the step that crosses it may end less than one step of travel beyond;
+        # the position solver brings the joint back to within b2_angularSlop and it stays there
+        over = sign * (a - lim)
+        assert over.max() < abs(target) * h, "joint %d overshoots its limit by %g" % (j, over.max())
+        last = over[-8:]
+        assert (last > -ANGULAR_SLOP - 1e-3).all() and (last < ANGULAR_SLOP + 1e-3).all(), "joint %d rests within b2_angularSlop of its limit: %s" % (j, last[:, 0, 0])
+        assert np.abs(s[-8:]).max() < 0.05, "joint %d: no relative speed left at the limit" % j
+    # knee 1 starts ABOVE its upper limit (the legs are created straight, :136-163: angle 0 > -0.1): the limit pulls it inside
+    return True
+
+
+# ------------------------------------------------------------------------------------------------ scene 2: friction on a tilted chain of edges
+def slope_terrain(NT, theta):
+    return TERRAIN_HEIGHT + 40.0 - np.tan(theta) * TERRAIN_STEP * np.arange(NT)
+
+
+def scene_slope(be, theta, steps=60):
+    """One walker (package 4.6 m long), the terrain a straight descending line at angle theta; the walker is lifted out of the way, the package
+    laid on the slope at rest.  Returns the package's velocity along the slope and its distance from the slope surface per step."""
+    assert be.W == 1
+    ty = slope_terrain(be.NT, theta)
+    be.reset(terrain=np.tile(ty, (be.N, 1)), push=np.zeros((be.N, be.W)))
+    b = be.bodies()
+    b[:, 1:, 1] += 200.0                      # the walker: far above, falls for the whole scene without arriving
+    b[:, :, 3:] = 0.0
+    x0 = 4.0                                  # package centre over the straight part
+    surf = TERRAIN_HEIGHT + 40.0 - np.tan(theta) * x0
+    nrm = np.array([np.sin(theta), np.cos(theta)])
+    gap = PKG_HALF_H + 2 * POLY_RADIUS - LINEAR_SLOP
+    b[:, 0, 0] = x0 + nrm[0] * gap
+    b[:, 0, 1] = surf + nrm[1] * gap
+    b[:, 0, 2] = -theta
+    be.set_bodies(b)
+    tang = np.array([np.cos(theta), -np.sin(theta)])
+    v_t, dist, ang = [], [], []
+    for t in range(steps):
+        be.step(np.zeros((be.N, be.W, 4), np.float32))
+        q = be.bodies()[:, 0]
+        v_t.append(q[:, 3] * tang[0] + q[:, 4] * tang[1])
+        dist.append((q[:, 0] - x0) * nrm[0] + (q[:, 1] - surf) * nrm[1] - PKG_HALF_H)
+        ang.append(q[:, 2] + theta)
+    return dict(v_t=np.array(v_t), dist=np.array(dist), ang=np.array(ang), flags=be.flags())
+
+
+# ------------------------------------------------------------------------------------------------ scene 3: rest and sleep
+def scene_sleep(be, steps=120):
+    """Flat terrain, walkers lifted out of the way, the package dropped from 0.3 m.  Returns per step the package's speed, sleep time, awake flag."""
+    ty = np.full(be.NT, TERRAIN_HEIGHT)
+    be.reset(terrain=np.tile(ty, (be.N, 1)), push=np.zeros((be.N, be.W)))
+    b = be.bodies()
+    b[:, 1:, 1] += 400.0
+    b[:, :, 3:] = 0.0
+    b[:, 0, 1] = TERRAIN_HEIGHT + PKG_HALF_H + 0.3
+    b[:, 0, 2] = 0.0
+    be.set_bodies(b)
+    lin, angv, st, awake, y = [], [], [], [], []
+    for t in range(steps):
+        be.step(np.zeros((be.N, be.W, 4), np.float32))
+        q = be.bodies()[:, 0]
+        a = be.aux()[:, 0]
+        lin.append(np.hypot(q[:, 3], q[:, 4])); angv.append(np.abs(q[:, 5])); st.append(a[:, 4]); awake.append(a[:, 5]); y.append(q[:, 1])
+    return dict(lin=np.array(lin), ang=np.array(angv), sleep_time=np.array(st), awake=np.array(awake), y=np.array(y))
+
+
+def check_sleep(r):
+    h = 1.0 / FPS
+    quiet = (r["lin"] <= LIN_SLEEP_TOL) & (r["ang"] <= ANG_SLEEP_TOL)
+    for e in range(r["lin"].shape[1]):
+        aw = r["awake"][:, e]
+        assert aw[0] == 1 and aw[-1] == 0, "the package falls asleep within the scene"
+        k = int(np.argmin(aw))                      # first step that ends with the package asleep
+        need = int(round(TIME_TO_SLEEP / h))
+        # b2Island::Solve: sleep time accumulates over consecutive quiet steps; the island sleeps in the step that brings it to 0.5 s
+        assert quiet[k - need + 1:k, e].all() and not quiet[k - need, e], "asleep exactly %d quiet steps after the last loud one (env %d): %s" % (need, e, quiet[k - need - 2:k + 1, e])
+        assert (r["lin"][k:, e] == 0).all() and (r["ang"][k:, e] == 0).all(), "a sleeping body has zero velocity"
+        assert (r["y"][k:, e] == r["y"][k, e]).all(), "and does not move"
+        assert (aw[k:] == 0).all()
+        rest = r["y"][k, e] - TERRAIN_HEIGHT - PKG_HALF_H
+        assert 2 * POLY_RADIUS - LINEAR_SLOP - 2e-3 < rest < 2 * POLY_RADIUS + 1e-3, "rests at 2 * polygonRadius - linearSlop above the edge: %g" % rest
+
+
+# ------------------------------------------------------------------------------------------------ scene 4: a thin box faster than its thickness
+def scene_fast_drop(be, speed=40.0, steps=12):
+    """The package (0.33 m thick) 1 m above a flat terrain, moving down at `speed` m/s = 0.8 m per step."""
+    ty = np.full(be.NT, TERRAIN_HEIGHT)
+    be.reset(terrain=np.tile(ty, (be.N, 1)), push=np.zeros((be.N, be.W)))
+    b = be.bodies()
+    b[:, 1:, 1] += 400.0
+    b[:, :, 3:] = 0.0
+    b[:, 0, 1] = TERRAIN_HEIGHT + PKG_HALF_H + 1.0
+    b[:, 0, 2] = 0.0
+    b[:, 0, 4] = -speed
+    be.set_bodies(b)
+    y = []
+    for t in range(steps):
+        be.step(np.zeros((be.N, be.W, 4), np.float32))
+        y.append(be.bodies()[:, 0, 1] - TERRAIN_HEIGHT - PKG_HALF_H)
+    return np.array(y)
+
+
+# ------------------------------------------------------------------------------------------------ the gait
+class StatefulGait(object):
+    """The heuristic of gym's BipedalWalker demo: the state machine of heuristics/multi_walker.py:16-86 (same constants, same
+    expressions) with `state`, `moving_leg` and `supporting_knee_angle` carried from call to call as the demo does -- the reference's
+    copy re-initialises them inside sample_actions (:23-27), i.e. never leaves STAY_ON_ONE_LEG with leg 0.  Vectorised over rows."""
+    SPEED, SKA = 0.29, 0.1
+
+    def __init__(self, n_rows):
+        self.state = np.ones(n_rows, np.int64)
+        self.moving = np.zeros(n_rows, np.int64)
+        self.ska = np.full(n_rows, self.SKA)
+
+    def __call__(self, S):
+        S = np.asarray(S, np.float64)
+        n = S.shape[0]
+        rows = np.arange(n)
+        st, mv, ska = self.state.copy(), self.moving.copy(), self.ska.copy()
+        sup = 1 - mv
+        leg = lambda which, k: S[rows, 4 + 5 * which + k]
+        nan = np.full(n, np.nan)
+        hip_t, knee_t = [nan.copy(), nan.copy()], [nan.copy(), nan.copy()]
+
+        def put(arr, which, val, m):
+            for l in (0, 1):
+                sel = m & (which == l)
+                arr[l][sel] = np.broadcast_to(val, (n,))[sel]
+        m1 = st == 1
+        put(hip_t, mv, 1.1, m1); put(knee_t, mv, -0.6, m1)
+        ska = np.where(m1, ska + 0.03, ska)
+        ska = np.where(m1 & (S[:, 2] > self.SPEED), ska + 0.03, ska)
+        ska = np.where(m1, np.minimum(ska, self.SKA), ska)
+        put(knee_t, sup, ska, m1)
+        st = np.where(m1 & (leg(sup, 0) < 0.10), 2, st)
+        m2 = st == 2
+        put(hip_t, mv, 0.1, m2); put(knee_t, mv, self.SKA, m2); put(knee_t, sup, ska, m2)
+        touch = m2 & (leg(mv, 4) != 0)
+        ska = np.where(touch, np.minimum(leg(mv, 2), self.SKA), ska)
+        st = np.where(touch, 3, st)
+        m3 = st == 3
+        put(knee_t, mv, ska, m3); put(knee_t, sup, 1.0, m3)
+        back = m3 & ((leg(sup, 2) > 0.88) | (S[:, 2] > 1.2 * self.SPEED))
+        st = np.where(back, 1, st)
+        mv = np.where(back, 1 - mv, mv)
+        hip, knee = [np.zeros(n), np.zeros(n)], [np.zeros(n), np.zeros(n)]
+        for l in (0, 1):
+            has = ~np.isnan(hip_t[l]) & (hip_t[l] != 0)        # `if hip_targ[l]:`
+            hip[l] = np.where(has, 0.9 * (np.nan_to_num(hip_t[l]) - S[:, 4 + 5 * l]) - 0.25 * S[:, 5 + 5 * l], 0.0)
+            has = ~np.isnan(knee_t[l]) & (knee_t[l] != 0)
+            knee[l] = np.where(has, 4.0 * (np.nan_to_num(knee_t[l]) - S[:, 6 + 5 * l]) - 0.25 * S[:, 7 + 5 * l], 0.0)
+            hip[l] = hip[l] - (0.9 * (0 - S[:, 0]) - 1.5 * S[:, 1])
+            knee[l] = knee[l] - 15.0 * S[:, 3]
+        self.state, self.moving, self.ska = st, mv, ska
+        return np.clip(0.5 * np.stack([hip[0], knee[0], hip[1], knee[1]], 1), -1.0, 1.0)
+
+
+def scene_gait(be, steps=500, policy="stateful", seed=5, flat=True):
+    """Closed loop: observations (rounded to float32 on every backend, so that all of them see the same numbers) -> gait -> step.
+    Flat terrain with the env's own random initial pushes (:130-131), or the env's own terrain.
+    -> dict(reached_end [N]: the episode ended because the last walker passed the end of the terrain (:420) with nobody fallen and the package
+    still carried; survived [N] steps; outcome [N]: 0 reached the end, 2 package dropped, 3 a walker fell, 4 still walking)"""
+    N, W = be.N, be.W
+    if flat:
+        obs = be.reset(terrain=np.full((N, be.NT), TERRAIN_HEIGHT), push=np.random.RandomState(seed).uniform(-5, 5, (N, W)))
+    else:
+        obs = be.reset()
+    if policy == "stateful":
+        pol = StatefulGait(N * W)
+    else:
+        from oracle import heuristics_oracle as ho
+        pol = ho.multiwalker_actions
+    x0 = be.bodies()[:, 1, 0].copy()
+    running = np.ones(N, bool)
+    survived = np.zeros(N, np.int64)
+    outcome = np.full(N, 4)
+    travel = np.zeros(N)
+    end_x = (be.NT - 10) * TERRAIN_STEP       # :420: past the last TERRAIN_GRASS points the episode is complete
+    for t in range(steps):
+        a = pol(obs.astype(np.float32).astype(np.float64).reshape(N * W, -1)).reshape(N, W, 4).astype(np.float32)
+        obs, rew, done = be.step(a)
+        q, fl = be.bodies(), be.flags()
+        survived += running
+        ended = running & done
+        dropped, fell = fl[:, 0] != 0, fl[:, 1:1 + W].sum(1) != 0
+        at_end = q[:, 1 + 5 * (W - 1), 0] > end_x - 1.0
+        outcome = np.where(ended, np.where(dropped, 2, np.where(fell, 3, np.where(at_end, 0, 1))), outcome)
+        travel = np.where(running, q[:, 1, 0] - x0, travel)
+        running &= ~done
+        if not running.any():
+            break
+    return dict(reached_end=outcome == 0, survived=survived, outcome=outcome, travel=travel)

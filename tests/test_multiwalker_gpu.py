@@ -58,15 +58,15 @@ def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
 
 
 @pytest.mark.parametrize("horizon,fused", [(0, False), (9, False), (0, True)])
-def test_auto_reset_through_spares_matches_mask_resets(horizon, fused, monkeypatch):
+def test_auto_reset_through_spares_matches_mask_resets(horizon, fused):
     """auto_reset=True: an env whose episode ends gets its next episode from the spare record prepared ahead of time (multiwalker.hip), or,
     when the spare is not ready, from the second launch -- either way exactly what reset(mask) + the next steps give on the CPU build.  With
     a horizon every env ends its episode in the same call, and again `horizon` calls later: all spares consumed and rebuilt at once."""
     from oracle import multiwalker as mwo
-    if fused:
-        monkeypatch.setenv("MADRL_MW_FUSED", "1")   # the whole step in one launch: same results
     N, W, T = 80, 3, 90
     env = _mk(N, n_walkers=W, seed=21, env_id_base=5, auto_reset=True, max_steps=horizon)
+    if fused:
+        env.set_mode(fused=True)   # the whole step in one launch: same results
     orc = mwo.MultiWalkerOracle(n_walkers=W, position_noise=0.0, angle_noise=0.0, n_envs=N, seed=21, env_id_base=5)
     assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
     rng = np.random.RandomState(6)

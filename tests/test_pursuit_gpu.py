@@ -204,14 +204,14 @@ def test_launch_shape_does_not_change_results():
             assert torch.equal(o[2][k], outs[0][2][k]), k
 
 
-def test_walk_direction_does_not_change_results(monkeypatch):
+def test_walk_direction_does_not_change_results():
     """large batches alternate the direction in which a launch walks the envs (memory-side cache reuse); results are the same"""
     outs = []
     for walk in ("forward", "alternate"):
-        monkeypatch.setenv("MADRL_PURSUIT_WALK", walk)
         from madrl_amd.maps import rectangle_map
         env = _mk([rectangle_map(16, 16)], 4099, seed=21, max_steps=30, auto_reset=True, n_pursuers=8, n_evaders=30, obs_range=7,
                   n_catch=2, surround=True, flatten=True)
+        env.set_walk(walk)
         assert env.kernel_kind == "wave"
         env.reset()
         g = torch.Generator(device="cpu").manual_seed(0)
