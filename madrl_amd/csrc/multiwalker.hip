@@ -15,6 +15,15 @@
 //
 // PARITY UNPINNED (Box2D is not available to pin against) -- see multiwalker_core.hpp.
 #include "common.hpp"
+#if defined(MADRL_MW_TIMING)
+// measurement build (scripts/variants.sh, never the shipped library): s_memtime stamps of a wavefront's first lane and a few per-env
+// counters, per block, for the solver launch (p = 0) and the continuous-pass launch (p = 1); read back by madrl_multiwalker_debug_read
+#define MW_DBG_BLOCKS 4096
+__device__ unsigned long long g_mw_stamp[2][MW_DBG_BLOCKS][8];
+__device__ int g_mw_val[2][MW_DBG_BLOCKS][16][4];
+#define MW_TSTAMP(p, k) do { if (threadIdx.x == 0 && blockIdx.x < MW_DBG_BLOCKS) g_mw_stamp[p][blockIdx.x][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MW_TVAL(p, k, v) do { if ((threadIdx.x & 3) == 0 && blockIdx.x < MW_DBG_BLOCKS) g_mw_val[p][blockIdx.x][threadIdx.x >> 2][k] = (int)(v); } while (0)
+#endif
 #include "multiwalker_core.hpp"
 
 #include <new>
@@ -94,6 +103,13 @@ struct GroupPar {
     __device__ __forceinline__ void sync() const { lds_sync(); }
     __device__ __forceinline__ int alloc(int *counter) const { return atomicAdd(counter, 1); }
     __device__ __forceinline__ void or_bits(uint32_t *p, uint32_t v) const { atomicOr(p, v); }
+    // OR over the four lanes of the env (a quad of the wavefront): two DPP quad permutes, no LDS
+    __device__ __forceinline__ uint32_t reduce_or(uint32_t v) const {
+        static_assert(NL == 4, "one env = one quad of lanes");
+        v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+        v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+        return v;
+    }
 };
 
 // ONE LAUNCH PER b2World::Step.  A wavefront takes its 16 envs through the whole step:
@@ -153,6 +169,8 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
     }
     if (!active) return;   // (a whole group: the lanes that stay only ever synchronise inside their wavefront)
     const bool fresh = spare || mode == 1;   // reset first, then the trailing zero-action step (:357)
+    if (PH == PH_SOLVE) MW_TSTAMP(0, 0);
+    if (PH == PH_TOI) MW_TSTAMP(1, 0);
     uint32_t *rec = (spare ? d.spare_state : d.state) + env * (int64_t)d.world_dw;
     mw::Cold *cold_g = reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
     mw::ColdView Cd = mw::cold_view(*cold_g);
@@ -202,9 +220,11 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
         if (PH & PH_COLLIDE) { const uint32_t *sd = reinterpret_cast<const uint32_t *>(&S); for (int k = lane; k < SOLVE_HDR_BYTES / 4; k += NL) sched_g[k] = sd[k]; }
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
         for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
+        if (PH == PH_SOLVE) MW_TSTAMP(0, 6);
         return;
     }
     mw::step_post(M, Wd, Cd, S, par);
+    if (PH == PH_TOI) MW_TSTAMP(1, 1);
     if (M.continuous) {
         // per lane: the time-of-impact cache of the body it works on (lane 0 may hold the package: the largest contact cache) and room
         // for the manifolds of a mini island past the four in registers -- in the manifold pool, free by now: most of it for lane 0,
@@ -219,6 +239,7 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
         TL.ovf_cap = lane == 0 ? c0 : CO;
         mw::solve_toi(M, Wd, Cd, S, *reinterpret_cast<mw::ToiWork *>(work), TL, par, 1.0f / mw::FPS);
     }
+    if (PH == PH_TOI) MW_TSTAMP(1, 4);
     const int OD = W * mw::obs_dim_of(d.cfg);
     float *obs_row = (spare ? d.spare_obs : io.obs) + env * OD;  // observation rows go straight to HBM
     if (lane == 0) *s_done = 0;
@@ -269,6 +290,7 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);
         for (int k = lane; k < (int)(sizeof(mw::Hot) / 4); k += NL) rec[k] = src[k];
     }
+    if (PH == PH_TOI) MW_TSTAMP(1, 5);
 }
 
 // first thing in a step() call: the list the call's own launch will append to starts empty
@@ -535,6 +557,15 @@ int madrl_multiwalker_set_mode(madrl_multiwalker *h, int32_t fused, int32_t use_
     h->use_spares = use_spares;
     return MADRL_OK;
 }
+
+#if defined(MADRL_MW_TIMING)
+int madrl_multiwalker_debug_read(unsigned long long *stamps_host, int *vals_host) {   // [2][4096][8], [2][4096][16][4]
+    MADRL_HIP_TRY(hipDeviceSynchronize());
+    MADRL_HIP_TRY(hipMemcpyFromSymbol(stamps_host, HIP_SYMBOL(g_mw_stamp), sizeof(g_mw_stamp)));
+    MADRL_HIP_TRY(hipMemcpyFromSymbol(vals_host, HIP_SYMBOL(g_mw_val), sizeof(g_mw_val)));
+    return MADRL_OK;
+}
+#endif
 
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain) {
     if (!h) return fail(MADRL_EINVAL, "handle is NULL");

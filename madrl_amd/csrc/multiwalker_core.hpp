@@ -73,6 +73,12 @@ inline int g_stats_lane();
 #define MW_PHASE(p) ((void)0)
 #endif
 
+// time stamps / per-env counters of measurement builds of the HIP kernels (scripts/mw_timing.py); nothing in every other build
+#ifndef MW_TSTAMP
+#define MW_TSTAMP(p, k) ((void)0)
+#define MW_TVAL(p, k, v) ((void)0)
+#endif
+
 // World::Step parameters of the env (multi_walker.py:365).  Overridable ONLY by the known-answer harness of the test
 // infrastructure, which replays the published Box2D HelloWorld scene (1/60 s, 6 velocity / 2 position iterations)
 // through this same solver.
@@ -439,7 +445,7 @@ constexpr int SOLVE_LANES = MAX_WALKERS;
 struct Scratch {  // per-step workspace (LDS on the GPU)
     // ---- what the solver launch keeps in LDS (up to `m_bA`)
     int nm;
-    int8_t n_isl, n_rounds, max_cnt, all_done;
+    int8_t n_isl, n_rounds, max_cnt, pad_;
     uint32_t moved;            // bit b: body b's proxy is in the broad phase's move buffer
     uint32_t in_island;        // bit b: body b was simulated by this step's Solve (b2Body::e_islandFlag after b2World::Solve)
     // mass data of the four shapes (package, hull, upper leg, lower leg), copied once per step
@@ -452,8 +458,7 @@ struct Scratch {  // per-step workspace (LDS on the GPU)
     uint8_t jn[MAX_WALKERS], jorder[MAX_WALKERS][4];
     int8_t j_island[MAXJ];     // island of joint j, -1: none (its bodies are asleep and were not reached)
     int8_t island_of[MAXB];    // island of body b in this step's Solve, -1: none (asleep and not reached)
-    uint8_t isl_done[MAXISL], isl_pos_solved[MAXISL], joint_ok[MAXJ];
-    float body_minsep[MAXB];
+    uint8_t isl_pos_solved[MAXISL];   // b2Island::Solve's positionSolved of island c (the sleep test asks for it)
     // ---- the other launches
     // what the island construction needs of manifold k without going to the pool: its bodies and its place in Box2D's lists
     int8_t m_bA[MAXM], m_bB[MAXM];
@@ -787,6 +792,7 @@ struct SerialPar {
     MW_HD void sync() const {}
     MW_HD int alloc(int *counter) const { return (*counter)++; }
     MW_HD void or_bits(uint32_t *p, uint32_t v) const { *p |= v; }
+    MW_HD uint32_t reduce_or(uint32_t v) const { return v; }   // OR over the lanes of the env: this one lane has seen everything
 };
 
 // b2Contact::Update of one contact whose new manifold is `mo`: impulses carried over by feature id, touching state, e_enabledFlag
@@ -1006,7 +1012,7 @@ MW_HD void build_islands(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S
         if ((flag >> seed) & 1u) continue;
         if (!((Wd.awake >> seed) & 1u)) continue;
         const int isl = n_isl++;
-        S.isl_done[isl] = 0; S.isl_pos_solved[isl] = 0;
+        S.isl_pos_solved[isl] = 0;
         int sp = 0;
         stack[sp++] = seed;
         flag |= 1u << seed;
@@ -1369,9 +1375,14 @@ MW_HD_INLINE float contact_solve_position(Hot &Wd, const Manifold &m, const Mass
     float aA = m.bA < 0 ? 0.0f : Wd.b[m.bA].a, aB = Wd.b[m.bB].a;
     const V2 lcA = q.lcA, lcB = q.lcB;
     const int np = m.type >> 1;   // b2ContactPositionConstraint::pointCount = the manifold's
+    // body A static (a terrain edge): its pose is the identity and stays it -- angle +0 (0 - 0 * x), whose sin / cos polynomial gives
+    // exactly (0, 1) -- so the polynomial is skipped for it and the same products and sums run on (0, 1)
+    const bool static_a = m.bA < 0;
     MW_UNROLL
     for (int i = 0; i < 2; ++i) if (i < np) {
-        const Xf xfA = xf_from(cA, aA, lcA), xfB = xf_from(cB, aB, lcB);
+        Xf xfA;
+        if (static_a) { xfA.q.s = 0.0f; xfA.q.c = 1.0f; xfA.p = cA - mul(xfA.q, lcA); } else xfA = xf_from(cA, aA, lcA);
+        const Xf xfB = xf_from(cB, aB, lcB);
         V2 normal, point; float sep;
         if ((m.type & 1) == 0) {
             normal = mul(xfA.q, m.local_normal);
@@ -1802,10 +1813,13 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
     }
     par.sync();
     if (M.continuous == 3) return;   // timing experiments only: 3 = set-up, 2 = set-up and one search without events
+    MW_TSTAMP(1, 2);
     // ---- the chains, one body per lane at a time
     for (int k = L0; k < NB; k += LN) toi_body_chain(M, Wd, Cd, S, T, TL, par, M.toi_body[k], h);
     par.sync();
+    MW_TSTAMP(1, 3);
     const int n = T.n_ev < TOI_MAX_EVENTS ? T.n_ev : TOI_MAX_EVENTS;
+    MW_TVAL(1, 0, n);
     if (n == 0 && T.overflow == 0) return;
     // ---- merge: Box2D's order of the events; event number r is followed by FindNewContacts call batch_base + 1 + r
     if (L0 == 0) {
@@ -1908,7 +1922,7 @@ MW_HD_INLINE void joint_position_part(const Model &M, const Scratch &S, int ji, 
 template <int NREG>
 struct SolveLane {
     JointCache jc[4];
-    int ji[4], jn;
+    int ji[4], jisl[4], jn;   // joint ids in island order and their islands
     Manifold mc[NREG];
     MassAB mq[NREG];
     int mrd[NREG], mix[NREG];   // round and pool index of mc[r] (-1: none)
@@ -1960,7 +1974,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
         }
         ls.jn = sl_ < NW ? S.jn[sl_] : 0;
         MW_UNROLL
-        for (int q = 0; q < 4; ++q) ls.ji[q] = q < ls.jn ? S.jorder[sl_][q] : 0;
+        for (int q = 0; q < 4; ++q) { ls.ji[q] = q < ls.jn ? S.jorder[sl_][q] : 0; ls.jisl[q] = q < ls.jn ? S.j_island[ls.ji[q]] : 0; }
         // the lane's manifolds past its private copies: slots of MO in lane order, then (no room) in place
         ls.mo_base = 0;
         for (int l2 = 0; l2 < sl_; ++l2) { const int c2 = S.lane_cnt[l2]; if (c2 > Par::MREG) ls.mo_base += c2 - Par::MREG; }
@@ -1991,6 +2005,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
         }                                                                                                                 \
     }
     // ---- contact constraints: b2ContactSolver::InitializeVelocityConstraints + WarmStart, in the island's order
+    MW_TSTAMP(0, 1); MW_TVAL(0, 0, max_cnt); MW_TVAL(0, 1, n_rounds);
     MW_CONTACT_SWEEP(contact_init_warm(Wd, m_, q_))
     // ---- joints: InitVelocityConstraints (+ warm start)
     MW_LANES { MW_LANE
@@ -1998,6 +2013,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
         for (int q = 0; q < 4; ++q) if (q < ls.jn) joint_init_warm(M, Wd, Cd, S, ls.ji[q], h, ls.jc[q]);
     }
     par.sync();
+    MW_TSTAMP(0, 2);
     // ---- velocity iterations: all joints, then all contacts
     for (int it = 0; it < VEL_ITERS; ++it) {
         MW_LANES { MW_LANE
@@ -2007,6 +2023,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
         par.sync();
         MW_CONTACT_SWEEP(contact_solve_velocity(Wd, m_, q_))
     }
+    MW_TSTAMP(0, 3);
     // the accumulated joint impulses and limit states go back to the world (warm start of the next step)
     MW_LANES { MW_LANE
         MW_UNROLL
@@ -2054,40 +2071,36 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
     }
     par.sync();
     // ---- position iterations: contacts then joints; each island stops on its own (b2Island::Solve early exit)
+    // b2ContactSolver::SolvePositionConstraints returns min separation >= -3 linearSlop over the island's contacts -- true exactly when
+    // every one of them is; b2Island::Solve ands that with every joint's answer.  So each lane collects one "not yet" bit per island
+    // from the constraints it runs, the lanes of the env OR their words together (registers; no per-body / per-joint flags in LDS, no
+    // serial pass over the islands), and every lane carries the same word of finished islands.
     const int n_isl = S.n_isl;
+    const uint32_t all_isl = (1u << n_isl) - 1u;
+    uint32_t isl_done = 0;
+    MW_TSTAMP(0, 4);
+    int pos_its_ = 0; (void)pos_its_;
     for (int it = 0; it < POS_ITERS; ++it) {
+        pos_its_ = it + 1;
         MW_STAT(pos_iters, 1); MW_STAT(pos_iters_step, 1);
-        for (int bi = L0; bi < NB; bi += LN) S.body_minsep[bi] = 0.0f;
-        for (int j = L0; j < 4 * NW; j += LN) S.joint_ok[j] = 1;
-        par.sync();
-        MW_CONTACT_SWEEP(if (!S.isl_done[m_.island]) { const int ob_ = m_.bB; S.body_minsep[ob_] = mnf(S.body_minsep[ob_], contact_solve_position(Wd, m_, q_)); })
+        uint32_t not_yet = 0;
+        MW_CONTACT_SWEEP(if (!((isl_done >> m_.island) & 1u)) { if (!(contact_solve_position(Wd, m_, q_) >= -3.0f * LINEAR_SLOP)) not_yet |= 1u << m_.island; })
         MW_LANES { MW_LANE
             MW_UNROLL
             for (int q = 0; q < 4; ++q) {
                 if (q >= ls.jn) continue;
-                const int ji = ls.ji[q];
-                if (S.isl_done[S.j_island[ji]]) continue;
-                if (!joint_solve_position(Wd, ls.jc[q])) S.joint_ok[ji] = 0;
+                const int jisl = ls.jisl[q];
+                if ((isl_done >> jisl) & 1u) continue;
+                if (!joint_solve_position(Wd, ls.jc[q])) not_yet |= 1u << jisl;
             }
         }
         par.sync();
-        if (L0 == 0) {
-            bool all_done = true;
-            for (int c = 0; c < n_isl; ++c) {
-                if (S.isl_done[c]) continue;
-                float ms = 0.0f;
-                bool jok = true;
-                for (int bi = 0; bi < NB; ++bi) if (S.island_of[bi] == c) ms = mnf(ms, S.body_minsep[bi]);
-                for (int j = 0; j < 4 * NW; ++j) if (S.j_island[j] == c) jok = jok && S.joint_ok[j];
-                if (ms >= -3.0f * LINEAR_SLOP && jok) { S.isl_done[c] = 1; S.isl_pos_solved[c] = 1; }
-                else all_done = false;
-            }
-            S.all_done = all_done ? 1 : 0;
-        }
-        par.sync();
-        if (S.all_done) break;
+        isl_done |= ~par.reduce_or(not_yet) & all_isl;
+        if (isl_done == all_isl) break;
     }
+    if (L0 == 0) for (int c = 0; c < n_isl; ++c) S.isl_pos_solved[c] = (uint8_t)((isl_done >> c) & 1u);   // positionSolved: stopped before the iterations ran out
     par.sync();
+    MW_TSTAMP(0, 5); MW_TVAL(0, 2, pos_its_);
 #undef MW_CONTACT_SWEEP
 #undef MW_POOL_MANIFOLD
 #undef MW_LANES
