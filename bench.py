@@ -151,8 +151,8 @@ class Timer(object):
     """the bench contract: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + synchronize on both sides;
     HIP events on the launch stream give the average launch duration"""
 
-    def __init__(self, world, dev):
-        self.world, self.dev = world, dev
+    def __init__(self, world, dev, streams=None):
+        self.world, self.dev, self.streams = world, dev, streams
 
     def barrier(self):
         import torch
@@ -164,17 +164,24 @@ class Timer(object):
     def region(self, step, K, tail=None):
         import torch
         self.barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        streams = self.streams or [torch.cuda.current_stream(self.dev)]
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
         t0 = time.perf_counter()
-        ev0.record()
+        for e, st in zip(ev0, streams):
+            e.record(st)
         for i in range(K):
             step(i, True)
-        ev1.record()  # events bracket the K step launches (and the small trajectory copies when N > 1)
+        for e, st in zip(ev1, streams):
+            e.record(st)  # events bracket the K step launches of every stream (and the small trajectory copies when N > 1)
         if tail is not None:
             tail()
         self.barrier()
         dt = time.perf_counter() - t0
-        kernel_ms = ev0.elapsed_time(ev1) / K  # average launch duration incl. inter-launch gaps
+        # HIP events on the streams the kernels are launched on: duration of one step = the slowest stream's K launches / K.  With
+        # several streams the launches of one step run CONCURRENTLY (one per stream), so this is the duration of the step, not of a
+        # kernel running alone
+        kernel_ms = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / K
         if self.world > 1:
             import torch.distributed as dist
             tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
@@ -203,15 +210,31 @@ def region_stats(region_ms):
             "region_ms_per_step_median": s[len(s) // 2], "value_is": "median region"}
 
 
-def roofline(bytes_per, N, kernel_ms, traffic, kernel, **more):
+def roofline(bytes_per, N, kernel_ms, traffic, kernel, streams=1, **more):
+    """N envs per step and GPU, stepped as `streams` concurrent launches of N / streams envs (one per HIP stream): `achieved` = the
+    algorithmic bytes of the launches that run together / the duration of the step (HIP events on every stream)."""
     achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "frac_vs_measured_copy": achieved / HBM_COPY_GBPS, "measured_copy_peak": HBM_COPY_GBPS,
            "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
-           "algorithmic_bytes_per_launch": bytes_per * N, "kernel": kernel, "kernel_ms": kernel_ms,
+           "algorithmic_bytes_per_launch": bytes_per * N // streams, "concurrent_launches_per_step": streams,
+           "algorithmic_bytes_per_step": bytes_per * N, "kernel": kernel, "kernel_ms": kernel_ms,
+           "kernel_ms_is": ("duration of one step = %d launches of %d envs each running CONCURRENTLY on %d HIP streams (events on every stream, "
+                            "slowest stream); a launch's own wall time is about the same, its share of the chip is 1 / %d" % (streams, N // streams, streams, streams))
+                           if streams > 1 else "average duration of the step's launch (HIP events on its stream)",
            "algorithmic_bytes_per_env_step": bytes_per}
     out.update(more)
     return out
+
+
+# sub-batches per GPU, each on its own HIP stream, when --streams is not given: what scripts/stream_sweep.sh measured fastest on MI355X
+# (the one-launch-per-step figure is reported next to it in every line: roofline.one_launch_per_step)
+DEFAULT_STREAMS = {"pursuit": 2, "pursuit_c5": 2, "pursuit_colocate": 1, "waterworld": 2, "waterworld_std": 2, "hostage": 2, "multiwalker": 4}
+
+
+def shard_count(args, N, workload):
+    S = max(1, int(args.streams)) if args.streams else DEFAULT_STREAMS[workload]
+    return S if N % S == 0 and N // S >= 64 else 1
 
 
 PURSUIT_VARIANTS = {
@@ -223,7 +246,7 @@ PURSUIT_VARIANTS = {
 }
 
 
-def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget):
+def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True):
     import numpy as np
     import torch
     from madrl_amd.maps import rectangle_map
@@ -232,12 +255,16 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget):
     MS, P, E, N0, mode = PURSUIT_VARIANTS[variant]
     N, R = (args.envs or N0), 7
     H = args.horizon
+    S = shard_count(args, N, variant) if streams is None else streams
+    per = N // S
     maps = [rectangle_map(MS, MS)]
     kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, reward_mech="local", **mode)
-    env = BatchedPursuitEvade(maps, n_envs=N, device=dev, seed=0, env_id_base=rank * N, max_steps=H,
-                              auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw)
-    D = env.obs_dim
-    rec_bytes = env.record_bytes
+    # the batch as S independent sub-batches, each on its own HIP stream (madrl_amd/sharded.py): env ids continue across them
+    envs = [BatchedPursuitEvade(maps, n_envs=per, device=dev, seed=0, env_id_base=rank * N + j * per, max_steps=H,
+                                auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw) for j in range(S)]
+    hip_streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    D = envs[0].obs_dim
+    rec_bytes = envs[0].record_bytes
     gen = torch.Generator(device=dev).manual_seed(rank)
     n_act = 16
     actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
@@ -250,12 +277,14 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget):
                  rewards=torch.zeros((chunk_len[c], N, P), dtype=torch.float32, device=dev),
                  dones=torch.zeros((chunk_len[c], N), dtype=torch.uint8, device=dev)) for c in range(n_chunks)] if world > 1 else []
     L = _lib.lib()
-    h = env._handle
-    obs_p, rew_p, done_p, rem_p = (_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._removed))
-    act_p = [_lib.ptr(a) for a in actions]
+    hs = [e._handle for e in envs]
+    outs = [[_lib.ptr(t) for t in (e._obs, e._rew, e._done, e._removed)] for e in envs]
+    sp = [C_void(st.cuda_stream) for st in hip_streams]
+    act_p = [[_lib.ptr(a[j * per:(j + 1) * per]) for a in actions] for j in range(S)]
     # N > 1: the step kernel writes rewards / dones straight into their slot of the trajectory chunk (the C ABI takes any
     # device pointer), only the action row is copied (int32 -> uint8)
-    slot_p = [(_lib.ptr(traj[c]["rewards"][j]), _lib.ptr(traj[c]["dones"][j])) for c in range(n_chunks) for j in range(chunk_len[c])] if world > 1 else []
+    slot_p = [[(_lib.ptr(traj[c]["rewards"][q][j * per:(j + 1) * per]), _lib.ptr(traj[c]["dones"][q][j * per:(j + 1) * per]))
+               for c in range(n_chunks) for q in range(chunk_len[c])] for j in range(S)] if world > 1 else []
     gatherer = None
     if world > 1:
         from madrl_amd.dist import ChunkedTrajectoryGather
@@ -265,32 +294,52 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget):
         if gatherer is not None:
             gatherer.reserve(traj)   # receive buffers + RCCL channel setup stay out of the timed region
 
+    def submit(chunk):
+        cur = torch.cuda.current_stream(dev)
+        for st in hip_streams:
+            if st != cur:
+                cur.wait_stream(st)       # the chunk is complete when every sub-batch has written its rows
+        gatherer.submit(chunk)            # async: overlaps with the next chunk's steps
+
     def one_step(i, record):
-        rp, dp = slot_p[i] if (record and world > 1) else (rew_p, done_p)
-        _lib.check(L.madrl_pursuit_step(h, act_p[i % n_act], None, obs_p, rp, dp, rem_p, _lib.current_stream(dev)))
-        if record and world > 1:
-            c, j = divmod(i, CH)
-            traj[c]["actions"][j].copy_(actions[i % n_act])
-            if (i + 1) % CH == 0:
-                gatherer.submit(traj[i // CH])      # async: overlaps with the next chunk's steps
+        for j in range(S):
+            rp, dp = slot_p[j][i] if (record and world > 1) else (outs[j][1], outs[j][2])
+            _lib.check(L.madrl_pursuit_step(hs[j], act_p[j][i % n_act], None, outs[j][0], rp, dp, outs[j][3], sp[j]))
+            if record and world > 1:
+                c, q = divmod(i, CH)
+                with torch.cuda.stream(hip_streams[j]):
+                    traj[c]["actions"][q][j * per:(j + 1) * per].copy_(actions[i % n_act][j * per:(j + 1) * per])
+        if record and world > 1 and (i + 1) % CH == 0:
+            submit(traj[i // CH])
 
     def tail():
         if gatherer is not None:
             if K % CH:
-                gatherer.submit(traj[-1])
+                submit(traj[-1])
             gathered = gatherer.finish()            # episode end: every rank holds every rank's trajectory
             assert sum(t.shape[1] for t in gathered["rewards"]) == K and gathered["rewards"][0].shape[0] == world
 
-    env.reset()
-    # steady state: episode ages uniform over [0, H) -- env n reaches the horizon (and runs the fused reset) at step H - age
-    env.set_state(dict(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H))
-    dt, kernel_ms, region_ms = Timer(world, dev).run(one_step, K, W, tail, prepare)
+    for j, env in enumerate(envs):
+        env.reset()
+        # steady state: episode ages uniform over [0, H) -- env n reaches the horizon (and runs the fused reset) at step H - age
+        env.set_state(dict(t=((torch.arange(per, device=dev, dtype=torch.int32) + j * per) * 7919) % H))
+    dt, kernel_ms, region_ms = Timer(world, dev, hip_streams).run(one_step, K, W, tail, prepare)
+    kernel_kind = envs[0].kernel_kind
+    del envs, outs, hs
+    one = None
+    if reference_pass and S > 1 and world == 1:
+        # the same batch as ONE launch per step on one stream, in the same process: what the sub-batch streams are compared with
+        one = bench_pursuit(args, variant, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False)
     if rank != 0:
         return None
     bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
     fast = ("pursuit_group_kernel<%d,%d,%d,%d,%d,%d,2>" if P + E > 64 else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))
-    kname = fast if env.kernel_kind == "wave" else "pursuit_kernel<NT>"
+    kname = fast if kernel_kind == "wave" else "pursuit_kernel<NT>"
     catch = "surround, n_catch 2" if mode["surround"] else "co-location catch, n_catch %d" % mode["n_catch"]
+    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(N, variant), kname, streams=S)
+    if one is not None:
+        roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
+        roof["one_launch_per_step"]["ms_per_step"] = one["ms_per_step"]
     out = {
         "metric": "env-steps/sec at fixed batch (PursuitEvade %dx%d, %dv%d)" % (MS, MS, P, E),
         "value": world * N * K / dt,
@@ -304,23 +353,30 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget):
         "vs_baseline": None,
         "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
         "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset; episode ages "
-                "start uniform over [0, %d): every launch resets ~%d of its %d envs through the two-observation-pass path)" % (H, N // H, N),
+                "start uniform over [0, %d): every step resets ~%d of its %d envs through the two-observation-pass path)" % (H, N // H, N),
         "config": dict({"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, %s, %s, local reward, "
                                     "%d envs per GPU, horizon %d" % (MS, MS, P, E, catch, "flatten" if mode["flatten"] else "(R,R,4) observations", N, H),
                         "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world,
+                        "streams_per_gpu": S, "envs_per_launch": per,
+                        "step_is": ("one pass of the step kernel over all %d envs of the GPU: %d launches of %d envs, one per HIP stream, not ordered "
+                                    "against each other (independent env instances)" % (N, S, per)) if S > 1 else "one launch of the step kernel over all %d envs" % N,
                         "rccl_ranks": world, "collective_backend": (os.environ.get("MADRL_BENCH_BACKEND", "nccl") if world > 1 else None),
                         "horizon_resets_per_env_in_timed_region": K / float(H),
-                        "horizon_resets_per_launch": N / float(H)}, **region_stats(region_ms)),
-        "roofline": roofline(bytes_per, N, kernel_ms, measured_traffic(N, variant), kname),
+                        "horizon_resets_per_step": N / float(H), "horizon_resets_per_launch": per / float(H)}, **region_stats(region_ms)),
+        "roofline": roof,
     }
     if cpu_budget:
         c2 = variant == "pursuit"
         attach_cpu_baselines(out, "pursuit" if c2 else None, "pursuit_c1" if c2 else None, lambda: cpu_baseline_port(maps, kw, cpu_budget))
-    del env
     return out
 
 
-def bench_other(args, workload, K, W, rank, world, dev, cpu_budget):
+def C_void(v):
+    import ctypes
+    return ctypes.c_void_p(v)
+
+
+def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True):
     """Waterworld (BASELINE configs[2]; `waterworld_std` = the same env under StandardizedEnv, which is how every reference run
     wraps it, runners/run_waterworld.py / run_pursuit.py:57-58), MultiWalker (configs[3]) and the hostage world on the same contract."""
     import numpy as np
@@ -328,37 +384,55 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget):
     from madrl_amd import _lib
     L = _lib.lib()
     extra, flop_per_env_step, live_key, rec_key = {}, None, None, None
+    N = args.envs or {"waterworld": 32768, "waterworld_std": 32768, "hostage": 32768, "multiwalker": 16384}[workload]
+    S = shard_count(args, N, workload) if streams is None else streams
+    per = N // S
+    hip_streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    sp = [C_void(st.cuda_stream) for st in hip_streams]
+    base = lambda j: rank * N + j * per
     if workload in ("waterworld", "waterworld_std"):
         from madrl_amd.waterworld import BatchedMAWaterWorld
-        N = args.envs or 32768
-        env = BatchedMAWaterWorld(5, 10, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
-                                  max_blocks=args.max_blocks)
-        acts = [(torch.rand((N, 5, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)]
-        rec = env._state.numel() // N
+        envs = [BatchedMAWaterWorld(5, 10, n_envs=per, device=dev, seed=0, env_id_base=base(j), auto_reset=True, max_blocks=args.max_blocks) for j in range(S)]
+        acts = [[(torch.rand((per, 5, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)] for j in range(S)]
+        rec = envs[0]._state.numel() // per
         sim_bytes = 40 + 20 + 1 + 8 + 2 * rec                 # actions, rewards, done, info, state record in + out
-        n_el = 5 * env.obs_dim
+        n_el = 5 * envs[0].obs_dim
         workload_s = "MAWaterWorld 5 pursuers / 10 evaders / 10 poison / 30 sensors, n_coop 2, %d envs per GPU, timestep_limit 1000" % N
         H = 1000
         if workload == "waterworld":
-            outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
-            step = lambda i, rec: _lib.check(L.madrl_waterworld_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
+            outs = [[_lib.ptr(t) for t in (e._obs, e._rew, e._done, e._info)] for e in envs]
+            ap = [[_lib.ptr(a) for a in acts[j]] for j in range(S)]
+            hs = [e._handle for e in envs]
+
+            def step(i, rec):
+                for j in range(S):
+                    _lib.check(L.madrl_waterworld_step(hs[j], ap[j][i % 8], None, *outs[j], sp[j]))
             bytes_per = sim_bytes + 4 * n_el
             kernel, binding = "waterworld_kernel<1,5,10,10,30>", "VALU / scalar-pipe issue of the sensing loop (profiles/*_waterworld/pmc_mix.txt), not HBM"
             live_key, rec_key = "waterworld", "waterworld_c3_single_env"
         else:
             from madrl_amd.wrappers import StandardizedEnv
-            wenv = StandardizedEnv(env, scale_reward=0.5, enable_obsnorm=True, enable_rewnorm=True)
-            assert wenv._fused, "the Waterworld engine fuses StandardizedEnv into its step kernel"
-            step = lambda i, rec: wenv.step(acts[i % 8])
-            # per observation element: float64 mean + var read and written (32 B) + the normalised float32 out (4 B); the raw row never
-            # reaches HBM.  Per agent: the reward statistics (32 B) + normalised reward (4 B).  DESIGN.md 4e
-            bytes_per = sim_bytes + 36 * n_el + 36 * 5
-            kernel = "waterworld_kernel<1,5,10,10,30> with the StandardizedEnv epilogue (madrl_waterworld_set_standardize)"
-            binding = "HBM: 32 of every 36 bytes are the per-env float64 running mean / variance (madrl_environments/__init__.py:242-257)"
+            wenvs = [StandardizedEnv(e, scale_reward=0.5, enable_obsnorm=True, enable_rewnorm=True, fused=args.std_fused) for e in envs]
+
+            def step(i, rec):
+                for j in range(S):
+                    with torch.cuda.stream(hip_streams[j]):
+                        wenvs[j].step(acts[j][i % 8])
+            if wenvs[0]._fused:
+                # per observation element: float64 mean + var read and written (32 B) + the normalised float32 out (4 B); the raw row never
+                # reaches HBM.  Per agent: the reward statistics (32 B) + normalised reward (4 B).  DESIGN.md 4e
+                bytes_per = sim_bytes + 36 * n_el + 36 * 5
+                kernel = "waterworld_kernel<1,5,10,10,30> with the StandardizedEnv epilogue (madrl_waterworld_set_standardize)"
+            else:
+                # the raw row is stored by the simulation launch (4 B) and read back by the epilogue launch (4 B) on top of that
+                bytes_per = sim_bytes + 44 * n_el + 40 * 5
+                kernel = "waterworld_kernel<1,5,10,10,30> + obsnorm_kernel + rewnorm_kernel (wrappers.hip)"
+            binding = "HBM: 32 of every 36 - 44 bytes are the per-env float64 running mean / variance (madrl_environments/__init__.py:242-257)"
             workload_s = "StandardizedEnv(obsnorm, rewnorm) around " + workload_s
 
         def age():  # steady state: episode ages uniform over [0, 1000)
-            env.set_state(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H)
+            for j, e in enumerate(envs):
+                e.set_state(t=((torch.arange(per, device=dev, dtype=torch.int32) + j * per) * 7919) % H)
 
         def cpu_fn():
             from oracle import waterworld as ww
@@ -375,19 +449,24 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget):
                         sample="float32 C oracle (oracle/waterworld_oracle.c, OpenMP; the simulation only, no wrapper), %d envs x %d steps, %.1f s" % (n, k, dt))
     elif workload == "hostage":
         from madrl_amd.hostage import BatchedContinuousHostageWorld
-        N = args.envs or 32768
-        env = BatchedContinuousHostageWorld(3, 10, 5, 2, 2, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
-                                            max_blocks=args.max_blocks)
-        acts = [(torch.rand((N, 3, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)]
-        outs = [_lib.ptr(t) for t in (env._obs, env._rew, env._done, env._info)]
-        step = lambda i, rec: _lib.check(L.madrl_hostage_step(env._handle, _lib.ptr(acts[i % 8]), None, *outs, _lib.current_stream(dev)))
-        bytes_per = 24 + 4 * 3 * env.obs_dim + 12 + 1 + 8 + 2 * (env._state.numel() // N)
+        envs = [BatchedContinuousHostageWorld(3, 10, 5, 2, 2, n_envs=per, device=dev, seed=0, env_id_base=base(j), auto_reset=True,
+                                              max_blocks=args.max_blocks) for j in range(S)]
+        acts = [[(torch.rand((per, 3, 2), device=dev) * 2 - 1).contiguous() for _ in range(8)] for j in range(S)]
+        outs = [[_lib.ptr(t) for t in (e._obs, e._rew, e._done, e._info)] for e in envs]
+        ap = [[_lib.ptr(a) for a in acts[j]] for j in range(S)]
+        hs = [e._handle for e in envs]
+
+        def step(i, rec):
+            for j in range(S):
+                _lib.check(L.madrl_hostage_step(hs[j], ap[j][i % 8], None, *outs[j], sp[j]))
+        bytes_per = 24 + 4 * 3 * envs[0].obs_dim + 12 + 1 + 8 + 2 * (envs[0]._state.numel() // per)
         kernel, binding = "hostage_kernel<1,3,10,5,30>", "the CU's scalar pipe / VALU issue (profiles/*_hostage/pmc_mix.txt), not HBM"
         workload_s = "ContinuousHostageWorld(3, 10, 5, 2, 2) (hostage.py:483), 30 sensors, %d envs per GPU, timestep_limit 1000" % N
         H = 1000
 
         def age():
-            env.set_state(t=(torch.arange(N, device=dev, dtype=torch.int32) * 7919) % H)
+            for j, e in enumerate(envs):
+                e.set_state(t=((torch.arange(per, device=dev, dtype=torch.int32) + j * per) * 7919) % H)
 
         def cpu_fn():
             from oracle import hostage as ho
@@ -406,27 +485,31 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget):
                         sample="float32 C oracle (oracle/hostage_oracle.c, OpenMP), %d envs x %d steps, %.1f s" % (n, k, dt))
     else:
         from madrl_amd.multiwalker import BatchedMultiWalkerEnv
-        N = args.envs or 16384
         H = 500
-        env = BatchedMultiWalkerEnv(n_walkers=3, n_envs=N, device=dev, seed=0, env_id_base=rank * N, auto_reset=True,
-                                    max_steps=H, max_blocks=args.max_blocks)
-        acts = [(torch.rand((N, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)]
+        envs = [BatchedMultiWalkerEnv(n_walkers=3, n_envs=per, device=dev, seed=0, env_id_base=base(j), auto_reset=True,
+                                      max_steps=H, max_blocks=args.max_blocks) for j in range(S)]
+        acts = [[(torch.rand((per, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)] for j in range(S)]
         done_rows = torch.zeros((max(K, 1), N), dtype=torch.uint8, device=dev)   # the timed steps write their done bytes here: no extra
-        outs = [_lib.ptr(t) for t in (env._obs, env._rew)]                       # launch in the timed region (how many envs ended is counted after it)
+        outs = [[_lib.ptr(t) for t in (e._obs, e._rew)] for e in envs]             # launch in the timed region (how many envs ended is counted after it)
+        ap = [[_lib.ptr(a) for a in acts[j]] for j in range(S)]
+        hs = [e._handle for e in envs]
+        dn_p = [[_lib.ptr(done_rows[q][j * per:(j + 1) * per]) for q in range(done_rows.shape[0])] for j in range(S)]
+        dn_own = [_lib.ptr(e._done) for e in envs]
 
         def step(i, rec):
-            dn = done_rows[i % done_rows.shape[0]] if rec else env._done
-            _lib.check(L.madrl_multiwalker_step(env._handle, _lib.ptr(acts[i % 8]), *outs, _lib.ptr(dn), _lib.current_stream(dev)))
+            for j in range(S):
+                dn = dn_p[j][i % done_rows.shape[0]] if rec else dn_own[j]
+                _lib.check(L.madrl_multiwalker_step(hs[j], ap[j][i % 8], *outs[j], dn, sp[j]))
         # algorithmic HBM bytes per env-step: actions in, observation / reward / done rows out, the per-env record (bodies, joints,
         # contact cache, terrain) read and written once
-        bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * env.world_bytes
+        bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * envs[0].world_bytes
         kernel = "mw_step_kernel<collide> + <solve> + <continuous pass> (three launches per step; kernel_ms is their sum)"
         # this path is not HBM-bound -- dependent FP32 work of 180 velocity + up to 60 position Gauss-Seidel sweeps
         # over 12 joints and the active manifolds, and the serial sub-steps of the continuous pass, against ~25 KB; a launch ends with
         # its slowest wavefront (16 envs in lockstep), so the binding resource is the latency of the longest per-env chain
         binding = ("latency of the longest per-env chain of dependent FP32 operations (180 + 60 Gauss-Seidel sweeps, time-of-impact sub-steps): "
                    "neither HBM nor VALU throughput (DESIGN.md 4c)")
-        flop_per_env_step, flop_src = env.flops_per_env_step()
+        flop_per_env_step, flop_src = envs[0].flops_per_env_step()
         extra = {"flop_per_env_step": flop_per_env_step, "flop_source": flop_src}
         workload_s = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % N
         # 200 warm-up steps: episodes last ~60 steps under random actions and all start together, so the first 100 steps see waves of
@@ -452,18 +535,30 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget):
             return dict(value=n * k / dt, unit="env-steps/s", cores=int(o.L.mwr_num_threads()), kind="port",
                         sample="independent C restatement of MultiWalkerEnv over a Box2D-2.3.0-ordered solver (oracle/multiwalker_ref.c, OpenMP; "
                                "PARITY UNPINNED like the kernel), %d envs x %d steps, %.1f s" % (n, k, dt))
-    env.reset()
+    for j, e in enumerate(envs):
+        with torch.cuda.stream(hip_streams[j]):
+            (wenvs[j] if workload == "waterworld_std" else e).reset()
+    torch.cuda.synchronize()
     age()
-    dt, kernel_ms, region_ms = Timer(world, dev).run(step, K, W)
+    dt, kernel_ms, region_ms = Timer(world, dev, hip_streams).run(step, K, W)
+    n_ended = float((done_rows[:K] != 0).sum().item()) / N if workload == "multiwalker" else None
+    del envs
+    one = None
+    if reference_pass and S > 1 and world == 1:
+        one = bench_other(args, workload, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False)
     if rank != 0:
         return None
-    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(N, workload), kernel, binding_resource=binding)
-    cfg = {"workload": workload_s, "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world, "rccl_ranks": world}
+    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(N, workload), kernel, streams=S, binding_resource=binding)
+    if one is not None:
+        roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
+        roof["one_launch_per_step"]["ms_per_step"] = one["ms_per_step"]
+    cfg = {"workload": workload_s, "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world, "rccl_ranks": world,
+           "streams_per_gpu": S, "envs_per_launch": per}
     cfg.update(region_stats(region_ms))
     if workload == "multiwalker":
         tf = flop_per_env_step * N / (kernel_ms * 1e-3) / 1e12
         roof.update({"valu_flops_achieved_TFLOPs": tf, "valu_peak_TFLOPs": VALU_PEAK_TFLOPS, "valu_frac": tf / VALU_PEAK_TFLOPS, **extra})
-        cfg["episode_ends_per_env_in_last_region"] = float((done_rows[:K] != 0).sum().item()) / N
+        cfg["episode_ends_per_env_in_last_region"] = n_ended
     else:
         cfg["horizon_resets_per_env_in_timed_region"] = K / float(H)
     out = {"metric": "env-steps/sec at fixed batch (%s)" % workload, "value": world * N * K / dt, "unit": "env-steps/s",
@@ -473,7 +568,6 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget):
            "config": cfg, "roofline": roof}
     if cpu_budget:
         attach_cpu_baselines(out, live_key, rec_key, cpu_fn)
-    del env
     return out
 
 
@@ -504,6 +598,11 @@ def main():
                     help="pursuit = BASELINE.json's metric (default, configs[1]); pursuit_c5 = configs[4]'s per-GPU shard "
                          "(32x32, 16 v 60, 32 768 envs: `--workload pursuit_c5 --gpus 8` IS configs[4], 262 144 envs); pursuit_colocate = the "
                          "survey's secondary catch mode; waterworld_std = Waterworld under StandardizedEnv; the others are the remaining north_star envs")
+    ap.add_argument("--streams", type=int, default=0, help="sub-batches per GPU, each stepped on its own HIP stream (madrl_amd/sharded.py); 1 = one launch "
+                                                           "per step; 0 (default) = the measured best per workload (DEFAULT_STREAMS)")
+    ap.add_argument("--std-fused", type=lambda v: None if v == "auto" else v not in ("0", "false", "no"), default=False,
+                    help="waterworld_std: StandardizedEnv fused into the step kernel (default: the stand-alone epilogue kernels, which overlap with "
+                         "the other sub-batch's simulation launch; auto = the wrapper's own default, fused)")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

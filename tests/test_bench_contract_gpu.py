@@ -63,7 +63,7 @@ def test_default_batch_line_carries_every_baseline_config():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     assert KEYS <= set(j) and j["config"]["envs_per_gpu"] == 65536
-    assert 0 < j["config"]["horizon_resets_per_env_in_timed_region"] < 1 and j["config"]["horizon_resets_per_launch"] > 100
+    assert 0 < j["config"]["horizon_resets_per_env_in_timed_region"] < 1 and j["config"]["horizon_resets_per_step"] > 100
     wl = j["workloads"]
     assert set(wl) == {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std"}
     assert j["cpu_baseline"]["value"] > 0 and j["roofline"]["frac_vs_measured_copy"] > j["roofline"]["frac"]
