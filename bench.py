@@ -51,10 +51,10 @@ def algorithmic_bytes_per_env_step(P, E, D, rec_bytes):
     return 4 * P + 4 * P * D + 4 * P + 1 + 4 + 2 * rec_bytes
 
 
-def measured_traffic(n_envs, workload="pursuit"):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/pmc_traffic.json,
-    FETCH_SIZE + WRITE_SIZE collected in separate runs by scripts/profile.sh); None if absent or
-    taken at another batch size.  bench.py cannot collect PMC counters on itself."""
+def measured_traffic(envs_per_launch, workload="pursuit", launches_per_step=1):
+    """HBM bytes per STEP (= per launch x the launches of a step) from the committed rocprofv3 PMC passes
+    (profiles/*/pmc_traffic.json, FETCH_SIZE + WRITE_SIZE collected in separate runs by scripts/profile_workload.sh); None if absent
+    or taken at another launch size.  bench.py cannot collect PMC counters on itself."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
@@ -62,8 +62,8 @@ def measured_traffic(n_envs, workload="pursuit"):
             j = json.load(open(f))
         except Exception:
             continue
-        if int(j.get("envs", -1)) == int(n_envs) and j.get("workload", "pursuit") == workload:
-            best = (float(j["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT))
+        if int(j.get("envs", -1)) == int(envs_per_launch) and j.get("workload", "pursuit") == workload:
+            best = (float(j["traffic_bytes_per_launch"]) * launches_per_step, os.path.relpath(f, ROOT))
     return best
 
 
@@ -265,6 +265,11 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     hip_streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
     D = envs[0].obs_dim
     rec_bytes = envs[0].record_bytes
+    if S > 1 and algorithmic_bytes_per_env_step(P, E, D, rec_bytes) * N > 375e6:
+        # the library walks the env range in alternating directions once ONE launch moves more than ~375 MB (the rows written last are
+        # then touched first, while the 256 MB memory-side cache still holds them); here the sub-batches together are that large
+        for e in envs:
+            e.set_walk("alternate")
     gen = torch.Generator(device=dev).manual_seed(rank)
     n_act = 16
     actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
@@ -336,7 +341,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     fast = ("pursuit_group_kernel<%d,%d,%d,%d,%d,%d,2>" if P + E > 64 else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))
     kname = fast if kernel_kind == "wave" else "pursuit_kernel<NT>"
     catch = "surround, n_catch 2" if mode["surround"] else "co-location catch, n_catch %d" % mode["n_catch"]
-    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(N, variant), kname, streams=S)
+    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(per, variant, S), kname, streams=S)
     if one is not None:
         roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
         roof["one_launch_per_step"]["ms_per_step"] = one["ms_per_step"]
@@ -488,6 +493,9 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
         H = 500
         envs = [BatchedMultiWalkerEnv(n_walkers=3, n_envs=per, device=dev, seed=0, env_id_base=base(j), auto_reset=True,
                                       max_steps=H, max_blocks=args.max_blocks) for j in range(S)]
+        if os.environ.get("MADRL_BENCH_MW_FUSED"):   # experiments (scripts/stream_sweep.sh): the whole step in one launch
+            for e in envs:
+                e.set_mode(fused=True)
         acts = [[(torch.rand((per, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)] for j in range(S)]
         done_rows = torch.zeros((max(K, 1), N), dtype=torch.uint8, device=dev)   # the timed steps write their done bytes here: no extra
         outs = [[_lib.ptr(t) for t in (e._obs, e._rew)] for e in envs]             # launch in the timed region (how many envs ended is counted after it)
@@ -548,7 +556,7 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
         one = bench_other(args, workload, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False)
     if rank != 0:
         return None
-    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(N, workload), kernel, streams=S, binding_resource=binding)
+    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(per, workload, S), kernel, streams=S, binding_resource=binding)
     if one is not None:
         roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
         roof["one_launch_per_step"]["ms_per_step"] = one["ms_per_step"]

@@ -151,7 +151,9 @@ int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t
  *                opponents are the pursuers, the array is [n_envs][P], entry j = pursuer j.)
  *   obs_dev      as in reset (IN/OUT);
  *   rew_dev      float32 [n_envs][P]  (computed in float64 like the reference, then rounded);
- *   done_dev     uint8 [n_envs]: bit0 = is_terminal (:383-389), bit1 = max_steps reached;
+ *   done_dev     uint8 [n_envs]: bit0 = is_terminal (:383-389), bit1 = max_steps reached; bit7 = count overflow: the env has had more
+ *                than 253 agents of one kind on ONE cell since its last reset (the kernel counts per cell in bytes; possible only with
+ *                more than 253 pursuers or evaders, up to 1 023 of each are accepted) -- its results are void until it is reset;
  *   removed_dev  int32 [n_envs]: info['removed'] (:261-262). */
 int madrl_pursuit_step(madrl_pursuit *h, const int32_t *actions_dev,
                        const int32_t *inj_evader_actions_dev, float *obs_dev, float *rew_dev,

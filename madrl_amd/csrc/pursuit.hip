@@ -35,7 +35,9 @@ enum : uint32_t { K_GRID = 0, K_ID = 1, K_FILL = 2, K_SKIP = 3 };
 
 constexpr uint32_t PAD_MAP = 0xFEu;  // map layer outside the map  -> vtab[0xFE] = 1/layer_norm
 constexpr uint32_t PAD_CNT = 0xFFu;  // count layers outside the map -> "do not store" (Q2)
-constexpr int MAX_COUNT = 253;       // byte grids: per-cell agent counts must stay < PAD_MAP
+constexpr int MAX_CELL_COUNT = 253;  // byte grids: the agents of one layer on ONE cell must stay < PAD_MAP (checked where they are counted)
+constexpr int MAX_COUNT = 1023;      // agents per layer.  The authors' largest launch line runs 100 pursuers / 300 evaders
+                                     // (runners/old/rllab/pursuit_cnn.sh:1); more than 253 of one kind on one cell raises the overflow bit
 
 struct PursuitDev {
     int32_t xs, ys, P, E, A, R, D;
@@ -73,8 +75,13 @@ struct PursuitIO {
 // state record: [u32 tick][u32 t][u32 map_id][u32 spare][u8 xy[2A]][u32 gone[ngw]][u32 term[ntw]]
 constexpr int HDR_BYTES = 16;
 
-__device__ __forceinline__ void lds_byte_add(uint8_t *grid, int idx) {
-    atomicAdd(reinterpret_cast<unsigned *>(grid + (idx & ~3)), 1u << (8 * (idx & 3)));
+// `ovf`: set when the cell already held MAX_CELL_COUNT agents -- its count leaves the byte's usable range (254 / 255 are the padding
+// sentinels, one more would carry into the neighbouring cell).  The env's results are void from there on: sticky word 3 of its
+// record, reported as bit 7 of the done byte (BatchedPursuitEvade raises for it); a new episode clears it.
+__device__ __forceinline__ void lds_byte_add(uint8_t *grid, int idx, uint32_t *ovf) {
+    const unsigned sh = 8u * (unsigned)(idx & 3);
+    const unsigned old = atomicAdd(reinterpret_cast<unsigned *>(grid + (idx & ~3)), 1u << sh);
+    if (((old >> sh) & 0xFFu) >= (unsigned)MAX_CELL_COUNT) *ovf = 1u;
 }
 __device__ __forceinline__ void lds_byte_sub(uint8_t *grid, int idx) {
     atomicSub(reinterpret_cast<unsigned *>(grid + (idx & ~3)), 1u << (8 * (idx & 3)));
@@ -98,13 +105,19 @@ __device__ __forceinline__ double np_pairwise_base(const double *a, int n) {
     for (; i < n; ++i) res += a[i];
     return res;
 }
-// n <= 256 (n_pursuers <= 253): at most one level of numpy's recursive split
-__device__ __forceinline__ double np_pairwise_sum(const double *a, int n) {
+// numpy's recursive split above 128 elements (pairwise_sum in numpy/core/src/umath/loops_utils.h): n <= 1024 needs three levels
+template <int DEPTH>
+__device__ __forceinline__ double np_pairwise_sum_t(const double *a, int n) {
     if (n <= 128) return np_pairwise_base(a, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return np_pairwise_base(a, n2) + np_pairwise_base(a + n2, n - n2);
+    if constexpr (DEPTH == 0) return np_pairwise_base(a, n);   // (not reached: MAX_COUNT <= 1024)
+    else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum_t<DEPTH - 1>(a, n2) + np_pairwise_sum_t<DEPTH - 1>(a + n2, n - n2);
+    }
 }
+__device__ __forceinline__ double np_pairwise_sum(const double *a, int n) { return np_pairwise_sum_t<3>(a, n); }
+static_assert(MAX_COUNT <= 1024, "np_pairwise_sum: three levels of numpy's split");
 
 // mode 0: reset(mask)   mode 1: step (+ fused auto-reset)
 template <int NT>
@@ -280,7 +293,7 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             // -------------------------------------------------------- pre-move evader counts (:364-365)
             for (int i = tid; i < d.E; i += nthr) {
                 if (!((s_gone[i >> 5] >> (i & 31)) & 1u))
-                    lds_byte_add(g_ec, (s_ax[d.P + i] + pad) * GW + s_ay[d.P + i] + pad);
+                    lds_byte_add(g_ec, (s_ax[d.P + i] + pad) * GW + s_ay[d.P + i] + pad, &s_misc[3]);
             }
             __syncthreads();
             // proximity reward on the PRE-move state, np.clip keeps border pursuers on their
@@ -349,7 +362,7 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
                 }
                 s_ax[a] = (uint8_t)x;
                 s_ay[a] = (uint8_t)y;
-                lds_byte_add(is_p ? g_pc : g_ec, (x + pad) * GW + y + pad);  // :244-246
+                lds_byte_add(is_p ? g_pc : g_ec, (x + pad) * GW + y + pad, &s_misc[3]);  // :244-246
             }
             __syncthreads();
             // -------------------------------------------------------- catch resolution (:463-521)
@@ -406,8 +419,9 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             tstep += 1;
             if (n_alive == 0) done_bits |= 1u;                               // :383-389
             if (d.max_steps > 0 && tstep >= d.max_steps) done_bits |= 2u;
+            const uint32_t overflow = s_misc[3] ? 0x80u : 0u;                // a cell's count left the byte range: results void
             if (tid == 0) {
-                io.done[env] = (uint8_t)done_bits;
+                io.done[env] = (uint8_t)(done_bits | overflow);
                 io.removed[env] = (int32_t)s_misc[4];
             }
             do_reset = d.auto_reset && done_bits != 0;
@@ -422,6 +436,7 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
         if (do_reset) {
             // ---------------------------------------------------------- reset (:173-207)
             __syncthreads();
+            if (tid == 0) s_misc[3] = 0u;                            // a new episode: the overflow mark goes
             for (int w = tid; w < d.ngw; w += nthr) s_gone[w] = 0u;  // :175-176
             for (int w = tid; w < d.ntw; w += nthr) s_term[w] = 0u;  // fresh agents
             if (io.inj_map != nullptr && mode == 0) {
@@ -479,7 +494,7 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
                 }
                 s_ax[a] = (uint8_t)x;
                 s_ay[a] = (uint8_t)y;
-                lds_byte_add(a < d.P ? g_pc : g_ec, (x + pad) * GW + y + pad);  // :201-203
+                lds_byte_add(a < d.P ? g_pc : g_ec, (x + pad) * GW + y + pad, &s_misc[3]);  // :201-203
             }
             tick += 1;
             tstep = 0;
@@ -497,6 +512,7 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             h[0] = tick;
             h[1] = (uint32_t)tstep;
             h[2] = (uint32_t)map_id;
+            h[3] = s_misc[3];   // sticky count-overflow mark of the episode (0 in every run that stays inside the byte grids)
         }
     }
 }

@@ -272,7 +272,9 @@ class BatchedPursuitEvade(AbstractMAEnv):
                                                  _lib.ptr(rew), _lib.ptr(dn), _lib.ptr(self._removed),
                                                  self._stream()))
         done = (dn & 1).bool()
-        info = {"removed": self._removed, "truncated": (dn & 2).bool(), "done_bits": dn}
+        # bit 7: more than 253 agents of one kind stood on ONE cell of this env (byte count grids of the generic kernel; possible only
+        # with more than 253 pursuers or evaders) -- its results are void until its next reset
+        info = {"removed": self._removed, "truncated": (dn & 2).bool(), "done_bits": dn, "count_overflow": (dn & 0x80).bool()}
         return self._obs_view(), rew, done, info
 
     def obs_rows_valid(self):
@@ -544,6 +546,8 @@ class PursuitEvade(SingleEnvDelegate, AbstractMAEnv):
                 eact = np.array([[int(self._evader_controller.act(ms)) for _ in range(P)]], dtype=np.int32)
             self._alive_at_step_start = alive
         obs, rew, done, info = self._env.step(torch.as_tensor(act.reshape(1, P)), evader_actions=eact)
+        if bool(info["count_overflow"][0].item()):
+            raise OverflowError("more than 253 agents of one kind on one cell: outside the byte count grids of the kernel")
         r = rew[0].detach().cpu().numpy().astype(np.float64)
         rewards = [float(r[0])] * P if self._env.reward_mech == "global" else r
         return self._obslist(obs), rewards, bool(done[0].item()), {"removed": int(info["removed"][0].item())}

@@ -274,6 +274,15 @@ def main():
                  dict(n_evaders=9, n_pursuers=5, obs_range=5, n_catch=2, surround=True, flatten=True,
                       reward_mech="local", random_opponents=True, max_opponents=10), episodes=10,
                  steps_per_episode=30, seed=12, chase=0.8)
+    # M: more evaders than a byte-sized agent count (the authors' largest launch line runs 100 pursuers / 300 evaders,
+    #    runners/old/rllab/pursuit_cnn.sh:1): a crowded 24 x 24 map
+    run_scenario(R, "crowd_20v300", [TM.rectangle_map(24, 24)],
+                 dict(n_evaders=300, n_pursuers=20, obs_range=9, n_catch=2, surround=True, flatten=True,
+                      reward_mech="local"), episodes=2, steps_per_episode=14, seed=13)
+    # N: more pursuers than numpy's pairwise sum takes in one block (rewards.mean() over 260 values splits twice, :261)
+    run_scenario(R, "crowd_260v40_global", [TM.rectangle_map(20, 20)],
+                 dict(n_evaders=40, n_pursuers=260, obs_range=5, n_catch=3, surround=False, flatten=True,
+                      reward_mech="global", catchr=0.1, urgency_reward=-0.05), episodes=2, steps_per_episode=10, seed=14)
 
 
 if __name__ == "__main__":

@@ -44,9 +44,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         kname = max(names, key=lambda k: len(names[k]))
         vals[c] = sum(names[kname]) / len(names[kname])
 if len(vals) == 2:
-    j = dict(workload=wl, kernel=kname, envs=line["config"]["envs_per_gpu"], FETCH_SIZE_KiB=vals["FETCH_SIZE"], WRITE_SIZE_KiB=vals["WRITE_SIZE"],
+    per_launch = line["config"].get("envs_per_launch", line["config"]["envs_per_gpu"])
+    j = dict(workload=wl, kernel=kname, envs=per_launch, envs_per_gpu=line["config"]["envs_per_gpu"], streams=line["config"].get("streams_per_gpu", 1),
+             FETCH_SIZE_KiB=vals["FETCH_SIZE"], WRITE_SIZE_KiB=vals["WRITE_SIZE"],
              traffic_bytes_per_launch=(vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
-             algorithmic_bytes_per_launch=line["roofline"]["algorithmic_bytes_per_env_step"] * line["config"]["envs_per_gpu"],
+             algorithmic_bytes_per_launch=line["roofline"]["algorithmic_bytes_per_env_step"] * per_launch,
              note="separate rocprofv3 --pmc passes (scripts/profile_workload.sh); counters in KiB; every read of these kernels is <= 4 B per lane, "
                   "so the gfx950 x2 correction for wide (16 B/lane) reads does not apply")
     j["traffic_over_algorithmic"] = j["traffic_bytes_per_launch"] / j["algorithmic_bytes_per_launch"]

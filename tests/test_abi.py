@@ -72,7 +72,7 @@ def test_invalid_configs_are_rejected_with_a_message():
     from madrl_amd import _lib
     L = _lib.lib()
     d = C.c_int32()
-    for bad in (dict(struct_size=4), dict(xs=0), dict(n_pursuers=0), dict(n_evaders=300), dict(layer_norm=0.0),
+    for bad in (dict(struct_size=4), dict(xs=0), dict(n_pursuers=0), dict(n_evaders=1024), dict(layer_norm=0.0),
                 dict(constraint_window=0.0), dict(obs_range=0)):
         rc = L.madrl_pursuit_obs_dim(C.byref(_cfg(**bad)), C.byref(d))
         assert rc == -1, bad

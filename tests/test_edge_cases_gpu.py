@@ -99,3 +99,26 @@ def test_step_runs_on_the_callers_stream():
     for (x1, y1, z1), (x2, y2, z2) in zip(sums_a, sums_b):
         assert float(x1) == float(x2) and float(y1) == float(y2) and int(z1) == int(z2)
     assert torch.equal(a.obs_buffer, b.obs_buffer)
+
+
+def test_more_than_253_agents_on_one_cell_raise_the_overflow_bit():
+    """The generic kernel counts agents per cell in bytes (254 / 255 are padding sentinels).  With up to 1 023 agents of a kind a cell can
+    in principle collect more than 253 of them: the env is then marked (bit 7 of the done byte, info['count_overflow']) instead of
+    silently wrong, and a reset clears the mark."""
+    import torch
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    N, P, E = 3, 4, 300
+    env = BatchedPursuitEvade([np.zeros((8, 8), np.int32)], n_envs=N, device="cuda:0", seed=0, n_pursuers=P, n_evaders=E, obs_range=3,
+                              n_catch=4, surround=False)
+    pos = np.zeros((N, P + E, 2), np.int32)
+    pos[:, :P] = [[7, 7], [7, 6], [6, 7], [6, 6]]
+    pos[0, P:] = [2, 2]                                    # env 0: all 300 evaders on one cell
+    pos[1, P:] = np.stack([np.arange(E) % 8, (np.arange(E) // 8) % 6], 1)   # env 1: spread out (<= 7 per cell)
+    pos[2, P:P + 253] = [3, 3]; pos[2, P + 253:] = [0, 0]   # env 2: exactly 253 on one cell -- still inside the byte's range
+    env.reset(positions=pos)
+    stay = torch.full((N, P), 4, dtype=torch.int32, device="cuda:0")
+    _, _, _, info = env.step(stay, evader_actions=np.full((N, E), 4, np.int32))
+    assert info["count_overflow"].cpu().numpy().tolist() == [True, False, False]
+    env.reset(mask=np.array([1, 0, 0], np.uint8), positions=pos[[1, 1, 1]])
+    _, _, _, info = env.step(stay, evader_actions=np.full((N, E), 4, np.int32))
+    assert not info["count_overflow"].any()

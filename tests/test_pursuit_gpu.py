@@ -87,6 +87,10 @@ CASES = {
                              reward_mech="global", sample_maps=True, random_opponents=True, max_opponents=45, catchr=0.1),
     "group_20v50_surround": dict(maps="pool16", n_pursuers=20, n_evaders=50, obs_range=5, n_catch=2, surround=True, flatten=True,
                                  reward_mech="local", sample_maps=True),
+    # the authors' largest launch line: runners/old/rllab/pursuit_cnn.sh:1 (100 pursuers / 300 evaders, obs_range 21, 128 x 128; their
+    # map_pool128.npy is not in the tree -> rectangle_map(128, 128))
+    "authors_cnn_100v300": dict(maps="rect128", n_pursuers=100, n_evaders=300, obs_range=21, n_catch=2, surround=True, flatten=False,
+                                reward_mech="local", n_envs=6, steps=20),
     "tiny_window": dict(maps="open6", n_pursuers=5, n_evaders=4, obs_range=5, n_catch=2, surround=True, flatten=True,
                         reward_mech="global", constraint_window=0.5),
 }
@@ -98,6 +102,8 @@ def _maps(name):
         return [rectangle_map(16, 16)]
     if name == "rect32":
         return [rectangle_map(32, 32)]
+    if name == "rect128":
+        return [rectangle_map(128, 128)]
     if name == "open6":
         return [np.zeros((6, 6), np.int32)]
     if name == "pool16":
@@ -114,7 +120,9 @@ def test_hip_matches_oracle_free_running(case, kernel):
     from oracle import pursuit as po
     kw = dict(CASES[case])
     maps = _maps(kw.pop("maps"))
-    N, T, H = 512, 120, 25
+    N, T, H = kw.pop("n_envs", 512), kw.pop("steps", 120), 25
+    if kernel == "auto" and kw["n_pursuers"] + kw["n_evaders"] > 128:
+        pytest.skip("no fast path above two wavefronts of agents: the generic kernel is what runs")
     env = _mk(maps, N, seed=2024, env_id_base=1000, max_steps=H, auto_reset=True, kernel=kernel, **kw)
     if kernel == "auto":
         assert env.kernel_kind == "wave"  # one wavefront per env, or a wavefront group for more than 64 agents
@@ -132,7 +140,7 @@ def test_hip_matches_oracle_free_running(case, kernel):
         oobs, orew, odone, orem = orc.step(act)
         tstep += 1
         bits = odone.astype(np.uint8) | ((tstep >= H).astype(np.uint8) << 1)
-        assert np.array_equal(info["done_bits"].cpu().numpy(), bits), "step %d done bits" % t
+        assert np.array_equal(info["done_bits"].cpu().numpy(), bits), "step %d done bits" % t   # (bit 7, count overflow, never set)
         assert np.array_equal(info["removed"].cpu().numpy(), orem), "step %d removed" % t
         assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), "step %d rewards" % t
         mask = (bits != 0).astype(np.uint8)
