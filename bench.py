@@ -38,6 +38,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the sub-batch streams of a GPU (madrl_amd/sharded.py) must not share a hardware queue: ROCm multiplexes HIP streams onto
+# GPU_MAX_HW_QUEUES queues (4 by default); read by the HIP runtime when it starts, so set before torch is imported
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # the same guide's measured copy rate (MI355X_MICROARCH.md:34-35): what a pure streaming kernel reaches
@@ -262,7 +265,8 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     # the batch as S independent sub-batches, each on its own HIP stream (madrl_amd/sharded.py): env ids continue across them
     envs = [BatchedPursuitEvade(maps, n_envs=per, device=dev, seed=0, env_id_base=rank * N + j * per, max_steps=H,
                                 auto_reset=True, threads=args.threads, max_blocks=args.max_blocks, **kw) for j in range(S)]
-    hip_streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    from madrl_amd.sharded import shared_streams
+    hip_streams = shared_streams(dev, S) if S > 1 else [torch.cuda.current_stream(dev)]
     D = envs[0].obs_dim
     rec_bytes = envs[0].record_bytes
     if S > 1 and algorithmic_bytes_per_env_step(P, E, D, rec_bytes) * N > 375e6:
@@ -392,7 +396,8 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
     N = args.envs or {"waterworld": 32768, "waterworld_std": 32768, "hostage": 32768, "multiwalker": 16384}[workload]
     S = shard_count(args, N, workload) if streams is None else streams
     per = N // S
-    hip_streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    from madrl_amd.sharded import shared_streams
+    hip_streams = shared_streams(dev, S) if S > 1 else [torch.cuda.current_stream(dev)]
     sp = [C_void(st.cuda_stream) for st in hip_streams]
     base = lambda j: rank * N + j * per
     if workload in ("waterworld", "waterworld_std"):
@@ -493,7 +498,11 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
         H = 500
         envs = [BatchedMultiWalkerEnv(n_walkers=3, n_envs=per, device=dev, seed=0, env_id_base=base(j), auto_reset=True,
                                       max_steps=H, max_blocks=args.max_blocks) for j in range(S)]
-        if os.environ.get("MADRL_BENCH_MW_FUSED"):   # experiments (scripts/stream_sweep.sh): the whole step in one launch
+        # several sub-batches in flight: the whole b2World::Step of a sub-batch as ONE launch (a wavefront then pays its own collide +
+        # solve + continuous-pass time, not the slowest wavefront's of every phase): 3.4 against 4.0 ms per step at four sub-batches;
+        # alone on the chip the two forms take the same 4.6 ms (scripts/stream_sweep.sh)
+        mw_fused = (S > 1) if "MADRL_BENCH_MW_FUSED" not in os.environ else os.environ["MADRL_BENCH_MW_FUSED"] == "1"
+        if mw_fused:
             for e in envs:
                 e.set_mode(fused=True)
         acts = [[(torch.rand((per, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)] for j in range(S)]
@@ -511,7 +520,8 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
         # algorithmic HBM bytes per env-step: actions in, observation / reward / done rows out, the per-env record (bodies, joints,
         # contact cache, terrain) read and written once
         bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * envs[0].world_bytes
-        kernel = "mw_step_kernel<collide> + <solve> + <continuous pass> (three launches per step; kernel_ms is their sum)"
+        kernel = ("mw_step_kernel<all phases> (one launch per sub-batch and step)" if mw_fused else
+                  "mw_step_kernel<collide> + <solve> + <continuous pass> (three launches per step; kernel_ms is their sum)")
         # this path is not HBM-bound -- dependent FP32 work of 180 velocity + up to 60 position Gauss-Seidel sweeps
         # over 12 joints and the active manifolds, and the serial sub-steps of the continuous pass, against ~25 KB; a launch ends with
         # its slowest wavefront (16 envs in lockstep), so the binding resource is the latency of the longest per-env chain

@@ -12,6 +12,26 @@ Results do not depend on the sharding: sub-batch j is created with env_id_base a
 multi-GPU sharding invisible (tests/test_sharded_gpu.py)."""
 import torch
 
+_POOL = {}
+
+
+def shared_streams(device, n):
+    """The process-wide sub-batch streams of `device`: the first `n` of a list that only ever grows.  HIP multiplexes its streams onto
+    a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and two sub-batch streams that end up on ONE queue run
+    their launches one after the other -- measured: Waterworld's two sub-batches 61 instead of 42 us per step when they were the third
+    and fourth stream a process had created; MultiWalker's four sub-batches 6.7 instead of 3.4 ms.  So every StreamSharded (and bench.py)
+    uses the same few streams, created and bound together; with more than two sub-batches next to other stream users, start the process
+    with GPU_MAX_HW_QUEUES=8 (read by the HIP runtime at start-up; bench.py sets it before importing torch)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    pool = _POOL.setdefault(key, [])
+    while len(pool) < max(n, 4):
+        s = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(s):     # first use binds the stream to its hardware queue: all of them now, in this order, whatever the
+            torch.zeros(1, device=device)   # process does later (a pair created on demand, after other streams had run, measured 61 / 42 us)
+        pool.append(s)
+    return pool[:n]
+
 
 class StreamSharded(object):
     def __init__(self, make_env, n_envs, n_streams=2, env_id_base=0, device="cuda:0"):
@@ -23,7 +43,7 @@ class StreamSharded(object):
             raise ValueError("n_envs=%d does not divide into %d sub-batches" % (n_envs, n_streams))
         self.n_envs, self.n_streams, self.per = int(n_envs), int(n_streams), int(n_envs) // int(n_streams)
         self.envs = [make_env(n_envs=self.per, env_id_base=int(env_id_base) + j * self.per, device=self.device) for j in range(self.n_streams)]
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)]
+        self.streams = shared_streams(self.device, self.n_streams)
 
     @property
     def agents(self):

@@ -51,7 +51,7 @@ def test_plain_python_gpus_2_launches_its_own_ranks():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = _last_json(r.stdout)
     assert KEYS <= set(j) and j["n_gpus"] == 2 and j["steps"] == 70 and j["config"]["rccl_ranks"] == 2
-    assert j["config"]["collective_backend"] == "gloo" and j["value"] > 1e6
+    assert j["config"]["collective_backend"] == "gloo" and j["value"] > 1e5
 
 
 def test_default_batch_line_carries_every_baseline_config():

@@ -90,7 +90,7 @@ CASES = {
     # the authors' largest launch line: runners/old/rllab/pursuit_cnn.sh:1 (100 pursuers / 300 evaders, obs_range 21, 128 x 128; their
     # map_pool128.npy is not in the tree -> rectangle_map(128, 128))
     "authors_cnn_100v300": dict(maps="rect128", n_pursuers=100, n_evaders=300, obs_range=21, n_catch=2, surround=True, flatten=False,
-                                reward_mech="local", n_envs=6, steps=20),
+                                reward_mech="local", n_envs=6, steps=20, expect_catches=False),   # (random pursuers surround nobody on a 128 x 128 map in 20 steps)
     "tiny_window": dict(maps="open6", n_pursuers=5, n_evaders=4, obs_range=5, n_catch=2, surround=True, flatten=True,
                         reward_mech="global", constraint_window=0.5),
 }
@@ -121,6 +121,7 @@ def test_hip_matches_oracle_free_running(case, kernel):
     kw = dict(CASES[case])
     maps = _maps(kw.pop("maps"))
     N, T, H = kw.pop("n_envs", 512), kw.pop("steps", 120), 25
+    expect_catches = kw.pop("expect_catches", True)
     if kernel == "auto" and kw["n_pursuers"] + kw["n_evaders"] > 128:
         pytest.skip("no fast path above two wavefronts of agents: the generic kernel is what runs")
     env = _mk(maps, N, seed=2024, env_id_base=1000, max_steps=H, auto_reset=True, kernel=kernel, **kw)
@@ -154,7 +155,7 @@ def test_hip_matches_oracle_free_running(case, kernel):
         if t % 10 == 0 or t == T - 1:
             _cmp_state(env.get_state(), orc.get_state(), "step %d" % t)
             assert np.array_equal(env.get_state()["t"].cpu().numpy(), tstep), "episode step counter"
-    assert n_removed > 0
+    assert n_removed > 0 or not expect_catches
 
 
 @pytest.mark.parametrize("shape", ["c2_wave", "c5_group"])
