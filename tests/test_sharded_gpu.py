@@ -53,3 +53,30 @@ def test_standardized_waterworld_sub_batches_equal_one_batch():
             parts = sh.step(act)
             assert torch.equal(o1, torch.cat([p[0] for p in parts])), (fused, t)
             assert torch.equal(r1, torch.cat([p[1] for p in parts])) and torch.equal(d1, torch.cat([p[2] for p in parts]))
+
+
+def test_sharded_rollout_collector_equals_the_plain_collector():
+    """policy in the loop: two sub-batches driven on their own streams, steps interleaved, give the trajectory of the one-batch collector"""
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from madrl_amd.rollout import RolloutCollector, ShardedRolloutCollector
+    from madrl_amd.sharded import StreamSharded
+    N, P, T = 512, 8, 30
+    mk = lambda n_envs=N, env_id_base=0, device=DEV: BatchedPursuitEvade([rectangle_map(16, 16)], n_envs=n_envs, device=device, seed=11, env_id_base=env_id_base,
+                                                                         max_steps=12, auto_reset=True, n_pursuers=P, n_evaders=30, obs_range=7, reward_mech="local")
+
+    def policy(obs):  # deterministic in the observation
+        s = obs.sum(dim=2)
+        return (s.abs() * 7.3).to(torch.int32) % 5, torch.tanh(s * 0.01)
+
+    one = RolloutCollector(mk(), policy, T, discount=0.95, gae_lambda=0.8, store_observations=True)
+    two = ShardedRolloutCollector(StreamSharded(mk, N, n_streams=2, device=DEV), [policy, policy], T, discount=0.95, gae_lambda=0.8, store_observations=True)
+    graphed = ShardedRolloutCollector(StreamSharded(mk, N, n_streams=2, device=DEV), [policy, policy], T, discount=0.95, gae_lambda=0.8, store_observations=True,
+                                      graph=True)   # one hipGraph per sub-batch and horizon, replayed on the sub-batch's stream
+    for it in range(3):
+        a = one.collect()
+        for col in (two, graphed):
+            parts = col.collect()
+            torch.cuda.synchronize()
+            for k in ("observations", "actions", "rewards", "dones", "returns", "advantages", "values"):
+                assert torch.equal(getattr(a, k), torch.cat([getattr(p, k) for p in parts], dim=1)), (it, k, col is graphed)
