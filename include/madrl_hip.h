@@ -71,7 +71,8 @@ typedef struct madrl_pursuit_config {
                               k shows the window of the k-th remaining evader among slots 0..n_pursuers-1 with id k/n_pursuers
                               (collect_obs walks range(n_agents()) = range(n_pursuers), :418-428), rows past the last such
                               evader are left untouched; rewards stay the pursuers' (:213, :254-256).  Needs
-                              n_evaders >= n_pursuers, no random_opponents; generic kernel only. */
+                              n_evaders >= n_pursuers, no random_opponents; shapes of up to 64 agents listed in
+                              pursuit_specializations.def run on the one-wavefront kernel, everything else on the generic one. */
     int32_t reserved0;
     double catchr;            /* :92 */
     double term_pursuit;      /* :95 */

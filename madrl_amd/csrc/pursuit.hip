@@ -640,6 +640,13 @@ namespace {
 
 template <class S>
 void wave_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t blocks, hipStream_t s) {
+    if constexpr (S::E >= S::P) {
+        if (io.control_evaders) {   // train_pursuit=False: the evader-control instantiations (reset, flexible step)
+            if (mode == 0) hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 0, false, true>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
+            else hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 1, true, true>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
+            return;
+        }
+    }
     if (mode == 0)
         hipLaunchKernelGGL((pw::pursuit_wave_kernel<S, 0, false>), dim3((unsigned)blocks), dim3(64), 0, s, d, io);
     else if (io.flex)
@@ -678,9 +685,9 @@ const WaveEntry WAVE_TABLE[] = {
 
 const WaveEntry *find_wave(const madrl_pursuit_config *c) {
     if (c->flatten && !c->include_id) return nullptr;
-    if (c->control_evaders) return nullptr;  // evader control runs on the generic kernel
     for (const WaveEntry &e : WAVE_TABLE) {
         const WaveGeom &g = e.g;
+        if (c->control_evaders && g.waves > 1) continue;  // evader control: the one-wavefront kernel or the generic one
         if (g.xs == c->xs && g.ys == c->ys && g.P == c->n_pursuers && g.E == c->n_evaders && g.R == c->obs_range &&
             g.flatten == (c->flatten ? 1 : 0))
             return &e;
@@ -790,6 +797,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         w.mask = io.mask; w.inj_pos = io.inj_pos; w.inj_map = io.inj_map; w.actions = io.actions;
         w.inj_eact = io.inj_eact; w.obs = io.obs; w.rew = io.rew; w.done = io.done; w.removed = io.removed;
         w.flex = (io.inj_eact != nullptr || h->dev.catchr_env != nullptr) ? 1 : 0;
+        w.control_evaders = h->dev.train_pursuit ? 0 : 1;
         int64_t blocks = h->max_blocks > 0 ? h->max_blocks : 256 * 4 * h->wave->g.occ / h->wave->g.waves;  // exactly the resident capacity
         if (blocks > h->dev.n_envs) blocks = h->dev.n_envs;
         // Large batches: successive step launches walk the env range in opposite directions, so the rows written last by

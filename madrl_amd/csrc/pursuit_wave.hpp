@@ -78,6 +78,7 @@ struct WaveIO {
     uint8_t *done;
     int32_t *removed;
     int32_t flex;            // host side only: 1 = launch the FLEX instantiation (injected evader actions and / or per-env catchr)
+    int32_t control_evaders; // host side only: 1 = launch the evader-control instantiations (madrl_pursuit_config::control_evaders)
 };
 
 // a wave-uniform float64 read through the scalar cache (s_load_dwordx2, counted by lgkmcnt -- not by the vmcnt the
@@ -119,7 +120,8 @@ struct Shape {
     static constexpr int X_VTAB = (X_ID + P + 3) / 4 * 4;        // 72 count values
     static constexpr int NVT = 72;
     static constexpr int X_NEED = X_VTAB + NVT;                  // XS*YS bytes, as dwords
-    static constexpr int LDS_DWORDS = X_NEED + (XS * YS + 3) / 4;
+    static constexpr int X_OBSV = X_NEED + (XS * YS + 3) / 4;    // evader control: window origin of the observer of row p (P dwords)
+    static constexpr int LDS_DWORDS = X_OBSV + (P + 3) / 4 * 4;
     // packed state record, identical to the generic kernel's layout() in pursuit.hip
     static constexpr int NGW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
     static constexpr int NTW = (A + 31) / 32;
@@ -291,8 +293,13 @@ __device__ __forceinline__ void put_zero_from(uint32_t &w) {
 // instead of Philox, and the catch reward is d.catchr_env[env] when per-env curriculum arrays are bound.
 // It is a template parameter because a conditional global load in the hot loop makes the
 // compiler's s_waitcnt pass put a vmcnt(0) on the common path (see "pipeline hinge" below).
-template <class S, int MODE, bool INJECT>
+// CTRL = evader control (train_pursuit=False, pursuit_evade.py:105-112, :204-241, :418-428): the P actions drive the first P REMAINING
+// evaders of the layer, the pursuers move by their controller (io.inj_eact [n_envs][P] or Philox, TAG_PURSUER_ACT), observation row k
+// shows the window of the k-th remaining evader among slots 0..P-1 and the rows past the last one stay untouched; rewards stay the
+// pursuers'.  Only instantiated for the FLEX step kernel and the reset kernel of shapes with E >= P.
+template <class S, int MODE, bool INJECT, bool CTRL = false>
 __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const WaveDev d, const WaveIO io) {
+    static_assert(!CTRL || (S::E >= S::P && (MODE == 0 || INJECT)), "evader control: n_evaders >= n_pursuers, flexible instantiation");
     constexpr int P = S::P, E = S::E, A = S::A, GW = S::GW, PAD = S::PAD, GSZ = S::GSZ, NS = S::NS;
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int lane = threadIdx.x;
@@ -451,7 +458,17 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                 const int kidx = __popcll((~gone) & ((1ull << (eslot & 63)) - 1ull));
                 int act = cur_act;
                 bool injected = false;
-                if constexpr (INJECT) {
+                if constexpr (CTRL) {
+                    // action k belongs to the k-th remaining evader (:229-230 with agent_layer = evader_layer); evaders past the first P of
+                    // the layer stay; every pursuer moves by one pursuer_controller.act() (:238-241)
+                    const int from_k = __builtin_amdgcn_ds_bpermute((kidx < P ? kidx : 0) * 4, cur_act);   // lane k holds action k
+                    injected = io.inj_eact != nullptr;
+                    int pact;
+                    if (injected) pact = isP() ? io.inj_eact[env * P + lane] : 4;
+                    else pact = (int)__umulhi(philox4x32_10(gid, tick, (uint32_t)lane, TAG_PURSUER_ACT, k0, k1).x, 5u);
+                    act = isP() ? pact : (kidx < P ? from_k : 4);
+                    injected = true;   // (nothing below draws evader moves)
+                } else if constexpr (INJECT) {
                     injected = io.inj_eact != nullptr;
                     if (injected && e_alive) act = io.inj_eact[env * E + kidx];
                 }
@@ -617,7 +634,18 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
 #endif
                 {
                     // byte offset of this pursuer's window origin in L; the slot constants are byte offsets too, so a cell address is one add
-                    const int origin = isP() ? ((x - S::OFF + PAD) * GW + (y - S::OFF + PAD)) * 4 : 0;
+                    int origin = isP() ? ((x - S::OFF + PAD) * GW + (y - S::OFF + PAD)) * 4 : 0;
+                    int n_rows = P;
+                    if constexpr (CTRL) {
+                        // observers (collect_obs walks range(n_pursuers) over evaders_gone, :418-428): the remaining evaders of slots
+                        // 0..P-1 in slot order; row k = the k-th of them.  Each tells lane k its window origin through LDS.
+                        const uint64_t obsv = ~gone & ((1ull << P) - 1ull);
+                        n_rows = __popcll(obsv);
+                        const bool is_obs = isE() && eslot < P && ((obsv >> (eslot & 63)) & 1ull);
+                        if (is_obs) L[S::X_OBSV + __popcll(obsv & ((1ull << (eslot & 63)) - 1ull))] = (uint32_t)(((x - S::OFF + PAD) * GW + (y - S::OFF + PAD)) * 4);
+                        wave_sync();
+                        origin = (isP() && lane < n_rows) ? (int)L[S::X_OBSV + lane] : 0;
+                    }
                     // SGPR base + one loop-invariant 32-bit VGPR offset (+ immediate) for every store of the row
                     const char *orow_u = (const char *)uniform_ptr(io.obs + env * (int64_t)(P * S::D));
                     // if that base came through v_readfirstlane (a VALU write of an SGPR), a vector-memory instruction may read it as its
@@ -641,8 +669,14 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                         const uint32_t nz4 = ((top >> 5) | (top >> 6)) & 0x01010101u;      // value != 0 (meaningful where inside)
                         const uint32_t old4 = (zm >> (NS - 1 - s)) & 0x01010101u;          // holds a value not known to be zero
                         const uint32_t dirty = out4 & old4;                                 // outside AND possibly non-zero: must stay untouched
-                        acc = (acc << 1) | ((out4 & old4) | (~out4 & nz4));
                         bool valid = (64 * (s + 1) <= S::NQ) ? true : (fresh(lane) + 64 * s < S::NQ);
+                        if constexpr (CTRL) {
+                            const bool row_live = (s_src[s] >> 2) < n_rows;   // rows of absent observers keep their contents -- and their flags
+                            acc = (acc << 1) | (row_live ? ((out4 & old4) | (~out4 & nz4)) : old4);
+                            valid = valid && row_live;
+                        } else {
+                            acc = (acc << 1) | ((out4 & old4) | (~out4 & nz4));
+                        }
                         bool clean = dirty == 0u;
 #if MADRL_ABLATE & 1
                         valid = d.n_envs < 0;

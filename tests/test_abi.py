@@ -65,7 +65,9 @@ def test_obs_dim_and_state_bytes():
     assert r.value == 112  # 16 B header + 76 B positions + masks, 16-B aligned
     assert b.value == 65536 * (112 + 256)  # records, then the fast path's stale-zero masks (256 B per env): all caller-owned
     assert L.madrl_pursuit_state_bytes(C.byref(_cfg(n_pursuers=7)), 65536, C.byref(b)) == 0 and b.value == 65536 * 112  # no fast path
-    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(control_evaders=1)), 1000, C.byref(b)) == 0 and b.value == 112128  # evader control: generic kernel only, records padded to 256 B
+    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(control_evaders=1)), 1000, C.byref(b)) == 0 and b.value == 112128 + 1000 * 256  # records padded to 256 B, then the masks
+    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(n_pursuers=16, n_evaders=60, xs=32, ys=32, control_evaders=1)), 1000, C.byref(b)) == 0 and b.value % 256 == 0 \
+        and b.value < 1000 * 512   # evader control above one wavefront of agents: generic kernel only, no masks
 
 
 def test_invalid_configs_are_rejected_with_a_message():

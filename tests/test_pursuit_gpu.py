@@ -333,13 +333,15 @@ def test_pickle_roundtrip_and_param_updates():
 from helpers import evadercontrol_golden_files, replay_evadercontrol  # noqa: E402
 
 
+@pytest.mark.parametrize("kernel", ["generic", "wave"])
 @pytest.mark.parametrize("path", evadercontrol_golden_files(), ids=golden_id)
-def test_hip_matches_reference_golden_evader_control(path):
-    """train_pursuit=False through the C ABI against the record of the unmodified reference."""
+def test_hip_matches_reference_golden_evader_control(path, kernel):
+    """train_pursuit=False through the C ABI against the record of the unmodified reference: the generic kernel and the
+    one-wavefront-per-env kernel's evader-control instantiation."""
     from oracle import pursuit as po
     g = np.load(path)
-    env = _mk(list(g["maps"]), 1, **po.config_from_golden(g))
-    assert env.kernel_kind == "generic" and not env.train_pursuit
+    env = _mk(list(g["maps"]), 1, kernel=kernel, **po.config_from_golden(g))
+    assert env.kernel_kind == kernel and not env.train_pursuit
 
     def state():
         st = env.get_state()
@@ -352,16 +354,18 @@ def test_hip_matches_reference_golden_evader_control(path):
     replay_evadercontrol(g, lambda pos: env.reset(positions=pos)[0].cpu().numpy(), step, state)
 
 
-def test_evader_control_free_running_and_dropin_types():
+@pytest.mark.parametrize("kernel,size", [("generic", 12), ("wave", 16), ("generic", 16)])
+def test_evader_control_free_running_and_dropin_types(kernel, size):
     """train_pursuit=False free-running (in-kernel Philox for the pursuers) against the C oracle, 256 envs with auto-reset; then
     the N == 1 drop-in's return types: None entries for the gone evader slots below n_pursuers (pursuit_evade.py:418-428)."""
     from oracle import pursuit as po
     from madrl_amd.maps import rectangle_map
     from madrl_amd.pursuit import PursuitEvade
-    maps = [rectangle_map(12, 12)]
+    maps = [rectangle_map(size, size)]     # 16 x 16, 5 v 9, obs_range 5 has a one-wavefront specialisation
     kw = dict(n_pursuers=5, n_evaders=9, obs_range=5, n_catch=2, surround=True, flatten=True, reward_mech="local", train_pursuit=False)
     N, T, H = 256, 80, 20
-    env = _mk(maps, N, seed=6, env_id_base=40, max_steps=H, auto_reset=True, **kw)
+    env = _mk(maps, N, seed=6, env_id_base=40, max_steps=H, auto_reset=True, kernel=kernel, **kw)
+    assert env.kernel_kind == kernel
     orc = po.PursuitOracle(maps, n_envs=N, seed=6, env_id_base=40, **kw)
     assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
     rng = np.random.RandomState(2)
@@ -384,7 +388,7 @@ def test_evader_control_free_running_and_dropin_types():
         valid = env.obs_rows_valid().cpu().numpy()
         assert np.array_equal(valid.sum(1), 5 - orc.get_state()["gone"][:, :5].sum(1))
     _cmp_state(env.get_state(), orc.get_state(), "end")
-    assert removed > 0
+    assert removed > 0 or size == 16   # (five random pursuers surround nobody on the larger map; catches on this path: the golden replays)
     one = PursuitEvade(maps, **kw)
     assert len(one.agents) == 5
     obs = one.reset()
