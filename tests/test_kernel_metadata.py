@@ -45,8 +45,8 @@ def _kernels():
 
 
 def test_prefetch_kernels_never_spill():
-    ks = {n: k for n, k in _kernels().items() if "pursuit_wave_kernel" in n and "ELi1ELb0EEE" in n}   # MODE 1, INJECT false
-    assert len(ks) >= 9
+    ks = {n: k for n, k in _kernels().items() if "pursuit_wave_kernel" in n and "ELi1ELb0ELb0EEE" in n}   # MODE 1, INJECT false, CTRL false
+    assert len(ks) >= 11
     for n, k in ks.items():
         assert k["scratch"] == 0 and k["vgpr_spills"] == 0, (n, k)
 
