@@ -232,7 +232,7 @@ def roofline(bytes_per, N, kernel_ms, traffic, kernel, streams=1, **more):
 
 # sub-batches per GPU, each on its own HIP stream, when --streams is not given: what scripts/stream_sweep.sh measured fastest on MI355X
 # (the one-launch-per-step figure is reported next to it in every line: roofline.one_launch_per_step)
-DEFAULT_STREAMS = {"pursuit": 2, "pursuit_c5": 2, "pursuit_colocate": 1, "waterworld": 2, "waterworld_std": 2, "hostage": 2, "multiwalker": 4}
+DEFAULT_STREAMS = {"pursuit": 2, "pursuit_c5": 2, "pursuit_colocate": 2, "waterworld": 2, "waterworld_std": 2, "hostage": 2, "multiwalker": 4}
 
 
 def shard_count(args, N, workload):
@@ -332,6 +332,13 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
         env.reset()
         # steady state: episode ages uniform over [0, H) -- env n reaches the horizon (and runs the fused reset) at step H - age
         env.set_state(dict(t=((torch.arange(per, device=dev, dtype=torch.int32) + j * per) * 7919) % H))
+    # ... and the steady state of the kernel's stale-zero masks: which cells outside the map are known to hold 0.0 decides
+    # between one 16-byte store and masked 4-byte stores per slot, and that knowledge takes ~2 000 steps to reach its equilibrium -- a
+    # launch costs 74 us in the first 500 steps after the masks were reset and 80 us from step 2 000 on (scripts/zmask_drift.py).
+    # Untimed, before the W warm-up steps; --prep 0 measures the young state the earlier rounds reported.
+    for i in range(args.prep):
+        one_step(i, False)
+    torch.cuda.synchronize()
     dt, kernel_ms, region_ms = Timer(world, dev, hip_streams).run(one_step, K, W, tail, prepare)
     kernel_kind = envs[0].kernel_kind
     del envs, outs, hs
@@ -362,7 +369,8 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
         "vs_baseline": None,
         "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic",
         "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset; episode ages "
-                "start uniform over [0, %d): every step resets ~%d of its %d envs through the two-observation-pass path)" % (H, N // H, N),
+                "start uniform over [0, %d): every step resets ~%d of its %d envs through the two-observation-pass path; %d untimed "
+                "steps before the warm-up bring the stale-zero masks of the observation rows to their equilibrium)" % (H, N // H, N, args.prep),
         "config": dict({"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, %s, %s, local reward, "
                                     "%d envs per GPU, horizon %d" % (MS, MS, P, E, catch, "flatten" if mode["flatten"] else "(R,R,4) observations", N, H),
                         "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world,
@@ -626,6 +634,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="headline only: do not time the other BASELINE configs")
     ap.add_argument("--horizon", type=int, default=500, help="max_path_length (runners/__init__.py:88)")
+    ap.add_argument("--prep", type=int, default=2000, help="Pursuit: untimed steps before the warm-up that bring the stale-zero masks of the observation "
+                                                            "rows to their equilibrium (a rollout's steady state, like the spread episode ages)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -176,6 +176,11 @@ int madrl_pursuit_set_state(madrl_pursuit *h, const int32_t *pos_p, const int32_
                             void *stream);
 /* The caller modified the observation buffer behind the library's back (see obs_dev above): forget what is known about it. */
 int madrl_pursuit_invalidate_obs(madrl_pursuit *h);
+/* The opposite promise: every element of obs_dev holds +0.0f right now (a freshly zeroed buffer, which is what the reference's
+ * local_obs starts as, pursuit_evade.py:119-120).  The fast path then knows that no cell outside the map can hold a stale value that
+ * needs protecting and stores whole 16-byte words from the first step on; without the promise a cell counts as "unknown" until it has
+ * been inside the map once.  Results are the same either way -- provided the promise is true. */
+int madrl_pursuit_declare_obs_zero(madrl_pursuit *h, const float *obs_dev, void *stream);
 
 /* Curriculum (PursuitEvade.update_curriculum, pursuit_evade.py:264-272; set_param_values, madrl_environments/__init__.py:64-67)
  * without re-creating the handle.  set_params replaces the batch-wide catchr / constraint_window of the config;

@@ -85,6 +85,7 @@ SIGNATURES = {
     "madrl_pursuit_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
     "madrl_pursuit_record_bytes": (C.c_int, [_vp, _vp]),
     "madrl_pursuit_invalidate_obs": (C.c_int, [_vp]),
+    "madrl_pursuit_declare_obs_zero": (C.c_int, [_vp, _vp, _vp]),
     "madrl_pursuit_set_params": (C.c_int, [_vp, C.c_double, C.c_double]),
     "madrl_pursuit_set_curriculum": (C.c_int, [_vp, _vp, _vp]),
     "madrl_pursuit_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp, _vp]),

@@ -1192,13 +1192,24 @@ int madrl_pursuit_set_state(madrl_pursuit *h, const int32_t *pos_p, const int32_
     hipLaunchKernelGGL(pursuit_set_state_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, h->dev, pos_p,
                        pos_e, gone, term_p, term_e, map_id, tick, t);
     MADRL_HIP_TRY(hipGetLastError());
-    h->zmask_obs = nullptr;  // a state written from outside usually comes with an observation buffer written from outside
+    // agents put somewhere else usually come with an observation buffer written from outside (a checkpoint restored): forget what is known
+    // about it.  Episode clocks and RNG ticks alone (t, tick) say nothing about the buffer.
+    if (pos_p || pos_e || gone || term_p || term_e || map_id) h->zmask_obs = nullptr;
     return MADRL_OK;
 }
 
 int madrl_pursuit_invalidate_obs(madrl_pursuit *h) {
     if (!h) return fail(MADRL_EINVAL, "handle is NULL");
     h->zmask_obs = nullptr;  // the next fast-path launch starts from "no cell is known to be zero"
+    return MADRL_OK;
+}
+
+int madrl_pursuit_declare_obs_zero(madrl_pursuit *h, const float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(MADRL_EINVAL, "declare_obs_zero: NULL argument");
+    if (h->zmask) {   // every cell of that buffer is known to hold +0.0f: no stale cell can need protecting
+        MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0, (size_t)h->dev.n_envs * 256 * h->wave->g.waves, (hipStream_t)stream));
+        h->zmask_obs = obs_dev;
+    }
     return MADRL_OK;
 }
 

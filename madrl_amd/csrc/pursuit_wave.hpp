@@ -695,7 +695,18 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                                                         md & __builtin_amdgcn_ballot_w64(v3 != SENT));
                         // One non-temporal float4 unless a cell must stay untouched; nothing if all four are outside and known zero.
                         // Outside cells (SENT = -1 as an integer) are written as the +0.0f they already hold.
-                        const uint64_t m_nt = __builtin_amdgcn_ballot_w64(valid && clean && out4 != 0x01010101u);
+                        uint64_t m_nt = __builtin_amdgcn_ballot_w64(valid && clean && out4 != 0x01010101u);
+                        // Whole 64-byte chunks: a slot that lies ENTIRELY outside the map and whose cells are known to hold zero normally
+                        // stores nothing -- but when another slot of its aligned group of four lanes is written, it is written too (as the
+                        // zeros it already holds), so that the group's 64 bytes leave the CU as one full chunk instead of a partial one the
+                        // memory side has to merge.  Round 4, mask equilibrium, 65 536 envs: 80.0 -> 71.6 us per launch (groups of two:
+                        // 74.0, of eight: 75.8; scripts/zmask_drift.py).  (The two-wavefront kernel, whose 32 x 32 map leaves far fewer cells outside, loses
+                        // with the same rule -- 86.5 against 80.4 us per 32 768-env launch -- and does not apply it.)
+                        {
+                            constexpr uint64_t lo4 = 0x1111111111111111ull;
+                            const uint64_t grp = (m_nt | (m_nt >> 1) | (m_nt >> 2) | (m_nt >> 3)) & lo4;   // bit 4g: group g stores something
+                            m_nt |= (grp * 0xFull) & __builtin_amdgcn_ballot_w64(valid && clean && out4 == 0x01010101u);
+                        }
                         const v4f_t val = {__uint_as_float((uint32_t)max((int)v0, 0)), __uint_as_float((uint32_t)max((int)v1, 0)),
                                            __uint_as_float((uint32_t)max((int)v2, 0)), __uint_as_float((uint32_t)max((int)v3, 0))};
                         store4_nt_masked<1024 * (s % 4)>(sb, voff, val, m_nt);

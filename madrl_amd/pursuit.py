@@ -140,6 +140,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
             self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
             self._removed = torch.zeros(N, dtype=torch.int32, device=dev)
             self._shape_key = shape_key
+            self._obs_is_fresh = True   # every element +0.0f, like the reference's local_obs at construction (:119-120)
         self.obs_dim = D
         self._destroy()
         h = C.c_void_p()
@@ -148,6 +149,8 @@ class BatchedPursuitEvade(AbstractMAEnv):
                                           dev_index, _lib.ptr(self._state), C.byref(h)))
         self._handle = h
         self._handle_key = self._create_key()
+        if getattr(self, "_obs_is_fresh", False):   # nothing has written the buffer yet: tell the fast path (no cell "unknown" at the start)
+            _lib.check(L.madrl_pursuit_declare_obs_zero(h, _lib.ptr(self._obs), _lib.current_stream(self.device)))
         self.handle_generation = getattr(self, "handle_generation", 0) + 1   # how many times the native handle was (re-)created
         if getattr(self, "_cw_env", None) is not None and self._cw_env.shape[0] == N:   # per-env curriculum follows the new handle
             _lib.check(L.madrl_pursuit_set_curriculum(h, _lib.ptr(self._cw_env), _lib.ptr(self._catchr_env)))
@@ -250,7 +253,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
             raise RuntimeError("the agent counts changed (update_curriculum / set_param_values): the whole batch must be reset() once")
         _lib.check(_lib.lib().madrl_pursuit_reset(self._handle, _lib.ptr(mask), _lib.ptr(pos), _lib.ptr(mid),
                                                   _lib.ptr(self._obs), self._stream()))
-        self._was_reset, self._needs_reset = True, False
+        self._was_reset, self._needs_reset, self._obs_is_fresh = True, False, False
         return self._obs_view()
 
     def step(self, actions, evader_actions=None, rew_out=None, done_out=None):
@@ -265,6 +268,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
         act = self._i32(actions, (N, P), "actions")
         # evader control (train_pursuit=False): the opponents are the pursuers, one injected action per pursuer
         eact = self._i32(evader_actions, (N, E if self.train_pursuit else P), "evader_actions")
+        self._obs_is_fresh = False
         rew = self._rew if rew_out is None else rew_out
         dn = self._done if done_out is None else done_out
         assert rew.dtype == torch.float32 and rew.numel() == N * P and dn.dtype == torch.uint8 and dn.numel() == N

@@ -3,14 +3,14 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" 
 tail -3 gpurun_out/smoke.log
-timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -8 gpurun_out/pytest_gpu.log
-timeout 400 python bench.py > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"
+timeout 600 python bench.py > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"
 tail -1 gpurun_out/bench.log | python -c "
 import json,sys
 j=json.loads(sys.stdin.read())
-print('headline %.4g %s  ms/step %.4f  frac %.3f' % (j['value'], j['unit'], j['ms_per_step'], j['roofline']['frac']))
+print('headline %.4g %s  ms/step %.4f %s frac %.3f  one-launch %.4f frac %.3f' % (j['value'], j['unit'], j['ms_per_step'], j['config']['region_ms_per_step'], j['roofline']['frac'], j['roofline']['one_launch_per_step']['ms_per_step'], j['roofline']['one_launch_per_step']['frac']))
 for k,v in j.get('workloads',{}).items():
-    print(' ', k, ('%.4g ms/step %.4f frac %.3f' % (v['value'], v['ms_per_step'], v['roofline']['frac'])) if 'value' in v else v)
+    print(' ', k, ('%.4g ms/step %.4f frac %.3f one-launch %s cpu %.3g' % (v['value'], v['ms_per_step'], v['roofline']['frac'], v['roofline'].get('one_launch_per_step',{}).get('ms_per_step'), v['cpu_baseline']['value'])) if 'value' in v else v)
 print('cpu_baseline', j.get('cpu_baseline',{}).get('value'))
 "
