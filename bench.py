@@ -374,7 +374,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
         "config": dict({"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, %s, %s, local reward, "
                                     "%d envs per GPU, horizon %d" % (MS, MS, P, E, catch, "flatten" if mode["flatten"] else "(R,R,4) observations", N, H),
                         "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world,
-                        "streams_per_gpu": S, "envs_per_launch": per,
+                        "streams_per_gpu": S, "envs_per_launch": per, "prep_steps": args.prep,
                         "step_is": ("one pass of the step kernel over all %d envs of the GPU: %d launches of %d envs, one per HIP stream, not ordered "
                                     "against each other (independent env instances)" % (N, S, per)) if S > 1 else "one launch of the step kernel over all %d envs" % N,
                         "rccl_ranks": world, "collective_backend": (os.environ.get("MADRL_BENCH_BACKEND", "nccl") if world > 1 else None),

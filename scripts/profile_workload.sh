@@ -34,9 +34,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     except Exception:
         pmc_line = None
     if tot > 0 and pmc_line:
-        n_steps = pmc_line["warmup"] + pmc_line["config"]["timed_regions"] * pmc_line["steps"]   # step() calls of the whole batch (+ one reset launch: < 1 %)
+        prep = pmc_line["config"].get("prep_steps", 0)   # Pursuit: untimed steps that bring the stale-zero masks to their equilibrium
+        n_steps = prep + pmc_line["warmup"] + pmc_line["config"]["timed_regions"] * pmc_line["steps"]   # step() calls of the whole batch (+ one reset launch: < 1 %)
         if S > 1 and "one_launch_per_step" in pmc_line["roofline"]:
-            n_steps += min(pmc_line["warmup"], 20) + pmc_line["config"]["timed_regions"] * pmc_line["steps"]   # the one-launch-per-step reference pass of the same run
+            n_steps += prep + min(pmc_line["warmup"], 20) + pmc_line["config"]["timed_regions"] * pmc_line["steps"]   # the one-launch-per-step reference pass of the same run
         vals[c] = tot / n_steps
 if len(vals) == 2:
     step_bytes = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
