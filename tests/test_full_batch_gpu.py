@@ -69,6 +69,44 @@ def test_pursuit_full_batch_bit_exact(case):
     assert n_resets >= N and n_removed > 0, (n_resets, n_removed)   # every env went through the fused reset at least once
 
 
+@pytest.mark.parametrize("mode", ["headline", "secondary_hwc"])
+@pytest.mark.parametrize("start", ["declared_zero", "nothing_known"])
+def test_long_rollout_into_the_mask_equilibrium_is_bit_exact(mode, start):
+    """The fast path decides per 16-byte slot between one whole store (cells outside the map that are KNOWN to hold 0.0 are written as
+    zeros, and all-outside slots complete their 64-byte chunk) and masked 4-byte stores (a stale value must survive), from the stale-zero
+    masks it keeps.  What is known changes for ~2 000 steps; this runs 2 048 envs for 1 200 steps from both starting states of the masks --
+    the buffer declared all-zero (what the Python layer does for the buffer it allocates) and "nothing known" (invalidate_obs) -- and
+    compares the WHOLE persistent observation buffer with the oracle's every 100 steps."""
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from oracle import pursuit as po
+    N, P, E, T, H = 2048, 8, 30, 1200, 97
+    maps = [rectangle_map(16, 16)]
+    kw = dict(n_pursuers=P, n_evaders=E, obs_range=7, reward_mech="local")
+    kw.update(dict(n_catch=2, surround=True, flatten=True) if mode == "headline" else dict(n_catch=2, surround=False, flatten=False))
+    env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=5, env_id_base=1 << 20, max_steps=H, auto_reset=True, **kw)
+    assert env.kernel_kind == "wave"
+    if start == "nothing_known":
+        env.invalidate_obs()
+    orc = po.PursuitOracle(maps, n_envs=N, seed=5, env_id_base=1 << 20, **kw)
+    assert np.array_equal(env.reset().cpu().numpy().reshape(N, P, -1), orc.reset())
+    rng = np.random.RandomState(3)
+    tstep = np.zeros(N, np.int64)
+    for t in range(T):
+        act = rng.randint(5, size=(N, P)).astype(np.int32)
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
+        oobs, orew, odone, orem = orc.step(act)
+        tstep += 1
+        mask = (odone.astype(np.uint8) | ((tstep >= H).astype(np.uint8) << 1)) != 0
+        if mask.any():
+            orc.reset(mask=mask.astype(np.uint8))
+            tstep[mask] = 0
+        if t % 100 == 99 or t < 3:
+            got = obs.cpu().numpy().reshape(N, P, -1)
+            assert np.array_equal(got, orc.obs), "step %d: %d observation cells differ" % (t, int((got != orc.obs).sum()))
+            assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)) and np.array_equal(info["removed"].cpu().numpy(), orem)
+
+
 def test_waterworld_c3_full_batch_matches_f32_oracle():
     """32 768 envs, free-running (no re-synchronisation), auto-reset at a short horizon so that the respawn / reset paths
     run inside the compared region: every output of every step equals the float32 oracle's bit for bit."""
