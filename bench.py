@@ -150,16 +150,24 @@ def attach_cpu_baselines(out, live_ref_key, record_key, port_fn):
         out["cpu_reference_recorded"] = rec
 
 
+def collective_on(world):
+    """The N > 1 machinery (process group, barrier, max over ranks, the chunked trajectory all-gather inside the timed region) runs when
+    there is more than one rank -- or when MADRL_BENCH_FORCE_COLLECTIVE=1 asks for it with ONE rank: the only way to take the RCCL
+    ("nccl") code path on a one-GPU box (two ranks on one device are refused by RCCL; tests/test_bench_contract_gpu.py)."""
+    return world > 1 or os.environ.get("MADRL_BENCH_FORCE_COLLECTIVE") == "1"
+
+
 class Timer(object):
     """the bench contract: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + synchronize on both sides;
     HIP events on the launch stream give the average launch duration"""
 
     def __init__(self, world, dev, streams=None):
         self.world, self.dev, self.streams = world, dev, streams
+        self.coll = collective_on(world)
 
     def barrier(self):
         import torch
-        if self.world > 1:
+        if self.coll:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -185,7 +193,7 @@ class Timer(object):
         # several streams the launches of one step run CONCURRENTLY (one per stream), so this is the duration of the step, not of a
         # kernel running alone
         kernel_ms = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / K
-        if self.world > 1:
+        if self.coll:
             import torch.distributed as dist
             tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -279,12 +287,13 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
     # compact trajectory of the timed region (what a sampler returns to the learner), cut into
     # chunks whose all-gather over RCCL/xGMI overlaps with the stepping of the next chunk
+    coll = collective_on(world)
     CH = 50
     n_chunks = (K + CH - 1) // CH
     chunk_len = [min(CH, K - c * CH) for c in range(n_chunks)]
     traj = [dict(actions=torch.zeros((chunk_len[c], N, P), dtype=torch.uint8, device=dev),
                  rewards=torch.zeros((chunk_len[c], N, P), dtype=torch.float32, device=dev),
-                 dones=torch.zeros((chunk_len[c], N), dtype=torch.uint8, device=dev)) for c in range(n_chunks)] if world > 1 else []
+                 dones=torch.zeros((chunk_len[c], N), dtype=torch.uint8, device=dev)) for c in range(n_chunks)] if coll else []
     L = _lib.lib()
     hs = [e._handle for e in envs]
     outs = [[_lib.ptr(t) for t in (e._obs, e._rew, e._done, e._removed)] for e in envs]
@@ -293,11 +302,11 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     # N > 1: the step kernel writes rewards / dones straight into their slot of the trajectory chunk (the C ABI takes any
     # device pointer), only the action row is copied (int32 -> uint8)
     slot_p = [[(_lib.ptr(traj[c]["rewards"][q][j * per:(j + 1) * per]), _lib.ptr(traj[c]["dones"][q][j * per:(j + 1) * per]))
-               for c in range(n_chunks) for q in range(chunk_len[c])] for j in range(S)] if world > 1 else []
+               for c in range(n_chunks) for q in range(chunk_len[c])] for j in range(S)] if coll else []
     gatherer = None
-    if world > 1:
+    if coll:
         from madrl_amd.dist import ChunkedTrajectoryGather
-        gatherer = ChunkedTrajectoryGather()
+        gatherer = ChunkedTrajectoryGather(always_collective=True)
 
     def prepare():
         if gatherer is not None:
@@ -312,13 +321,13 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
 
     def one_step(i, record):
         for j in range(S):
-            rp, dp = slot_p[j][i] if (record and world > 1) else (outs[j][1], outs[j][2])
+            rp, dp = slot_p[j][i] if (record and coll) else (outs[j][1], outs[j][2])
             _lib.check(L.madrl_pursuit_step(hs[j], act_p[j][i % n_act], None, outs[j][0], rp, dp, outs[j][3], sp[j]))
-            if record and world > 1:
+            if record and coll:
                 c, q = divmod(i, CH)
                 with torch.cuda.stream(hip_streams[j]):
                     traj[c]["actions"][q][j * per:(j + 1) * per].copy_(actions[i % n_act][j * per:(j + 1) * per])
-        if record and world > 1 and (i + 1) % CH == 0:
+        if record and coll and (i + 1) % CH == 0:
             submit(traj[i // CH])
 
     def tail():
@@ -343,7 +352,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     kernel_kind = envs[0].kernel_kind
     del envs, outs, hs
     one = None
-    if reference_pass and S > 1 and world == 1:
+    if reference_pass and S > 1 and not coll:
         # the same batch as ONE launch per step on one stream, in the same process: what the sub-batch streams are compared with
         one = bench_pursuit(args, variant, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False)
     if rank != 0:
@@ -377,7 +386,8 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
                         "streams_per_gpu": S, "envs_per_launch": per, "prep_steps": args.prep,
                         "step_is": ("one pass of the step kernel over all %d envs of the GPU: %d launches of %d envs, one per HIP stream, not ordered "
                                     "against each other (independent env instances)" % (N, S, per)) if S > 1 else "one launch of the step kernel over all %d envs" % N,
-                        "rccl_ranks": world, "collective_backend": (os.environ.get("MADRL_BENCH_BACKEND", "nccl") if world > 1 else None),
+                        "rccl_ranks": world, "collective_backend": (os.environ.get("MADRL_BENCH_BACKEND", "nccl") if coll else None),
+                        "trajectory_gather_in_timed_region": bool(coll),
                         "horizon_resets_per_env_in_timed_region": K / float(H),
                         "horizon_resets_per_step": N / float(H), "horizon_resets_per_launch": per / float(H)}, **region_stats(region_ms)),
         "roofline": roof,
@@ -651,15 +661,21 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if collective_on(world):
         import torch.distributed as dist
+        if world == 1 and "MASTER_ADDR" not in os.environ:   # MADRL_BENCH_FORCE_COLLECTIVE: a one-rank group needs a rendezvous too
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+            sk.close()
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
     K, W = args.steps, args.warmup
-    cpu = (not args.no_cpu_baseline) and world == 1   # the CPU baselines are reported with the 1-GPU line only
+    cpu = (not args.no_cpu_baseline) and not collective_on(world)   # the CPU baselines are reported with the plain 1-GPU line only
     scale = float(os.environ.get("MADRL_BENCH_CPU_BUDGET", "1"))   # tests shorten the CPU samples
     head_cpu, side_cpu = (10.0 * scale, 3.0 * scale) if cpu else (0, 0)
     if args.workload.startswith("pursuit"):
@@ -668,7 +684,7 @@ def main():
         out = bench_other(args, args.workload, K, W, rank, world, dev, head_cpu)
     # The same driver run times every other BASELINE config (N = 1, default workload, default batch): bounded steps and a bounded
     # CPU sample (3 s) each
-    if args.workload == "pursuit" and world == 1 and not args.no_workloads and not args.envs:
+    if args.workload == "pursuit" and not collective_on(world) and not args.no_workloads and not args.envs:
         wl = {}
         for name, k, w in (("waterworld", min(K, 200), min(W, 20)), ("multiwalker", min(K, 50), W), ("pursuit_c5", min(K, 200), min(W, 20)),
                            ("pursuit_colocate", min(K, 200), min(W, 20)), ("waterworld_std", min(K, 100), min(W, 20))):
@@ -682,7 +698,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if collective_on(world):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -79,16 +79,19 @@ class ChunkedTrajectoryGather(object):
     single blocking gather at the end would cost ~30 % of the rollout; chunking hides it.
     """
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_collective=False):
+        """always_collective: issue the all-gathers even in a one-rank group (they are then copies made by the backend) instead of
+        returning views -- how a one-GPU box exercises the RCCL path (bench.py, MADRL_BENCH_FORCE_COLLECTIVE=1)."""
         self.group = group
         self.pending = []   # (name, buffer, work)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.local_only = self.world == 1 and not (always_collective and dist.is_initialized())
         self._reserved = {}  # id(local tensor) -> receive buffer
 
     def reserve(self, chunks):
         """Allocate the receive buffers of the given chunks (list of dicts name -> tensor) ahead of the rollout and run one
         tiny collective, so that neither hipMalloc nor RCCL's lazy channel setup lands between two step launches."""
-        if self.world == 1:
+        if self.local_only:
             return
         for local in chunks:
             for k in sorted(local):
@@ -104,7 +107,7 @@ class ChunkedTrajectoryGather(object):
         out = {}
         for k in sorted(local):
             v = local[k].contiguous()
-            if self.world == 1:
+            if self.local_only:
                 out[k] = v.unsqueeze(0)
                 self.pending.append((k, out[k], None))
                 continue

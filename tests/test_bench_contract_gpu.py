@@ -54,6 +54,21 @@ def test_plain_python_gpus_2_launches_its_own_ranks():
     assert j["config"]["collective_backend"] == "gloo" and j["value"] > 1e5
 
 
+def test_one_rank_takes_the_rccl_path():
+    """backend "nccl" (= RCCL) with ONE rank on the one visible GPU: process group on the device, barrier, max over ranks, and the
+    chunked asynchronous all-gather of the compact trajectory inside the timed region -- the code an 8-GPU run takes, minus the peers
+    (two ranks on one device are refused by RCCL, so the two-rank tests above run over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MADRL_BENCH_BACKEND")}
+    env.update(MADRL_BENCH_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--envs", "8192", "--steps", "120", "--warmup", "5", "--prep", "50"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    j = _last_json(r.stdout)
+    assert KEYS <= set(j) and j["n_gpus"] == 1 and j["steps"] == 120 and j["config"]["rccl_ranks"] == 1
+    assert j["config"]["collective_backend"] == "nccl" and j["config"]["trajectory_gather_in_timed_region"] is True
+    assert j["value"] > 1e7 and "workloads" not in j and "cpu_baseline" not in j
+
+
 def test_default_batch_line_carries_every_baseline_config():
     """the default invocation (BASELINE batch sizes) times Waterworld, MultiWalker and the configs[4] shard in the same run and
     reports them under `workloads`; every launch of the headline carries fused resets (steady-state episode ages)"""
