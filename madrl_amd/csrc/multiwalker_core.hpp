@@ -1242,13 +1242,19 @@ MW_HD_INLINE void joint_init_warm(const Model &M, Hot &Wd, const ColdView &Cd, S
 }
 
 // b2RevoluteJoint::SolveVelocityConstraints
+// Box2D branches on the limit state (point-to-point only | limit + point, with or without the "reduce" fallback to the 2 x 2 system).
+// The lanes of a wavefront hold joints in every one of those states, so a branching version runs all the paths one after the other
+// behind exec masks.  Here the paths share what they have in common -- Cdot1, ONE 2 x 2 solve whose right-hand side is selected, one
+// application of the impulse -- and the rest is value selects: every lane computes exactly the expressions its own branch of Box2D
+// would (a select never changes a value), at two thirds of the instructions and without the exec bookkeeping.
 MW_HD_INLINE void joint_solve_velocity(Hot &Wd, JointCache &c) {
     Body &A = Wd.b[c.bA], &B = Wd.b[c.bB];
     const float mA = c.mA, iA = c.iA, mB = c.mB, iB = c.iB;
     const V2 rA = c.rA, rB = c.rB;
     V2 vA = A.v, vB = B.v; float wA = A.w, wB = B.w;
-    MW_FLOPS((c.limit_state != 3 ? 9 : 0) + (c.limit_state != 0 ? 73 : 38));
-    if (c.limit_state != 3) {  // motor (enableMotor is always true)
+    const int ls = c.limit_state;
+    MW_FLOPS((ls != 3 ? 9 : 0) + (ls != 0 ? 73 : 38));
+    if (ls != 3) {  // motor (enableMotor is always true)
         const float Cdot = wB - wA - c.motor_speed;
         float imp = -c.motor_mass * Cdot;
         const float old = c.motor_impulse, maxi = c.maxi;
@@ -1256,37 +1262,28 @@ MW_HD_INLINE void joint_solve_velocity(Hot &Wd, JointCache &c) {
         imp = c.motor_impulse - old;
         wA -= iA * imp; wB += iB * imp;
     }
-    if (c.limit_state != 0) {  // limit + point constraint (3x3)
-        const V2 Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA);
-        const float Cdot2 = wB - wA;
-        float ix, iy, iz;
-        solve33(c.k, c.c33x, c.c33y, c.c33z, c.idet33, Cdot1.x, Cdot1.y, Cdot2, ix, iy, iz);
-        ix = -ix; iy = -iy; iz = -iz;
-        bool reduce = false;
-        if (c.limit_state == 3) { c.ix += ix; c.iy += iy; c.iz += iz; }
-        else if (c.limit_state == 1) { reduce = (c.iz + iz) < 0.0f; }
-        else { reduce = (c.iz + iz) > 0.0f; }
-        if (c.limit_state != 3) {
-            if (reduce) {
-                const float rx = -Cdot1.x + c.iz * c.k[6], ry = -Cdot1.y + c.iz * c.k[7];
-                float qx, qy;
-                solve22(c.k, c.idet22, rx, ry, qx, qy);
-                ix = qx; iy = qy; iz = -c.iz;
-                c.ix += qx; c.iy += qy; c.iz = 0.0f;
-            } else { c.ix += ix; c.iy += iy; c.iz += iz; }
-        }
-        const V2 P = v2(ix, iy);
-        vA = vA - mA * P; wA -= iA * (cross(rA, P) + iz);
-        vB = vB + mB * P; wB += iB * (cross(rB, P) + iz);
-    } else {  // point-to-point only
-        const V2 Cdot = vB + cross(wB, rB) - vA - cross(wA, rA);
-        float ix, iy;
-        solve22(c.k, c.idet22, -Cdot.x, -Cdot.y, ix, iy);
-        c.ix += ix; c.iy += iy;
-        const V2 P = v2(ix, iy);
-        vA = vA - mA * P; wA -= iA * cross(rA, P);
-        vB = vB + mB * P; wB += iB * cross(rB, P);
-    }
+    const bool p2p = ls == 0;   // point-to-point only
+    const V2 Cdot1 = vB + cross(wB, rB) - vA - cross(wA, rA);
+    const float Cdot2 = wB - wA;
+    float jx, jy, jz;           // limit + point constraint (3 x 3); unused (and possibly not finite) on a point-to-point lane
+    solve33(c.k, c.c33x, c.c33y, c.c33z, c.idet33, Cdot1.x, Cdot1.y, Cdot2, jx, jy, jz);
+    jx = -jx; jy = -jy; jz = -jz;
+    const float sum = c.iz + jz;
+    const bool reduce = (ls == 1 && sum < 0.0f) || (ls == 2 && sum > 0.0f);
+    // the 2 x 2 system: right-hand side -Cdot (point-to-point) or -Cdot1 + m_impulse.z * (ez.x, ez.y) ("reduce")
+    const float rx0 = -Cdot1.x, ry0 = -Cdot1.y;
+    const float rx1 = rx0 + c.iz * c.k[6], ry1 = ry0 + c.iz * c.k[7];
+    float qx, qy;
+    solve22(c.k, c.idet22, reduce ? rx1 : rx0, reduce ? ry1 : ry0, qx, qy);
+    const bool two = p2p || reduce;
+    const float ix = two ? qx : jx, iy = two ? qy : jy;
+    const float iz = reduce ? -c.iz : jz;                    // (not applied on a point-to-point lane)
+    c.ix += ix; c.iy += iy;
+    c.iz = reduce ? 0.0f : (p2p ? c.iz : sum);
+    const V2 P = v2(ix, iy);
+    const float tA = cross(rA, P), tB = cross(rB, P);
+    vA = vA - mA * P; wA -= iA * (p2p ? tA : tA + iz);
+    vB = vB + mB * P; wB += iB * (p2p ? tB : tB + iz);
     A.v = vA; A.w = wA; B.v = vB; B.w = wB;
 }
 
