@@ -32,7 +32,7 @@ def test_oracle_reproduces_reference_records(path):
         if not g["is_reset_step"][t]:
             assert np.abs(rew[0] - g["rew"][t]).max() < 1e-12, (t, rew[0], g["rew"][t])
             assert int(done[0]) == int(g["done"][t]) and list(info[0]) == list(g["info"][t]), t
-    assert (g["resp"][..., 0] >= 0).sum() > 3
+    assert (g["resp"][..., 0] >= 0).sum() > 3 or "fuzz" in path   # the hand-written scenarios must exercise respawns; the drawn ones take what comes
 
 
 def test_reset_sampling_ranges_and_key_persistence():
