@@ -11,6 +11,15 @@ box2d-py` and the reference checkout can pin them:
 
 Exit status 0 and a message when Box2D is missing (nothing written).
 
+    python oracle/make_golden_multiwalker.py --envlayer      # what this repository CAN record: tests/golden/multiwalker_envlayer_*.npz
+
+--envlayer puts oracle/shims_box2d on the path: a package named `Box2D` whose b2World is the World of oracle/multiwalker_ref.c (the
+independent restatement of the Box2D 2.3.0 subset the env uses).  The UNMODIFIED reference module then imports and runs here: its reset()
+builds the world call by call, its apply_action / get_observation / ContactDetector / LidarCallback / rewards / termination run on the restated
+dynamics.  Those files pin this repository's ENV LAYER (and the world its reset constructs) to the reference's own code --
+tests/test_multiwalker_envlayer.py replays them through the oracle, the product source and the kernels, free-running -- and say nothing
+about the dynamics (b2World::Step stays restated: PARITY UNPINNED).
+
 What is recorded, per episode of n_walkers walkers under seeded random actions with stretches of zero actions (walkers collapse:
 hull contacts, dropped package, resets):
   terrain_y [NT] float64        env.terrain_y after reset (multi_walker.py:516-612)            -> reset_with(terrain=)
@@ -52,11 +61,11 @@ def flags_of(env):
     return np.asarray(f, np.uint8)
 
 
-def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed):
+def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed, prefix="multiwalker_box2d_", zero_from=44, **env_kw):
     rng = np.random.RandomState(seed)
     out = []
     for ep in range(episodes):
-        env = MultiWalkerEnv(n_walkers=n_walkers, position_noise=0.0, angle_noise=0.0, reward_mech=reward_mech)
+        env = MultiWalkerEnv(n_walkers=n_walkers, position_noise=0.0, angle_noise=0.0, reward_mech=reward_mech, **env_kw)
         env.seed(int(rng.randint(2 ** 31 - 1)))
         pushes = []
         real_uniform = env.np_random.uniform
@@ -72,7 +81,7 @@ def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed):
                    obs=[np.asarray(obs0, np.float32)], rew=[], done=[], flags=[flags_of(env)])
         for t in range(steps):
             a = rng.uniform(-1, 1, (n_walkers, 4)).astype(np.float32)
-            if t % 60 > 44:
+            if t % 60 > zero_from:
                 a[:] = 0
             o, r, d, _ = env.step(a)
             rec["actions"].append(a); rec["obs"].append(np.asarray(o, np.float32)); rec["rew"].append(np.asarray(r, np.float64).reshape(-1) * np.ones(n_walkers))
@@ -80,8 +89,11 @@ def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed):
             if d:
                 break
         out.append({k: np.asarray(v) for k, v in rec.items()})
-    path = os.path.join(OUT, "multiwalker_box2d_%s.npz" % name)
+    path = os.path.join(OUT, "%s%s.npz" % (prefix, name))
     flat = {"n_episodes": np.int64(len(out)), "n_walkers": np.int64(n_walkers), "reward_global": np.int64(reward_mech == "global")}
+    for k in ("forward_reward", "fall_reward", "drop_reward"):
+        flat["cfg_" + k] = np.float64(getattr(env, k))
+    flat["cfg_terminate_on_fall"] = np.int64(bool(env.terminate_on_fall))
     for i, r in enumerate(out):
         for k, v in r.items():
             flat["ep%d_%s" % (i, k)] = v
@@ -90,18 +102,36 @@ def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed):
 
 
 def main():
+    envlayer = "--envlayer" in sys.argv[1:]
+    root = os.environ.get("MADRL_REFERENCE_ROOT", "/root/reference")
+    if envlayer:
+        sys.path.insert(0, os.path.join(HERE, "shims_box2d"))
     try:
-        import Box2D  # noqa: F401
+        import Box2D
     except Exception as e:  # pragma: no cover
         print("Box2D cannot be imported here (%s): no MultiWalker goldens written; the MultiWalker oracles stay PARITY UNPINNED." % e)
         return 0
-    root = os.environ.get("MADRL_REFERENCE_ROOT", "/root/reference")
+    if envlayer != ("shim" in getattr(Box2D, "__version__", "")):
+        print("refusing to mix the two kinds of recording: --envlayer=%s but `import Box2D` gave %r" % (envlayer, getattr(Box2D, "__version__", "?")))
+        return 1
     for p in (root, os.path.join(HERE, "shims")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    os.environ.setdefault("MPLBACKEND", "Agg")
     from madrl_environments.walker.multi_walker import MultiWalkerEnv
-    run(MultiWalkerEnv, "w3_local", 3, "local", episodes=6, steps=200, seed=31)
-    run(MultiWalkerEnv, "w2_global", 2, "global", episodes=4, steps=200, seed=32)
+    if not envlayer:
+        run(MultiWalkerEnv, "w3_local", 3, "local", episodes=6, steps=200, seed=31)
+        run(MultiWalkerEnv, "w2_global", 2, "global", episodes=4, steps=200, seed=32)
+        return 0
+    # the reference's env layer on the restated dynamics: BASELINE configs[3] (three walkers), the module's own example (two), one and
+    # four walkers, both reward mechanisms, every reward coefficient changed, terminate_on_fall off (walkers keep falling, the package is dropped)
+    pre = "multiwalker_envlayer_"
+    run(MultiWalkerEnv, "w3_local", 3, "local", episodes=6, steps=160, seed=31, prefix=pre)
+    run(MultiWalkerEnv, "w2_global", 2, "global", episodes=4, steps=160, seed=32, prefix=pre)
+    run(MultiWalkerEnv, "w3_noterminate", 3, "local", episodes=3, steps=200, seed=33, prefix=pre, zero_from=25, terminate_on_fall=False, forward_reward=2.0,
+        fall_reward=-7.0, drop_reward=-33.0)
+    run(MultiWalkerEnv, "w1_local", 1, "local", episodes=3, steps=120, seed=34, prefix=pre)
+    run(MultiWalkerEnv, "w4_global", 4, "global", episodes=3, steps=120, seed=35, prefix=pre, fall_reward=-10.0)
     return 0
 
 

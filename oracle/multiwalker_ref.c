@@ -2362,6 +2362,134 @@ void mwr_helloworld(float *out, int steps) {
         out[3 * i] = w.bodies[body].xf.p.x; out[3 * i + 1] = w.bodies[body].xf.p.y; out[3 * i + 2] = w.bodies[body].sweep.a;
     }
 }
+/* ------------------------------------------------------------------------------------------------ a bare world behind a C API
+ * For oracle/shims_box2d: a Python package named `Box2D` with the few classes multi_walker.py uses, whose b2World is THIS file's World.
+ * With it the UNMODIFIED reference module imports and runs here -- its own reset() builds the world call by call, its own
+ * apply_action / get_observation / ContactDetector / LidarCallback / reward and termination code run on top of the dynamics of this
+ * restatement -- and oracle/make_golden_multiwalker.py records it (tests/golden/multiwalker_envlayer_*.npz).  That pins the ENV LAYER
+ * (everything multi_walker.py itself computes, and the world it constructs) to the reference's own code; it does NOT pin the dynamics:
+ * Box2D is still restated, not run (PARITY of b2World::Step UNPINNED). */
+#define MWB_MAX_EVENTS 4096
+typedef struct {
+    World w;
+    int n_events, dropped;
+    int32_t events[MWB_MAX_EVENTS][3];   /* begin (1) / end (0), body A, body B -- in the order b2ContactListener would have been called */
+} mwb_world;
+static void mwb_listener(void *user, World *w, int ci, int begin) {
+    mwb_world *m = (mwb_world *)user;
+    if (m->n_events >= MWB_MAX_EVENTS) { m->dropped += 1; return; }
+    int32_t *e = m->events[m->n_events++];
+    e[0] = begin; e[1] = w->contacts[ci].bodyA; e[2] = w->contacts[ci].bodyB;
+}
+mwb_world *mwb_create(float gx, float gy, int continuous_physics) {   /* b2World(gravity, doSleep = True) */
+    mwb_world *m = (mwb_world *)calloc(1, sizeof(mwb_world));
+    world_init(&m->w, V(gx, gy));
+    m->w.continuousPhysics = continuous_physics;
+    m->w.listener = mwb_listener; m->w.listenerUser = m;
+    return m;
+}
+void mwb_destroy(mwb_world *m) { free(m); }
+/* shape_kind 0: b2PolygonShape::Set(vertices), 1: SetAsBox(verts[0], verts[1]), 2: b2EdgeShape::Set(v1, v2).  -> body id, -1: no room */
+int mwb_create_body(mwb_world *m, int dynamic, float x, float y, float angle, int shape_kind, const float *verts, int n_verts, float density,
+                    float friction, int category_bits, int mask_bits) {
+    if (m->w.bodyCount >= MWR_MAX_BODIES) return -1;
+    Shape s;
+    memset(&s, 0, sizeof(s));
+    if (shape_kind == 0) {
+        Vec2 pts[b2_maxPolygonVertices];
+        if (n_verts > b2_maxPolygonVertices) return -1;
+        for (int k = 0; k < n_verts; ++k) pts[k] = V(verts[2 * k], verts[2 * k + 1]);
+        polygon_set(&s, pts, n_verts);
+    } else if (shape_kind == 1) polygon_set_as_box(&s, verts[0], verts[1]);
+    else { s.type = SHAPE_EDGE; s.count = 2; s.radius = b2_polygonRadius; s.v[0] = V(verts[0], verts[1]); s.v[1] = V(verts[2], verts[3]); }
+    return world_create_body(&m->w, dynamic ? BODY_DYNAMIC : BODY_STATIC, V(x, y), angle, &s, density, friction, (uint16_t)category_bits, (uint16_t)mask_bits);
+}
+/* b2RevoluteJointDef from keyword arguments (referenceAngle 0, collideConnected false); enableMotor and enableLimit must be set: this
+ * restatement has no other kind */
+int mwb_create_revolute(mwb_world *m, int bodyA, int bodyB, float ax, float ay, float bx, float by, float lower, float upper, float max_motor_torque,
+                        float motor_speed, int enable_motor, int enable_limit) {
+    if (!enable_motor || !enable_limit || m->w.jointCount >= MWR_MAX_JOINTS) return -1;
+    return world_create_revolute(&m->w, bodyA, bodyB, V(ax, ay), V(bx, by), lower, upper, max_motor_torque, motor_speed);
+}
+void mwb_apply_force_to_center(mwb_world *m, int body, float fx, float fy, int wake) {   /* b2Body::ApplyForceToCenter */
+    Body *b = &m->w.bodies[body];
+    if (b->type != BODY_DYNAMIC) return;
+    if (wake && !b->awake) body_set_awake(b, 1);
+    if (b->awake) b->force = vadd(b->force, V(fx, fy));
+}
+void mwb_set_motor_speed(mwb_world *m, int joint, float speed) {   /* b2RevoluteJoint::SetMotorSpeed */
+    RevoluteJoint *j = &m->w.joints[joint];
+    body_set_awake(&m->w.bodies[j->bodyA], 1); body_set_awake(&m->w.bodies[j->bodyB], 1);
+    j->motorSpeed = speed;
+}
+void mwb_set_max_motor_torque(mwb_world *m, int joint, float torque) {   /* b2RevoluteJoint::SetMaxMotorTorque */
+    RevoluteJoint *j = &m->w.joints[joint];
+    body_set_awake(&m->w.bodies[j->bodyA], 1); body_set_awake(&m->w.bodies[j->bodyB], 1);
+    j->maxMotorTorque = torque;
+}
+/* b2World::Step; returns the number of Begin / EndContact calls it made (mwb_events reads them), -1 when the log overflowed */
+int mwb_step(mwb_world *m, float dt, int velocity_iterations, int position_iterations) {
+    m->n_events = 0; m->dropped = 0;
+    world_step(&m->w, dt, velocity_iterations, position_iterations);
+    return m->dropped ? -1 : m->n_events;
+}
+void mwb_events(const mwb_world *m, int32_t *out) { memcpy(out, m->events, sizeof(int32_t) * 3 * (size_t)m->n_events); }
+/* out[10] = position (the body origin, b2Body::GetPosition) x, y, angle, linear velocity x, y, angular velocity, world centre x, y, awake, mass */
+void mwb_body_state(const mwb_world *m, int body, float *out) {
+    const Body *b = &m->w.bodies[body];
+    out[0] = b->xf.p.x; out[1] = b->xf.p.y; out[2] = b->sweep.a; out[3] = b->linearVelocity.x; out[4] = b->linearVelocity.y; out[5] = b->angularVelocity;
+    out[6] = b->sweep.c.x; out[7] = b->sweep.c.y; out[8] = (float)b->awake; out[9] = b->type == BODY_DYNAMIC ? b->mass : 0.0f;
+}
+/* out[4] = GetJointAngle, GetJointSpeed, motorSpeed, maxMotorTorque */
+void mwb_joint_state(const mwb_world *m, int joint, float *out) {
+    const RevoluteJoint *j = &m->w.joints[joint];
+    const Body *bA = &m->w.bodies[j->bodyA], *bB = &m->w.bodies[j->bodyB];
+    out[0] = bB->sweep.a - bA->sweep.a - j->referenceAngle; out[1] = bB->angularVelocity - bA->angularVelocity; out[2] = j->motorSpeed; out[3] = j->maxMotorTorque;
+}
+/* b2World::RayCast reduced to what LidarCallback accepts (D2): the CLOSEST hit among the edge fixtures whose category has a bit of
+ * `category_mask`.  Returns the body hit (-1: none); out[5] = fraction, point x, y, normal x, y (b2EdgeShape::RayCast's output). */
+int mwb_raycast_closest(const mwb_world *m, float x1, float y1, float x2, float y2, int category_mask, float *out) {
+    const World *w = &m->w;
+    const Vec2 p1w = V(x1, y1), p2w = V(x2, y2);
+    float best = 1.0f;
+    int hit = -1;
+    for (int bi = 0; bi < w->bodyCount; ++bi) {
+        const Body *b = &w->bodies[bi];
+        if (b->shape.type != SHAPE_EDGE || (b->categoryBits & (uint16_t)category_mask) == 0) continue;
+        const Vec2 p1 = rmulT(b->xf.q, vsub(p1w, b->xf.p)), p2 = rmulT(b->xf.q, vsub(p2w, b->xf.p));
+        const Vec2 d = vsub(p2, p1);
+        const Vec2 v1 = b->shape.v[0], v2 = b->shape.v[1];
+        const Vec2 e = vsub(v2, v1);
+        Vec2 normal = V(e.y, -e.x);
+        vnormalize(&normal);
+        const float numerator = vdot(normal, vsub(v1, p1)), denominator = vdot(normal, d);
+        if (denominator == 0.0f) continue;
+        const float t = numerator / denominator;
+        if (t < 0.0f || 1.0f < t) continue;
+        const Vec2 q = vadd(p1, vscale(t, d));
+        const Vec2 r = vsub(v2, v1);
+        const float rr = vdot(r, r);
+        if (rr == 0.0f) continue;
+        const float s = vdot(vsub(q, v1), r) / rr;
+        if (s < 0.0f || 1.0f < s) continue;
+        if (t < best) {
+            best = t; hit = bi;
+            const Vec2 nl = numerator > 0.0f ? V(-normal.x, -normal.y) : normal;   /* output->normal = numerator > 0 ? -R(normal) : R(normal) */
+            const Vec2 nw = rmul(b->xf.q, nl);
+            const Vec2 pw = vadd(p1w, vscale(t, vsub(p2w, p1w)));                  /* b2World::RayCast: point = (1 - fraction) p1 + fraction p2 */
+            out[0] = t; out[1] = pw.x; out[2] = pw.y; out[3] = nw.x; out[4] = nw.y;
+        }
+    }
+    return hit;
+}
+int mwb_counts(const mwb_world *m, int32_t *bodies, int32_t *joints, int32_t *contacts) {
+    *bodies = m->w.bodyCount; *joints = m->w.jointCount;
+    int n = 0;
+    for (int ci = m->w.contactList; ci >= 0; ci = m->w.contacts[ci].next) ++n;
+    *contacts = n;
+    return 0;
+}
+
 int mwr_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -35,7 +35,20 @@ def test_hip_matches_reference_golden_teacher_forced(path):
     assert np.array_equal(st["saved"], post_saved)
     assert np.array_equal(st["flags"] & 3, g["post_gate"] | (g["post_bombed"] << 1))
     assert np.array_equal(st["t"], g["post_t"])
-    assert np.abs(obs.cpu().numpy() - g["obs"]).max() < 1e-5
+    # float32 against the reference's float64: within 1e-5 -- except where a `<=` of the sensing decides the other way on a value that is a
+    # rounding error away from its threshold.  Such a step is recognised by the float32 ORACLE, same arithmetic as the
+    # kernel, leaving the tolerance too; the kernel must then equal that oracle, and the hand-written records hold no such step at all (of the
+    # drawn ones, fuzz_03 has one: step 92, one sensor reading of rescuer 1).
+    err = np.abs(obs.cpu().numpy() - g["obs"]).reshape(T, -1).max(1)
+    beyond = np.nonzero(err >= 1e-5)[0]
+    if len(beyond):
+        assert "fuzz" in path and len(beyond) <= 1, (beyond, err[beyond])
+        o32 = ho.HostageOracle(n_envs=1, sensors=g["sensors"], dtype=np.float32, **kw)
+        for t in beyond:
+            o32.set_state(**ho.golden_pre_state(g, t))
+            oobs = o32.step(g["act"][t][None], resp=resp[t][None])[0]
+            assert np.abs(oobs[0] - g["obs"][t]).max() >= 1e-5, "step %d: the float32 oracle stays within the tolerance, the kernel does not" % t
+            assert np.array_equal(obs[t].cpu().numpy(), oobs[0].astype(np.float32)), "step %d: kernel != float32 oracle" % t
     real = g["is_reset_step"] == 0
     assert np.abs(rew.cpu().numpy()[real] - g["rew"][real]).max() < 1e-5
     assert np.array_equal(done.cpu().numpy()[real], g["done"][real] == 1)

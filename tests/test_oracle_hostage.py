@@ -35,6 +35,27 @@ def test_oracle_reproduces_reference_records(path):
     assert (g["resp"][..., 0] >= 0).sum() > 3 or "fuzz" in path   # the hand-written scenarios must exercise respawns; the drawn ones take what comes
 
 
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[8:-4] for f in FILES])
+def test_float32_oracle_stays_within_tolerance_of_the_reference_records(path):
+    """the kernel's arithmetic (the float32 build of the same restatement, which tests/test_hostage_gpu.py requires the kernel to equal bit
+    for bit): every recorded step within 1e-5 of the unmodified reference -- except a sensing `<=` decided the other way on a value one rounding
+    error from its threshold: none in the hand-written records, one in the drawn ones (fuzz_03, step 92)"""
+    g = np.load(path)
+    o = ho.HostageOracle(n_envs=1, sensors=g["sensors"], dtype=np.float32, **ho.kwargs_from_golden(g))
+    flips = []
+    for t in range(len(g["pre_t"])):
+        o.set_state(**ho.golden_pre_state(g, t))
+        resp = np.where(g["resp"][t] >= 0, g["resp"][t], 0.0)
+        obs, rew, done, info = o.step(g["act"][t][None], resp=resp[None])
+        st = o.get_state()
+        assert np.abs(st["pos"][0] - g["post_pos"][t]).max() < 1e-6 and np.abs(st["vel"][0] - g["post_vel"][t]).max() < 1e-6, t
+        if np.abs(obs[0] - g["obs"][t]).max() >= 1e-5:
+            flips.append(t)
+        if not g["is_reset_step"][t]:
+            assert np.abs(rew[0] - g["rew"][t]).max() < 1e-5 and int(done[0]) == int(g["done"][t]) and list(info[0]) == list(g["info"][t]), t
+    assert flips == ([92] if path.endswith("hostage_fuzz_03.npz") else []), flips
+
+
 def test_reset_sampling_ranges_and_key_persistence():
     o = ho.HostageOracle(3, 10, 5, 2, 2, n_envs=512, seed=3)
     o.reset()

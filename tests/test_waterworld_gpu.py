@@ -62,6 +62,9 @@ CASES = {
     # runners/run_waterworld.py:16-20 defaults: the second specialised shape (two 64-bit words per collision matrix)
     "runner_default_8v10": dict(n_pursuers=8, n_evaders=10, n_coop=4, n_poison=10),
     "runner_default_8v10_coop1": dict(n_pursuers=8, n_evaders=10, n_coop=1, n_poison=10, ev_speed=0.05, radius=0.03),
+    # the other shapes the reference's own scripts construct (specialised: waterworld_specializations.def)
+    "gru_test_3_10_2_5": dict(n_pursuers=3, n_evaders=10, n_coop=2, n_poison=5, ev_speed=0.04, radius=0.03),   # rllabwrapper/rllab_gru_test.py:13
+    "con_runner_3v5": dict(n_pursuers=3, n_evaders=5, n_coop=2, n_poison=10, ev_speed=0.04, radius=0.03),     # runners/old/rltools/run_con_waterworld.py:57-61
     "coop1_dense": dict(n_pursuers=6, n_evaders=12, n_coop=1, n_poison=12, ev_speed=0.05, action_scale=0.05, n_sensors=20,
                         radius=0.03),
 }
