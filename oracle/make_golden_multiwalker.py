@@ -28,7 +28,7 @@ hull contacts, dropped package, resets):
   bodies    [T + 1, NB, 6] float32   every body's (worldCenter.x, .y, angle, linearVelocity.x, .y, angularVelocity) BEFORE step t
                                 (row 0: after reset) in the order package, then per walker hull, leg0 upper, leg0 lower, leg1 upper,
                                 leg1 lower -- what the oracles are teacher-forced on
-  obs       [T + 1, W, 32] float32   reset() / step() observations (position / angle noise set to 0)
+  obs       [T + 1, W, 32] float64   reset() / step() observations (position / angle noise set to 0)
   rew       [T, W] float64 ; done [T] uint8
   flags     [T + 1, 1 + 3W] uint8    game_over, fallen[W], ground_contact[W][2] (ContactDetector :50-84)
 """
@@ -61,44 +61,166 @@ def flags_of(env):
     return np.asarray(f, np.uint8)
 
 
-def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed, prefix="multiwalker_box2d_", zero_from=44, **env_kw):
+class ScriptedNormal(object):
+    """np.random.normal for the observation noise (:389-395; the reference draws it from the global, unseeded generator) replaced, while a
+    recording runs, by the draws THIS repository's RNG contract assigns to (seed, env id, episode, observation): Philox4x32-10 with counter
+    (env id, episode, observation << 4 | 4 i + q, tag 34), Box-Muller on (r.x, r.y) -> z[2q], z[2q + 1]; walker i uses z[0..3] for the
+    neighbours it has, in order, and z[4], z[5], z[6] for the package.  The reference asks for loc + scale * z call by call; which z goes
+    with which call is mirrored here from the ORDER of its calls only."""
+
+    def __init__(self, seed, gid, n_walkers):
+        self.key, self.gid, self.W = [seed & 0xFFFFFFFF, seed >> 32], gid, n_walkers
+        self.episode, self.tick, self.queue = 1, 0, []
+
+    def _fill(self):
+        import math
+        from oracle import pursuit as po
+        for i in range(self.W):
+            z = []
+            for q in range(4):
+                r = po.philox([self.gid, self.episode, (self.tick << 4) | (4 * i + q), 34], self.key)
+                u1, u2 = float((int(r[0]) >> 8) + 1) / 16777216.0, float(int(r[1]) >> 8) / 16777216.0
+                rad = math.sqrt(-2.0 * math.log(u1))
+                z += [rad * math.cos(2.0 * 3.14159265358979323846 * u2), rad * math.sin(2.0 * 3.14159265358979323846 * u2)]
+            n_nb = (i - 1 >= 0) + (i + 1 < self.W)
+            self.queue += z[:2 * n_nb] + z[4:7]
+        self.tick += 1
+
+    def __call__(self, loc=0.0, scale=1.0, size=None):
+        assert size is None
+        if not self.queue:
+            self._fill()
+        return loc + scale * self.queue.pop(0)
+
+
+def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed, prefix="multiwalker_box2d_", zero_from=44, noise=None, **env_kw):
+    """noise = (position_noise, angle_noise, seed, first env id): the observation noise on, scripted (ScriptedNormal); episode k is env id + k"""
     rng = np.random.RandomState(seed)
     out = []
+    real_normal = np.random.normal
     for ep in range(episodes):
-        env = MultiWalkerEnv(n_walkers=n_walkers, position_noise=0.0, angle_noise=0.0, reward_mech=reward_mech, **env_kw)
+        if noise:
+            np.random.normal = ScriptedNormal(noise[2], noise[3] + ep, n_walkers)
+        env = MultiWalkerEnv(n_walkers=n_walkers, position_noise=noise[0] if noise else 0.0, angle_noise=noise[1] if noise else 0.0, reward_mech=reward_mech, **env_kw)
+        if noise:   # the constructor ran a whole reset() of its own (setup(), :303): the recording starts at the next one, observation 0 of episode 1
+            np.random.normal = ScriptedNormal(noise[2], noise[3] + ep, n_walkers)
         env.seed(int(rng.randint(2 ** 31 - 1)))
         pushes = []
-        real_uniform = env.np_random.uniform
-        def spy(lo, hi, *a, **k):
-            v = real_uniform(lo, hi, *a, **k)
-            if np.isscalar(v) and (lo, hi) == (-5.0, 5.0):     # INITIAL_RANDOM (:130)
-                pushes.append(float(v))
-            return v
-        env.np_random.uniform = spy
+
+        class SpyRandom(object):
+            """the walkers' own generators (BipedalWalker._seed, :109-111) draw the initial pushes (:130-131)"""
+
+            def __init__(self, rs):
+                self.rs = rs
+
+            def uniform(self, lo, hi, *a, **k):
+                v = self.rs.uniform(lo, hi, *a, **k)
+                if np.isscalar(v) and (lo, hi) == (-5, 5):     # INITIAL_RANDOM
+                    pushes.append(float(v))
+                return v
+
+            def __getattr__(self, k):
+                return getattr(self.rs, k)
+
+        for w in env.walkers:
+            w._seed(int(rng.randint(2 ** 31 - 1)))          # (BipedalWalker seeds itself from the clock otherwise: recordings would not regenerate)
+            w.np_random = SpyRandom(w.np_random)
         obs0 = env.reset()
-        env.np_random.uniform = real_uniform
+        for w in env.walkers:
+            w.np_random = w.np_random.rs
+        assert len(pushes) == n_walkers
         rec = dict(terrain_y=np.asarray(env.terrain_y, np.float64), push=np.asarray(pushes[-n_walkers:], np.float64), actions=[], bodies=[bodies_of(env)],
-                   obs=[np.asarray(obs0, np.float32)], rew=[], done=[], flags=[flags_of(env)])
+                   obs=[np.asarray(obs0, np.float64)], rew=[], done=[], flags=[flags_of(env)])
         for t in range(steps):
             a = rng.uniform(-1, 1, (n_walkers, 4)).astype(np.float32)
             if t % 60 > zero_from:
                 a[:] = 0
             o, r, d, _ = env.step(a)
-            rec["actions"].append(a); rec["obs"].append(np.asarray(o, np.float32)); rec["rew"].append(np.asarray(r, np.float64).reshape(-1) * np.ones(n_walkers))
+            rec["actions"].append(a); rec["obs"].append(np.asarray(o, np.float64)); rec["rew"].append(np.asarray(r, np.float64).reshape(-1) * np.ones(n_walkers))
             rec["done"].append(int(bool(d))); rec["bodies"].append(bodies_of(env)); rec["flags"].append(flags_of(env))
             if d:
                 break
+        if noise:
+            assert not np.random.normal.queue, "the reference left noise draws of an observation unused"
+        np.random.normal = real_normal
         out.append({k: np.asarray(v) for k, v in rec.items()})
     path = os.path.join(OUT, "%s%s.npz" % (prefix, name))
     flat = {"n_episodes": np.int64(len(out)), "n_walkers": np.int64(n_walkers), "reward_global": np.int64(reward_mech == "global")}
     for k in ("forward_reward", "fall_reward", "drop_reward"):
         flat["cfg_" + k] = np.float64(getattr(env, k))
     flat["cfg_terminate_on_fall"] = np.int64(bool(env.terminate_on_fall))
+    flat["cfg_one_hot"] = np.int64(bool(env.one_hot))
+    flat["cfg_position_noise"], flat["cfg_angle_noise"] = np.float64(env.position_noise), np.float64(env.angle_noise)
+    flat["cfg_seed"], flat["cfg_env_id_base"] = np.uint64(noise[2] if noise else 0), np.int64(noise[3] if noise else 0)
     for i, r in enumerate(out):
         for k, v in r.items():
             flat["ep%d_%s" % (i, k)] = v
     np.savez_compressed(path, **flat)
     print("%s: %d episodes, %d steps, %.1f KB" % (path, len(out), sum(len(r["done"]) for r in out), os.path.getsize(path) / 1024.0))
+
+
+def record_philox_resets(MultiWalkerEnv, n_walkers, seed, gid0, n, prefix):
+    """The reference's reset() fed with the draws THIS repository's reset makes (RNG contract: Philox4x32-10, key = seed,
+    counter = (global env id, episode, index, tag 32 terrain | 33 push)): uniform(-1, 1) = 2 u24(r.x) - 1 per terrain point,
+    randint(5, 10) = 5 + mulhi(r.y, 5) when the grass counter runs out, push = (2 u24(r.x) - 1) * 5 per walker.  The scripted generator
+    hands them to the reference in the order ITS code asks for them; what the reference then builds -- terrain_y (the smoothed walk with
+    its one-shot counters, :516-612), the world after reset() and its observation -- is what the plain, un-injected reset of the oracle /
+    product / kernels must produce for (seed, env id).  -> <prefix>philox_w<W>.npz"""
+    from oracle import pursuit as po
+    NT = int(200 * n_walkers / 8)
+    key = [seed & 0xFFFFFFFF, seed >> 32]
+    u24 = lambda r: float(int(r) >> 8) / 16777216.0
+    rec = dict(terrain_y=[], push=[], bodies=[], obs=[], flags=[])
+    for gid in range(gid0, gid0 + n):
+        script = []
+        counter, oneshot = 20, False                          # TERRAIN_STARTPAD; mirrors only WHEN the reference draws, not what it computes
+        for i in range(NT):
+            r = po.philox([gid, 0, i, 32], key)
+            if not oneshot and i > 20:
+                script.append(("uniform", (-1, 1), 2.0 * u24(r[0]) - 1.0))
+            oneshot = False
+            counter -= 1
+            if counter == 0:
+                counter = 5 + ((int(r[1]) * 5) >> 32)
+                script.append(("randint", (5.0, 10), counter))
+                oneshot = True
+        pushes = [(2.0 * u24(po.philox([gid, 0, w, 33], key)[0]) - 1.0) * 5 for w in range(n_walkers)]
+
+        class Scripted(object):
+            def __init__(self, items, rest):
+                self.items, self.rest, self.k = items, rest, 0
+
+            def _next(self, kind, args):
+                if self.k < len(self.items):
+                    k, a, v = self.items[self.k]
+                    assert k == kind and tuple(a) == tuple(args), "the reference asked for %s%r where the script holds %s%r" % (kind, args, k, a)
+                    self.k += 1
+                    return v
+                return None
+
+            def uniform(self, lo, hi, *a, **kw):
+                v = self._next("uniform", (lo, hi))
+                return self.rest.uniform(lo, hi, *a, **kw) if v is None else v
+
+            def randint(self, lo, hi=None, *a, **kw):
+                v = self._next("randint", (lo, hi))
+                return self.rest.randint(int(lo), hi, *a, **kw) if v is None else v
+
+            def __getattr__(self, k):
+                return getattr(self.rest, k)
+
+        env = MultiWalkerEnv(n_walkers=n_walkers, position_noise=0.0, angle_noise=0.0)
+        terrain_rng = Scripted(script, np.random.RandomState(1))     # (the clouds, :622-634, draw from the rest)
+        env.np_random = terrain_rng
+        for w, walker in enumerate(env.walkers):
+            walker.np_random = Scripted([("uniform", (-5, 5), pushes[w])], np.random.RandomState(2))
+        obs = env.reset()
+        assert terrain_rng.k == len(script) and all(wk.np_random.k == 1 for wk in env.walkers), "the reference did not consume the script"
+        rec["terrain_y"].append(np.asarray(env.terrain_y, np.float64)); rec["push"].append(np.asarray(pushes, np.float64))
+        rec["bodies"].append(bodies_of(env)); rec["obs"].append(np.asarray(obs, np.float64)); rec["flags"].append(flags_of(env))
+    path = os.path.join(OUT, "%sphilox_w%d.npz" % (prefix, n_walkers))
+    np.savez_compressed(path, n_walkers=np.int64(n_walkers), seed=np.uint64(seed), env_id_base=np.int64(gid0), **{k: np.asarray(v) for k, v in rec.items()})
+    print("%s: %d resets, %.1f KB" % (path, n, os.path.getsize(path) / 1024.0))
 
 
 def main():
@@ -132,6 +254,13 @@ def main():
         fall_reward=-7.0, drop_reward=-33.0)
     run(MultiWalkerEnv, "w1_local", 1, "local", episodes=3, steps=120, seed=34, prefix=pre)
     run(MultiWalkerEnv, "w4_global", 4, "global", episodes=3, steps=120, seed=35, prefix=pre, fall_reward=-10.0)
+    run(MultiWalkerEnv, "w2_onehot", 2, "local", episodes=2, steps=60, seed=36, prefix=pre, one_hot=True)   # np.eye(MAX_AGENTS)[i] instead of i / n (:397-400)
+    # the reference's DEFAULT configuration has the observation noise on (position_noise = angle_noise = 1e-3, :250)
+    run(MultiWalkerEnv, "w3_noise", 3, "local", episodes=4, steps=80, seed=37, prefix=pre, noise=(1e-3, 1e-3, 0xC0FFEE123, 500))
+    run(MultiWalkerEnv, "w2_noise_global", 2, "global", episodes=2, steps=60, seed=38, prefix=pre, noise=(5e-3, 2e-2, 11, 0))
+    # files named multiwalker_resetdraws_*: a different layout (no episodes), replayed by its own test
+    record_philox_resets(MultiWalkerEnv, 3, seed=0x1234567890ABCDEF, gid0=1000, n=24, prefix="multiwalker_resetdraws_")
+    record_philox_resets(MultiWalkerEnv, 2, seed=7, gid0=0, n=12, prefix="multiwalker_resetdraws_")
     return 0
 
 

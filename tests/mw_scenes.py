@@ -34,9 +34,10 @@ PKG_HALF_H = 5 / SCALE
 class Backend(object):
     """one interface over the three restatements; arrays are numpy on every side"""
 
-    def __init__(self, kind, n_envs, n_walkers=3, continuous=True, terminate_on_fall=True, seed=0):
+    def __init__(self, kind, n_envs, n_walkers=3, continuous=True, terminate_on_fall=True, seed=0, **env_kw):
         self.kind, self.N, self.W = kind, n_envs, n_walkers
         kw = dict(n_walkers=n_walkers, n_envs=n_envs, seed=seed, position_noise=0.0, angle_noise=0.0, terminate_on_fall=terminate_on_fall)
+        kw.update(env_kw)
         if kind == "ref":
             from oracle import multiwalker_ref as mwr
             self.o = mwr.MultiWalkerRef(poly=True, continuous_physics=continuous, **kw)
