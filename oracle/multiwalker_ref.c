@@ -15,6 +15,12 @@
  * `import Box2D` works).  The one published anchor, the six printed lines of the "Hello Box2D" manual page, is replayed by
  * mwr_helloworld() below (tests/test_multiwalker_cpu.py).
  *
+ * What IS pinned (round 4): the multi_walker.py half of this file.  The `mwb_*` entry points at the end expose the bare World;
+ * oracle/shims_box2d wraps them as a package named `Box2D`, over which the UNMODIFIED reference module imports and runs.  Its
+ * recordings (oracle/make_golden_multiwalker.py --envlayer) are reproduced by mw_reset_world / mw_step free-running: the world the
+ * reset constructs and every body state after it bit for bit, observations and rewards to 1e-12, ContactDetector flags and done
+ * exactly, also with the observation noise and the reset draws scripted from the Philox contract (tests/test_multiwalker_envlayer.py).
+ *
  * What follows Box2D 2.3.0 here (file names as in that tree):
  *   Dynamics/b2World.cpp         Step -> (FindNewContacts) -> Collide -> Solve (islands by DFS from the body list) -> SolveTOI
  *   Dynamics/b2ContactManager    AddPair / Destroy / Collide / FindNewContacts (fat AABBs, pairs sorted by proxy id)
