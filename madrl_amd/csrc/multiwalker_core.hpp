@@ -64,7 +64,8 @@ namespace mw {
 // optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
 #ifdef MW_STATS
 struct Stats { long steps, sub_a, sub_b, manifolds, merged, pos_iters, toi_full, toi_culled, toi_events, toi_undone, toi_vel_iters, toi_hist[10], toi_nisl[6], cnt_hist[24], rounds_hist[12], toi_multi, toi_ties, toi_pairs, toi_hullpkg, lane_cost[4], cur_lane, pos_iters_step, maxcnt_step;
-               long flops, phase, flops_by[6]; };   // phase: 0 collide, 1 solve, 2 broad phase after the solve, 3 time-of-impact search, 4 sub-steps, 5 observation   // float32 / float64 additions, multiplications, divisions, square roots: hand-counted per primitive (MW_FLOPS below)
+               long flops, phase, flops_by[6];
+               int ev_n; unsigned char ev_body[64]; short ev_sweeps[64], ev_full[64]; long toi_full_chain; };   // the events of the current step (reset by the harness): body, velocity sweeps, full root-finder runs of the search before it   // phase: 0 collide, 1 solve, 2 broad phase after the solve, 3 time-of-impact search, 4 sub-steps, 5 observation   // float32 / float64 additions, multiplications, divisions, square roots: hand-counted per primitive (MW_FLOPS below)
 extern Stats g_stats;
 #define MW_STAT(f, v) (g_stats.f += (v))
 inline int g_stats_lane();
@@ -1585,6 +1586,9 @@ struct ToiWork {            // shared by the lanes of an env (LDS in the HIP ker
     ToiEvent ev[TOI_MAX_EVENTS];
     float fat_log[TOI_MAX_PAIR_EVENTS][4];       // the fat AABB after an event that moved the proxy of the package or a hull
     float fat0[1 + MAX_WALKERS][4];              // ... and their boxes when the pass began (package, hull 0, hull 1, ...)
+    // the bodies whose first search found an event (see solve_toi): body, the event's contact slot (index into the body's cache), its time
+    int n_pend;
+    struct { uint8_t body, k; uint16_t pad_; float alpha; } pend[MAXB];
 };
 struct ToiLaneWork {        // per lane: the cached times of impact of the contacts of the body it is working on
     float *alpha;           // [Model::slot_cap of the body]
@@ -1605,8 +1609,11 @@ MW_HD uint32_t toi_final_batch(const ToiWork &T, int n, int b, int idx) {
 #ifdef MW_STATS
 inline int g_stats_lane() { return (int)(g_stats.cur_lane & 3); }
 #endif
+// first_k == TOI_SEARCH_ONLY: the chain's first search alone -- an event it finds is put on ToiWork::pend and the chain stops there;
+// first_k >= 0: the chain from that event on (the search that found it is not repeated: slot first_k of the body's cache at time first_alpha)
+constexpr int TOI_SEARCH_ONLY = -2;
 template <class Par>
-MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, int mover, float h) {
+MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scratch &S, ToiWork &T, ToiLaneWork &TL, Par par, int mover, float h, int first_k, float first_alpha) {
     const int base = M.slot_base[mover], cap = M.slot_cap[mover];
     const Shape &msh = M.shape[shape_of_body(mover)];
 #ifdef MW_STATS
@@ -1627,6 +1634,8 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
         float min_alpha = 1.0f;
         uint64_t min_key = 0;
         int min_k = -1;
+        if (guard == 0 && first_k >= 0) { min_k = first_k; min_alpha = first_alpha; }   // found by the search-only call (nothing has touched the body since)
+        else
         for (uint64_t o2 = occ; o2 != 0;) {
             const int k = pop_lowest(o2);
             const Slot &sl = Cd.slot[base + k];
@@ -1642,6 +1651,11 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             if (alpha < min_alpha || (min_k >= 0 && key > min_key)) { min_alpha = alpha; min_k = k; min_key = key; }
         }
         if (min_k < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha || M.continuous == 2) break;   // no more TOI events
+        if (first_k == TOI_SEARCH_ONLY) {
+            const int pi = mover == 0 ? 0 : par.alloc(&T.n_pend);   // entry 0 is the package's (see solve_toi); at most one entry per body: MAXB is room enough
+            T.pend[pi].body = (uint8_t)mover; T.pend[pi].k = (uint8_t)min_k; T.pend[pi].pad_ = 0; T.pend[pi].alpha = min_alpha;
+            break;
+        }
         const int min_slot = base + min_k;
         MW_PHASE(4);
         // ---- advance the body to the time of impact (b2Body::Advance); the static edge does not move
@@ -1657,6 +1671,10 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
         const bool touching = toi_update_contact(M, Wd, Cd, Cd.slot[min_slot], mover, mo);   // the TOI contact likely has some new contact points
         TL.meta[min_k] = (uint8_t)((TL.meta[min_k] & ~1u) + 4u);   // e_toiFlag cleared, ++m_toiCount
         MW_STAT(toi_events, 1);
+#ifdef MW_STATS
+        if (g_stats.ev_n < 64) { g_stats.ev_body[g_stats.ev_n] = (unsigned char)mover; g_stats.ev_sweeps[g_stats.ev_n] = 0; }
+        g_stats.ev_n += 1;
+#endif
         if (!touching) {  // not solid after all: disable the contact, restore the sweep
             MW_STAT(toi_undone, 1);
             TL.meta[min_k] |= 2;
@@ -1742,6 +1760,9 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             int stop_at = VEL_ITERS;   // sweeps [0, stop_at) are run
             for (int it = 0; it < stop_at; ++it) {
                 MW_STAT(toi_vel_iters, 1); MW_STAT(lane_cost[mover & 3], 300 * n_isl + 60);
+#ifdef MW_STATS
+                if (g_stats.ev_n > 0 && g_stats.ev_n <= 64) g_stats.ev_sweeps[g_stats.ev_n - 1] += 1;
+#endif
                 bool changed = false;
                 MW_ISLAND_SWEEP(contact_solve_velocity_t<true>(m_, qm, vA, wA, vB, wB, changed))
                 if (!changed) { MW_STAT(toi_hist[it / 20], 1); break; }   // no impulse moved: the velocity did not either, and every further sweep is this one
@@ -1811,15 +1832,29 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
     const int NB = M.NB;
     if (L0 == 0) {
         T.n_ev = 0; T.n_fat = 0; T.overflow = 0; T.batch_base = Wd.batch;
+        T.n_pend = 1; T.pend[0].body = 255;   // entry 0 is kept for the package: whichever pass, its chain runs on lane 0, the one whose
+                                              // time-of-impact cache has room for the package's contact slots (ToiLaneWork, MwDev::toi_lane0_bytes)
         for (int q = 0; q < 4; ++q) T.fat0[0][q] = Cd.fat[0][q];
         for (int w = 0; w < M.W; ++w) for (int q = 0; q < 4; ++q) T.fat0[1 + w][q] = Cd.fat[hull_of(w)][q];
     }
     par.sync();
     if (M.continuous == 3) return;   // timing experiments only: 3 = set-up, 2 = set-up and one search without events
     MW_TSTAMP(1, 2);
-    // ---- the chains, one body per lane at a time
-    for (int k = L0; k < NB; k += LN) toi_body_chain(M, Wd, Cd, S, T, TL, par, M.toi_body[k], h);
-    par.sync();
+    // ---- the chains.  An event is the expensive part of a chain (contact update, mini island, 20 position iterations, up to 180 velocity
+    // sweeps, a new search) and only one body in twenty has one in a step -- but among the 64 bodies that the lanes of a wavefront work on
+    // at the same moment there nearly always is one, and all of them wait for it.  So the first search of EVERY body runs first (pass 0: the
+    // bodies dealt to the lanes in Model::toi_body order; a body with an event goes on ToiWork::pend), and then the pending chains are
+    // dealt to the env's lanes (pass 1): the events of a step run side by side instead of one group of bodies after the other.  A chain
+    // touches nothing but its own body and that body's contacts with the static terrain, so when it runs decides nothing.
+    for (int pass = 0; pass < 2; ++pass) {
+        const int n_items = pass == 0 ? NB : (T.n_pend < NB ? T.n_pend : NB);
+        for (int k = L0; k < n_items; k += LN) {
+            const int body = pass == 0 ? M.toi_body[k] : T.pend[k].body;
+            if (body == 255) continue;   // (the package has no event)
+            toi_body_chain(M, Wd, Cd, S, T, TL, par, body, h, pass == 0 ? TOI_SEARCH_ONLY : (int)T.pend[k].k, pass == 0 ? 0.0f : T.pend[k].alpha);
+        }
+        par.sync();
+    }
     MW_TSTAMP(1, 3);
     const int n = T.n_ev < TOI_MAX_EVENTS ? T.n_ev : TOI_MAX_EVENTS;
     MW_TVAL(1, 0, n);

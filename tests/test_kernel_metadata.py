@@ -80,4 +80,6 @@ def test_multiwalker_launches_have_no_scratch():
     ks = {n: k for n, k in _kernels().items() if "mw_step_kernel" in n}
     assert len(ks) == 4, sorted(ks)
     for n, k in ks.items():
-        assert k["scratch"] == 0 and k["vgpr_spills"] == 0, (n, k)
+        # (.vgpr_spill_count may be non-zero with no private segment: at one wavefront per SIMD the allocator parks values in the 256
+        # accumulation registers, a register copy each way -- what must not happen is a private segment, i.e. memory)
+        assert k["scratch"] == 0, (n, k)
