@@ -23,6 +23,13 @@ __device__ unsigned long long g_mw_stamp[2][MW_DBG_BLOCKS][8];
 __device__ int g_mw_val[2][MW_DBG_BLOCKS][16][4];
 #define MW_TSTAMP(p, k) do { if (threadIdx.x == 0 && blockIdx.x < MW_DBG_BLOCKS) g_mw_stamp[p][blockIdx.x][k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define MW_TVAL(p, k, v) do { if ((threadIdx.x & 3) == 0 && blockIdx.x < MW_DBG_BLOCKS) g_mw_val[p][blockIdx.x][threadIdx.x >> 2][k] = (int)(v); } while (0)
+// shader clocks a wavefront spends in region k of the continuous pass's chains, summed over the step (the first ACTIVE lane adds them up:
+// the regions run under exec masks)
+__device__ unsigned long long g_mw_acc[MW_DBG_BLOCKS][8];
+#define MW_TACC_T0(v) unsigned long long v = __builtin_amdgcn_s_memtime()
+#define MW_TACC(k, v) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                              \
+        if ((int)threadIdx.x == __ffsll((long long)__ballot(1)) - 1 && blockIdx.x < MW_DBG_BLOCKS) atomicAdd(&g_mw_acc[blockIdx.x][k], n_ - v); \
+        v = n_; } while (0)
 #endif
 #include "multiwalker_core.hpp"
 
@@ -563,6 +570,12 @@ int madrl_multiwalker_debug_read(unsigned long long *stamps_host, int *vals_host
     MADRL_HIP_TRY(hipDeviceSynchronize());
     MADRL_HIP_TRY(hipMemcpyFromSymbol(stamps_host, HIP_SYMBOL(g_mw_stamp), sizeof(g_mw_stamp)));
     MADRL_HIP_TRY(hipMemcpyFromSymbol(vals_host, HIP_SYMBOL(g_mw_val), sizeof(g_mw_val)));
+    return MADRL_OK;
+}
+int madrl_multiwalker_debug_read_acc(unsigned long long *acc_host, int reset) {   // [4096][8]; reset != 0: zero the accumulators afterwards
+    MADRL_HIP_TRY(hipDeviceSynchronize());
+    MADRL_HIP_TRY(hipMemcpyFromSymbol(acc_host, HIP_SYMBOL(g_mw_acc), sizeof(g_mw_acc)));
+    if (reset) { static unsigned long long zero[MW_DBG_BLOCKS][8]; MADRL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_mw_acc), zero, sizeof(zero))); }
     return MADRL_OK;
 }
 #endif

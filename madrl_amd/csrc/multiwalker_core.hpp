@@ -85,6 +85,10 @@ inline int g_stats_lane();
 #define MW_TSTAMP(p, k) ((void)0)
 #define MW_TVAL(p, k, v) ((void)0)
 #endif
+#ifndef MW_TACC
+#define MW_TACC_T0(v) ((void)0)
+#define MW_TACC(k, v) ((void)0)
+#endif
 
 // World::Step parameters of the env (multi_walker.py:365).  Overridable ONLY by the known-answer harness of the test
 // infrastructure, which replays the published Box2D HelloWorld scene (1/60 s, 6 velocity / 2 position iterations)
@@ -1631,6 +1635,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
     int n_events = 0;   // events of this chain that reached FindNewContacts
     for (int guard = 0; guard < (MAX_SUB_STEPS + 2) * cap; ++guard) {
         // ---- this body's contact with the smallest time of impact; among equal times the first of the contact list (largest key)
+        MW_TACC_T0(ta_);
         float min_alpha = 1.0f;
         uint64_t min_key = 0;
         int min_k = -1;
@@ -1650,6 +1655,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             const uint64_t key = mover == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), pb);
             if (alpha < min_alpha || (min_k >= 0 && key > min_key)) { min_alpha = alpha; min_k = k; min_key = key; }
         }
+        MW_TACC(first_k == TOI_SEARCH_ONLY ? 6 : 0, ta_);
         if (min_k < 0 || 1.0f - 10.0f * B2_EPSILON < min_alpha || M.continuous == 2) break;   // no more TOI events
         if (first_k == TOI_SEARCH_ONLY) {
             const int pi = mover == 0 ? 0 : par.alloc(&T.n_pend);   // entry 0 is the package's (see solve_toi); at most one entry per body: MAXB is room enough
@@ -1682,6 +1688,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             Wd.b[mover].c = bk_c; Wd.b[mover].a = bk_a;
             continue;
         }
+        MW_TACC(1, ta_);
         // ---- mini island: the event's contact, then the body's other contacts with static bodies in its contact-edge order, each
         // updated at the time-of-impact pose and added when it touches
         Manifold mm[TOI_MREG];
@@ -1720,12 +1727,14 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             for (int q_ = 0; q_ < TOI_MREG; ++q_) if (q_ < n_isl) { Manifold &m_ = mm[q_]; F_; }                   \
             for (int q_ = TOI_MREG; q_ < n_isl; ++q_) { Manifold &m_ = TL.ovf[q_ - TOI_MREG]; F_; }                \
         }
+        MW_TACC(2, ta_);
         // ---- b2Island::SolveTOI
         for (int it = 0; it < 20; ++it) {   // subStep.positionIterations = 20
             float ms_min = 0.0f;
             MW_ISLAND_SWEEP(ms_min = mnf(ms_min, contact_solve_toi_position(Wd, m_, qm)))
             if (ms_min >= -1.5f * LINEAR_SLOP) break;
         }
+        MW_TACC(3, ta_);
         Cd.sweep_c0[mover] = Wd.b[mover].c; Cd.sweep_a0[mover] = Wd.b[mover].a;  // "leap of faith to new safe state"
         {   // InitializeVelocityConstraints on velocities that stay untouched (impulses are zero: nothing to warm start)
             const V2 v_keep = Wd.b[mover].v; const float w_keep = Wd.b[mover].w;
@@ -1789,6 +1798,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             Wd.b[mover].v = vB; Wd.b[mover].w = wB;
         }
 #undef MW_ISLAND_SWEEP
+        MW_TACC(4, ta_);
         {   // integrate the rest of the step
             const float hs = (1.0f - min_alpha) * h;
             Body &b = Wd.b[mover];
@@ -1821,6 +1831,7 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
             }
             ++n_events;
             box = swept_box(msh, sweep_of_body(M, Wd, Cd, mover));   // its new sweep: from the safe pose to the end of the sub-step
+            MW_TACC(5, ta_);
             MW_PHASE(3);
         }
     }
@@ -1854,6 +1865,7 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
             toi_body_chain(M, Wd, Cd, S, T, TL, par, body, h, pass == 0 ? TOI_SEARCH_ONLY : (int)T.pend[k].k, pass == 0 ? 0.0f : T.pend[k].alpha);
         }
         par.sync();
+        if (pass == 0) { MW_TSTAMP(1, 6); }
     }
     MW_TSTAMP(1, 3);
     const int n = T.n_ev < TOI_MAX_EVENTS ? T.n_ev : TOI_MAX_EVENTS;

@@ -23,8 +23,22 @@ torch.cuda.synchronize()
 L = _lib.lib()
 L.madrl_multiwalker_debug_read.argtypes = [C.c_void_p, C.c_void_p]
 MHZ = 100.0   # s_memtime counts shader clocks here (~2.1 GHz): the printed "us" are units of 100 clocks = 0.047 us
+has_acc = hasattr(L, "madrl_multiwalker_debug_read_acc")
+if has_acc:
+    L.madrl_multiwalker_debug_read_acc.argtypes = [C.c_void_p, C.c_int]
 for rep in range(3):
+    if has_acc:
+        acc = np.zeros((4096, 8), np.uint64)
+        L.madrl_multiwalker_debug_read_acc(acc.ctypes.data_as(C.c_void_p), 1)   # zero the region accumulators
     env.step(acts[rep % 4])
+    if has_acc:
+        L.madrl_multiwalker_debug_read_acc(acc.ctypes.data_as(C.c_void_p), 0)
+        nb_ = (N + 15) // 16
+        a = acc[nb_:2 * nb_].astype(np.float64) / MHZ
+        names = ("re-search after an event", "advance + update of the event's contact", "mini island (other contacts updated)", "20 position iterations",
+                 "init + velocity sweeps", "integrate, SynchronizeFixtures, FindNewContacts, swept box", "first searches (pass 0)", "-")
+        print("step %d, continuous pass, regions of the chains per wavefront (us, summed over the step): " % rep +
+              " | ".join("%s: mean %.0f max %.0f" % (names[k], a[:, k].mean(), a[:, k].max()) for k in range(7)))
     stamps = np.zeros((2, 4096, 8), np.uint64)
     vals = np.zeros((2, 4096, 16, 4), np.int32)
     assert L.madrl_multiwalker_debug_read(stamps.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p)) == 0
@@ -60,6 +74,10 @@ for rep in range(3):
         else:
             ne = v[..., 0]
             ch = (st[:, 3] - st[:, 2]) / MHZ
+            if (st[ok][:, 6] > 0).all():   # two-pass continuous pass: stamp 6 sits between the first searches and the pending chains
+                sr, evs = (st[:, 6] - st[:, 2]) / MHZ, (st[:, 3] - st[:, 6]) / MHZ
+                print("    chains = first searches of every body: mean %.0f p90 %.0f max %.0f | pending chains (events): mean %.0f p90 %.0f max %.0f" % (
+                    sr[ok].mean(), np.percentile(sr[ok], 90), sr[ok].max(), evs[ok].mean(), np.percentile(evs[ok], 90), evs[ok].max()))
             print("    events per env: mean %.2f; max over the wavefront's envs: histogram 0..8 %s" % (ne[ok].mean(), np.bincount(ne[ok].max(1).clip(0, 8), minlength=9)))
             for k in range(0, 7):
                 m = ok & (ne.max(1) == k)
