@@ -24,7 +24,7 @@
 // What IS pinned to the reference (round 4): the ENV LAYER.  Everything multi_walker.py itself computes -- the world its reset()
 // constructs call by call, the terrain walk, the pushes, apply_action, get_observation with the lidar callback, ContactDetector,
 // the neighbour / package observations with their noise, rewards, termination, the one-hot id -- is recorded from the UNMODIFIED
-// module running over a package named `Box2D` whose b2World is multiwalker_ref.c's (oracle/shims_box2d), and this file, free-running
+// module running over a package named `Box2D` whose b2World is multiwalker_ref.c's (the test infrastructure's Box2D shim), and this file, free-running
 // on the same terrain / pushes / actions, reproduces those recordings: body states bit for bit, float32 observations and rewards to
 // 1e-6, flags and done exactly (tests/test_multiwalker_envlayer.py).  The dynamics (b2World::Step) stay restated, not run.
 // Lane-parallel execution keeps Box2D's results: two constraints without a common body commute exactly, so any
