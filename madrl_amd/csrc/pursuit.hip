@@ -675,10 +675,16 @@ constexpr WaveGeom wave_geom(int waves = 1, int occ = 4) {
 #define XG(XS, YS, NP, NE, R, FL, NW)
 const WaveEntry WAVE_TABLE[] = {
 #include "pursuit_specializations.def"
+#if __has_include("pursuit_specializations.local.def")   // shapes added on this machine by `python -m madrl_amd.build --pursuit-shape ...` (git-ignored)
+#include "pursuit_specializations.local.def"
+#endif
 #undef X
 #define X(XS, YS, NP, NE, R, FL)
 #define XG(XS, YS, NP, NE, R, FL, NW) {wave_geom<pw::GShape<XS, YS, NP, NE, R, FL, NW>>(NW), group_launch<pw::GShape<XS, YS, NP, NE, R, FL, NW>>},
 #include "pursuit_specializations.def"
+#if __has_include("pursuit_specializations.local.def")   // shapes added on this machine by `python -m madrl_amd.build --pursuit-shape ...` (git-ignored)
+#include "pursuit_specializations.local.def"
+#endif
 };
 #undef X
 #undef XG

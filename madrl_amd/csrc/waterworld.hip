@@ -776,6 +776,9 @@ void ww_launch_spec(const WwDev &d, const WwIO &io, int mode, bool fused, dim3 g
 #define X(NP_, NE_, NPO_, K_, D_) {NP_, NE_, NPO_, K_, D_, ww_launch_spec<NP_, NE_, NPO_, K_, D_>},
 const WwSpec WW_SPECS[] = {
 #include "waterworld_specializations.def"
+#if __has_include("waterworld_specializations.local.def")   // shapes added on this machine by `python -m madrl_amd.build --waterworld-shape ...` (git-ignored)
+#include "waterworld_specializations.local.def"
+#endif
 };
 #undef X
 

@@ -160,11 +160,30 @@ class BatchedPursuitEvade(AbstractMAEnv):
             _lib.check(L.madrl_pursuit_set_launch(h, self._threads, self._max_blocks))
         if getattr(self, "_kernel", "auto") != "auto":
             self.set_kernel(self._kernel)
+        elif N >= 4096:
+            self._hint_fast_path()
         if getattr(self, "_walk", "auto") != "auto":
             self.set_walk(self._walk)
         obs_shape = (D,) if self.flatten else (self.obs_range, self.obs_range, 4)
         self.pursuers = [PursuitAgent(obs_shape) for _ in range(P)]
         self.act_dims = [5] * P
+
+    _hinted = set()
+
+    def _hint_fast_path(self):
+        """A large batch of a shape that COULD have a compile-time specialised kernel but runs on the generic one (about half the speed): say
+        once per shape how to get it (python -m madrl_amd.build --pursuit-shape ...; csrc/pursuit_specializations.def)."""
+        from . import build as _build
+        shape = (self.xs, self.ys, int(self.n_pursuers), int(self.n_evaders), int(self.obs_range), int(bool(self.flatten)))
+        if shape in BatchedPursuitEvade._hinted or self.kernel_kind != "generic" or not self.train_pursuit and shape[2] + shape[3] > 64:
+            return
+        kind, _ = _build.pursuit_fast_path(*shape, include_id=bool(self.include_id))
+        if kind is not None:
+            import warnings
+            BatchedPursuitEvade._hinted.add(shape)
+            warnings.warn("PursuitEvade %dx%d, %d v %d, obs_range %d runs on the generic kernel; `python -m madrl_amd.build --pursuit-shape %s` "
+                          "compiles the specialised kernel for this shape (results are identical, a step takes about half the time)"
+                          % (shape[0], shape[1], shape[2], shape[3], shape[4], " ".join(str(v) for v in shape)), stacklevel=3)
 
     def set_kernel(self, kind):
         """'auto' | 'generic' | 'wave' (one wavefront per env, compile-time specialised shapes only)"""

@@ -143,3 +143,37 @@ def test_batch_size_limits_are_checked_at_create():
     hc.radius, hc.bad_speed, hc.sensor_range, hc.action_scale, hc.bomb_radius, hc.key_radius = 0.015, 0.01, 0.2, 0.01, 0.03, 0.0225
     assert L.madrl_hostage_create(C.byref(hc), sens.ctypes.data_as(C.c_void_p), 2**31 - 10, 0, dummy, C.byref(out)) == -1
     assert b"too large" in L.madrl_last_error()
+
+
+def test_which_shapes_can_have_a_fast_path_and_how_they_are_added(tmp_path, monkeypatch):
+    """madrl_amd.build.pursuit_fast_path mirrors the static_asserts of pursuit_wave.hpp / pursuit_group.hpp (a shape they refuse must be refused
+    before it breaks the build); --pursuit-shape / --waterworld-shape append to a git-ignored *.local.def that the sources include"""
+    from madrl_amd import build as b
+    assert b.pursuit_fast_path(16, 16, 8, 30, 7, 1) == ("X", None) and b.pursuit_fast_path(32, 32, 16, 60, 7, 1) == ("XG", 2)
+    assert b.pursuit_fast_path(16, 16, 8, 30, 7, 0) == ("X", None) and b.pursuit_fast_path(20, 8, 7, 1, 3, 0) == ("X", None)
+    for shape, why in (((10, 10, 4, 4, 4, 1), "even"), ((128, 128, 100, 300, 21, 0), "more than 64"), ((5, 10, 16, 7, 7, 1), "slots"),
+                       ((200, 200, 8, 30, 7, 1), "LDS"), ((24, 24, 70, 58, 3, 1), "more than 64")):
+        kind, reason = b.pursuit_fast_path(*shape)
+        assert kind is None and why in reason, (shape, reason)
+    assert b.pursuit_fast_path(16, 16, 8, 30, 7, 1, include_id=False)[0] is None
+    # every committed line passes its own check
+    for line in open(os.path.join(ROOT, "madrl_amd", "csrc", "pursuit_specializations.def")):
+        m = re.match(r"\s*(XG?)\(([^)]*)\)", line)
+        if m:
+            v = [int(x) for x in m.group(2).split(",")]
+            kind, nw = b.pursuit_fast_path(*v[:6])
+            assert kind == m.group(1) and (kind == "X" or nw == v[6]), line
+    # appending: a new shape lands in the local file once, a committed one not at all
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    for f in ("pursuit_specializations.def", "waterworld_specializations.def"):
+        (csrc / f).write_text(open(os.path.join(ROOT, "madrl_amd", "csrc", f)).read())
+    monkeypatch.setattr(b, "CSRC", str(csrc))
+    assert b.add_pursuit_shape(20, 20, 6, 10, 5, 1) is True and b.add_pursuit_shape(20, 20, 6, 10, 5, 1) is False
+    assert b.add_pursuit_shape(16, 16, 8, 30, 7, 1) is False and b.add_waterworld_shape(4, 8, 6, 24) is True and b.add_waterworld_shape(5, 10, 10, 30) is False
+    assert (csrc / "pursuit_specializations.local.def").read_text().startswith("X(20, 20, 6, 10, 5, 1)")
+    assert (csrc / "waterworld_specializations.local.def").read_text().startswith("X(4, 8, 6, 24, 171)")
+    with pytest.raises(ValueError):
+        b.add_pursuit_shape(10, 10, 4, 4, 4, 1)
+    for src in ("pursuit.hip", "waterworld.hip"):
+        assert "specializations.local.def" in open(os.path.join(ROOT, "madrl_amd", "csrc", src)).read()
