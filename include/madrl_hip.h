@@ -307,7 +307,9 @@ int madrl_hostage_set_state(madrl_hostage *h, const float *pos, const float *vel
  * The rigid-body dynamics the reference delegates to Box2D (`world.Step(1/50, 180, 60)`,
  * multi_walker.py:365) are restated from scratch in Box2D 2.3.0's own order (islands by depth-first search, contact list
  * order, sleeping, fat-AABB broad phase, continuous pass); parity with Box2D itself is UNPINNED (DESIGN.md "MultiWalker"):
- * the checker is an independent plain-C restatement (oracle/multiwalker_ref.c), not the library.
+ * the checker is an independent plain-C restatement (oracle/multiwalker_ref.c), not the library.  The env layer around the
+ * dynamics -- the world reset constructs, apply_action (:194-203), get_observation (:205-237), ContactDetector (:50-84), the
+ * step tail (:369-428) -- IS pinned: to recordings of the unmodified module (tests/test_multiwalker_envlayer.py).
  * ---------------------------------------------------------------------------------------- */
 
 /* Constructor arguments of MultiWalkerEnv.__init__ (multi_walker.py:256-270). */

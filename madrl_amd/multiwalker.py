@@ -7,7 +7,10 @@ Same constructor arguments / defaults (:256-258), `agents`, `reward_mech`, `rese
 `MultiWalkerEnv(...)` is the N == 1 drop-in with the reference's return types.
 
 The rigid-body dynamics (Box2D in the reference) are restated from scratch in
-madrl_amd/csrc/multiwalker_core.hpp; parity with Box2D is UNPINNED (DESIGN.md).
+madrl_amd/csrc/multiwalker_core.hpp; parity of those dynamics with Box2D is UNPINNED.
+Everything the reference module itself computes around `world.Step` -- the world reset() builds,
+observations, contact flags, rewards, termination -- is checked against recordings of the
+unmodified module (tests/test_multiwalker_envlayer.py).
 """
 import ctypes as C
 
