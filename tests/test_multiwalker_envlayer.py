@@ -27,10 +27,14 @@ FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__))
 ids = [os.path.basename(p)[len("multiwalker_envlayer_"):-4] for p in FILES]
 
 
-def _replay(kind, path, obs_tol, rew_tol):
+def _replay(kind, path, obs_tol, rew_tol, copies=1):
+    """copies > 1: every recorded episode `copies` times in one batch, interleaved (the kernels take 16 envs per wavefront: copies of one
+    episode then sit in different lanes, wavefronts and blocks and must all come out the same).  Only without observation noise -- the
+    noise is keyed by the env id, which a copy does not share."""
     g = np.load(path)
-    W, E = int(g["n_walkers"]), int(g["n_episodes"])
-    ep = [{k: g["ep%d_%s" % (e, k)] for k in ("terrain_y", "push", "actions", "bodies", "obs", "rew", "done", "flags")} for e in range(E)]
+    W, E = int(g["n_walkers"]), int(g["n_episodes"]) * copies
+    ep = [{k: g["ep%d_%s" % (e % (E // copies), k)] for k in ("terrain_y", "push", "actions", "bodies", "obs", "rew", "done", "flags")} for e in range(E)]
+    assert copies == 1 or float(g["cfg_position_noise"]) == 0.0
     T = [len(r["done"]) for r in ep]
     be = Backend(kind, E, n_walkers=W, terminate_on_fall=bool(g["cfg_terminate_on_fall"]), reward_mech="global" if int(g["reward_global"]) else "local",
                  forward_reward=float(g["cfg_forward_reward"]), fall_reward=float(g["cfg_fall_reward"]), drop_reward=float(g["cfg_drop_reward"]),
@@ -87,6 +91,13 @@ def test_product_source_env_layer_is_the_references(path):
 @pytest.mark.parametrize("path", FILES, ids=ids)
 def test_kernels_env_layer_is_the_references(path):
     _replay("hip", path, 1e-6, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", [p for p in FILES if "noise" not in p], ids=[i for i in ids if "noise" not in i])
+def test_kernels_env_layer_in_every_lane(path):
+    """37 interleaved copies of every recorded episode: more than two wavefronts of envs per episode set, at every position of a wavefront"""
+    _replay("hip", path, 1e-6, 1e-6, copies=37)
 
 
 # ------------------------------------------------------------------------------------------------ the un-injected reset
