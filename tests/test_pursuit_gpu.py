@@ -118,16 +118,41 @@ def _maps(name):
 def test_hip_matches_oracle_free_running(case, kernel):
     """Seeded free-running rollouts with auto-reset: HIP kernels and the C oracle each run their
     own Philox; every output and the whole state must agree on every step."""
-    from oracle import pursuit as po
     kw = dict(CASES[case])
     maps = _maps(kw.pop("maps"))
-    N, T, H = kw.pop("n_envs", 512), kw.pop("steps", 120), 25
+    N, T = kw.pop("n_envs", 512), kw.pop("steps", 120)
     expect_catches = kw.pop("expect_catches", True)
     if kernel == "auto" and kw["n_pursuers"] + kw["n_evaders"] > 128:
         pytest.skip("no fast path above two wavefronts of agents: the generic kernel is what runs")
+    _free_run(maps, kw, kernel, N, T, expect_catches, want_kind="wave" if kernel == "auto" else None)
+
+
+def _drawn_cases(n=16, seed=20260927):
+    """configurations drawn like the recorded ones of oracle/make_golden_pursuit_fuzz.py, from another seed: here nothing is injected --
+    reset sampling, map draws, random_opponents and the evaders' moves all come from the Philox contract on both sides"""
+    from oracle.make_golden_pursuit_fuzz import draw_case
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        maps, cfg, _run = draw_case(rng)
+        if rng.rand() < 0.3:
+            cfg["constraint_window"] = float(rng.choice([0.3, 0.5, 0.8]))
+        out.append((maps, cfg))
+    return out
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_drawn_configurations_free_running_vs_oracle(i):
+    maps, cfg = _drawn_cases()[i]
+    big = cfg["n_pursuers"] + cfg["n_evaders"] > 64
+    _free_run(maps, cfg, "auto", 96 if big else 256, 50, expect_catches=False)
+
+
+def _free_run(maps, kw, kernel, N, T, expect_catches, want_kind=None, H=25):
+    from oracle import pursuit as po
     env = _mk(maps, N, seed=2024, env_id_base=1000, max_steps=H, auto_reset=True, kernel=kernel, **kw)
-    if kernel == "auto":
-        assert env.kernel_kind == "wave"  # one wavefront per env, or a wavefront group for more than 64 agents
+    if want_kind:
+        assert env.kernel_kind == want_kind  # one wavefront per env, or a wavefront group for more than 64 agents
     orc = po.PursuitOracle(maps, n_envs=N, seed=2024, env_id_base=1000, **kw)
     obs = env.reset()
     oobs = orc.reset().copy()
