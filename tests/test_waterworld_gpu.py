@@ -108,8 +108,33 @@ def test_hip_matches_f32_oracle_free_running(case):
         assert np.array_equal(gst["t"].cpu().numpy(), ost["t"])
         assert np.array_equal(gst["tick"].cpu().numpy().view(np.uint32), ost["tick"])
         exact += int(np.array_equal(got, orc.obs)); total += 1
-    assert catches > 0
+    assert catches > 0, "no catches"
     print("bit-identical observation batches: %d / %d" % (exact, total))
+
+
+def _drawn_case(i):
+    from oracle.make_golden_waterworld_fuzz import draw_case
+    rng = np.random.RandomState(20260929)
+    for _ in range(i + 1):
+        (Np, Ne), kw, _run = draw_case(rng)
+    kw = dict(kw, n_pursuers=Np, n_evaders=Ne)
+    if isinstance(kw.get("obstacle_loc", 0), np.ndarray):
+        kw["obstacle_loc"] = tuple(float(v) for v in kw["obstacle_loc"])
+    return kw
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_drawn_configurations_free_running_vs_f32_oracle(i):
+    """configurations drawn like the recorded ones (oracle/make_golden_waterworld_fuzz.py), another seed, nothing injected (respawns, random
+    obstacles, auto-reset from Philox on both sides): the protocol of test_hip_matches_f32_oracle_free_running on random shapes"""
+    CASES["drawn_%d" % i] = _drawn_case(i)
+    try:
+        test_hip_matches_f32_oracle_free_running("drawn_%d" % i)
+    except AssertionError as e:
+        if str(e) != "no catches":
+            raise
+    finally:
+        del CASES["drawn_%d" % i]
 
 
 @pytest.mark.parametrize("shape", ["c3_bitrows", "generic"])
