@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction mix and issue / wait cycles of one workload's step kernel (separate --pmc passes, no trace domains).
-#   scripts/pmc_mix.sh <workload> <kernel-substring> <envs> [extra bench args]   -> gpurun_out/pmc_mix/<workload>/summary.txt
+#   scripts/pmc_mix.sh <workload> <kernel-substring>[,<kernel-substring>...] <envs> [extra bench args]   -> gpurun_out/pmc_mix/<workload>/summary.txt
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 WL=$1; KSUB=$2; ENVS=$3; shift 3
@@ -16,21 +16,22 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR S
 done
 python - "$OUT" "$KSUB" "$ENVS" <<'PY' | tee $OUT/summary.txt
 import csv, glob, collections, sys
-out, ksub, envs = sys.argv[1], sys.argv[2], float(sys.argv[3])
-for f in sorted(glob.glob(out + "/*/**/*counter_collection*.csv", recursive=True)):
-    acc = collections.defaultdict(list)
-    names = collections.Counter()
-    for row in csv.DictReader(open(f)):
-        if ksub in row["Kernel_Name"]:
-            names[row["Kernel_Name"]] += 1
-    if not names:
-        continue
-    kname = max(names, key=names.get)   # the step launches, not the single reset launch
-    for row in csv.DictReader(open(f)):
-        if row["Kernel_Name"] == kname:
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    print("==", kname[:100])
-    for k, v in sorted(acc.items()):
-        print("%-28s n=%3d mean=%.6g  per_env=%.1f" % (k, len(v), sum(v) / len(v), sum(v) / len(v) / envs))
+out, ksubs, envs = sys.argv[1], sys.argv[2].split(","), float(sys.argv[3])
+for ksub in ksubs:
+  for f in sorted(glob.glob(out + "/*/**/*counter_collection*.csv", recursive=True)):
+      acc = collections.defaultdict(list)
+      names = collections.Counter()
+      for row in csv.DictReader(open(f)):
+          if ksub in row["Kernel_Name"]:
+              names[row["Kernel_Name"]] += 1
+      if not names:
+          continue
+      kname = max(names, key=names.get)   # the step launches, not the single reset launch
+      for row in csv.DictReader(open(f)):
+          if row["Kernel_Name"] == kname:
+              acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+      print("==", kname[:100])
+      for k, v in sorted(acc.items()):
+          print("%-28s n=%3d mean=%.6g  per_env=%.1f" % (k, len(v), sum(v) / len(v), sum(v) / len(v) / envs))
 PY
 rm -rf $OUT/s1 $OUT/s2 $OUT/s3
