@@ -13,6 +13,7 @@ csrc/*_specializations.local.def (git-ignored, included after the committed list
 round step by step like NumPy does in the reference; an FMA contraction would change bits.
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -24,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # per-source additions.  multiwalker: the SLP vectorizer pairs the solver's scalar float math into packed-fp32 instructions, which
 # need every loop constant replicated into register pairs -- the 180-sweep loop then runs out of VGPRs (AGPR copies, scratch)
-EXTRA_FLAGS = {"multiwalker.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"multiwalker_c": ["-fno-slp-vectorize"]}   # file-name prefix -> flags (the capacity classes multiwalker_c4 / _c8 / _c10.hip)
 
 
 def pursuit_fast_path(xs, ys, n_pursuers, n_evaders, obs_range, flatten, include_id=True):
@@ -87,25 +88,43 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _deps():
-    inc = os.path.join(os.path.dirname(HERE), "include")
-    out = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".def"))]
-    out += [os.path.join(inc, f) for f in os.listdir(inc)]
-    return out
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps(src, seen=None):
+    """the files one source depends on: itself and, recursively, every `#include "..."` in it that exists (the git-ignored *.local.def
+    lists are behind __has_include: they count once they exist) -- so appending a Pursuit shape re-compiles pursuit.hip and nothing else"""
+    seen = set() if seen is None else seen
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    for inc in _INC.findall(open(src).read()):
+        _deps(os.path.normpath(os.path.join(os.path.dirname(src), inc)), seen)
+    return seen
+
+
+def _compile(src, obj, verbose):
+    cmd = [HIPCC] + FLAGS + [f for pat, fl in EXTRA_FLAGS.items() if os.path.basename(src).startswith(pat) for f in fl] + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
 
 
 def build(force=False, verbose=False):
-    objs = []
+    objs, stale = [], []
     for src in sources():
         obj = src[:-4] + ".o"
         objs.append(obj)
-        stale = force or not os.path.exists(obj) or any(
-            os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps())
-        if stale:
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
+            stale.append((src, obj))
+    if stale:   # the objects are independent: compile them side by side (the three MultiWalker classes take a minute each)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 1)) as ex:
+            for f in [ex.submit(_compile, src, obj, verbose) for src, obj in stale]:
+                f.result()
+    for f in os.listdir(CSRC):   # objects whose source is gone (a renamed file) must not be linked
+        if f.endswith(".o") and os.path.join(CSRC, f) not in objs:
+            os.remove(os.path.join(CSRC, f))
     if force or not os.path.exists(SO) or any(os.path.getmtime(o) > os.path.getmtime(SO) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
         if verbose:

@@ -59,7 +59,23 @@
 #define MW_UNROLL
 #endif
 
-namespace mw {
+// One build of this source has room for MW_CAPW walkers and spreads an env over MW_NLANES lanes (multiwalker.hip is compiled once per
+// capacity class -- 4 walkers on 4 lanes, 8 on 8, 10 on 16: the reference's curriculum runs n_walkers = 2 .. 10,
+// lessons/multiwalker/env.yaml -- and the C ABI picks the class by n_walkers).  Every class lives in its own namespace, so that the
+// three builds can be linked into one library; `mw` is an alias of the class the including file asked for.
+#ifndef MW_CAPW
+#define MW_CAPW 4
+#endif
+#ifndef MW_NLANES
+#define MW_NLANES 4
+#endif
+#define MW_CAT2_(a, b) a##b
+#define MW_CAT_(a, b) MW_CAT2_(a, b)
+#define MW_NS MW_CAT_(mw_c, MW_CAPW)
+namespace MW_NS {}
+namespace mw = MW_NS;
+
+namespace MW_NS {
 
 // optional counters of the CPU build (scripts/mw_stats.cpp): how many sub-slots / position iterations a step really runs
 #ifdef MW_STATS
@@ -119,15 +135,23 @@ constexpr float MAX_TRANSLATION = 2.0f, MAX_ROTATION = 0.5f * B2_PI, BAUMGARTE =
 constexpr float GRAVITY_Y = -10.0f;  // b2World() default in pybox2d: gravity=(0,-10)
 constexpr int VEL_ITERS = MW_VEL_ITERS, POS_ITERS = MW_POS_ITERS;
 
-constexpr int MAX_WALKERS = 4;
+constexpr int MAX_WALKERS = MW_CAPW;
+static_assert(MAX_WALKERS >= 1 && MAX_WALKERS <= 12, "body / joint flag sets are at most 64 bits wide");
 constexpr int MAXB = 5 * MAX_WALKERS + 1;        // package + 5 bodies per walker
 constexpr int MAXJ = 4 * MAX_WALKERS;
 constexpr int MAXT = TERRAIN_LENGTH * MAX_WALKERS / 8;  // terrain points (:301)
 // contacts a body's cache holds (Model::slot_cap): the edges under its fat AABB (leg <= 6, hull <= 8 at the speeds of this env) PLUS the
 // ones it has just left, which Box2D destroys only in the next step's Collide
-constexpr int EDGE_SLOTS_LEG = 12, EDGE_SLOTS_HULL = 16, EDGE_SLOTS_PKG_MAX = 56;
+constexpr int EDGE_SLOTS_LEG = 12, EDGE_SLOTS_HULL = 16;
+// the package's cache: its length grows with the number of walkers (:293-294), and so does the run of edges under it
+constexpr int package_slot_cap(int n_walkers) { return (int)(((float)(240.0 / 30.0 * (n_walkers / 1.75)) + 1.5f) / TERRAIN_STEP) + 12; }
+constexpr int EDGE_SLOTS_PKG_MAX = (package_slot_cap(MAX_WALKERS) + 3) / 4 * 4;
+static_assert(EDGE_SLOTS_PKG_MAX <= 128, "occupancy words of a contact cache");
 constexpr int MAXSLOT = 4 * MAX_WALKERS * EDGE_SLOTS_LEG + MAX_WALKERS * EDGE_SLOTS_HULL + EDGE_SLOTS_PKG_MAX + MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
-constexpr int MAXM = 40;  // largest active-manifold pool (Model::max_manifolds <= MAXM)
+// the active-manifold pool of a step (Model::max_manifolds <= MAXM): see build_model
+constexpr int manifold_pool(int n_walkers) { return n_walkers <= 1 ? 20 : (n_walkers == 2 ? 28 : (n_walkers == 3 ? 36 : (n_walkers == 4 ? 40 : 6 * n_walkers + 16))); }
+constexpr int MAXM = manifold_pool(MAX_WALKERS);
+static_assert(MAXM <= 128, "manifold flag set of build_islands");
 constexpr double TERRAIN_HEIGHT64 = 400.0 / 30.0 / 4, LEG_H64 = 34.0 / 30.0, LEG_DOWN64 = -8.0 / 30.0;   // the reference's float64 constants (:26-36)
 
 struct V2 { float x, y; };
@@ -144,6 +168,48 @@ MW_HD V2 cross(float s, V2 a) { return v2(-s * a.y, s * a.x); }
 MW_HD float mnf(float a, float b) { return a < b ? a : b; }
 MW_HD float mxf(float a, float b) { return a > b ? a : b; }
 MW_HD float clampf(float a, float lo, float hi) { return mxf(lo, mnf(a, hi)); }
+// Flag sets (one bit per body / joint / manifold / cache entry), as wide as the capacity class needs: one dword for four walkers -- the
+// layout and the code of the rounds before the classes existed -- one or two qwords beyond.  No arrays: a word picked by a run-time index
+// would be an indexed local object, which the GPU build keeps in scratch memory.
+struct Bits32 {
+    uint32_t v;
+    MW_HD bool test(int i) const { return (v >> i) & 1u; }
+    MW_HD void set(int i) { v |= 1u << i; }
+    MW_HD void clear(int i) { v &= ~(1u << i); }
+    MW_HD bool any() const { return v != 0; }
+    MW_HD void join(Bits32 o) { v |= o.v; }
+    MW_HD int pop_lowest() { const int k = __builtin_ctz(v); v &= v - 1; return k; }
+    static MW_HD Bits32 none() { Bits32 b; b.v = 0; return b; }
+    static MW_HD Bits32 first(int n) { Bits32 b; b.v = n >= 32 ? ~0u : (1u << n) - 1u; return b; }
+};
+struct Bits64 {
+    uint64_t v;
+    MW_HD bool test(int i) const { return (v >> i) & 1ull; }
+    MW_HD void set(int i) { v |= 1ull << i; }
+    MW_HD void clear(int i) { v &= ~(1ull << i); }
+    MW_HD bool any() const { return v != 0; }
+    MW_HD void join(Bits64 o) { v |= o.v; }
+    MW_HD int pop_lowest() { const int k = __builtin_ctzll(v); v &= v - 1; return k; }
+    static MW_HD Bits64 none() { Bits64 b; b.v = 0; return b; }
+    static MW_HD Bits64 first(int n) { Bits64 b; b.v = n >= 64 ? ~0ull : (1ull << n) - 1ull; return b; }
+};
+struct Bits128 {
+    uint64_t lo, hi;
+    MW_HD bool test(int i) const { return ((i < 64 ? lo : hi) >> (i & 63)) & 1ull; }
+    MW_HD void set(int i) { const uint64_t m = 1ull << (i & 63); if (i < 64) lo |= m; else hi |= m; }
+    MW_HD void clear(int i) { const uint64_t m = ~(1ull << (i & 63)); if (i < 64) lo &= m; else hi &= m; }
+    MW_HD bool any() const { return (lo | hi) != 0; }
+    MW_HD void join(Bits128 o) { lo |= o.lo; hi |= o.hi; }
+    MW_HD int pop_lowest() { if (lo != 0) { const int k = __builtin_ctzll(lo); lo &= lo - 1; return k; } const int k = __builtin_ctzll(hi); hi &= hi - 1; return 64 + k; }
+    static MW_HD Bits128 none() { Bits128 b; b.lo = 0; b.hi = 0; return b; }
+};
+template <int N, bool A = (N <= 32), bool B = (N <= 64)> struct BitsFor { typedef Bits128 type; };
+template <int N> struct BitsFor<N, true, true> { typedef Bits32 type; };
+template <int N> struct BitsFor<N, false, true> { typedef Bits64 type; };
+typedef BitsFor<MAXB>::type BodyBits;               // one bit per dynamic body
+typedef BitsFor<MAXJ>::type JointBits;
+typedef BitsFor<MAXM>::type ManifoldBits;           // ... per entry of the step's manifold pool
+typedef BitsFor<EDGE_SLOTS_PKG_MAX <= 64 ? 64 : 128>::type SlotBits;   // ... per entry of one body's contact cache
 struct Rot { float s, c; };
 // sin/cos from +,-,* only (Cody-Waite reduction by pi/2, cephes single-precision minimax
 // polynomials on [-pi/4, pi/4]): the host build and the device build of this file then agree
@@ -173,9 +239,9 @@ MW_HD V2 mulT(Xf t, V2 v) { return mulT(t.q, v - t.p); }
 MW_HD Rot mulT(Rot q, Rot r) { Rot o; o.s = q.c * r.s - q.s * r.c; o.c = q.c * r.c + q.s * r.s; return o; }
 MW_HD Xf mulT(Xf A, Xf B) { Xf C; C.q = mulT(A.q, B.q); C.p = mulT(A.q, B.p - A.p); return C; }
 
-}  // namespace mw
+}  // namespace MW_NS
 #include "multiwalker_toi.hpp"
-namespace mw {
+namespace MW_NS {
 
 
 // ---------------------------------------------------------------- static model (per n_walkers)
@@ -209,7 +275,8 @@ struct Model {
     int slot_base[MAXB], slot_cap[MAXB];  // body-vs-terrain contact ranges in Cold::slot (contact with edge e lives in slot e % cap)
     uint8_t slot_body[MAXSLOT];           // the body whose cache holds terrain slot s
     int n_slots;                          // slots in use: the terrain caches and the pairs
-    uint8_t toi_body[MAXB];               // the order in which the lanes take the bodies' event chains in the continuous pass (see build_model)
+    uint8_t toi_body[MAXB + MW_NLANES];    // the order in which the lanes take the bodies' event chains in the continuous pass (see build_model; 255: nobody)
+    int n_toi;                            // entries of toi_body
     int dyn_slot_base, n_dyn_pairs;
     int dyn_a[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS], dyn_b[MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS];
 };
@@ -301,8 +368,9 @@ inline void build_model(Model &M, int n_walkers) {
     M.W = n_walkers; M.NB = 5 * n_walkers + 1; M.NJ = 4 * n_walkers;
     M.continuous = 1;
     // active-manifold pool: observed maxima of simultaneously touching pairs over long random / collapsed rollouts are 18, 25, 34
-    // for 2, 3, 4 walkers; a pair past the pool is ignored for the step and raises the sticky Hot::overflow bit
-    M.max_manifolds = n_walkers <= 1 ? 20 : (n_walkers == 2 ? 28 : (n_walkers == 3 ? 36 : MAXM));
+    // for 2, 3, 4 walkers and 30 .. 44 for 5 .. 10 (6 per walker + 16 there); a pair past the pool is ignored for the step and raises the
+    // sticky Hot::overflow bit
+    M.max_manifolds = manifold_pool(n_walkers);
     M.NT = (int)(TERRAIN_LENGTH * n_walkers * 1 / 8.0);          // :301
     const double scale64 = n_walkers / 1.75;                      // :293
     M.package_scale = (float)scale64;
@@ -351,18 +419,21 @@ inline void build_model(Model &M, int n_walkers) {
     for (int b = 0; b < M.NB; ++b) {
         M.slot_base[b] = base;
         // candidate edges = those whose fat AABB overlaps the body's: a run no longer than (fat width + edge margins) / TERRAIN_STEP + 1
-        M.slot_cap[b] = (b == 0) ? (int)((M.package_length + 1.5f) / TERRAIN_STEP) + 12 : (is_hull(b) ? EDGE_SLOTS_HULL : EDGE_SLOTS_LEG);
+        M.slot_cap[b] = (b == 0) ? package_slot_cap(n_walkers) : (is_hull(b) ? EDGE_SLOTS_HULL : EDGE_SLOTS_LEG);
         base += M.slot_cap[b];
     }
     {   // Continuous pass: the k-th body of this list goes to lane k % lanes, and the lanes work through their bodies in lockstep -- all the
         // "first" bodies, then all the "second" ones ...  Each such group costs as much as its longest chain of events, so the bodies that
         // have events (lower legs, then upper legs) share groups instead of being spread over all of them; the package comes first in the
-        // last group: lane 0 (4W is a multiple of the four lanes), which has the contact cache sized for it.
+        // last group: lane 0, which has the contact cache sized for it (4W is a multiple of four lanes; with more lanes per env the list
+        // is padded with empty entries up to the next multiple).
         int k = 0;
         for (int w = 0; w < n_walkers; ++w) { M.toi_body[k++] = (uint8_t)(hull_of(w) + 2); M.toi_body[k++] = (uint8_t)(hull_of(w) + 4); }
         for (int w = 0; w < n_walkers; ++w) { M.toi_body[k++] = (uint8_t)(hull_of(w) + 1); M.toi_body[k++] = (uint8_t)(hull_of(w) + 3); }
+        while (k % MW_NLANES != 0) M.toi_body[k++] = 255;
         M.toi_body[k++] = 0;
         for (int w = 0; w < n_walkers; ++w) M.toi_body[k++] = (uint8_t)hull_of(w);
+        M.n_toi = k;
     }
     M.dyn_slot_base = base;
     int np = 0;
@@ -410,12 +481,12 @@ struct Hot {
     float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
     double prev_shaping[MAX_WALKERS], prev_package_shaping;   // float64 like the reference's Python side (:403-411)
     uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, overflow;   // overflow: sticky, a contact did not fit its cache / the pool
-    uint8_t pad_[2];
+    uint8_t pad_[2 + (4 - (3 * MAX_WALKERS) % 4) % 4];
     uint32_t tick;                // observations of the current episode so far (noise draws)
     uint32_t episode;             // resets of this env so far (a reset's draws)
     uint32_t pad2_;
     int32_t t;
-    uint32_t awake;               // bit b: body b is awake (b2Body::e_awakeFlag)
+    BodyBits awake;               // bit b: body b is awake (b2Body::e_awakeFlag)
     uint32_t batch;               // FindNewContacts calls so far in this world (contact_key)
 };
 struct Cold {
@@ -452,13 +523,14 @@ constexpr int NDYN = MAX_WALKERS * (MAX_WALKERS - 1) / 2 + MAX_WALKERS;
 constexpr int MAXISL = MAX_WALKERS + 1;
 // The island solver runs on SOLVE_LANES lanes per env: lane w owns the four joints of walker w, and the step's contacts are dealt out to
 // the lanes by build_islands.  (The CPU build executes the lanes one after the other.)
-constexpr int SOLVE_LANES = MAX_WALKERS;
+constexpr int SOLVE_LANES = MW_NLANES;
+static_assert(SOLVE_LANES >= MAX_WALKERS, "one solver lane per walker");
 struct Scratch {  // per-step workspace (LDS on the GPU)
     // ---- what the solver launch keeps in LDS (up to `m_bA`)
     int nm;
     int8_t n_isl, n_rounds, max_cnt, pad_;
-    uint32_t moved;            // bit b: body b's proxy is in the broad phase's move buffer
-    uint32_t in_island;        // bit b: body b was simulated by this step's Solve (b2Body::e_islandFlag after b2World::Solve)
+    BodyBits moved;            // bit b: body b's proxy is in the broad phase's move buffer
+    BodyBits in_island;        // bit b: body b was simulated by this step's Solve (b2Body::e_islandFlag after b2World::Solve)
     // mass data of the four shapes (package, hull, upper leg, lower leg), copied once per step
     float sh_im[N_SHAPES], sh_ii[N_SHAPES];
     V2 sh_lc[N_SHAPES];
@@ -474,6 +546,12 @@ struct Scratch {  // per-step workspace (LDS on the GPU)
     // what the island construction needs of manifold k without going to the pool: its bodies and its place in Box2D's lists
     int8_t m_bA[MAXM], m_bB[MAXM];
     uint64_t m_key[MAXM];
+#if MW_CAPW > 4
+    // build_islands' bookkeeping.  With up to four walkers these are local arrays of the one lane that builds the islands, small enough for
+    // the compiler to hold in registers; beyond, they would be scratch memory (tests/test_kernel_metadata.py), so they live here
+    int8_t bi_lane[MAXB], bi_pos[MAXB], bi_round[MAXB], bi_lane_round[SOLVE_LANES];
+    uint8_t bi_stack[MAXB + 2];
+#endif
     alignas(16) Manifold m[MAXM];  // LAST member.  The CPU build's pool; the HIP kernels leave the pool in the state buffer (Model::max_manifolds entries)
 };
 
@@ -803,6 +881,7 @@ struct SerialPar {
     MW_HD void sync() const {}
     MW_HD int alloc(int *counter) const { return (*counter)++; }
     MW_HD void or_bits(uint32_t *p, uint32_t v) const { *p |= v; }
+    template <class B> MW_HD void or_bits(B *p, B v) const { p->join(v); }
     MW_HD uint32_t reduce_or(uint32_t v) const { return v; }   // OR over the lanes of the env: this one lane has seen everything
 };
 
@@ -847,18 +926,17 @@ MW_HD void edge_polygon_manifold(const Model &M, const ColdView &Cd, int e, cons
 // Which entries of a body's contact cache hold a contact (bit k: slots[k].edge >= 0).  The cache lives in HBM in the HIP kernels: the
 // loads of one group of eight are independent, so a scan costs a few memory round trips instead of one per entry, and the callers then
 // touch only the occupied entries (a handful out of 12 - 44).
-MW_HD uint64_t occupied_slots(const Slot *slots, int cap) {
-    uint64_t m = 0;
+MW_HD SlotBits occupied_slots(const Slot *slots, int cap) {
+    SlotBits m = SlotBits::none();
     for (int k = 0; k < cap; k += 8) {
         int e[8];
         MW_UNROLL
         for (int q = 0; q < 8; ++q) e[q] = k + q < cap ? (int)slots[k + q].edge : -1;
         MW_UNROLL
-        for (int q = 0; q < 8; ++q) if (e[q] >= 0) m |= 1ull << (k + q);
+        for (int q = 0; q < 8; ++q) if (e[q] >= 0) m.set(k + q);
     }
     return m;
 }
-MW_HD int pop_lowest(uint64_t &m) { const int k = __builtin_ctzll(m); m &= m - 1; return k; }
 
 // b2ContactManager::Collide for the contacts of body `bi` with terrain edges.  Box2D walks the world's contact list (newest
 // first); the only thing that order decides here is a lower leg's ground_contact when one pass holds both a Begin and an End
@@ -875,8 +953,8 @@ MW_HD void collide_body_terrain(const Model &M, Hot &Wd, const ColdView &Cd, Scr
     uint64_t ev_key = ~0ull;
     int ev_kind = 0;
     const float fr = sqrtf(FRICTION * s.friction);   // b2MixFriction
-    for (uint64_t occ = occupied_slots(slots, cap); occ != 0;) {
-        const int k = pop_lowest(occ);
+    for (SlotBits occ = occupied_slots(slots, cap); occ.any();) {
+        const int k = occ.pop_lowest();
         Slot &sl = slots[k];
         const int e = sl.edge;
         // (0, edge) for the package, (edge, body) for a walker's body: b2Contact::Create stores the edge as fixture A either way
@@ -919,7 +997,7 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, const ColdView &Cd, Scratch
     const int ev = contact_update(sl, mo);
     if (ev == 1) contact_begin_flags(Wd, bA, bB);
     if (ev != 0) {   // "if (touching != wasTouching) bodyA->SetAwake(true), bodyB->SetAwake(true)"
-        for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; } }
+        for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!Wd.awake.test(b)) { Wd.awake.set(b); Cd.sleep_time[b] = 0.0f; } }
     }
     (void)was;
     if (sl.touching)
@@ -966,11 +1044,11 @@ MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, const ColdView &Cd
         sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.reserved_ = tag;
     }
 }
-MW_HD void find_new_pair_contacts(const Model &M, const ColdView &Cd, uint32_t moved, uint32_t batch) {
+MW_HD void find_new_pair_contacts(const Model &M, const ColdView &Cd, BodyBits moved, uint32_t batch) {
     for (int p = 0; p < M.n_dyn_pairs; ++p) {
         const int bA = M.dyn_a[p], bB = M.dyn_b[p];
         Slot &sl = Cd.slot[M.dyn_slot_base + p];
-        if (sl.edge >= 0 || !(((moved >> bA) | (moved >> bB)) & 1u)) continue;
+        if (sl.edge >= 0 || !(moved.test(bA) || moved.test(bB))) continue;
         if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) continue;
         sl.edge = 0; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch;
     }
@@ -1007,35 +1085,41 @@ MW_HD void build_islands(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S
     const int NB = M.NB, NW = M.W;
     const int nm = S.nm < M.max_manifolds ? S.nm : M.max_manifolds;
     // the last contact constraint scheduled on body b: its lane, position in that lane's list and round (lane -1: none yet)
+#if MW_CAPW > 4
+    int8_t (&b_lane)[MAXB] = S.bi_lane, (&b_pos)[MAXB] = S.bi_pos, (&b_round)[MAXB] = S.bi_round;
+    int8_t (&lane_round)[SOLVE_LANES] = S.bi_lane_round;
+    uint8_t (&stack)[MAXB + 2] = S.bi_stack;
+#else
     int8_t b_lane[MAXB], b_pos[MAXB], b_round[MAXB];
     int8_t lane_round[SOLVE_LANES];
-    uint32_t flag = 0;       // e_islandFlag of the bodies
-    uint32_t jflag = 0;      // of the joints
-    uint64_t cflag = 0;      // of the manifolds (pool index)
+    int stack[MAXB + 2];
+#endif
+    BodyBits flag = BodyBits::none();           // e_islandFlag of the bodies
+    JointBits jflag = JointBits::none();        // of the joints
+    ManifoldBits cflag = ManifoldBits::none();  // of the manifolds (pool index)
     for (int b = 0; b < NB; ++b) { S.island_of[b] = -1; b_lane[b] = -1; b_pos[b] = 0; b_round[b] = 0; }
     for (int j = 0; j < 4 * NW; ++j) S.j_island[j] = -1;
     for (int l = 0; l < SOLVE_LANES; ++l) { S.lane_cnt[l] = 0; lane_round[l] = 0; }
     for (int w = 0; w < NW; ++w) S.jn[w] = 0;
     int n_isl = 0, max_round = -1, max_cnt = 0;
-    int stack[MAXB + 2];
     for (int s = 0; s < NB; ++s) {
         const int seed = s < NB - 1 ? NB - 1 - s : 0;   // body list: the walkers' bodies newest first, (static terrain,) the package last
-        if ((flag >> seed) & 1u) continue;
-        if (!((Wd.awake >> seed) & 1u)) continue;
+        if (flag.test(seed)) continue;
+        if (!Wd.awake.test(seed)) continue;
         const int isl = n_isl++;
         S.isl_pos_solved[isl] = 0;
         int sp = 0;
         stack[sp++] = seed;
-        flag |= 1u << seed;
+        flag.set(seed);
         while (sp > 0) {
             const int b = stack[--sp];
             S.island_of[b] = (int8_t)isl;
-            if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; }   // "make sure the body is awake"
+            if (!Wd.awake.test(b)) { Wd.awake.set(b); Cd.sleep_time[b] = 0.0f; }   // "make sure the body is awake"
             uint64_t below = ~0ull, key;
             for (int mi = next_contact_edge(S, nm, b, below, key); mi >= 0; mi = next_contact_edge(S, nm, b, below, key)) {
                 below = key;
-                if ((cflag >> mi) & 1ull) continue;     // already in an island (reached from its other body)
-                cflag |= 1ull << mi;
+                if (cflag.test(mi)) continue;     // already in an island (reached from its other body)
+                cflag.set(mi);
                 struct { int bA, bB; } m = {S.m_bA[mi], S.m_bB[mi]};
                 MP[mi].island = (uint8_t)isl;
                 // schedule: a sweep runs round by round and inside a round position by position of the lanes' lists, all lanes at once.
@@ -1051,7 +1135,7 @@ MW_HD void build_islands(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S
                         const int need = b_pos[x] < p_ ? b_round[x] : b_round[x] + 1;
                         if (need > r_) r_ = need;
                     }
-                    const int key = r_ * 64 + p_;
+                    const int key = r_ * 256 + p_;
                     if (key < best) { best = key; ln = l; pos = p_; rd = r_; }
                 }
                 S.lane_list[ln][pos] = (uint8_t)mi; S.m_round[mi] = (uint8_t)rd; S.lane_cnt[ln] = (uint8_t)(pos + 1);
@@ -1061,9 +1145,9 @@ MW_HD void build_islands(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S
                 if (pos + 1 > max_cnt) max_cnt = pos + 1;
                 const int other = m.bB == b ? m.bA : m.bB;
                 if (other < 0) continue;                // static terrain: islands do not propagate across static bodies
-                if ((flag >> other) & 1u) continue;
+                if (flag.test(other)) continue;
                 stack[sp++] = other;
-                flag |= 1u << other;
+                flag.set(other);
             }
             if (b >= 1) {   // joint edges, newest first: hull [hip1, hip0]; upper leg [knee, hip]; lower leg [knee]
                 const int w = (b - 1) / 5, r = (b - 1) % 5;
@@ -1073,15 +1157,15 @@ MW_HD void build_islands(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S
                 else { jl[0] = 4 * w + (r - 2) + 1; nj = 1; }
                 for (int q = 0; q < nj; ++q) {
                     const int ji = jl[q];
-                    if ((jflag >> ji) & 1u) continue;
-                    jflag |= 1u << ji;
+                    if (jflag.test(ji)) continue;
+                    jflag.set(ji);
                     const int jA = M.jd[ji].bA, jB = M.jd[ji].bB;
                     S.j_island[ji] = (int8_t)isl;
                     S.jorder[w][S.jn[w]++] = (uint8_t)ji;   // a walker's joints only share bodies with each other: its lane runs them in island order
                     const int other = jA == b ? jB : jA;
-                    if ((flag >> other) & 1u) continue;
+                    if (flag.test(other)) continue;
                     stack[sp++] = other;
-                    flag |= 1u << other;
+                    flag.set(other);
                 }
             }
         }
@@ -1549,12 +1633,12 @@ constexpr int MAX_TOI_CONTACTS = 32;  // b2_maxTOIContacts
 constexpr int MAX_SUB_STEPS = 8;      // b2_maxSubSteps
 
 // the next terrain contact of body b after the one with key `below` in its contact-edge list (descending key), touching or not
-MW_HD int next_terrain_slot(const Model &M, const ColdView &Cd, int b, uint64_t occ, uint64_t below, uint64_t &key_out) {
+MW_HD int next_terrain_slot(const Model &M, const ColdView &Cd, int b, SlotBits occ, uint64_t below, uint64_t &key_out) {
     int best = -1;
     uint64_t bk = 0;
     const int base = M.slot_base[b];
-    while (occ != 0) {   // occ: occupied_slots of the body's cache
-        const int k = pop_lowest(occ);
+    while (occ.any()) {   // occ: occupied_slots of the body's cache
+        const int k = occ.pop_lowest();
         const Slot &sl = Cd.slot[base + k];
         const uint64_t key = b == 0 ? contact_key(sl.batch, 0, proxy_of_edge(sl.edge)) : contact_key(sl.batch, proxy_of_edge(sl.edge), proxy_of_body(b, M.NT));
         if (key < below && (best < 0 || key > bk)) { best = base + k; bk = key; }
@@ -1580,8 +1664,10 @@ MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const ColdView &Cd, Slot 
 // in Box2D's lists) and which box of the other body a new package / hull pair is tested against.  Every chain therefore logs its events
 // (time, contact), numbers the contacts it creates provisionally, and afterwards one lane merges the logs into Box2D's order -- smallest
 // time first, among equal times the contact nearest the front of the world's list -- hands out the final numbers and creates the pairs.
-constexpr int TOI_MAX_EVENTS = 16;   // events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7)
-constexpr int TOI_MAX_PAIR_EVENTS = 4;
+// events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7 with up to four walkers, and about
+// three per walker in the step that follows a reset, when every leg arrives at the ground at once)
+constexpr int TOI_MAX_EVENTS = MAX_WALKERS <= 4 ? 16 : 6 * MAX_WALKERS;
+constexpr int TOI_MAX_PAIR_EVENTS = MAX_WALKERS <= 4 ? 4 : MAX_WALKERS + 2;   // ... those of them that moved the proxy of the package or of a hull
 struct ToiEvent { float alpha; uint16_t slot, batch; uint8_t body, idx, moved, fat_i; };
 struct ToiWork {            // shared by the lanes of an env (LDS in the HIP kernel)
     int n_ev, n_fat;
@@ -1593,6 +1679,11 @@ struct ToiWork {            // shared by the lanes of an env (LDS in the HIP ker
     // the bodies whose first search found an event (see solve_toi): body, the event's contact slot (index into the body's cache), its time
     int n_pend;
     struct { uint8_t body, k; uint16_t pad_; float alpha; } pend[MAXB];
+#if MW_CAPW > 4
+    // the merge's bookkeeping (one lane; local arrays up to four walkers, see Scratch::bi_lane)
+    uint8_t mg_next_idx[MAXB];
+    float mg_cur_fat[1 + MAX_WALKERS][4];
+#endif
 };
 struct ToiLaneWork {        // per lane: the cached times of impact of the contacts of the body it is working on
     float *alpha;           // [Model::slot_cap of the body]
@@ -1624,9 +1715,9 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
     g_stats.cur_lane = mover;
 #endif
     Cd.sweep_alpha0[mover] = 0.0f;   // "if (m_stepComplete)": alpha0 = 0, every contact's cached TOI invalid, its sub-step count 0, enabled
-    if (!((Wd.awake >> mover) & 1u)) return;   // a sleeping body against static terrain: no active body
-    uint64_t occ = occupied_slots(Cd.slot + base, cap);
-    if (occ == 0) return;
+    if (!Wd.awake.test(mover)) return;   // a sleeping body against static terrain: no active body
+    SlotBits occ = occupied_slots(Cd.slot + base, cap);
+    if (!occ.any()) return;
     for (int k = 0; k < cap; ++k) TL.meta[k] = 0;
     const float fr = sqrtf(FRICTION * msh.friction);
     const MassAB qm = mass_of_pair(S, -1, mover);
@@ -1641,8 +1732,8 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
         int min_k = -1;
         if (guard == 0 && first_k >= 0) { min_k = first_k; min_alpha = first_alpha; }   // found by the search-only call (nothing has touched the body since)
         else
-        for (uint64_t o2 = occ; o2 != 0;) {
-            const int k = pop_lowest(o2);
+        for (SlotBits o2 = occ; o2.any();) {
+            const int k = o2.pop_lowest();
             const Slot &sl = Cd.slot[base + k];
             const uint8_t meta = TL.meta[k];
             if ((meta & 2) || (meta >> 2) > MAX_SUB_STEPS) continue;
@@ -1858,7 +1949,7 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
     // dealt to the env's lanes (pass 1): the events of a step run side by side instead of one group of bodies after the other.  A chain
     // touches nothing but its own body and that body's contacts with the static terrain, so when it runs decides nothing.
     for (int pass = 0; pass < 2; ++pass) {
-        const int n_items = pass == 0 ? NB : (T.n_pend < NB ? T.n_pend : NB);
+        const int n_items = pass == 0 ? M.n_toi : (T.n_pend < NB ? T.n_pend : NB);
         for (int k = L0; k < n_items; k += LN) {
             const int body = pass == 0 ? M.toi_body[k] : T.pend[k].body;
             if (body == 255) continue;   // (the package has no event)
@@ -1873,9 +1964,14 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
     if (n == 0 && T.overflow == 0) return;
     // ---- merge: Box2D's order of the events; event number r is followed by FindNewContacts call batch_base + 1 + r
     if (L0 == 0) {
+#if MW_CAPW > 4
+        uint8_t (&next_idx)[MAXB] = T.mg_next_idx;
+        float (&cur_fat)[1 + MAX_WALKERS][4] = T.mg_cur_fat;
+#else
         uint8_t next_idx[MAXB];
-        for (int b = 0; b < NB; ++b) next_idx[b] = 0;
         float cur_fat[1 + MAX_WALKERS][4];
+#endif
+        for (int b = 0; b < NB; ++b) next_idx[b] = 0;
         for (int p = 0; p <= M.W; ++p) for (int q = 0; q < 4; ++q) cur_fat[p][q] = T.fat0[p][q];
         for (int r = 0; r < n; ++r) {
             int best = -1;
@@ -1939,7 +2035,7 @@ MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, const ColdView &Cd, Scra
     const int L0 = par.lane(), LN = par.n();
     const int NB = M.NB, NDP = M.n_dyn_pairs;
     for (int sh = L0; sh < N_SHAPES; sh += LN) { S.sh_im[sh] = M.shape[sh].inv_mass; S.sh_ii[sh] = M.shape[sh].inv_I; S.sh_lc[sh] = M.shape[sh].centroid; }
-    if (L0 == 0) { S.nm = 0; S.moved = 0; }
+    if (L0 == 0) { S.nm = 0; S.moved = BodyBits::none(); }
     par.sync();
     // ---- b2ContactManager::Collide: every contact is updated (D4); Begin / EndContact -> ContactDetector flags
     for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, MP, par, bi);
@@ -2173,7 +2269,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
             if (min_sleep >= TIME_TO_SLEEP && S.isl_pos_solved[c])
                 for (int bi = 0; bi < NB; ++bi) {
                     if (S.island_of[bi] != c) continue;
-                    Wd.awake &= ~(1u << bi); Cd.sleep_time[bi] = 0.0f;
+                    Wd.awake.clear(bi); Cd.sleep_time[bi] = 0.0f;
                     Wd.b[bi].v = v2(0, 0); Wd.b[bi].w = 0.0f;
                 }
         }
@@ -2187,13 +2283,13 @@ template <class Par>
 MW_HD_INLINE void step_post(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, Par par) {
     const int L0 = par.lane(), LN = par.n(), NB = M.NB;
     {
-        uint32_t mv = 0;
+        BodyBits mv = BodyBits::none();
         for (int bi = L0; bi < NB; bi += LN)
-            if (S.island_of[bi] >= 0 && sync_fixture(M, Wd, Cd, bi)) { mv |= 1u << bi; find_new_terrain_contacts(M, Wd, Cd, bi, Wd.batch); }
-        if (mv) par.or_bits(&S.moved, mv);
+            if (S.island_of[bi] >= 0 && sync_fixture(M, Wd, Cd, bi)) { mv.set(bi); find_new_terrain_contacts(M, Wd, Cd, bi, Wd.batch); }
+        if (mv.any()) par.or_bits(&S.moved, mv);
     }
     par.sync();
-    if (L0 == 0 && S.moved) find_new_pair_contacts(M, Cd, S.moved, Wd.batch);
+    if (L0 == 0 && S.moved.any()) find_new_pair_contacts(M, Cd, S.moved, Wd.batch);
     par.sync();
 }
 
@@ -2336,7 +2432,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, const ColdV
     }
     // broad phase: every proxy is created with its tight box fattened by b2_aabbExtension and buffered as moved; the first Step
     // begins with FindNewContacts (e_newFixture): batch 0
-    Wd.awake = (1u << M.NB) - 1u;
+    Wd.awake = BodyBits::first(M.NB);
     Wd.batch = 0;
     for (int b = 0; b < M.NB; ++b) {
         Cd.sleep_time[b] = 0.0f;
@@ -2344,7 +2440,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, const ColdV
         set_body_fat(Cd, b, fatten(poly_aabb(M.shape[shape_of_body(b)], body_xf(M, Wd.b[b], b))));
     }
     for (int b = 0; b < M.NB; ++b) find_new_terrain_contacts(M, Wd, Cd, b, 0);
-    find_new_pair_contacts(M, Cd, (1u << M.NB) - 1u, 0);
+    find_new_pair_contacts(M, Cd, BodyBits::first(M.NB), 0);
     Wd.episode = tick + 1;
     Wd.tick = 0;
 }
@@ -2363,7 +2459,7 @@ MW_HD_INLINE void env_apply_actions(const Model &M, Hot &Wd, const ColdView &Cd,
         }
     }
     if (par.lane() == 0) {   // b2RevoluteJoint::SetMotorSpeed / SetMaxMotorTorque wake both bodies of every joint: all the walkers' bodies
-        for (int b = 1; b < M.NB; ++b) if (!((Wd.awake >> b) & 1u)) { Wd.awake |= 1u << b; Cd.sleep_time[b] = 0.0f; }
+        for (int b = 1; b < M.NB; ++b) if (!Wd.awake.test(b)) { Wd.awake.set(b); Cd.sleep_time[b] = 0.0f; }
     }
     par.sync();
 }
@@ -2420,7 +2516,7 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView 
             a = 0.0f; b = 0.0f;
             if (!noisy) return;
             uint32_t r[4];
-            philox10(gid, Wd.episode, (Wd.tick << 4) | (uint32_t)(w * 4 + q), TAG_MW_NOISE, C.k0, C.k1, r);
+            philox10(gid, Wd.episode, (Wd.tick << 6) | (uint32_t)(w * 4 + q), TAG_MW_NOISE, C.k0, C.k1, r);
             const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u24f(r[1]);
             const float rad = sqrtf(-2.0f * logf(u1));
             float bs, bc;
@@ -2472,4 +2568,4 @@ MW_HD void env_observe(const Model &M, const EnvCfg &C, Hot &Wd, const ColdView 
     if (done) *done = dn ? 1 : 0;
 }
 
-}  // namespace mw
+}  // namespace MW_NS

@@ -5,7 +5,7 @@
 // Host/device code like multiwalker_core.hpp, which includes this file.  PARITY UNPINNED (see there).
 #pragma once
 
-namespace mw {
+namespace MW_NS {
 
 constexpr float B2_EPSILON = 1.1920928955078125e-7f;  // FLT_EPSILON
 constexpr int TOI_MAX_VERTS = 5;
@@ -249,4 +249,4 @@ MW_HD int time_of_impact(float &t_out, const Proxy &pA, Sweep sA, const Proxy &p
     return state;
 }
 
-}  // namespace mw
+}  // namespace MW_NS

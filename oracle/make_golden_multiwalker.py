@@ -64,7 +64,7 @@ def flags_of(env):
 class ScriptedNormal(object):
     """np.random.normal for the observation noise (:389-395; the reference draws it from the global, unseeded generator) replaced, while a
     recording runs, by the draws THIS repository's RNG contract assigns to (seed, env id, episode, observation): Philox4x32-10 with counter
-    (env id, episode, observation << 4 | 4 i + q, tag 34), Box-Muller on (r.x, r.y) -> z[2q], z[2q + 1]; walker i uses z[0..3] for the
+    (env id, episode, observation << 6 | 4 i + q, tag 34), Box-Muller on (r.x, r.y) -> z[2q], z[2q + 1]; walker i uses z[0..3] for the
     neighbours it has, in order, and z[4], z[5], z[6] for the package.  The reference asks for loc + scale * z call by call; which z goes
     with which call is mirrored here from the ORDER of its calls only."""
 
@@ -78,7 +78,7 @@ class ScriptedNormal(object):
         for i in range(self.W):
             z = []
             for q in range(4):
-                r = po.philox([self.gid, self.episode, (self.tick << 4) | (4 * i + q), 34], self.key)
+                r = po.philox([self.gid, self.episode, (self.tick << 6) | (4 * i + q), 34], self.key)
                 u1, u2 = float((int(r[0]) >> 8) + 1) / 16777216.0, float(int(r[1]) >> 8) / 16777216.0
                 rad = math.sqrt(-2.0 * math.log(u1))
                 z += [rad * math.cos(2.0 * 3.14159265358979323846 * u2), rad * math.sin(2.0 * 3.14159265358979323846 * u2)]
@@ -258,9 +258,18 @@ def main():
     # the reference's DEFAULT configuration has the observation noise on (position_noise = angle_noise = 1e-3, :250)
     run(MultiWalkerEnv, "w3_noise", 3, "local", episodes=4, steps=80, seed=37, prefix=pre, noise=(1e-3, 1e-3, 0xC0FFEE123, 500))
     run(MultiWalkerEnv, "w2_noise_global", 2, "global", episodes=2, steps=60, seed=38, prefix=pre, noise=(5e-3, 2e-2, 11, 0))
+    # the rest of the reference's curriculum (lessons/multiwalker/env.yaml: n_walkers 2 .. 10; the package and the terrain grow with the
+    # walker count, :293-301): the walker counts the larger capacity classes of the kernels run, default noise on in two of them
+    run(MultiWalkerEnv, "w5_local", 5, "local", episodes=3, steps=120, seed=39, prefix=pre)
+    run(MultiWalkerEnv, "w8_noise_global", 8, "global", episodes=2, steps=100, seed=40, prefix=pre, noise=(1e-3, 1e-3, 0xABCDEF, 40))
+    run(MultiWalkerEnv, "w10_local", 10, "local", episodes=2, steps=120, seed=41, prefix=pre, zero_from=30)
+    run(MultiWalkerEnv, "w10_onehot_noise", 10, "local", episodes=2, steps=60, seed=42, prefix=pre, one_hot=True, noise=(1e-3, 1e-3, 99, 7),
+        terminate_on_fall=False)
     # files named multiwalker_resetdraws_*: a different layout (no episodes), replayed by its own test
     record_philox_resets(MultiWalkerEnv, 3, seed=0x1234567890ABCDEF, gid0=1000, n=24, prefix="multiwalker_resetdraws_")
     record_philox_resets(MultiWalkerEnv, 2, seed=7, gid0=0, n=12, prefix="multiwalker_resetdraws_")
+    record_philox_resets(MultiWalkerEnv, 10, seed=0xFEEDFACE, gid0=77, n=6, prefix="multiwalker_resetdraws_")
+    record_philox_resets(MultiWalkerEnv, 6, seed=5, gid0=3, n=6, prefix="multiwalker_resetdraws_")
     return 0
 
 

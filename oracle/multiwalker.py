@@ -1,10 +1,32 @@
 """ctypes wrapper over oracle/multiwalker_oracle.cpp (CPU build of the MultiWalker solver source).
 TEST INFRASTRUCTURE ONLY; parity unpinned -- see the header of multiwalker_oracle.cpp."""
 import ctypes as C
+import os
+import subprocess
 
 import numpy as np
 
-from . import pursuit as _po
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def capacity_class(n_walkers):
+    """the capacity class of the product source a walker count runs on (madrl_amd/csrc/multiwalker.hip: 4 walkers on 4 lanes per env,
+    8 on 8, 10 on 16)"""
+    return 4 if n_walkers <= 4 else (8 if n_walkers <= 8 else 10)
+
+
+def lib(n_walkers):
+    """the CPU build of multiwalker_core.hpp for the capacity class of `n_walkers` (oracle/Makefile)"""
+    c = capacity_class(n_walkers)
+    if c not in _LIBS:
+        so = os.path.join(_HERE, "_build", "libmadrl_mwo_c%d.so" % c)
+        deps = [os.path.join(_HERE, "multiwalker_oracle.cpp")] + [os.path.join(os.path.dirname(_HERE), "madrl_amd", "csrc", f)
+                                                                   for f in ("multiwalker_core.hpp", "multiwalker_toi.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        _LIBS[c] = C.CDLL(so)
+    return _LIBS[c]
 
 
 def _p(a):
@@ -15,7 +37,7 @@ class MultiWalkerOracle(object):
     def __init__(self, n_walkers=2, position_noise=1e-3, angle_noise=1e-3, reward_mech="local", forward_reward=1.0,
                  fall_reward=-100.0, drop_reward=-100.0, terminate_on_fall=True, one_hot=False, n_envs=1, seed=0,
                  env_id_base=0, lanes_descending=False):
-        L = _po.lib()
+        L = lib(n_walkers)
         self.L = L
         L.mwo_create.restype = C.c_void_p
         L.mwo_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -28,6 +50,7 @@ class MultiWalkerOracle(object):
         self.N, self.W = int(n_envs), n_walkers
         self.h = L.mwo_create(n_walkers, int(reward_mech == "global"), int(terminate_on_fall), position_noise, angle_noise,
                               forward_reward, fall_reward, drop_reward, self.N, int(seed), int(env_id_base))
+        assert self.h, "unsupported n_walkers"
         L.mwo_get_contacts.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         L.mwo_set_one_hot.argtypes = [C.c_void_p, C.c_int]
         L.mwo_set_one_hot(self.h, int(bool(one_hot)))

@@ -9,7 +9,11 @@
  * host/device code) with g++ for the CPU.  It serves two checks: the GPU *port* (LDS, lane
  * mapping, launch sequence, spare records) bit for bit against this build, and the ALGORITHM of that source against
  * multiwalker_ref.c step by step (tests/test_multiwalker_cpu.py, no GPU needed).
+ *
+ * Built once per capacity class of the product source (-DMW_CAPW=4 / 8 / 10 with -DMW_NLANES=4 / 8 / 16, see the Makefile), like the
+ * kernels: libmadrl_mwo_c4.so / _c8.so / _c10.so export the same symbols, oracle/multiwalker.py loads the one for its n_walkers.
  */
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -32,11 +36,21 @@ void mwo_set_one_hot(MwOracle *o, int one_hot) { o->C.one_hot = one_hot ? 1 : 0;
 void mwo_set_lane_order(MwOracle *o, int descending) { o->rev = descending != 0; }
 void mwo_set_continuous(MwOracle *o, int on) { o->M.continuous = on ? 1 : 0; }  /* b2World continuousPhysics: experiments only */
 int mwo_world_bytes(void) { return (int)sizeof(mw::World); }
+/* layout figures the kernels' LDS blocks are computed from (multiwalker_impl.hpp k_create): sizeof(Hot), the solver's part of Scratch, Scratch without
+ * the pool, sizeof(ToiWork), sizeof(Manifold), sizeof(World), sizeof(Cold) */
+void mwo_sizes(int32_t *out) {
+    out[0] = (int32_t)sizeof(mw::Hot); out[1] = (int32_t)offsetof(mw::Scratch, m_bA); out[2] = (int32_t)offsetof(mw::Scratch, m);
+    out[3] = (int32_t)sizeof(mw::ToiWork); out[4] = (int32_t)sizeof(mw::Manifold); out[5] = (int32_t)sizeof(mw::World); out[6] = (int32_t)sizeof(mw::Cold);
+}
+int mwo_capacity(void) { return mw::MAX_WALKERS; }
+int mwo_lanes(void) { return mw::SOLVE_LANES; }
 
 MwOracle *mwo_create(int n_walkers, int reward_global, int terminate_on_fall, float position_noise, float angle_noise,
                      float forward_reward, float fall_reward, float drop_reward, int64_t n_envs, uint64_t seed,
                      int64_t env_id_base) {
+    if (n_walkers < 1 || n_walkers > mw::MAX_WALKERS) return nullptr;
     MwOracle *o = new MwOracle();
+    memset(&o->M, 0, sizeof(o->M));
     mw::build_model(o->M, n_walkers);
     memset(&o->C, 0, sizeof(o->C));
     o->C.n_walkers = n_walkers; o->C.reward_global = reward_global; o->C.terminate_on_fall = terminate_on_fall;
@@ -138,7 +152,7 @@ void mwo_get_aux(const MwOracle *o, float *out) {
         for (int b = 0; b < NB; ++b) {
             float *p = out + (n * NB + b) * 6;
             for (int k = 0; k < 4; ++k) p[k] = o->worlds[n].c.fat[b][k];
-            p[4] = o->worlds[n].c.sleep_time[b]; p[5] = (float)((o->worlds[n].h.awake >> b) & 1u);
+            p[4] = o->worlds[n].c.sleep_time[b]; p[5] = o->worlds[n].h.awake.test(b) ? 1.0f : 0.0f;
         }
 }
 /* the contacts of env n in WORLD LIST ORDER (descending key), same record as mwr_get_contacts of multiwalker_ref.c */

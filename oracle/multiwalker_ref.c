@@ -818,9 +818,9 @@ static int time_of_impact(float *t_out, const DProxy *pA, const Sweep *sweepA_in
 }
 
 /* ------------------------------------------------------------------------------------------------ world data (b2Body, b2Contact, b2Joint) */
-#define MWR_MAX_BODIES 128      /* 1 package + 5 x 4 walker bodies + (TERRAIN_LENGTH * 4 / 8 - 1) terrain edges */
-#define MWR_MAX_CONTACTS 1024
-#define MWR_MAX_JOINTS 16
+#define MWR_MAX_BODIES 320      /* 1 package + 5 x 10 walker bodies + (TERRAIN_LENGTH * 10 / 8 - 1) terrain edges: the reference's curriculum runs 2 .. 10 walkers (lessons/multiwalker/env.yaml) */
+#define MWR_MAX_CONTACTS 2048
+#define MWR_MAX_JOINTS 40
 enum { BODY_STATIC = 0, BODY_DYNAMIC = 2 };
 enum { LIMIT_INACTIVE = 0, LIMIT_AT_LOWER = 1, LIMIT_AT_UPPER = 2, LIMIT_EQUAL = 3 };
 
@@ -1923,7 +1923,7 @@ static float world_raycast_closest(const World *w, Vec2 p1w, Vec2 p2w, uint16_t 
 #define MW_FRICTION 2.5
 #define MW_WALKER_SEPERATION 10
 #define MW_MAX_AGENTS 40
-#define MW_MAX_WALKERS 4
+#define MW_MAX_WALKERS 10
 static const double HULL_POLY[5][2] = {{-30, +9}, {+6, +9}, {+34, +1}, {+34, -8}, {-30, -8}};
 static const double PACKAGE_POLY[4][2] = {{-120, 5}, {120, 5}, {120, -5}, {-120, -5}};
 
@@ -1955,7 +1955,7 @@ typedef struct {
 } mwr_handle;
 
 /* Philox4x32-10 (Salmon et al., SC'11), restated from the paper; key = seed; counter = (env id, episode, index, tag) for the draws of a
- * reset and (env id, episode, observation << 4 | index, tag) for the observation noise: a reset's world is a function of the env and of
+ * reset and (env id, episode, observation << 6 | index, tag) for the observation noise: a reset's world is a function of the env and of
  * how many episodes it has had, not of when the previous episode ended */
 static void mwr_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
     for (int r = 0; r < 10; ++r) {
@@ -2153,7 +2153,7 @@ static void mw_step(const mwr_config *cfg, MwEnv *e, uint32_t gid, const float *
         if (cfg->position_noise != 0.0 || cfg->angle_noise != 0.0) {
             for (int q = 0; q < 4; ++q) {
                 uint32_t r[4];
-                mwr_philox(gid, e->episode, (e->tick << 4) | (uint32_t)(i * 4 + q), MWR_TAG_NOISE, k0, k1, r);
+                mwr_philox(gid, e->episode, (e->tick << 6) | (uint32_t)(i * 4 + q), MWR_TAG_NOISE, k0, k1, r);
                 const double u1 = (double)((r[0] >> 8) + 1u) / 16777216.0, u2 = u24(r[1]);
                 const double rad = sqrt(-2.0 * log(u1));
                 nz[2 * q] = rad * cos(2.0 * 3.14159265358979323846 * u2);

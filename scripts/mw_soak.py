@@ -1,11 +1,15 @@
 """CPU soak (no GPU): the product's MultiWalker source (CPU build) against the independent Box2D-ordered oracle, free-running without any
-re-synchronisation, 3 x 96 000 env-steps with stretches of zero actions; every body state, joint state, fat AABB, sleep time, done flag must stay
+re-synchronisation, 96 000 env-steps per walker count (--walkers 5 8 10: the larger capacity classes) with stretches of zero actions; every body state, joint state, fat AABB, sleep time, done flag must stay
 identical and the sticky overflow bits zero.   python scripts/mw_soak.py   (~15 s)"""
 import sys, numpy as np, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import multiwalker as mwo, multiwalker_ref as mwr
-for W, seed in ((3, 101), (4, 102), (2, 103)):
-    N, T = 64, 1500
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument('--walkers', type=int, nargs='*', default=[3, 4, 2]); ap.add_argument('--steps', type=int, default=1500)
+args = ap.parse_args()
+for W in args.walkers:
+    seed = {3: 101, 4: 102, 2: 103}.get(W, 100 + W)
+    N, T = 64, args.steps
     ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=seed, position_noise=0, angle_noise=0, poly=True)
     core = mwo.MultiWalkerOracle(n_walkers=W, n_envs=N, seed=seed, position_noise=0.0, angle_noise=0.0, lanes_descending=(W == 4))
     ref.reset(); core.reset()

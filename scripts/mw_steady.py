@@ -1,10 +1,10 @@
-"""MultiWalker C4 timing by simulation phase (16 384 envs, n_walkers = 3): the work per step grows as walkers fall, so the
+"""MultiWalker C4 timing by simulation phase (16 384 envs, n_walkers = 3; MW_N / MW_W change them): the work per step grows as walkers fall, so the
 first steps after a reset are not the steady state of a rollout.  Prints ms / step in windows of 10 steps."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from madrl_amd.multiwalker import BatchedMultiWalkerEnv
-dev = torch.device("cuda:0"); N, W = int(os.environ.get("MW_N", 16384)), 3
+dev = torch.device("cuda:0"); N, W = int(os.environ.get("MW_N", 16384)), int(os.environ.get("MW_W", 3))
 import itertools
 combos = [(True, True)] if '--one' in sys.argv else [(True, True), (False, True)] if '--quick' in sys.argv else list(itertools.product((True, False), (True, False)))
 for cont, tof in combos:

@@ -78,7 +78,9 @@ def test_multiwalker_launches_have_no_scratch():
     accesses inside GJK, a kernel with a few hundred bytes of scratch per lane made the runtime re-allocate scratch around every other
     kernel on the stream: +3 ms per step next to a policy's torch kernels."""
     ks = {n: k for n, k in _kernels().items() if "mw_step_kernel" in n}
-    assert len(ks) == 4, sorted(ks)
+    # three capacity classes (mwk_c4 / _c8 / _c10: 4 / 8 / 16 lanes per env) x (collide | solve | continuous pass) + the one-launch form of
+    # the first two (multiwalker_impl.hpp HAVE_FUSED)
+    assert len(ks) == 11 and sum("mwk_c10" in n for n in ks) == 3, sorted(ks)
     for n, k in ks.items():
         # (.vgpr_spill_count may be non-zero with no private segment: at one wavefront per SIMD the allocator parks values in the 256
         # accumulation registers, a register copy each way -- what must not happen is a private segment, i.e. memory)

@@ -195,7 +195,11 @@ def _contacts_equal(a, b):
 
 
 @pytest.mark.parametrize("n_walkers,reward_mech,descending", [(3, "local", False), (3, "local", True), (2, "global", False), (4, "local", True),
-                                                              (4, "local", False), (1, "local", False)])
+                                                              (4, "local", False), (1, "local", False),
+                                                              # the capacity classes beyond four walkers (8 lanes per env: 5 .. 8, 16 lanes: 9, 10) --
+                                                              # the reference's curriculum, lessons/multiwalker/env.yaml
+                                                              (5, "local", False), (6, "global", True), (7, "local", True), (8, "local", False),
+                                                              (9, "local", True), (10, "global", False), (10, "local", True)])
 def test_product_source_matches_the_independent_oracle_bit_for_bit(n_walkers, reward_mech, descending):
     """The product's solver runs on four lanes per env (lane w: walker w's joints and contacts), scheduled so that constraints which share
     a body keep the island's order; the CPU build runs the lanes one after the other, in ascending or descending order -- the schedule

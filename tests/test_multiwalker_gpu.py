@@ -21,7 +21,10 @@ def _mk(n_envs, **kw):
     return BatchedMultiWalkerEnv(n_envs=n_envs, device=DEV, **kw)
 
 
-@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local"), (3, "one_hot")])
+@pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local"), (3, "one_hot"),
+                                                   # the capacity classes beyond four walkers (lessons/multiwalker/env.yaml runs 2 .. 10):
+                                                   # eight lanes per env for 5 .. 8 walkers, sixteen for 9 and 10
+                                                   (5, "local"), (6, "global"), (7, "local"), (8, "local"), (9, "global"), (10, "local"), (10, "one_hot")])
 def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
     """The GPU execution (four lanes per env, sixteen envs per wavefront, the step in three launches, contact cache in HBM) against the
     CPU build of the same source (the lanes one after the other): the WHOLE per-env world record -- bodies, joints, every contact with its list position and impulses,
@@ -57,13 +60,13 @@ def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
             env.reset(mask=odone)
 
 
-@pytest.mark.parametrize("horizon,fused", [(0, False), (9, False), (0, True)])
-def test_auto_reset_through_spares_matches_mask_resets(horizon, fused):
+@pytest.mark.parametrize("horizon,fused,n_walkers", [(0, False, 3), (9, False, 3), (0, True, 3), (7, False, 6), (0, True, 10), (11, False, 10)])
+def test_auto_reset_through_spares_matches_mask_resets(horizon, fused, n_walkers):
     """auto_reset=True: an env whose episode ends gets its next episode from the spare record prepared ahead of time (multiwalker.hip), or,
     when the spare is not ready, from the second launch -- either way exactly what reset(mask) + the next steps give on the CPU build.  With
     a horizon every env ends its episode in the same call, and again `horizon` calls later: all spares consumed and rebuilt at once."""
     from oracle import multiwalker as mwo
-    N, W, T = 80, 3, 90
+    N, W, T = 80, n_walkers, 90
     env = _mk(N, n_walkers=W, seed=21, env_id_base=5, auto_reset=True, max_steps=horizon)
     if fused:
         env.set_mode(fused=True)   # the whole step in one launch: same results
@@ -93,7 +96,7 @@ def test_auto_reset_through_spares_matches_mask_resets(horizon, fused):
     assert n_resets > N // 2 and (horizon == 0 or n_resets >= N * (T // horizon))
 
 
-@pytest.mark.parametrize("n_walkers", [3, 2])
+@pytest.mark.parametrize("n_walkers", [3, 2, 5, 8, 10])
 def test_hip_matches_the_independent_oracle(n_walkers):
     """HIP kernel through the C ABI (get_state / set_state / reset_with) against oracle/multiwalker_ref.c -- the independent
     Box2D-2.3.0-ordered restatement -- teacher-forced on the bodies: tolerance 1e-5 as north_star asks, zero flag / done
@@ -165,7 +168,7 @@ def test_full_batch_invariants_c4():
 
 def test_determinism_and_launch_shape():
     outs = []
-    for blocks in (0, 37):
+    for blocks in (0, 37):   # (max_blocks: accepted and ignored since the launches became one wavefront per group of envs)
         env = _mk(300, seed=4, max_blocks=blocks)
         env.reset()
         g = torch.Generator(device="cpu").manual_seed(1)
