@@ -221,11 +221,15 @@ def region_stats(region_ms):
             "region_ms_per_step_median": s[len(s) // 2], "value_is": "median region"}
 
 
-def roofline(bytes_per, N, kernel_ms, traffic, kernel, streams=1, **more):
-    """N envs per step and GPU, stepped as `streams` concurrent launches of N / streams envs (one per HIP stream): `achieved` = the
-    algorithmic bytes of the launches that run together / the duration of the step (HIP events on every stream)."""
-    achieved = bytes_per * N / (kernel_ms * 1e-3) / 1e9
+def roofline(bytes_per, N, kernel_ms, wall_ms, traffic, kernel, streams=1, **more):
+    """N envs per step and GPU, stepped as `streams` concurrent launches of N / streams envs (one per HIP stream).  `achieved` / `frac` = the
+    algorithmic bytes of the launches that run together / the duration of a step by the WALL CLOCK of the timed region (ms_per_step: what the
+    driver's own clock sees); `achieved_kernel` / `frac_kernel` = the same bytes / the duration by HIP events on every launch stream, which
+    leaves out the host's share of the region (2 - 3 % kinder)."""
+    achieved = bytes_per * N / (wall_ms * 1e-3) / 1e9
+    achieved_k = bytes_per * N / (kernel_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+           "achieved_kernel": achieved_k, "frac_kernel": achieved_k / HBM_PEAK_GBPS,
            "frac_vs_measured_copy": achieved / HBM_COPY_GBPS, "measured_copy_peak": HBM_COPY_GBPS,
            "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
            "algorithmic_bytes_per_launch": bytes_per * N // streams, "concurrent_launches_per_step": streams,
@@ -240,7 +244,7 @@ def roofline(bytes_per, N, kernel_ms, traffic, kernel, streams=1, **more):
 
 # sub-batches per GPU, each on its own HIP stream, when --streams is not given: what scripts/stream_sweep.sh measured fastest on MI355X
 # (the one-launch-per-step figure is reported next to it in every line: roofline.one_launch_per_step)
-DEFAULT_STREAMS = {"pursuit": 2, "pursuit_c5": 2, "pursuit_colocate": 2, "waterworld": 2, "waterworld_std": 2, "hostage": 2, "multiwalker": 4}
+DEFAULT_STREAMS = {"pursuit": 2, "pursuit_c5": 2, "pursuit_colocate": 2, "waterworld": 2, "waterworld_std": 2, "hostage": 2, "multiwalker": 4, "multiwalker_w10": 4}
 
 
 def shard_count(args, N, workload):
@@ -361,9 +365,9 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     fast = ("pursuit_group_kernel<%d,%d,%d,%d,%d,%d,2>" if P + E > 64 else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))
     kname = fast if kernel_kind == "wave" else "pursuit_kernel<NT>"
     catch = "surround, n_catch 2" if mode["surround"] else "co-location catch, n_catch %d" % mode["n_catch"]
-    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(per, variant, S), kname, streams=S)
+    roof = roofline(bytes_per, N, kernel_ms, dt / K * 1e3, measured_traffic(per, variant, S), kname, streams=S)
     if one is not None:
-        roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
+        roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_kernel", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
         roof["one_launch_per_step"]["ms_per_step"] = one["ms_per_step"]
     out = {
         "metric": "env-steps/sec at fixed batch (PursuitEvade %dx%d, %dv%d)" % (MS, MS, P, E),
@@ -398,6 +402,59 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     return out
 
 
+def bench_rollout(args, K, W, rank, world, dev):
+    """Policy in the loop (the sampler loop the reference's runners drive, runners/rurllab.py:298-305; in-tree instance heuristics/pursuit.py:71-85):
+    BASELINE configs[1]'s batch, the device chase policy (madrl_amd/heuristics.py) choosing every action from the observation the step
+    kernel just wrote, trajectory tensors filled in place, returns scanned at the end of each horizon -- ShardedRolloutCollector over
+    sub-batches on their own streams, one captured hipGraph per sub-batch and horizon.  A "step" is one env step of the whole batch
+    with everything around it; the horizon is min(K, 50) steps and a timed region is K // horizon collect() calls."""
+    import torch
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from madrl_amd.heuristics import PursuitHeuristicPolicy
+    from madrl_amd.rollout import ShardedRolloutCollector
+    from madrl_amd.sharded import StreamSharded
+    MS, P, E, N0, mode = PURSUIT_VARIANTS["pursuit"]
+    N, R, H = (args.envs or N0), 7, args.horizon
+    S = max(1, int(args.streams)) if args.streams else 2
+    if N % S or N // S < 64:
+        S = 1
+    T = max(1, min(K, 50))
+    calls = max(1, K // T)
+    kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, reward_mech="local", **mode)
+    sh = StreamSharded(lambda n_envs, env_id_base, device: BatchedPursuitEvade([rectangle_map(MS, MS)], n_envs=n_envs, device=device, seed=0,
+                                                                                env_id_base=rank * N + env_id_base, max_steps=H, auto_reset=True, **kw),
+                       N, n_streams=S, device=dev)
+    col = ShardedRolloutCollector(sh, [PursuitHeuristicPolicy(R, flatten=True, seed=1, row_id_base=(rank * N + j * (N // S)) * P) for j in range(S)], T,
+                                  discount=0.99, graph=True)
+    D, rec_bytes = sh.envs[0].obs_dim, sh.envs[0].record_bytes
+    for j, env in enumerate(sh.envs):
+        env.reset()
+        env.set_state(dict(t=((torch.arange(N // S, device=dev, dtype=torch.int32) + j * (N // S)) * 7919) % H))
+    for _ in range(max(3, W // T)):   # the first call allocates, the second captures the graphs
+        col.collect()
+
+    def step(i, record):
+        col.collect()
+    dt, kernel_ms, region_ms = Timer(world, dev, None).run(step, calls, 0)
+    steps = calls * T
+    if rank != 0:
+        return None
+    # the step kernel's bytes + what the policy needs: the evader channel of every row in, one int32 per pursuer out
+    bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes) + 4 * P * R * R + 4 * P
+    ms = dt / steps * 1e3
+    region_ms = [x * calls / steps for x in region_ms]
+    roof = roofline(bytes_per, N, kernel_ms * calls / steps, ms, None, "pursuit_wave_kernel<16,16,8,30,7,1> + pursuit_policy_kernel (+ gae_kernel per horizon)", streams=S)
+    cfg = {"workload": "policy-in-the-loop rollout: PursuitEvade 16x16, 8v30, %d envs per GPU, device chase policy, horizon %d, %d sub-batches, hipGraph per horizon"
+                       % (N, T, S), "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world, "rccl_ranks": world,
+           "streams_per_gpu": S, "envs_per_launch": N // S, "horizon": T, "collect_calls_per_region": calls}
+    cfg.update(region_stats(region_ms))
+    return {"metric": "env-steps/sec with the policy in the loop (PursuitEvade 16x16, 8v30)", "value": world * N * steps / dt, "unit": "env-steps/s", "n_gpus": world,
+            "steps": steps, "warmup": W, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic", "data": "synthetic (chase policy on the env's own observations)",
+            "config": cfg, "roofline": roof}
+
+
 def C_void(v):
     import ctypes
     return ctypes.c_void_p(v)
@@ -411,7 +468,8 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
     from madrl_amd import _lib
     L = _lib.lib()
     extra, flop_per_env_step, live_key, rec_key = {}, None, None, None
-    N = args.envs or {"waterworld": 32768, "waterworld_std": 32768, "hostage": 32768, "multiwalker": 16384}[workload]
+    N = args.envs or {"waterworld": 32768, "waterworld_std": 32768, "hostage": 32768, "multiwalker": 16384, "multiwalker_w10": 16384}[workload]
+    traffic_key = workload
     S = shard_count(args, N, workload) if streams is None else streams
     per = N // S
     from madrl_amd.sharded import shared_streams
@@ -514,16 +572,20 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
     else:
         from madrl_amd.multiwalker import BatchedMultiWalkerEnv
         H = 500
-        envs = [BatchedMultiWalkerEnv(n_walkers=3, n_envs=per, device=dev, seed=0, env_id_base=base(j), auto_reset=True,
-                                      max_steps=H, max_blocks=args.max_blocks) for j in range(S)]
+        # `multiwalker` = BASELINE configs[3] (three walkers); `multiwalker_w10` = the last lesson of the reference's curriculum
+        # (lessons/multiwalker/env.yaml: n_walkers 2 .. 10), which runs on the sixteen-lanes-per-env class of the kernels
+        MW = 10 if workload == "multiwalker_w10" else 3
+        envs = [BatchedMultiWalkerEnv(n_walkers=MW, n_envs=per, device=dev, seed=0, env_id_base=base(j), auto_reset=True,
+                                      max_steps=H) for j in range(S)]
         # several sub-batches in flight: the whole b2World::Step of a sub-batch as ONE launch (a wavefront then pays its own collide +
         # solve + continuous-pass time, not the slowest wavefront's of every phase): 3.4 against 4.0 ms per step at four sub-batches;
         # alone on the chip the two forms take the same 4.6 ms (scripts/stream_sweep.sh)
         mw_fused = (S > 1) if "MADRL_BENCH_MW_FUSED" not in os.environ else os.environ["MADRL_BENCH_MW_FUSED"] == "1"
+        mw_fused = mw_fused and envs[0].lanes_per_env < 16   # (the one-launch kernel is not built for the sixteen-lane class)
         if mw_fused:
             for e in envs:
                 e.set_mode(fused=True)
-        acts = [[(torch.rand((per, 3, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)] for j in range(S)]
+        acts = [[(torch.rand((per, MW, 4), device=dev) * 2 - 1).contiguous() for _ in range(8)] for j in range(S)]
         done_rows = torch.zeros((max(K, 1), N), dtype=torch.uint8, device=dev)   # the timed steps write their done bytes here: no extra
         outs = [[_lib.ptr(t) for t in (e._obs, e._rew)] for e in envs]             # launch in the timed region (how many envs ended is counted after it)
         ap = [[_lib.ptr(a) for a in acts[j]] for j in range(S)]
@@ -537,7 +599,7 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
                 _lib.check(L.madrl_multiwalker_step(hs[j], ap[j][i % 8], *outs[j], dn, sp[j]))
         # algorithmic HBM bytes per env-step: actions in, observation / reward / done rows out, the per-env record (bodies, joints,
         # contact cache, terrain) read and written once
-        bytes_per = 48 + 4 * 3 * 32 + 12 + 1 + 2 * envs[0].world_bytes
+        bytes_per = 16 * MW + 4 * MW * 32 + 4 * MW + 1 + 2 * envs[0].world_bytes
         kernel = ("mw_step_kernel<all phases> (one launch per sub-batch and step)" if mw_fused else
                   "mw_step_kernel<collide> + <solve> + <continuous pass> (three launches per step; kernel_ms is their sum)")
         # this path is not HBM-bound -- dependent FP32 work of 180 velocity + up to 60 position Gauss-Seidel sweeps
@@ -547,7 +609,7 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
                    "neither HBM nor VALU throughput (DESIGN.md 4c)")
         flop_per_env_step, flop_src = envs[0].flops_per_env_step()
         extra = {"flop_per_env_step": flop_per_env_step, "flop_source": flop_src}
-        workload_s = "MultiWalkerEnv n_walkers=3, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % N
+        workload_s = "MultiWalkerEnv n_walkers=%d, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % (MW, N)
         # 200 warm-up steps: episodes last ~60 steps under random actions and all start together, so the first 100 steps see waves of
         # simultaneous falls; after 200 the episode phases of the envs are mixed (the steady state of a rollout)
         K, W = min(K, 50), max(W, 200)
@@ -559,9 +621,9 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
             # the INDEPENDENT plain-C restatement (oracle/multiwalker_ref.c), not the product source compiled for the host
             from oracle import multiwalker_ref as mwr
             n = 1024
-            o = mwr.MultiWalkerRef(n_walkers=3, n_envs=n, seed=0, position_noise=0.0, angle_noise=0.0, poly=True)
+            o = mwr.MultiWalkerRef(n_walkers=MW, n_envs=n, seed=0, position_noise=0.0, angle_noise=0.0, poly=True)
             o.reset()
-            a = np.random.RandomState(0).uniform(-1, 1, (n, 3, 4)).astype(np.float32)
+            a = np.random.RandomState(0).uniform(-1, 1, (n, MW, 4)).astype(np.float32)
             t0 = time.time(); k = 0
             while time.time() - t0 < cpu_budget:
                 _, _, d = o.step(a); k += 1
@@ -577,21 +639,21 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
     torch.cuda.synchronize()
     age()
     dt, kernel_ms, region_ms = Timer(world, dev, hip_streams).run(step, K, W)
-    n_ended = float((done_rows[:K] != 0).sum().item()) / N if workload == "multiwalker" else None
+    n_ended = float((done_rows[:K] != 0).sum().item()) / N if workload.startswith("multiwalker") else None
     del envs
     one = None
     if reference_pass and S > 1 and world == 1:
         one = bench_other(args, workload, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False)
     if rank != 0:
         return None
-    roof = roofline(bytes_per, N, kernel_ms, measured_traffic(per, workload, S), kernel, streams=S, binding_resource=binding)
+    roof = roofline(bytes_per, N, kernel_ms, dt / K * 1e3, measured_traffic(per, traffic_key, S), kernel, streams=S, binding_resource=binding)
     if one is not None:
-        roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
+        roof["one_launch_per_step"] = {k: one["roofline"][k] for k in ("achieved", "frac", "frac_kernel", "frac_vs_measured_copy", "kernel_ms", "algorithmic_bytes_per_launch")}
         roof["one_launch_per_step"]["ms_per_step"] = one["ms_per_step"]
     cfg = {"workload": workload_s, "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world, "rccl_ranks": world,
            "streams_per_gpu": S, "envs_per_launch": per}
     cfg.update(region_stats(region_ms))
-    if workload == "multiwalker":
+    if workload.startswith("multiwalker"):
         tf = flop_per_env_step * N / (kernel_ms * 1e-3) / 1e12
         roof.update({"valu_flops_achieved_TFLOPs": tf, "valu_peak_TFLOPs": VALU_PEAK_TFLOPS, "valu_frac": tf / VALU_PEAK_TFLOPS, **extra})
         cfg["episode_ends_per_env_in_last_region"] = n_ended
@@ -605,6 +667,56 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
     if cpu_budget:
         attach_cpu_baselines(out, live_key, rec_key, cpu_fn)
     return out
+
+
+def _r(x, nd=4):
+    """numbers of the printed line: 6 significant digits are plenty and keep it short"""
+    return float("%.6g" % x) if isinstance(x, float) else x
+
+
+def compact_roofline(r, side=False):
+    keep = ["bound", "achieved", "peak", "unit", "frac", "frac_kernel", "traffic", "kernel", "kernel_ms"]
+    out = {k: _r(r[k]) for k in keep if k in r}
+    if "one_launch_per_step" in r:
+        out["one_launch_ms"] = _r(r["one_launch_per_step"]["ms_per_step"])
+        out["one_launch_frac"] = _r(r["one_launch_per_step"]["frac"])
+    for k in ("valu_frac", "flop_per_env_step"):
+        if k in r:
+            out[k] = _r(r[k])
+    if side:
+        out.pop("peak", None); out.pop("unit", None); out.pop("bound", None)
+    return out
+
+
+def compact_line(out):
+    """The ONE JSON line rank 0 prints: the contract's fields, short enough (a few KB) that a log tail holds every workload.  What the
+    fields mean is in DESIGN.md "Measurement"; the long form of this record (every key of the rounds before, prose included) goes to
+    --full-record / gpurun_out/bench_full.json."""
+    line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype")}
+    line["data"] = "synthetic"
+    c = out["config"]
+    line["config"] = {k: c[k] for k in ("workload", "envs_per_gpu", "envs_total", "parallelism", "streams_per_gpu", "rccl_ranks", "collective_backend",
+                                        "trajectory_gather_in_timed_region") if k in c}
+    line["config"]["region_ms_per_step"] = [_r(float(x)) for x in c["region_ms_per_step"]]
+    line["roofline"] = compact_roofline(out["roofline"])
+    if "cpu_baseline" in out:
+        b = out["cpu_baseline"]
+        line["cpu_baseline"] = {"value": _r(float(b["value"])), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "sample": b["sample"][:160]}
+    if "cpu_reference_recorded" in out:
+        b = out["cpu_reference_recorded"]
+        line["cpu_reference_recorded"] = {"value": _r(float(b["value"])), "cores": b["cores"], "kind": b["kind"], "host": b["host"][:80]}
+    if "workloads" in out:
+        line["workloads"] = {}
+        for name, w in out["workloads"].items():
+            if "error" in w:
+                line["workloads"][name] = {"error": w["error"][:200]}
+                continue
+            e = {"value": _r(float(w["value"])), "ms_per_step": _r(float(w["ms_per_step"])), "steps": w["steps"], "workload": w["config"]["workload"][:100],
+                 "envs": w["config"]["envs_per_gpu"], "streams": w["config"]["streams_per_gpu"], "roofline": compact_roofline(w["roofline"], side=True)}
+            if "cpu_baseline" in w:
+                e["cpu_baseline"] = {"value": _r(float(w["cpu_baseline"]["value"])), "cores": w["cpu_baseline"]["cores"], "kind": w["cpu_baseline"]["kind"]}
+            line["workloads"][name] = e
+    return line
 
 
 def self_launch(args):
@@ -621,7 +733,7 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
-WORKLOADS = ["pursuit", "pursuit_c5", "pursuit_colocate", "waterworld", "waterworld_std", "multiwalker", "hostage"]
+WORKLOADS = ["pursuit", "pursuit_c5", "pursuit_colocate", "pursuit_rollout", "waterworld", "waterworld_std", "multiwalker", "multiwalker_w10", "hostage"]
 
 
 def main():
@@ -642,6 +754,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full", action="store_true", help="print the long record (every key, prose included) instead of the compact line")
+    ap.add_argument("--full-record", default="", help="also write the long record to this file (default: gpurun_out/bench_full.json when that directory exists)")
     ap.add_argument("--no-workloads", action="store_true", help="headline only: do not time the other BASELINE configs")
     ap.add_argument("--horizon", type=int, default=500, help="max_path_length (runners/__init__.py:88)")
     ap.add_argument("--prep", type=int, default=2000, help="Pursuit: untimed steps before the warm-up that bring the stale-zero masks of the observation "
@@ -678,7 +792,9 @@ def main():
     cpu = (not args.no_cpu_baseline) and not collective_on(world)   # the CPU baselines are reported with the plain 1-GPU line only
     scale = float(os.environ.get("MADRL_BENCH_CPU_BUDGET", "1"))   # tests shorten the CPU samples
     head_cpu, side_cpu = (10.0 * scale, 3.0 * scale) if cpu else (0, 0)
-    if args.workload.startswith("pursuit"):
+    if args.workload == "pursuit_rollout":
+        out = bench_rollout(args, K, W, rank, world, dev)
+    elif args.workload.startswith("pursuit"):
         out = bench_pursuit(args, args.workload, K, W, rank, world, dev, head_cpu)
     else:
         out = bench_other(args, args.workload, K, W, rank, world, dev, head_cpu)
@@ -687,16 +803,25 @@ def main():
     if args.workload == "pursuit" and not collective_on(world) and not args.no_workloads and not args.envs:
         wl = {}
         for name, k, w in (("waterworld", min(K, 200), min(W, 20)), ("multiwalker", min(K, 50), W), ("pursuit_c5", min(K, 200), min(W, 20)),
-                           ("pursuit_colocate", min(K, 200), min(W, 20)), ("waterworld_std", min(K, 100), min(W, 20))):
+                           ("pursuit_colocate", min(K, 200), min(W, 20)), ("waterworld_std", min(K, 100), min(W, 20)), ("multiwalker_w10", min(K, 20), W),
+                           ("pursuit_rollout", min(K, 200), min(W, 20))):
             try:
-                r = bench_pursuit(args, name, k, w, rank, world, dev, side_cpu) if name.startswith("pursuit") else \
+                r = bench_rollout(args, k, w, rank, world, dev) if name == "pursuit_rollout" else \
+                    bench_pursuit(args, name, k, w, rank, world, dev, side_cpu) if name.startswith("pursuit") else \
                     bench_other(args, name, k, w, rank, world, dev, side_cpu)
                 wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline") if f in r}
             except Exception as e:  # a failing side workload must not take the headline down; it shows up as an error entry
                 wl[name] = {"error": repr(e)}
         out["workloads"] = wl
     if rank == 0:
-        print(json.dumps(out))
+        full_path = args.full_record or (os.path.join(ROOT, "gpurun_out", "bench_full.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+        if full_path:
+            try:
+                with open(full_path, "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError:
+                pass
+        print(json.dumps(out if args.full else compact_line(out), separators=(",", ":")))
         sys.stdout.flush()
     if collective_on(world):
         import torch.distributed as dist

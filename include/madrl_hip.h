@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MADRL_ABI_VERSION 4
+#define MADRL_ABI_VERSION 5
 
 #define MADRL_OK 0
 #define MADRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -159,6 +159,26 @@ int madrl_pursuit_reset(madrl_pursuit *h, const uint8_t *mask_dev, const int32_t
 int madrl_pursuit_step(madrl_pursuit *h, const int32_t *actions_dev,
                        const int32_t *inj_evader_actions_dev, float *obs_dev, float *rew_dev,
                        uint8_t *done_dev, int32_t *removed_dev, void *stream);
+
+/* One batch stepped as n_shards independent sub-batches, each a handle of its own (created with env_id_base advanced by its offset)
+ * on its own HIP stream: ONE host call issues every launch.  Env instances never interact (the reference's own parallelism is N
+ * pickled env copies in sampler workers, runners/rurllab.py:259), so nothing orders sub-batch A's step t + 1 against sub-batch
+ * B's step t: one launch's drain overlaps the other's ramp-up.  fork != 0: every sub-batch stream first waits for what
+ * caller_stream holds so far (the actions); join != 0: caller_stream then waits for every sub-batch (before it reads their
+ * observations / rewards).  Both as events recorded and waited for inside this call -- the five event calls per step a Python
+ * caller would make (madrl_amd/sharded.py).  A sampler that drives each sub-batch from its own stream passes 0 / 0.
+ * io[j]: the arguments of madrl_pursuit_step for sub-batch j and the stream it runs on. */
+typedef struct madrl_pursuit_shard_io {
+    const int32_t *actions;
+    const int32_t *inj_evader_actions;   /* or NULL */
+    float *obs;
+    float *rew;
+    uint8_t *done;
+    int32_t *removed;
+    void *stream;
+} madrl_pursuit_shard_io;
+int madrl_pursuit_step_sharded(madrl_pursuit *const *hs, const madrl_pursuit_shard_io *io, int32_t n_shards, void *caller_stream,
+                               int32_t fork, int32_t join);
 
 /* Unpacked view of the env state (device pointers; any may be NULL to skip).  This is the
  * checkpoint / parity-injection hook (the reference pokes AgentLayer.set_position,
@@ -315,7 +335,8 @@ int madrl_hostage_set_state(madrl_hostage *h, const float *pos, const float *vel
 /* Constructor arguments of MultiWalkerEnv.__init__ (multi_walker.py:256-270). */
 typedef struct madrl_multiwalker_config {
     int32_t struct_size;      /* = sizeof(madrl_multiwalker_config) */
-    int32_t n_walkers;        /* 1..4 */
+    int32_t n_walkers;        /* 1..10: the reference's curriculum runs 2 .. 10 (lessons/multiwalker/env.yaml:1-27); the package and the
+                                 terrain grow with it (multi_walker.py:293-301) */
     int32_t reward_global;    /* reward_mech != 'local' (:426-428) */
     int32_t terminate_on_fall;
     int32_t one_hot;          /* 1: the id is np.eye(MAX_AGENTS = 40)[i] instead of i / n_walkers (:397-400): obs_dim 71 */
@@ -339,10 +360,15 @@ int madrl_multiwalker_create(const madrl_multiwalker_config *cfg, int64_t n_envs
                              madrl_multiwalker **out);
 void madrl_multiwalker_destroy(madrl_multiwalker *h);
 /* How a step is issued.  fused: 0 (default) = three launches per b2World::Step (collide | solve | continuous pass + observe), 1 = one
- * launch.  use_spares: 1 (default) = an env whose episode ends takes the next episode prepared ahead of time, 0 = every auto-reset
+ * launch (9 and 10 walkers always take three: the one-launch kernel is not built for the sixteen-lane class, multiwalker_impl.hpp).  use_spares: 1 (default) = an env whose episode ends takes the next episode prepared ahead of time, 0 = every auto-reset
  * runs the reset + trailing step in a second pass.  Results do not depend on either (tests/test_multiwalker_gpu.py). */
 int madrl_multiwalker_set_mode(madrl_multiwalker *h, int32_t fused, int32_t use_spares);
 int madrl_multiwalker_dims(const madrl_multiwalker *h, int32_t *n_bodies, int32_t *n_terrain);
+/* The kernels exist in three capacity classes -- room for 4 / 8 / 10 walkers, an env spread over 4 / 8 / 16 lanes of a wavefront (16 / 8 / 4
+ * envs per wavefront) -- and a handle belongs to the smallest one that holds its n_walkers.  Record sizes (madrl_multiwalker_state_bytes,
+ * madrl_multiwalker_record_bytes) depend on the class: a change of n_walkers (the reference's update_curriculum builds a new env,
+ * runners/curriculum.py:56-91) is a new handle over a new state buffer.  Either pointer may be NULL. */
+int madrl_multiwalker_lanes(const madrl_multiwalker *h, int32_t *cap_walkers, int32_t *lanes_per_env);
 /* layout of the state buffer: first n_envs blocks of stride_bytes each -- the world record (world_bytes: bodies, flags, joints,
  * contacts, broad phase, terrain) followed by the step's scratch (solver schedule and manifolds, handed from launch to launch: one
  * step is a sequence of kernel launches); behind them the library's own part (pending flags, the spare records of the auto-reset,

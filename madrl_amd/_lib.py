@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MADRL_HIP_LIB") or os.path.join(_HERE, "libmadrl_hip.so")  # override: profiling variants only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
 
@@ -64,6 +64,11 @@ class MultiWalkerConfig(C.Structure):
         "discrete_only")] + [(n, C.c_double) for n in (
             "position_noise", "angle_noise", "forward_reward", "fall_reward", "drop_reward")] + [
                 ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
+
+
+class PursuitShardIO(C.Structure):
+    """mirror of madrl_pursuit_shard_io (include/madrl_hip.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("actions", "inj_evader_actions", "obs", "rew", "done", "removed", "stream")]
 
 
 class StandardizeArgs(C.Structure):
@@ -116,6 +121,7 @@ SIGNATURES = {
     "madrl_hostage_step": (C.c_int, [_vp] * 8),
     "madrl_hostage_get_state": (C.c_int, [_vp] * 10),
     "madrl_hostage_set_state": (C.c_int, [_vp] * 10),
+    "madrl_pursuit_step_sharded": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32]),
     "madrl_multiwalker_obs_dim": (C.c_int, [_vp, _vp]),
     "madrl_multiwalker_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
     "madrl_multiwalker_create": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp]),
@@ -123,6 +129,7 @@ SIGNATURES = {
     "madrl_multiwalker_set_mode": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "madrl_pursuit_set_walk": (C.c_int, [_vp, C.c_int32]),
     "madrl_multiwalker_dims": (C.c_int, [_vp, _vp, _vp]),
+    "madrl_multiwalker_lanes": (C.c_int, [_vp, _vp, _vp]),
     "madrl_multiwalker_record_bytes": (C.c_int, [_vp, _vp, _vp]),
     "madrl_multiwalker_reset": (C.c_int, [_vp] * 4),
     "madrl_multiwalker_step": (C.c_int, [_vp] * 6),

@@ -12,7 +12,11 @@ enum : uint32_t { TAG_HEURISTIC_ACT = 3 };
 // order among equals), then a direction from atan2 quadrants.  The quadrant logic is a table over the evader's window cell,
 // built on the host with the reference's own float64 expression (madrl_amd/heuristics.py); 255 in the table or an empty
 // window = the reference's action_space.sample(), here Philox(row id, tick).
-// 8 lanes per row: lane s scans window rows s, s+8, ...; the packed (distance^2, cell) keys are min-reduced by shuffles.
+// 8 lanes per row: lane s scans window rows s, s + 8, ... (R consecutive floats each, loaded in independent batches of eight before any is
+// compared); the packed (distance^2, cell) keys are min-reduced by shuffles.  The kernel reads one channel of every row -- a third of the
+// bytes -- but not a third of the DRAM traffic: measured 44 - 56 us for the 524 288 rows of 65 536 envs whichever way the lanes are dealt
+// (16 lanes per row with 64-byte coalesced passes: 56 us, the same in persistent blocks: 51 us; this mapping: see DESIGN.md), against
+// ~50 us for streaming the whole 310 MB buffer.
 __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__restrict__ obs, int64_t n_rows, int R, int64_t row_stride,
                                                              int cell_stride, int ch_offset, const uint8_t *__restrict__ table,
                                                              uint32_t k0, uint32_t k1, int64_t row_id_base, uint32_t tick,
@@ -24,11 +28,18 @@ __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__rest
     if (row < n_rows) {
         const float *o = obs + row * row_stride + ch_offset;
         for (int i = sub; i < R; i += 8)
-            for (int j = 0; j < R; ++j)
-                if (o[(int64_t)(i * R + j) * cell_stride] != 0.0f) {
-                    const uint32_t d2 = (uint32_t)((i - c) * (i - c) + (j - c) * (j - c));
-                    key = min(key, (d2 << 16) | (uint32_t)(i * R + j));
-                }
+            for (int j0 = 0; j0 < R; j0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = j0 + q < R ? o[(int64_t)(i * R + j0 + q) * cell_stride] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (v[q] != 0.0f) {
+                        const int j = j0 + q;
+                        const uint32_t d2 = (uint32_t)((i - c) * (i - c) + (j - c) * (j - c));
+                        key = min(key, (d2 << 16) | (uint32_t)(i * R + j));
+                    }
+            }
     }
     key = min(key, (uint32_t)__shfl_xor((int)key, 1, 8));
     key = min(key, (uint32_t)__shfl_xor((int)key, 2, 8));

@@ -617,6 +617,7 @@ struct madrl_pursuit {
     int walk_mode = 0;        // 0 auto (alternate above ~375 MB per launch), 1 always alternate, 2 always forward; fixed at create
     void *wtables;
     int kernel_kind;  // MADRL_KERNEL_AUTO / _GENERIC / _WAVE (requested)
+    hipEvent_t ev_fork = nullptr, ev_done = nullptr;   // madrl_pursuit_step_sharded: created on first use, destroyed with the handle
 };
 
 namespace {
@@ -1133,6 +1134,8 @@ void madrl_pursuit_destroy(madrl_pursuit *h) {
     if (!h) return;
     if (h->tables) (void)hipFree(h->tables);
     if (h->wtables) (void)hipFree(h->wtables);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     delete h;
 }
 
@@ -1178,6 +1181,37 @@ int madrl_pursuit_step(madrl_pursuit *h, const int32_t *actions_dev, const int32
     io.done = done_dev;
     io.removed = removed_dev;
     return launch(h, io, 1, stream);
+}
+
+int madrl_pursuit_step_sharded(madrl_pursuit *const *hs, const madrl_pursuit_shard_io *io, int32_t n_shards, void *caller_stream,
+                               int32_t fork, int32_t join) {
+    if (!hs || !io || n_shards < 1) return fail(MADRL_EINVAL, "step_sharded: NULL argument or n_shards < 1");
+    for (int j = 0; j < n_shards; ++j) {
+        if (!hs[j] || !io[j].actions || !io[j].obs || !io[j].rew || !io[j].done || !io[j].removed) return fail(MADRL_EINVAL, "step_sharded: shard %d has a NULL argument", j);
+        if (!hs[j]->ev_done) {
+            MADRL_HIP_TRY(hipEventCreateWithFlags(&hs[j]->ev_done, hipEventDisableTiming));
+            MADRL_HIP_TRY(hipEventCreateWithFlags(&hs[j]->ev_fork, hipEventDisableTiming));
+        }
+    }
+    hipStream_t cs = (hipStream_t)caller_stream;
+    if (fork) {   // every sub-batch stream waits for what the caller's stream holds so far (the actions)
+        MADRL_HIP_TRY(hipEventRecord(hs[0]->ev_fork, cs));
+        for (int j = 0; j < n_shards; ++j) if ((hipStream_t)io[j].stream != cs) MADRL_HIP_TRY(hipStreamWaitEvent((hipStream_t)io[j].stream, hs[0]->ev_fork, 0));
+    }
+    for (int j = 0; j < n_shards; ++j) {
+        PursuitIO p;
+        memset(&p, 0, sizeof(p));
+        p.actions = io[j].actions; p.inj_eact = io[j].inj_evader_actions; p.obs = io[j].obs; p.rew = io[j].rew; p.done = io[j].done; p.removed = io[j].removed;
+        const int rc = launch(hs[j], p, 1, io[j].stream);
+        if (rc) return rc;
+    }
+    if (join)     // ... and the caller's stream waits for every sub-batch
+        for (int j = 0; j < n_shards; ++j) {
+            if ((hipStream_t)io[j].stream == cs) continue;
+            MADRL_HIP_TRY(hipEventRecord(hs[j]->ev_done, (hipStream_t)io[j].stream));
+            MADRL_HIP_TRY(hipStreamWaitEvent(cs, hs[j]->ev_done, 0));
+        }
+    return MADRL_OK;
 }
 
 int madrl_pursuit_get_state(madrl_pursuit *h, int32_t *pos_p, int32_t *pos_e, uint8_t *gone, uint8_t *term_p,

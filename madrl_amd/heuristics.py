@@ -52,6 +52,10 @@ class _DevicePolicy(object):
 class PursuitHeuristicPolicy(_DevicePolicy):
     """obs: flatten rows [N, P, 3*R*R+1] or windows [N, P, R, R, 4] of BatchedPursuitEvade -> int32 [N, P]"""
 
+    def __call__(self, obs, out=None):
+        """out: optional contiguous int32 destination of the actions (e.g. a slot of a trajectory tensor): no copy afterwards"""
+        return self.sample_actions(obs, out=out)[0]
+
     def __init__(self, obs_range, flatten=True, seed=0, row_id_base=0):
         self.R, self.flatten, self.seed, self.row_id_base = int(obs_range), bool(flatten), int(seed), int(row_id_base)
         self._tick = None  # uint32 draw counter on the device (a host counter would be frozen into a captured hipGraph)
@@ -59,23 +63,28 @@ class PursuitHeuristicPolicy(_DevicePolicy):
         self._table = None
         self._act = None
 
-    def sample_actions(self, obs, deterministic=True):
+    def sample_actions(self, obs, deterministic=True, out=None):
         obs = obs.contiguous()
         R = self.R
         n_rows = obs.shape[0] * obs.shape[1]
         if self._table is None or self._table.device != obs.device:
             self._table = torch.as_tensor(self._table_host, device=obs.device)
-        if self._act is None or self._act.numel() != n_rows or self._act.device != obs.device:
-            self._act = torch.empty(obs.shape[:2], dtype=torch.int32, device=obs.device)
+        if out is not None:
+            assert out.dtype == torch.int32 and out.is_contiguous() and out.numel() == n_rows and out.device == obs.device
+            act = out
+        else:
+            if self._act is None or self._act.numel() != n_rows or self._act.device != obs.device:
+                self._act = torch.empty(obs.shape[:2], dtype=torch.int32, device=obs.device)
+            act = self._act
         if self._tick is None or self._tick.device != obs.device:
             self._tick = torch.zeros(1, dtype=torch.int32, device=obs.device)
         row_stride = obs.numel() // n_rows
         cell_stride, ch_off = (1, 2 * R * R) if self.flatten else (4, 2)
         _lib.check(_lib.lib().madrl_heuristic_pursuit(_lib.ptr(obs), n_rows, R, row_stride, cell_stride, ch_off, _lib.ptr(self._table),
-                                                      self.seed, self.row_id_base, 0, _lib.ptr(self._tick), _lib.ptr(self._act),
+                                                      self.seed, self.row_id_base, 0, _lib.ptr(self._tick), _lib.ptr(act),
                                                       _lib.current_stream(obs.device)))
         self._tick += 1
-        return self._act, None
+        return act, None
 
 
 class WaterworldHeuristicPolicy(_DevicePolicy):

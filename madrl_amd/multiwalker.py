@@ -50,7 +50,7 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         self.drop_reward, self.terminate_on_fall, self.one_hot = drop_reward, terminate_on_fall, one_hot
         self.n_envs, self.device = int(n_envs), torch.device(device)
         self._seed_value, self.env_id_base = int(seed), int(env_id_base)
-        self.max_steps, self.auto_reset, self._max_blocks = int(max_steps), bool(auto_reset), int(max_blocks)
+        self.max_steps, self.auto_reset = int(max_steps), bool(auto_reset)   # (max_blocks: accepted for old call sites, unused -- a launch is one wavefront per group of envs)
         self.continuous_physics = bool(continuous_physics)  # b2World.continuousPhysics (Box2D default True; the reference never changes it)
         self._handle = None
         self.setup()
@@ -98,6 +98,9 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         stride, wb = C.c_int32(), C.c_int32()
         _lib.check(L.madrl_multiwalker_record_bytes(h, C.byref(stride), C.byref(wb)))
         self.record_stride, self.world_bytes = stride.value, wb.value   # block per env (world record + step scratch), world record alone
+        capw, lanes = C.c_int32(), C.c_int32()
+        _lib.check(L.madrl_multiwalker_lanes(h, C.byref(capw), C.byref(lanes)))
+        self.capacity_walkers, self.lanes_per_env = capw.value, lanes.value   # the capacity class of the kernels this walker count runs on
         self.walkers = [BipedalWalker(self.obs_dim) for _ in range(W)]
         self.package_scale = W / 1.75
         self.package_length = 240 / 30.0 * self.package_scale
@@ -203,8 +206,8 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
     # float32 / float64 additions, multiplications, divisions and square roots per env-step under uniform random actions with
     # terminate_on_fall (the bench workload), by n_walkers: every primitive of the step (joint / contact velocity and position solves,
     # sub-step sweeps, GJK and root-finder iterations, narrow phase, lidar, ...) carries a hand count of its arithmetic, and the CPU build
-    # of the kernel source counts how often each runs (scripts/mw_stats.cpp, 19 500 env-steps per entry)
-    COUNTED_FLOPS = {1: 88998.0, 2: 188102.0, 3: 262265.0, 4: 341100.0}
+    # of the kernel source counts how often each runs (scripts/mw_stats.cpp, 19 500 env-steps per entry; recounted in round 5 for 1 .. 10 walkers)
+    COUNTED_FLOPS = {1: 87999.0, 2: 186156.0, 3: 259551.0, 4: 337449.0, 5: 409865.0, 6: 485901.0, 7: 561309.0, 8: 632568.0, 9: 707722.0, 10: 784104.0}
 
     def flops_per_env_step(self):
         """(floating-point operations per env-step, how the figure was obtained) for the roofline line of bench.py"""

@@ -270,10 +270,25 @@ class BatchedPursuitEvade(AbstractMAEnv):
         mid = self._i32(map_ids, (N,), "map_ids")
         if mask is not None and getattr(self, "_needs_reset", False):
             raise RuntimeError("the agent counts changed (update_curriculum / set_param_values): the whole batch must be reset() once")
+        self._check_obs_untouched()
         _lib.check(_lib.lib().madrl_pursuit_reset(self._handle, _lib.ptr(mask), _lib.ptr(pos), _lib.ptr(mid),
                                                   _lib.ptr(self._obs), self._stream()))
         self._was_reset, self._needs_reset, self._obs_is_fresh = True, False, False
+        self._obs_version = self._obs._version
         return self._obs_view()
+
+    def _check_obs_untouched(self):
+        """The returned observation tensor IS the persistent IN / OUT buffer (the reference's local_obs, pursuit_evade.py:119-120, whose
+        (R, R, 4) views it hands out the same way, :441-449).  The fast path remembers which of its never-stored cells hold 0.0 (stale-zero
+        masks); a caller that edits the tensor in place -- `obs.sub_(mean)` -- would make that memory wrong without anybody noticing.
+        PyTorch counts in-place operations per tensor (`_version`, shared by every view): if the count moved since this env last wrote the
+        buffer, the masks are reset to "nothing known" before the next launch.  The edit itself stays in the stale cells, exactly as an
+        edit of local_obs would in the reference; writes PyTorch cannot see (another library writing through the raw pointer) still need
+        invalidate_obs()."""
+        if getattr(self, "_obs_version", None) is not None and self._obs._version != self._obs_version:
+            _lib.check(_lib.lib().madrl_pursuit_invalidate_obs(self._handle))
+            self._obs_is_fresh = False
+        self._obs_version = self._obs._version
 
     def step(self, actions, evader_actions=None, rew_out=None, done_out=None):
         """pursuit_evade.py:209-262.  actions: int [N, P] (0..4).  evader_actions: optional int
@@ -287,6 +302,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
         act = self._i32(actions, (N, P), "actions")
         # evader control (train_pursuit=False): the opponents are the pursuers, one injected action per pursuer
         eact = self._i32(evader_actions, (N, E if self.train_pursuit else P), "evader_actions")
+        self._check_obs_untouched()
         self._obs_is_fresh = False
         rew = self._rew if rew_out is None else rew_out
         dn = self._done if done_out is None else done_out
@@ -294,6 +310,25 @@ class BatchedPursuitEvade(AbstractMAEnv):
         _lib.check(_lib.lib().madrl_pursuit_step(self._handle, _lib.ptr(act), _lib.ptr(eact), _lib.ptr(self._obs),
                                                  _lib.ptr(rew), _lib.ptr(dn), _lib.ptr(self._removed),
                                                  self._stream()))
+        return self._step_result(rew, dn)
+
+    def step_into(self, actions, rew_out, done_out):
+        """The launch of step() alone, for a sampler loop that keeps everything on the device: rewards and done bits go to the given
+        trajectory slots, the observation view is returned, and none of the small torch kernels that build step()'s `done` / `info`
+        tensors run (six launches of ~5 us each: a third of a 65 536-env rollout step, profiles/r05_rollout).  actions: int32 [N, P]
+        contiguous on the env's device."""
+        N, P = self.n_envs, int(self.n_pursuers)
+        if getattr(self, "_needs_reset", False):
+            raise RuntimeError("update_curriculum / set_param_values changed the agent counts -- call reset() first")
+        assert actions.dtype == torch.int32 and actions.is_contiguous() and actions.numel() == N * P
+        assert rew_out.dtype == torch.float32 and rew_out.numel() == N * P and done_out.dtype == torch.uint8 and done_out.numel() == N
+        self._check_obs_untouched()
+        self._obs_is_fresh = False
+        _lib.check(_lib.lib().madrl_pursuit_step(self._handle, _lib.ptr(actions), None, _lib.ptr(self._obs), _lib.ptr(rew_out), _lib.ptr(done_out),
+                                                 _lib.ptr(self._removed), self._stream()))
+        return self._obs_view()
+
+    def _step_result(self, rew, dn):
         done = (dn & 1).bool()
         # bit 7: more than 253 agents of one kind stood on ONE cell of this env (byte count grids of the generic kernel; possible only
         # with more than 253 pursuers or evaders) -- its results are void until its next reset
@@ -411,8 +446,10 @@ class BatchedPursuitEvade(AbstractMAEnv):
         return torch.full((self.n_envs,), float(self.constraint_window), **f64), torch.full((self.n_envs,), float(self.catchr), **f64)
 
     def invalidate_obs(self):
-        """Call after writing into `obs_buffer` yourself (include/madrl_hip.h, obs_dev contract)."""
+        """Call after writing into `obs_buffer` through something PyTorch does not see (include/madrl_hip.h, obs_dev contract); in-place
+        tensor operations are noticed without it (_check_obs_untouched)."""
         _lib.check(_lib.lib().madrl_pursuit_invalidate_obs(self._handle))
+        self._obs_is_fresh = False   # a re-created handle must not declare this buffer all-zero
 
     # ------------------------------------------------------------------ state exchange
     def get_state(self):
@@ -447,10 +484,13 @@ class BatchedPursuitEvade(AbstractMAEnv):
             args.append(v)
         self._keepalive = args
         _lib.check(_lib.lib().madrl_pursuit_set_state(self._handle, *[_lib.ptr(a) for a in args], self._stream()))
+        self._obs_is_fresh = False
 
     @property
     def obs_buffer(self):
-        """the persistent IN/OUT observation tensor (reference: self.local_obs)"""
+        """the persistent IN/OUT observation tensor (reference: self.local_obs).  Handing it out ends the "freshly zeroed" promise a
+        re-created handle would otherwise make for it (the caller may write through it)."""
+        self._obs_is_fresh = False
         return self._obs
 
     # ------------------------------------------------------------------ pickling (EzPickle-style)

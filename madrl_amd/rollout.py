@@ -67,6 +67,11 @@ class RolloutCollector(object):
         self._use_graph, self._graph, self._calls = bool(graph), None, 0
         import inspect
         self._direct = "rew_out" in inspect.signature(env.step).parameters   # envs whose step() can write into caller buffers
+        self._into = hasattr(env, "step_into")                               # ... and that offer the launch alone (no done / info tensors built)
+        try:
+            self._policy_out = "out" in inspect.signature(policy).parameters   # policies that write into a trajectory slot
+        except (TypeError, ValueError):
+            self._policy_out = False
 
     def _alloc(self, obs, act, val):
         T, dev = self.T, obs.device
@@ -110,16 +115,21 @@ class RolloutCollector(object):
 
     def _step(self, t):
         env, obs = self.env, self._obs
-        act, val = self._act(obs)
-        if self._buf is None:
-            self._buf = self._alloc(obs, act, val)
+        if self._policy_out and self._buf is not None:   # the policy writes its actions straight into their trajectory slot
+            act, val = self.policy(obs, out=self._buf["actions"][t]), None
+        else:
+            act, val = self._act(obs)
+            if self._buf is None:
+                self._buf = self._alloc(obs, act, val)
+            self._buf["actions"][t].copy_(act)
         b = self._buf
         if b["observations"] is not None:
             b["observations"][t].copy_(obs)
-        b["actions"][t].copy_(act)
         if val is not None:
             b["values"][t].copy_(val)
-        if self._direct:   # the step kernel writes rewards / done bits straight into their trajectory slot
+        if self._into and act.dtype == torch.int32 and act.is_contiguous():
+            obs = env.step_into(act, b["rewards"][t], b["dones"][t])
+        elif self._direct:   # the step kernel writes rewards / done bits straight into their trajectory slot
             obs, rew, done, info = env.step(act, rew_out=b["rewards"][t], done_out=b["dones"][t])
         else:
             obs, rew, done, info = env.step(act)

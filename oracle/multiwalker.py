@@ -20,11 +20,11 @@ def lib(n_walkers):
     """the CPU build of multiwalker_core.hpp for the capacity class of `n_walkers` (oracle/Makefile)"""
     c = capacity_class(n_walkers)
     if c not in _LIBS:
-        so = os.path.join(_HERE, "_build", "libmadrl_mwo_c%d.so" % c)
+        so = os.path.join(_HERE, os.environ.get("MADRL_ORACLE_BUILD", "_build"), "libmadrl_mwo_c%d.so" % c)
         deps = [os.path.join(_HERE, "multiwalker_oracle.cpp")] + [os.path.join(os.path.dirname(_HERE), "madrl_amd", "csrc", f)
                                                                    for f in ("multiwalker_core.hpp", "multiwalker_toi.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            subprocess.check_call(["make", "-s", "-C", _HERE])
+            subprocess.check_call(["make", "-s", "-C", _HERE] + (["asan"] if os.environ.get("MADRL_ORACLE_BUILD") == "_build_asan" else []))
         _LIBS[c] = C.CDLL(so)
     return _LIBS[c]
 

@@ -20,10 +20,10 @@ class MwrConfig(C.Structure):
 
 def lib(poly=False):
     if poly not in _LIBS:
-        so = os.path.join(_HERE, "_build", "libmadrl_mwref_poly.so" if poly else "libmadrl_mwref.so")
+        so = os.path.join(_HERE, os.environ.get("MADRL_ORACLE_BUILD", "_build"), "libmadrl_mwref_poly.so" if poly else "libmadrl_mwref.so")
         src = os.path.join(_HERE, "multiwalker_ref.c")
         if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
-            subprocess.check_call(["make", "-s", "-C", _HERE])
+            subprocess.check_call(["make", "-s", "-C", _HERE] + (["asan"] if os.environ.get("MADRL_ORACLE_BUILD") == "_build_asan" else []))
         L = C.CDLL(so)
         L.mwr_create.restype = C.c_void_p
         L.mwr_create.argtypes = [C.c_void_p, C.c_int64]

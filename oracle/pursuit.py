@@ -32,6 +32,7 @@ def lib():
         _LIB.po_get_state.argtypes = [C.c_void_p] * 8
         _LIB.po_set_state.argtypes = [C.c_void_p] * 8
         _LIB.po_get_local_obs.argtypes = [C.c_void_p] * 2
+        _LIB.po_set_local_obs.argtypes = [C.c_void_p] * 2
         _LIB.po_obs_dim_of.argtypes = [C.c_void_p]
         _LIB.po_philox4x32_10.argtypes = [C.c_void_p] * 3
         _LIB.po_set_curriculum.argtypes = [C.c_void_p] * 3
@@ -140,6 +141,12 @@ class PursuitOracle(object):
         out = np.zeros((self.N, self.P, 4, R, R), np.float64)
         lib().po_get_local_obs(self.h, _p(out))
         return out
+
+    def set_local_obs(self, lo):
+        """overwrite the persistent float64 local_obs [N, P, 4, R, R] (the effect of a caller's in-place edit of the reference's observation views)"""
+        R = self.cfg.obs_range
+        lo = np.ascontiguousarray(np.asarray(lo, np.float64).reshape(self.N, self.P, 4, R, R))
+        lib().po_set_local_obs(self.h, _p(lo))
 
 
 def config_from_golden(g):

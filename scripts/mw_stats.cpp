@@ -8,7 +8,7 @@
 mw::Stats mw::g_stats;
 int main() {
     using namespace mw;
-    for (int W = 1; W <= 4; ++W) {
+    for (int W = 1; W <= MAX_WALKERS; ++W) {
         Model M; memset(&M, 0, sizeof(M)); build_model(M, W);
         EnvCfg C; memset(&C, 0, sizeof(C)); C.n_walkers = W; C.terminate_on_fall = 1; C.forward_reward = 1; C.fall_reward = -100; C.drop_reward = -100; C.k0 = 1;
         std::vector<World> worlds(64); memset(worlds.data(), 0, sizeof(World) * 64);
@@ -16,7 +16,7 @@ int main() {
         memset(&g_stats, 0, sizeof(g_stats));
         uint32_t lcg = 12345;
         for (int n = 0; n < 64; ++n) {
-            Scratch S; uint8_t done = 0; float zero[16] = {0};
+            Scratch S; uint8_t done = 0; float zero[4 * MAX_WALKERS] = {0};
             env_reset_world(M, C, worlds[n].h, cold_view(worlds[n].c), n);
             env_step(M, C, worlds[n].h, cold_view(worlds[n].c), S, SerialPar(), n, zero, obs.data(), nullptr, nullptr);
             memset(&g_stats, 0, 0);

@@ -8,10 +8,10 @@ export TMPDIR=/tmp
 WL=$1; NAME=$2; KSUB=$3; shift 3
 OUT=gpurun_out/profile/$NAME
 rm -rf $OUT; mkdir -p $OUT
-python bench.py --workload $WL --steps 200 --warmup 20 --no-cpu-baseline --no-workloads "$@" 2>/dev/null | tail -1 > $OUT/bench_line.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --workload $WL --steps 200 --warmup 20 --no-cpu-baseline --no-workloads "$@" > $OUT/trace.log 2>&1
+python bench.py --workload $WL --steps 200 --warmup 20 --no-cpu-baseline --no-workloads --full "$@" 2>/dev/null | tail -1 > $OUT/bench_line.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --workload $WL --steps 200 --warmup 20 --no-cpu-baseline --no-workloads --full "$@" > $OUT/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-workloads "$@" > $OUT/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-workloads --full "$@" > $OUT/pmc_$c.log 2>&1
 done
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 python - "$OUT" "$WL" "$KSUB" <<'PY'

@@ -4,6 +4,7 @@ own streams one sub-batch's drain overlaps another's ramp-up -- and, when the st
 step t + 1 starts while another's step t is still draining.  Prints us per step of the WHOLE batch (wall clock over K steps)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 from madrl_amd.maps import rectangle_map
 from madrl_amd.pursuit import BatchedPursuitEvade
@@ -62,6 +63,25 @@ for S in (2, 4):
                         streams[j].wait_event(ev0)
                         L.madrl_pursuit_step(e._handle, _lib.ptr(a[i % 8]), None, *p, streams[j].cuda_stream)
                         evs[j].record(streams[j]); main.wait_event(evs[j])
+        import ctypes as C
+        io = (_lib.PursuitShardIO * S)()
+        hs = (C.c_void_p * S)(*[e._handle.value for e, _, _ in parts])
+        for j, (e, a, p) in enumerate(parts):
+            io[j].inj_evader_actions = None
+            io[j].obs, io[j].rew, io[j].done, io[j].removed = (q.value for q in p)
+            io[j].stream = streams[j].cuda_stream
+        aptr = [[_lib.ptr(x).value for x in a] for _, a, _ in parts]
+
+        def native(fork, join):
+            def fn(k):   # ONE call of the C ABI per step: fork + S launches + join (madrl_pursuit_step_sharded)
+                cs = main.cuda_stream
+                for i in range(k):
+                    for j in range(S):
+                        io[j].actions = aptr[j][i % 8]
+                    L.madrl_pursuit_step_sharded(hs, io, S, cs, fork, join)
+            return fn
+        print("%d sub-batches, %4s workgroups each, one C call per step, joined:       min %.1f  median %.1f us" % ((S, blocks or "dflt") + timed(native(1, 1))), flush=True)
+        print("%d sub-batches, %4s workgroups each, one C call per step, free-running: min %.1f  median %.1f us" % ((S, blocks or "dflt") + timed(native(0, 0))), flush=True)
         print("%d sub-batches, %4s workgroups each, free-running streams:   min %.1f  median %.1f us" % ((S, blocks or "dflt") + timed(free)), flush=True)
         print("%d sub-batches, %4s workgroups each, joined after every step: min %.1f  median %.1f us" % ((S, blocks or "dflt") + timed(joined)), flush=True)
         del parts

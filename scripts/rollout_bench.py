@@ -9,8 +9,9 @@ from madrl_amd.pursuit import BatchedPursuitEvade
 from madrl_amd.heuristics import PursuitHeuristicPolicy
 from madrl_amd.rollout import RolloutCollector
 dev = "cuda:0"
-for N, T in ((65536, 50), (1024, 50)):
-    for graph in (False, True):
+ONLY = os.environ.get("ROLLOUT_ONLY", "")   # "single": the one-batch eager collector at 65 536 envs and nothing else (profiling runs)
+for N, T in ((65536, 50),) if ONLY == "single" else ((65536, 50), (1024, 50)):
+    for graph in (False,) if ONLY == "single" else (False, True):
         env = BatchedPursuitEvade([rectangle_map(16, 16)], n_envs=N, device=dev, seed=0, max_steps=500, auto_reset=True, n_pursuers=8,
                                   n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local")
         col = RolloutCollector(env, PursuitHeuristicPolicy(7, flatten=True, seed=1), T, discount=0.99, graph=graph)
@@ -25,7 +26,7 @@ for N, T in ((65536, 50), (1024, 50)):
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from madrl_amd.sharded import StreamSharded
 from madrl_amd.rollout import ShardedRolloutCollector
-for S, graph in ((2, False), (2, True), (4, True)):
+for S, graph in () if ONLY == "single" else ((2, False), (2, True), (4, False), (4, True)):
     N, T = 65536, 50
     sh = StreamSharded(lambda n_envs, env_id_base, device: BatchedPursuitEvade([rectangle_map(16, 16)], n_envs=n_envs, device=device, seed=0, env_id_base=env_id_base,
                                                                                 max_steps=500, auto_reset=True, n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2,

@@ -27,7 +27,7 @@ def test_single_process_line():
     assert KEYS <= set(j) and j["n_gpus"] == 1 and j["steps"] == 30 and j["warmup"] == 5 and j["unit"] == "env-steps/s"
     assert j["value"] > 1e7 and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
     rf = j["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and "workload" in j["config"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and "workload" in j["config"]   # (six significant digits in the line)
 
 
 def test_two_ranks_gather_path():
@@ -38,7 +38,7 @@ def test_two_ranks_gather_path():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 70 and j["config"]["parallelism"] == "env-sharded x2" and "cpu_baseline" not in j
-    assert j["config"]["rccl_ranks"] == 2 and j["config"]["envs_total"] == 4096 and j["config"]["timed_regions"] == 3
+    assert j["config"]["rccl_ranks"] == 2 and j["config"]["envs_total"] == 4096 and len(j["config"]["region_ms_per_step"]) == 3
 
 
 def test_plain_python_gpus_2_launches_its_own_ranks():
@@ -73,21 +73,36 @@ def test_default_batch_line_carries_every_baseline_config():
     """the default invocation (BASELINE batch sizes) times Waterworld, MultiWalker and the configs[4] shard in the same run and
     reports them under `workloads`; every launch of the headline carries fused resets (steady-state episode ages)"""
     env = dict(os.environ, MADRL_BENCH_CPU_BUDGET="0.5")   # every workload still runs its CPU sample, just a short one
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2"], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=600)
+    full = os.path.join(ROOT, "gpurun_out", "bench_full_test.json")
+    os.makedirs(os.path.dirname(full), exist_ok=True)
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--full-record", full], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][0]
+    # the driver keeps the TAIL of the output: the whole line -- every BASELINE config -- must fit a few KB (round 4's 15 KB line lost
+    # Waterworld and half of MultiWalker)
+    assert len(line) <= 6144, len(line)
     j = _last_json(r.stdout)
-    assert KEYS <= set(j) and j["config"]["envs_per_gpu"] == 65536
-    assert 0 < j["config"]["horizon_resets_per_env_in_timed_region"] < 1 and j["config"]["horizon_resets_per_step"] > 100
+    assert KEYS <= set(j) and j["config"]["envs_per_gpu"] == 65536 and j["data"] == "synthetic"
     wl = j["workloads"]
-    assert set(wl) == {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std"}
-    assert j["cpu_baseline"]["value"] > 0 and j["roofline"]["frac_vs_measured_copy"] > j["roofline"]["frac"]
-    assert len(j["config"]["region_ms_per_step"]) == 3 and j["config"]["region_ms_per_step_min"] <= j["ms_per_step"] + 1e-9
+    assert set(wl) == {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std", "multiwalker_w10", "pursuit_rollout"}
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
+    rf = j["roofline"]
+    # `frac` is priced by the wall clock of the timed region (ms_per_step), `frac_kernel` by the HIP events around the launches
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["frac_kernel"] >= rf["frac"] * 0.98 and rf["one_launch_ms"] > 0
+    assert len(j["config"]["region_ms_per_step"]) == 3 and min(j["config"]["region_ms_per_step"]) <= j["ms_per_step"] + 1e-6
+    assert j["config"]["rccl_ranks"] == 1 and j["config"]["collective_backend"] is None
     for name, w in wl.items():
         assert "error" not in w, (name, w)
-        assert w["value"] > 1e5 and w["roofline"]["frac"] > 0 and "workload" in w["config"], name
-        cb = w["cpu_baseline"]
-        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"], name
-    assert "multiwalker_ref.c" in wl["multiwalker"]["cpu_baseline"]["sample"]     # the independent restatement, not the product source
+        assert w["value"] > 1e5 and w["roofline"]["frac"] > 0 and w["workload"], name
+        if name != "pursuit_rollout":
+            cb = w["cpu_baseline"]
+            assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port", name
     assert wl["pursuit_colocate"]["roofline"]["kernel"].startswith("pursuit_wave_kernel")
-    assert wl["multiwalker"]["roofline"]["valu_frac"] > 0 and wl["multiwalker"]["config"]["envs_per_gpu"] == 16384
+    assert wl["multiwalker"]["roofline"]["valu_frac"] > 0 and wl["multiwalker"]["envs"] == 16384
+    assert wl["multiwalker_w10"]["roofline"]["valu_frac"] > 0 and "n_walkers=10" in wl["multiwalker_w10"]["workload"]
+    # the long record (prose, every key of the earlier rounds) goes to the file
+    fj = json.load(open(full))
+    assert 0 < fj["config"]["horizon_resets_per_env_in_timed_region"] < 1 and fj["config"]["horizon_resets_per_step"] > 100
+    assert "multiwalker_ref.c" in fj["workloads"]["multiwalker"]["cpu_baseline"]["sample"]     # the independent restatement, not the product source
+    assert fj["roofline"]["frac_vs_measured_copy"] > fj["roofline"]["frac"]

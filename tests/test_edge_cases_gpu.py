@@ -67,8 +67,9 @@ def test_configurations_the_library_refuses():
         BatchedMAWaterWorld(2, 2, n_sensors=300, n_envs=4, device=DEV)
     with pytest.raises(_lib.MadrlError, match="61 particles"):
         BatchedContinuousHostageWorld(10, 30, 22, 2, 2, n_envs=4, device=DEV)
-    with pytest.raises(_lib.MadrlError, match="n_walkers"):
-        BatchedMultiWalkerEnv(n_walkers=5, n_envs=4, device=DEV)
+    for w in (0, 11):   # 1 .. 10 run (the reference's curriculum, lessons/multiwalker/env.yaml)
+        with pytest.raises(_lib.MadrlError, match="n_walkers"):
+            BatchedMultiWalkerEnv(n_walkers=w, n_envs=4, device=DEV)
     with pytest.raises(_lib.MadrlError, match="no CPU path"):
         BatchedMAWaterWorld(2, 2, n_envs=4, device="cpu")
     env = BatchedMAWaterWorld(2, 2, n_envs=4, device=DEV)

@@ -423,3 +423,50 @@ def test_evader_control_free_running_and_dropin_types(kernel, size):
     obs, rew, done, info = one.step([4] * 5)
     assert [o is None for o in obs] == [False, True, False, False, True] and isinstance(rew, np.ndarray) and rew.shape == (5,)
     assert obs[2][75] == np.float32(1 / 5.0)   # id = index in the compacted layer (1: slot 1 is gone) / n_pursuers
+
+
+@pytest.mark.parametrize("kernel", ["wave", "generic"])
+def test_in_place_edits_of_the_returned_observations_are_noticed(kernel):
+    """step() / reset() return the persistent IN / OUT buffer itself -- the reference's local_obs (pursuit_evade.py:119-120), which it hands
+    out as views in its (R, R, 4) mode and as copies in its flatten mode (:441-449).  A caller that edits the tensor in place -- a
+    normaliser's `obs.sub_(mean)` -- changes the never-stored cells outside the map for good, as an edit of the reference's views would;
+    what it must NOT do is leave the fast path's stale-zero masks describing a buffer that no longer exists (they would write +0 over the
+    edited cells).  PyTorch's per-tensor version counter tells the env (BatchedPursuitEvade._check_obs_untouched): the run below equals
+    the oracle's, whose local_obs receives the edited buffer at every edit, bit for bit -- without any invalidate_obs() call."""
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from oracle import pursuit as po
+    maps = [rectangle_map(16, 16)]
+    kw = dict(n_pursuers=8, n_evaders=30, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local")
+    N, P, R = 192, 8, 7
+    env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=5, **kw)
+    env.set_kernel(kernel)
+    orc = po.PursuitOracle(maps, n_envs=N, seed=5, **kw)
+    obs, oobs = env.reset(), orc.reset()
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    rng = np.random.RandomState(4)
+    edits = 0
+
+    def mirror():   # the oracle's persistent buffer takes the values the edited tensor holds (channels 0 - 2 of every row; the id is not part of local_obs)
+        lo = orc.local_obs()
+        lo[:, :, :3] = obs.cpu().numpy()[:, :, :3 * R * R].reshape(N, P, 3, R, R).astype(np.float64)
+        orc.set_local_obs(lo)
+
+    for t in range(40):
+        if t % 7 == 3:      # an in-place edit of everything: never-stored cells that held 0 hold 0.25 from here on
+            obs.add_(0.25); mirror(); edits += 1
+        if t % 7 == 5:
+            obs.mul_(2.0); mirror(); edits += 1
+        if t == 20:         # ... and through a view
+            obs[:, 0].zero_(); mirror(); edits += 1
+        act = rng.randint(5, size=(N, 8))
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
+        oobs, orew, odone, orem = orc.step(act)
+        assert np.array_equal(obs.cpu().numpy(), oobs), "step %d: observations (never-stored cells included)" % t
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32))
+        if odone.any():
+            m = odone.astype(np.uint8)
+            obs, oobs = env.reset(mask=m), orc.reset(mask=m)
+            assert np.array_equal(obs.cpu().numpy(), oobs)
+    g = obs.cpu().numpy()[:, :, R * R:3 * R * R]
+    assert edits >= 10 and (np.abs(g) > 1.5).any(), "edited values survive in the never-stored cells (nothing in the map's range is that large)"
