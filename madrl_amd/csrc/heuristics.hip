@@ -12,48 +12,51 @@ enum : uint32_t { TAG_HEURISTIC_ACT = 3 };
 // order among equals), then a direction from atan2 quadrants.  The quadrant logic is a table over the evader's window cell,
 // built on the host with the reference's own float64 expression (madrl_amd/heuristics.py); 255 in the table or an empty
 // window = the reference's action_space.sample(), here Philox(row id, tick).
-// 8 lanes per row: lane s scans window rows s, s + 8, ... (R consecutive floats each, loaded in independent batches of eight before any is
-// compared); the packed (distance^2, cell) keys are min-reduced by shuffles.  The kernel reads one channel of every row -- a third of the
-// bytes -- but not a third of the DRAM traffic: measured 44 - 56 us for the 524 288 rows of 65 536 envs whichever way the lanes are dealt
-// (16 lanes per row with 64-byte coalesced passes: 56 us, the same in persistent blocks: 51 us; this mapping: see DESIGN.md), against
-// ~50 us for streaming the whole 310 MB buffer.
+// 16 lanes per row: lane s looks at window cells s, s + 16, ... of the evader channel (four independent loads in flight, then the
+// comparisons), so the 16 lanes of a row read 64 consecutive bytes per pass (flatten rows; the (R, R, 4) layout strides by its four
+// channels); the packed (distance^2, cell) keys are min-reduced by shuffles.  A block walks the rows in strides of the grid: few,
+// long-lived wavefronts.  The kernel reads one channel of every row -- a third of the bytes -- but nowhere near a third of the time of a
+// full pass over the buffer (~50 us for its 310 MB at 65 536 envs).  Measured for those 524 288 rows (kernel under rocprofv3 / rollout
+// step of scripts/rollout_bench.py): round 4's mapping -- 8 lanes per row, a lane per window row, load - compare - branch per cell --
+// 44 us; the same with its loads batched: 133 us per rollout step; 16 lanes per row, one short-lived wavefront per four rows: 56 / 132;
+// this form: 51 / 125 (two sub-batches: 119).
 __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__restrict__ obs, int64_t n_rows, int R, int64_t row_stride,
                                                              int cell_stride, int ch_offset, const uint8_t *__restrict__ table,
                                                              uint32_t k0, uint32_t k1, int64_t row_id_base, uint32_t tick,
                                                              const uint32_t *__restrict__ tick_dev, int32_t *__restrict__ actions) {
-    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const int sub = threadIdx.x & 7;
+    const int sub = threadIdx.x & 15;
     const int c = R / 2;  // :23 (Python 2 integer division)
-    uint32_t key = 0xFFFFFFFFu;
-    if (row < n_rows) {
+    const int cells = R * R;
+    for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += (int64_t)gridDim.x * 16) {
+        uint32_t key = 0xFFFFFFFFu;
         const float *o = obs + row * row_stride + ch_offset;
-        for (int i = sub; i < R; i += 8)
-            for (int j0 = 0; j0 < R; j0 += 8) {
-                float v[8];
+        for (int kb = sub; kb < cells; kb += 64) {
+            float v[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = j0 + q < R ? o[(int64_t)(i * R + j0 + q) * cell_stride] : 0.0f;
+            for (int q = 0; q < 4; ++q) v[q] = kb + 16 * q < cells ? o[(int64_t)(kb + 16 * q) * cell_stride] : 0.0f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (v[q] != 0.0f) {
-                        const int j = j0 + q;
-                        const uint32_t d2 = (uint32_t)((i - c) * (i - c) + (j - c) * (j - c));
-                        key = min(key, (d2 << 16) | (uint32_t)(i * R + j));
-                    }
-            }
-    }
-    key = min(key, (uint32_t)__shfl_xor((int)key, 1, 8));
-    key = min(key, (uint32_t)__shfl_xor((int)key, 2, 8));
-    key = min(key, (uint32_t)__shfl_xor((int)key, 4, 8));
-    if (row < n_rows && sub == 0) {
-        int act = 255;
-        if (key != 0xFFFFFFFFu) act = table[key & 0xFFFFu];
-        if (act == 255) {
-            const uint64_t id = (uint64_t)(row_id_base + row);
-            const uint32_t tk = tick + (tick_dev ? *tick_dev : 0u);  // device counter: survives hipGraph replay
-            const u32x4 r = philox4x32_10((uint32_t)id, tk, (uint32_t)(id >> 32), TAG_HEURISTIC_ACT, k0, k1);
-            act = (int)__umulhi(r.x, 5u);
+            for (int q = 0; q < 4; ++q)
+                if (v[q] != 0.0f) {
+                    const int k = kb + 16 * q, i = k / R, j = k - i * R;
+                    const uint32_t d2 = (uint32_t)((i - c) * (i - c) + (j - c) * (j - c));
+                    key = min(key, (d2 << 16) | (uint32_t)k);
+                }
         }
-        actions[row] = act;
+        key = min(key, (uint32_t)__shfl_xor((int)key, 8, 16));
+        key = min(key, (uint32_t)__shfl_xor((int)key, 1, 16));
+        key = min(key, (uint32_t)__shfl_xor((int)key, 2, 16));
+        key = min(key, (uint32_t)__shfl_xor((int)key, 4, 16));
+        if (sub == 0) {
+            int act = 255;
+            if (key != 0xFFFFFFFFu) act = table[key & 0xFFFFu];
+            if (act == 255) {
+                const uint64_t id = (uint64_t)(row_id_base + row);
+                const uint32_t tk = tick + (tick_dev ? *tick_dev : 0u);  // device counter: survives hipGraph replay
+                const u32x4 r = philox4x32_10((uint32_t)id, tk, (uint32_t)(id >> 32), TAG_HEURISTIC_ACT, k0, k1);
+                act = (int)__umulhi(r.x, 5u);
+            }
+            actions[row] = act;
+        }
     }
 }
 
@@ -143,8 +146,9 @@ int madrl_heuristic_pursuit(const float *obs, int64_t n_rows, int32_t obs_range,
                             int32_t ch_offset, const uint8_t *table_dev, uint64_t seed, int64_t row_id_base, uint32_t tick,
                             const uint32_t *tick_dev, int32_t *actions, void *stream) {
     if (!obs || !table_dev || !actions || n_rows < 1 || obs_range < 1 || obs_range > 255) return fail(MADRL_EINVAL, "heuristic_pursuit: bad argument");
-    const int64_t threads = n_rows * 8;
-    hipLaunchKernelGGL(pursuit_policy_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, n_rows,
+    int64_t blocks = (n_rows + 15) / 16;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // 16 four-wavefront blocks per CU: two rounds of resident wavefronts
+    hipLaunchKernelGGL(pursuit_policy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, obs, n_rows,
                        (int)obs_range, row_stride, (int)cell_stride, (int)ch_offset, table_dev, (uint32_t)seed, (uint32_t)(seed >> 32),
                        row_id_base, tick, tick_dev, actions);
     MADRL_HIP_TRY(hipGetLastError());

@@ -10,6 +10,7 @@
 #include "multiwalker_class.hpp"
 
 #include <new>
+#include <stdlib.h>
 
 struct madrl_multiwalker {
     const madrl::MwClassApi *api;
@@ -27,6 +28,12 @@ const MwClassApi *mw_class_of(const madrl_multiwalker_config *c) {
         return nullptr;
     }
     const MwClassApi *classes[3] = {&madrl_mw_class_c4, &madrl_mw_class_c8, &madrl_mw_class_c10};
+#ifdef MADRL_EXPERIMENTS   // measurement builds only (scripts/mw_occupancy.sh): run a walker count on a LARGER class than it needs (fewer envs per wavefront)
+    if (const char *e = getenv("MADRL_MW_MIN_CLASS")) {
+        const int want = atoi(e);
+        for (const MwClassApi *k : classes) if (c->n_walkers >= 1 && c->n_walkers <= k->cap_walkers && k->cap_walkers >= want) return k;
+    }
+#endif
     if (c->n_walkers >= 1)
         for (const MwClassApi *k : classes) if (c->n_walkers <= k->cap_walkers) return k;
     (void)fail(MADRL_EINVAL, "n_walkers=%d unsupported (1..%d)", c->n_walkers, madrl_mw_class_c10.cap_walkers);

@@ -105,19 +105,21 @@ __device__ __forceinline__ double np_pairwise_base(const double *a, int n) {
     for (; i < n; ++i) res += a[i];
     return res;
 }
-// numpy's recursive split above 128 elements (pairwise_sum in numpy/core/src/umath/loops_utils.h): n <= 1024 needs three levels
+// numpy's recursive split above 128 elements (pairwise_sum in numpy/core/src/umath/loops_utils.h).  The halves are uneven (n2 = n / 2 rounded
+// down to a multiple of 8, the rest goes right): 1 023 -> 504 + 519 -> ... 263 -> 128 + 135, and 135 splits once more -- four levels for
+// n <= 1 024 (three left the 49 counts 969 .. 1 023 with a flat sum over more than 128 elements at the bottom: another order of additions)
 template <int DEPTH>
 __device__ __forceinline__ double np_pairwise_sum_t(const double *a, int n) {
     if (n <= 128) return np_pairwise_base(a, n);
-    if constexpr (DEPTH == 0) return np_pairwise_base(a, n);   // (not reached: MAX_COUNT <= 1024)
+    if constexpr (DEPTH == 0) return np_pairwise_base(a, n);   // (not reached: MAX_COUNT <= 1024, tests/test_advice_regressions.py)
     else {
         int n2 = n / 2;
         n2 -= n2 % 8;
         return np_pairwise_sum_t<DEPTH - 1>(a, n2) + np_pairwise_sum_t<DEPTH - 1>(a + n2, n - n2);
     }
 }
-__device__ __forceinline__ double np_pairwise_sum(const double *a, int n) { return np_pairwise_sum_t<3>(a, n); }
-static_assert(MAX_COUNT <= 1024, "np_pairwise_sum: three levels of numpy's split");
+__device__ __forceinline__ double np_pairwise_sum(const double *a, int n) { return np_pairwise_sum_t<4>(a, n); }
+static_assert(MAX_COUNT <= 1024, "np_pairwise_sum: four levels of numpy's split");
 
 // mode 0: reset(mask)   mode 1: step (+ fused auto-reset)
 template <int NT>

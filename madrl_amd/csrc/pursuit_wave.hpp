@@ -684,6 +684,21 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
 #if MADRL_ABLATE & 2
                         clean = true;
 #endif
+#if MADRL_ABLATE & 32
+                        // what a scheme that REMEMBERS small stale values (two bits per cell: 0, 0.1, 0.2, other) and rebuilds them would add to
+                        // this pass: about twenty vector instructions per slot (second byte of the four values, two flag planes, byte-to-float
+                        // conversions, one fused multiply-add per cell).  With `& 2` (every float4 stored whole) this prices the scheme:
+                        // its stores at their best, its instructions at their count (Pursuit fast path, "stale values remembered").
+                        {
+                            uint32_t burn = acc;
+                            asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n"
+                                         "v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n"
+                                         "v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n"
+                                         "v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1"
+                                         : "+v"(burn) : "v"(v0));
+                            acc = burn;   // (an even number of XORs with the same value: unchanged)
+                        }
+#endif
                         // An outside cell with a non-zero stale value: leave it alone (Q2), store the inside cells one by one.  Plain
                         // (L2-cached) stores: partial lines must merge in L2 -- nontemporal partial writes cost a read-modify-write
                         // at the memory side (3x slower).  They are issued BEFORE the non-temporal store of the slot's other lanes: the

@@ -239,3 +239,52 @@ def test_zeroed_pursuit_config_keeps_the_reference_default_cpu():
     assert c.control_evaders == 0 and _lib.lib().madrl_pursuit_state_bytes(C.byref(c), 8, C.byref(b)) == 0
     c.control_evaders = 1
     assert _lib.lib().madrl_pursuit_state_bytes(C.byref(c), 8, C.byref(b)) == -1   # MADRL_EINVAL: n_evaders < n_pursuers
+
+
+def test_pairwise_sum_of_the_global_reward_is_numpys_for_every_count_cpu():
+    """rewards.mean() over n_pursuers float64 values (pursuit_evade.py:261) is numpy's pairwise add.reduce: halves of UNEVEN size above 128
+    elements (n2 = n / 2 rounded down to a multiple of 8).  1 023 -> 504 + 519 -> 256 + 263 -> 128 + 135 -> 64 + 71: FOUR levels of recursion
+    for n <= 1 024 -- the generic kernel's unrolled recursion had three, which left the counts 969 .. 1 023 with a flat sum at the bottom
+    (round 4's review).  The C restatement is checked against numpy itself for every count the library accepts, and the depth the kernel
+    source instantiates (np_pairwise_sum_t<DEPTH> in pursuit.hip) against the depth numpy's rule needs."""
+    import ctypes as C
+    import os
+    import re
+    from oracle import pursuit as po
+    L = po.lib()
+    L.po_pairwise_sum.restype = C.c_double
+    L.po_pairwise_sum.argtypes = [C.c_void_p, C.c_int]
+    L.po_pairwise_depth.argtypes = [C.c_int]
+    rng = np.random.RandomState(3)
+    deepest = 0
+    for n in list(range(1, 300)) + list(range(960, 1025)):
+        a = np.ascontiguousarray(rng.uniform(-5, 5, n) * 10.0 ** rng.randint(-6, 6, n))
+        assert L.po_pairwise_sum(a.ctypes.data_as(C.c_void_p), n) == float(np.add.reduce(a)), n
+        deepest = max(deepest, L.po_pairwise_depth(n))
+    assert deepest == 4 and L.po_pairwise_depth(968) == 3 and L.po_pairwise_depth(969) == 4
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "madrl_amd", "csrc", "pursuit.hip")).read()
+    assert int(re.search(r"return np_pairwise_sum_t<(\d+)>\(a, n\);", src).group(1)) >= deepest
+
+
+@pytest.mark.gpu
+def test_global_reward_mean_over_a_thousand_pursuers():
+    """... and the kernel itself at the top of the range: 1 000 pursuers, global reward, against the C oracle (exact)"""
+    from madrl_amd.maps import rectangle_map
+    from madrl_amd.pursuit import BatchedPursuitEvade
+    from oracle import pursuit as po
+    maps = [rectangle_map(40, 40)]
+    kw = dict(n_pursuers=1000, n_evaders=12, obs_range=3, n_catch=1, surround=False, flatten=True, reward_mech="global", urgency_reward=-0.1)
+    N = 8
+    env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=3, **kw)
+    orc = po.PursuitOracle(maps, n_envs=N, seed=3, **kw)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    rng = np.random.RandomState(0)
+    seen = set()
+    for t in range(12):
+        act = rng.randint(5, size=(N, 1000))
+        obs, rew, done, info = env.step(torch.as_tensor(act, device=DEV))
+        oobs, orew, odone, orem = orc.step(act)
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), t
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        seen.update(np.unique(orew).tolist())
+    assert len(seen) > 3
