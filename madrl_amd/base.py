@@ -110,6 +110,15 @@ class SingleEnvDelegate(object):
             raise AttributeError(name)
         return getattr(env, name)
 
+    def set_param_values(self, lut):
+        """madrl_environments/__init__.py:64-67 (setattr + setup()) on the engine that holds the parameters -- not on this shell, where the
+        mixin's own AbstractMAEnv.set_param_values would put them"""
+        self._env.set_param_values(lut)
+        self._after_set_params()
+
+    def _after_set_params(self):
+        """classes whose reference setup() ends in reset() (multi_walker.py:303) redo it here"""
+
     def __getstate__(self):
         return dict(self.__dict__)  # `_env`, the batched engine, pickles by constructor arguments (EzPickle-style)
 

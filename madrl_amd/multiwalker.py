@@ -237,6 +237,9 @@ class MultiWalkerEnv(SingleEnvDelegate, AbstractMAEnv):
     def _after_unpickle(self):
         self.reset()  # EzPickle re-runs the constructor, which ends in reset() (:271, :303)
 
+    def _after_set_params(self):
+        self.reset()  # setup() ends in reset() (:303)
+
     @property
     def agents(self):
         return self._env.agents

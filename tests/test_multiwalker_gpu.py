@@ -192,3 +192,36 @@ def test_n1_dropin_api_matches_reference_types():
     genv = MultiWalkerEnv(n_walkers=2, reward_mech="global", device=DEV)
     o, r, done, info = genv.step(np.zeros(8))
     assert isinstance(r, list) and len(r) == 2 and r[0] == r[1]
+
+
+def test_the_reference_curriculum_walks_through_the_capacity_classes():
+    """lessons/multiwalker/env.yaml: n_walkers 2, 3, ..., 10, applied by runners/curriculum.py:56-91 through set_param_values -> setup()
+    (madrl_environments/__init__.py:64-67).  Here a new walker count may mean another capacity class of the kernels: another handle over
+    another state buffer.  Every lesson must then behave like a freshly constructed env of that size (CPU build, byte for byte), and the N == 1
+    drop-in must follow too."""
+    from madrl_amd.multiwalker import MultiWalkerEnv
+    from oracle import multiwalker as mwo
+    N = 24
+    env = _mk(N, n_walkers=2, seed=13)
+    classes = []
+    rng = np.random.RandomState(8)
+    for W in (2, 3, 4, 5, 6, 7, 8, 9, 10, 3):
+        env.set_param_values({"n_walkers": W})
+        assert env.n_bodies == 5 * W + 1 and env.n_terrain == 200 * W // 8 and len(env.agents) == W
+        assert abs(env.package_length - 240 / 30.0 * W / 1.75) < 1e-12           # multi_walker.py:293-294
+        classes.append((env.capacity_walkers, env.lanes_per_env))
+        orc = mwo.MultiWalkerOracle(n_walkers=W, position_noise=0.0, angle_noise=0.0, n_envs=N, seed=13)
+        assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+        for t in range(6):
+            a = rng.uniform(-1, 1, (N, W, 4)).astype(np.float32)
+            obs, rew, done, _ = env.step(a)
+            oobs, orew, odone = orc.step(a)
+            assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone.astype(bool))
+        assert (env.state_buffer.cpu().numpy()[:, :orc.world_bytes] == orc.worlds()).all()
+    assert classes == [(4, 4)] * 3 + [(8, 8)] * 4 + [(10, 16)] * 2 + [(4, 4)]
+    one = MultiWalkerEnv(n_walkers=2, device=DEV)
+    one.set_param_values({"n_walkers": 9})
+    obs = one.reset()
+    assert len(obs) == 9 and len(one.agents) == 9
+    o, r, d, info = one.step(np.zeros((9, 4)))
+    assert len(o) == 9 and len(r) == 9
