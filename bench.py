@@ -607,6 +607,8 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
         # its slowest wavefront (16 envs in lockstep), so the binding resource is the latency of the longest per-env chain
         binding = ("latency of the longest per-env chain of dependent FP32 operations (180 + 60 Gauss-Seidel sweeps, time-of-impact sub-steps): "
                    "neither HBM nor VALU throughput (DESIGN.md 4c)")
+        if MW == 3:   # the unmodified multi_walker.py over the Box2D shim, timed in the build container (scripts/cpu_reference_bench.py)
+            rec_key = "multiwalker_c4_single_env_over_shim"
         flop_per_env_step, flop_src = envs[0].flops_per_env_step()
         extra = {"flop_per_env_step": flop_per_env_step, "flop_source": flop_src}
         workload_s = "MultiWalkerEnv n_walkers=%d, %d envs per GPU, horizon 500 (dynamics: from-scratch Box2D-subset solver, PARITY UNPINNED)" % (MW, N)

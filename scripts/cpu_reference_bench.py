@@ -14,6 +14,7 @@ Workloads, driven the way heuristics/pursuit.py:64-85 drives the env (reset, the
               flatten=True, reward_mech='local'); np.random.seed(0); actions RandomState(0).randint(5, size=8)
               (pursuit_evade.py:209-262)
   waterworld  MAWaterWorld(5, 10) defaults; actions U(-1, 1) [5, 2] (waterworld.py:220-436)
+  multiwalker MultiWalkerEnv(n_walkers=3) over the Box2D shim (round 5; see run_multiwalker)
 each as 1 process and as multiprocessing.Pool(os.cpu_count()) with one env per process, OMP_NUM_THREADS=1.
 """
 import argparse
@@ -84,6 +85,40 @@ def run_waterworld(arg):
     return steps, time.perf_counter() - t0, n_resets
 
 
+def run_multiwalker(arg):
+    """the UNMODIFIED multi_walker.py (n_walkers = 3, BASELINE configs[3]) -- over the test infrastructure's Box2D shim, i.e. the reference's
+    own Python env layer on the restated dynamics of oracle/multiwalker_ref.c: the only form in which this module runs in an image without
+    Box2D.  (With pybox2d the C++ library would take the place of that C file; the Python side, which dominates, is the reference's.)"""
+    seed, steps = arg
+    import numpy as np
+    from oracle import ref_loader
+    ref_loader.load()
+    shim = os.path.join(ROOT, "oracle", "shims_box2d")
+    if shim not in sys.path:
+        sys.path.insert(0, shim)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    from madrl_environments.walker.multi_walker import MultiWalkerEnv
+    np.random.seed(seed)
+    env = MultiWalkerEnv(n_walkers=3)
+    env.seed(seed)
+    rng = np.random.RandomState(seed)
+    env.reset()
+    for _ in range(10):
+        env.step(rng.uniform(-1, 1, (3, 4)))
+    env.reset()
+    t_in = 0
+    n_resets = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, _, done, _ = env.step(rng.uniform(-1, 1, (3, 4)))
+        t_in += 1
+        if done or t_in >= 500:
+            env.reset()
+            t_in = 0
+            n_resets += 1
+    return steps, time.perf_counter() - t0, n_resets
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -125,7 +160,7 @@ def port_same_host():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=1500)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_cpu_reference", "record.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_cpu_reference", "record.json"))
     args = ap.parse_args()
     from oracle import ref_loader
     if not ref_loader.reference_available():
@@ -142,6 +177,10 @@ def main():
                               **measure(run_pursuit, args.steps, cores)),
            "waterworld_c3_single_env": dict(config="MAWaterWorld(5, 10) defaults, 30 sensors; waterworld.py:220-436",
                                             **measure(run_waterworld, args.steps, cores)),
+           "multiwalker_c4_single_env_over_shim": dict(
+               config="MultiWalkerEnv(n_walkers=3) defaults (BASELINE configs[3]); the unmodified multi_walker.py over oracle/shims_box2d: the reference's "
+                      "Python env layer on the restated dynamics (oracle/multiwalker_ref.c) -- NOT pybox2d, which this image does not have",
+               **measure(run_multiwalker, max(200, args.steps // 5), cores)),
            "c_port_same_host": port_same_host(),
            "unit": "env-steps/s", "script": "scripts/cpu_reference_bench.py"}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

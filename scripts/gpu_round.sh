@@ -1,4 +1,5 @@
-# One GPU call that produces what a round is judged by: smoke, the whole GPU test suite, the default bench line (+ its long record).
+# One GPU call that produces what a round is judged by: smoke, the whole GPU test suite, the bench line as the driver asks for it
+# (python bench.py --gpus 1 --steps 20 --warmup 5) + its long record.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -6,7 +7,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; 
 tail -2 gpurun_out/smoke.log
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -8 gpurun_out/pytest_gpu.log
-timeout 900 python bench.py > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench.log 2>gpurun_out/bench.err; echo "bench rc=$?"
 tail -1 gpurun_out/bench.log | wc -c
 tail -1 gpurun_out/bench.log | python -c "
 import json,sys
