@@ -141,6 +141,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
             self._removed = torch.zeros(N, dtype=torch.int32, device=dev)
             self._shape_key = shape_key
             self._obs_is_fresh = True   # every element +0.0f, like the reference's local_obs at construction (:119-120)
+            self._obs_version = None    # (no launch has written this tensor yet: nothing to compare its version counter with)
         self.obs_dim = D
         self._destroy()
         h = C.c_void_p()
