@@ -84,6 +84,20 @@ def add_waterworld_shape(n_pursuers, n_evaders, n_poison, n_sensors, obs_dim=Non
     return _append_local("waterworld_specializations.def", "X(%d, %d, %d, %d, %d)   // added by madrl_amd.build" % (n_pursuers, n_evaders, n_poison, n_sensors, obs_dim))
 
 
+def specialised_shapes(def_name):
+    """the X(...) / XG(...) argument tuples of a csrc/*_specializations.def list and of its git-ignored .local.def companion"""
+    out = set()
+    for path in (os.path.join(CSRC, def_name), os.path.join(CSRC, def_name.replace(".def", ".local.def"))):
+        if os.path.exists(path):
+            for m in re.finditer(r"^\s*XG?\(([^)]*)\)", open(path).read(), re.M):
+                out.add(tuple(int(v) for v in m.group(1).split(",")))
+    return out
+
+
+def waterworld_is_specialised(n_pursuers, n_evaders, n_poison, n_sensors, obs_dim):
+    return (int(n_pursuers), int(n_evaders), int(n_poison), int(n_sensors), int(obs_dim)) in specialised_shapes("waterworld_specializations.def")
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 

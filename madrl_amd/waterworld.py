@@ -112,6 +112,8 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         self._handle = h
         if self._max_blocks:
             _lib.check(L.madrl_waterworld_set_launch(h, self._max_blocks))
+        if N >= 4096:
+            self._hint_fast_path(D)
         self._pursuers = [Archea(i + 1, D) for i in range(Np)]
         # A fused StandardizedEnv binding belongs to the handle that was just replaced (seed() and set_param_values() come
         # through here): bind the new handle to the SAME statistics / output tensors, or -- when the shapes changed -- to
@@ -124,6 +126,21 @@ class BatchedMAWaterWorld(AbstractMAEnv):
                 fresh = self.bind_standardize(tensors=None, **self._std_kwargs)
                 old.clear(); old.update(fresh)
                 self._std = old
+
+    _hinted = set()
+
+    def _hint_fast_path(self, D):
+        """A large batch of a shape that is not in csrc/waterworld_specializations.def runs on the generic instantiation (dynamic LDS layout,
+        run-time loop bounds: about half the speed): say once per shape how to give it its own kernel.  Results are identical either way."""
+        from . import build as _build
+        shape = (int(self.n_pursuers), int(self.n_evaders), int(self.n_poison), int(self.n_sensors), int(D))
+        if shape in BatchedMAWaterWorld._hinted or _build.waterworld_is_specialised(*shape):
+            return
+        import warnings
+        BatchedMAWaterWorld._hinted.add(shape)
+        warnings.warn("MAWaterWorld with %d pursuers / %d evaders / %d poison / %d sensors (obs_dim %d) runs on the generic kernel; `python -m madrl_amd.build "
+                      "--waterworld-shape %d %d %d %d %d` compiles the specialised kernel for this shape (results are identical, a step takes about half the "
+                      "time)" % (shape + shape), stacklevel=3)
 
     def set_launch(self, max_blocks=0):
         self._max_blocks = int(max_blocks)

@@ -173,6 +173,8 @@ def test_which_shapes_can_have_a_fast_path_and_how_they_are_added(tmp_path, monk
     assert b.add_pursuit_shape(16, 16, 8, 30, 7, 1) is False and b.add_waterworld_shape(4, 8, 6, 24) is True and b.add_waterworld_shape(5, 10, 10, 30) is False
     assert (csrc / "pursuit_specializations.local.def").read_text().startswith("X(20, 20, 6, 10, 5, 1)")
     assert (csrc / "waterworld_specializations.local.def").read_text().startswith("X(4, 8, 6, 24, 171)")
+    # ... and is then a specialised shape for the hint a large generic-kernel batch gives (madrl_amd/waterworld.py _hint_fast_path)
+    assert b.waterworld_is_specialised(4, 8, 6, 24, 171) and b.waterworld_is_specialised(5, 10, 10, 30, 213) and not b.waterworld_is_specialised(4, 8, 6, 25, 178)
     with pytest.raises(ValueError):
         b.add_pursuit_shape(10, 10, 4, 4, 4, 1)
     for src in ("pursuit.hip", "waterworld.hip"):

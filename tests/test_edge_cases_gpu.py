@@ -123,3 +123,22 @@ def test_more_than_253_agents_on_one_cell_raise_the_overflow_bit():
     env.reset(mask=np.array([1, 0, 0], np.uint8), positions=pos[[1, 1, 1]])
     _, _, _, info = env.step(stay, evader_actions=np.full((N, E), 4, np.int32))
     assert not info["count_overflow"].any()
+
+
+def test_large_generic_waterworld_batch_says_how_to_get_its_kernel():
+    """a shape outside csrc/waterworld_specializations.def runs (about half as fast) on the generic instantiation: a batch of 4 096 envs or more
+    says so once per shape, with the command that compiles its kernel; specialised shapes and small batches stay quiet"""
+    import warnings
+    from madrl_amd.waterworld import BatchedMAWaterWorld
+    BatchedMAWaterWorld._hinted.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        BatchedMAWaterWorld(5, 10, n_envs=4096, device=DEV)            # BASELINE shape: specialised
+        BatchedMAWaterWorld(4, 7, n_envs=256, device=DEV)              # small batch
+        assert not [x for x in w if "generic kernel" in str(x.message)]
+        e = BatchedMAWaterWorld(4, 7, n_envs=4096, device=DEV)
+        BatchedMAWaterWorld(4, 7, n_envs=4096, device=DEV)             # once per shape
+    msgs = [str(x.message) for x in w if "generic kernel" in str(x.message)]
+    assert len(msgs) == 1 and "--waterworld-shape 4 7 10 30 213" in msgs[0]
+    obs = e.reset()
+    assert obs.shape == (4096, 4, 213)
