@@ -997,7 +997,10 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, const ColdView &Cd, Scratch
     const int ev = contact_update(sl, mo);
     if (ev == 1) contact_begin_flags(Wd, bA, bB);
     if (ev != 0) {   // "if (touching != wasTouching) bodyA->SetAwake(true), bodyB->SetAwake(true)"
-        for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!Wd.awake.test(b)) { Wd.awake.set(b); Cd.sleep_time[b] = 0.0f; } }
+        // (the pairs are dealt over the env's lanes: the flag word is OR-ed atomically; two lanes waking the same body do the same thing)
+        BodyBits wake = BodyBits::none();
+        for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!Wd.awake.test(b)) { wake.set(b); Cd.sleep_time[b] = 0.0f; } }
+        if (wake.any()) par.or_bits(&Wd.awake, wake);
     }
     (void)was;
     if (sl.touching)
@@ -1664,9 +1667,10 @@ MW_HD bool toi_update_contact(const Model &M, Hot &Wd, const ColdView &Cd, Slot 
 // in Box2D's lists) and which box of the other body a new package / hull pair is tested against.  Every chain therefore logs its events
 // (time, contact), numbers the contacts it creates provisionally, and afterwards one lane merges the logs into Box2D's order -- smallest
 // time first, among equal times the contact nearest the front of the world's list -- hands out the final numbers and creates the pairs.
-// events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7 with up to four walkers, and about
-// three per walker in the step that follows a reset, when every leg arrives at the ground at once)
-constexpr int TOI_MAX_EVENTS = MAX_WALKERS <= 4 ? 16 : 6 * MAX_WALKERS;
+// events of one env in one SolveTOI that the log holds (sticky Hot::overflow bit 2 past it; seen: <= 7 with up to four walkers, and at most
+// two per walker beyond -- 10, 12, 14, 16, 18, 20 for 5 .. 10 walkers, in the step that follows a reset, when both lower legs of every
+// walker arrive at the ground at once: 256 envs x 200 steps each)
+constexpr int TOI_MAX_EVENTS = MAX_WALKERS <= 4 ? 16 : 4 * MAX_WALKERS;
 constexpr int TOI_MAX_PAIR_EVENTS = MAX_WALKERS <= 4 ? 4 : MAX_WALKERS + 2;   // ... those of them that moved the proxy of the package or of a hull
 struct ToiEvent { float alpha; uint16_t slot, batch; uint8_t body, idx, moved, fat_i; };
 struct ToiWork {            // shared by the lanes of an env (LDS in the HIP kernel)
@@ -1680,9 +1684,9 @@ struct ToiWork {            // shared by the lanes of an env (LDS in the HIP ker
     int n_pend;
     struct { uint8_t body, k; uint16_t pad_; float alpha; } pend[MAXB];
 #if MW_CAPW > 4
-    // the merge's bookkeeping (one lane; local arrays up to four walkers, see Scratch::bi_lane)
+    // the merge's bookkeeping (one lane; a local array up to four walkers, see Scratch::bi_lane).  (Its other array, the current boxes of the
+    // package and the hulls, is fat0 itself: nothing reads the boxes of the pass's beginning once the merge has started.)
     uint8_t mg_next_idx[MAXB];
-    float mg_cur_fat[1 + MAX_WALKERS][4];
 #endif
 };
 struct ToiLaneWork {        // per lane: the cached times of impact of the contacts of the body it is working on
@@ -1966,13 +1970,13 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
     if (L0 == 0) {
 #if MW_CAPW > 4
         uint8_t (&next_idx)[MAXB] = T.mg_next_idx;
-        float (&cur_fat)[1 + MAX_WALKERS][4] = T.mg_cur_fat;
+        float (&cur_fat)[1 + MAX_WALKERS][4] = T.fat0;
 #else
         uint8_t next_idx[MAXB];
         float cur_fat[1 + MAX_WALKERS][4];
+        for (int p = 0; p <= M.W; ++p) for (int q = 0; q < 4; ++q) cur_fat[p][q] = T.fat0[p][q];
 #endif
         for (int b = 0; b < NB; ++b) next_idx[b] = 0;
-        for (int p = 0; p <= M.W; ++p) for (int q = 0; q < 4; ++q) cur_fat[p][q] = T.fat0[p][q];
         for (int r = 0; r < n; ++r) {
             int best = -1;
             float best_alpha = 0.0f;
@@ -2040,7 +2044,9 @@ MW_HD_INLINE void step_collide(const Model &M, Hot &Wd, const ColdView &Cd, Scra
     // ---- b2ContactManager::Collide: every contact is updated (D4); Begin / EndContact -> ContactDetector flags
     for (int bi = L0; bi < NB; bi += LN) collide_body_terrain(M, Wd, Cd, S, MP, par, bi);
     par.sync();
-    if (L0 == 0) for (int p = 0; p < NDP; ++p) collide_dyn_pair(M, Wd, Cd, S, MP, par, p);   // may wake bodies: one lane
+    // package - hull and hull - hull pairs (n (n + 1) / 2 of them: 55 with ten walkers), dealt over the lanes: a pair touches its own cache slot,
+    // sets flags that only ever go from 0 to 1 and wakes bodies through an atomic OR, so which lane runs it when decides nothing
+    for (int p = L0; p < NDP; p += LN) collide_dyn_pair(M, Wd, Cd, S, MP, par, p);
     par.sync();
     // ---- b2World::Solve: islands, constraint order and schedule (one lane)
     if (L0 == 0) build_islands(M, Wd, Cd, S, MP);
