@@ -265,6 +265,9 @@ def main():
     run(MultiWalkerEnv, "w10_local", 10, "local", episodes=2, steps=120, seed=41, prefix=pre, zero_from=30)
     run(MultiWalkerEnv, "w10_onehot_noise", 10, "local", episodes=2, steps=60, seed=42, prefix=pre, one_hot=True, noise=(1e-3, 1e-3, 99, 7),
         terminate_on_fall=False)
+    run(MultiWalkerEnv, "w6_global", 6, "global", episodes=2, steps=100, seed=43, prefix=pre, fall_reward=-20.0)
+    run(MultiWalkerEnv, "w7_noterminate", 7, "local", episodes=2, steps=120, seed=44, prefix=pre, zero_from=20, terminate_on_fall=False, drop_reward=-50.0)
+    run(MultiWalkerEnv, "w9_local", 9, "local", episodes=2, steps=100, seed=45, prefix=pre)
     # files named multiwalker_resetdraws_*: a different layout (no episodes), replayed by its own test
     record_philox_resets(MultiWalkerEnv, 3, seed=0x1234567890ABCDEF, gid0=1000, n=24, prefix="multiwalker_resetdraws_")
     record_philox_resets(MultiWalkerEnv, 2, seed=7, gid0=0, n=12, prefix="multiwalker_resetdraws_")
