@@ -1,10 +1,12 @@
 # round 5: kernel stats + PMC traffic of every workload of the bench line -> gpurun_out/profile/<name>/ (copy to profiles/)
+#   scripts/profile_r05.sh [workload-name-filter]
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for spec in "pursuit r05_wave pursuit_wave_kernel" "multiwalker r05_multiwalker mw_step_kernel" "multiwalker_w10 r05_multiwalker_w10 mw_step_kernel" \
             "pursuit_rollout r05_rollout pursuit_" "waterworld r05_waterworld waterworld_kernel" "pursuit_c5 r05_c5 pursuit_group_kernel" \
             "pursuit_colocate r05_colocate pursuit_wave_kernel" "waterworld_std r05_waterworld_std obsnorm_pairs"; do
   set -- $spec
+  if [ -n "$FILTER" ] && [ "$1" != "$FILTER" ]; then continue; fi
   echo "=== profile $1"; bash scripts/profile_workload.sh $1 $2 $3 2>&1 | tail -5
 done
-echo "=== profile pursuit, one launch per step"; bash scripts/profile_workload.sh pursuit r05_wave_one_launch pursuit_wave_kernel --streams 1 2>&1 | tail -4
+if [ -z "$FILTER" ]; then echo "=== profile pursuit, one launch per step"; bash scripts/profile_workload.sh pursuit r05_wave_one_launch pursuit_wave_kernel --streams 1 2>&1 | tail -4; fi
