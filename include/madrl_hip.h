@@ -344,6 +344,12 @@ typedef struct madrl_multiwalker_config {
     int32_t auto_reset;
     int32_t discrete_only;    /* 0 (default): Box2D's continuous pass (b2World::SolveTOI, continuousPhysics = true, the b2World default
                                  the reference runs with) follows every discrete solve; 1: b2World.continuousPhysics = False */
+    int32_t polygon_revision; /* which b2CollidePolygons the hull / package pairs go through.  0 (default): Box2D 2.3.0 -- hill-climbing
+                                 b2FindMaxSeparation from the edge that faces the other centroid, reference face by the 0.98 / 0.001
+                                 hysteresis.  1: later 2.3.x revisions -- every edge normal against the deepest vertex, poly1 = B only beyond
+                                 0.1 * b2_linearSlop.  The revision the authors' pybox2d wrapped is not recorded in the reference tree; the two
+                                 differ on about 1 - 4 % of env-steps.  Both restatements implement both. */
+    int32_t reserved0;        /* 0 */
     double position_noise, angle_noise, forward_reward, fall_reward, drop_reward;
     uint64_t seed;
     int64_t env_id_base;

@@ -61,7 +61,7 @@ class MultiWalkerConfig(C.Structure):
     """mirror of madrl_multiwalker_config (include/madrl_hip.h)"""
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "n_walkers", "reward_global", "terminate_on_fall", "one_hot", "max_steps", "auto_reset",
-        "discrete_only")] + [(n, C.c_double) for n in (
+        "discrete_only", "polygon_revision", "reserved0")] + [(n, C.c_double) for n in (
             "position_noise", "angle_noise", "forward_reward", "fall_reward", "drop_reward")] + [
                 ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 

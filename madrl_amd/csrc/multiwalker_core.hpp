@@ -265,6 +265,7 @@ struct Model {
     int W, NB, NJ, NT;  // walkers, bodies, joints, terrain points
     int max_manifolds;  // size of the active-manifold pool of a step (Scratch::m)
     int continuous;     // b2World continuousPhysics (Box2D's default: on)
+    int poly_rev;       // which b2CollidePolygons the hull / package pairs go through: 0 = Box2D 2.3.0 (default), 1 = later 2.3.x revisions
     Shape shape[N_SHAPES];
     JointDef jd[MAXJ];
     float package_length, package_scale;
@@ -367,6 +368,7 @@ inline void poly_mass(Shape &s, float density) {
 inline void build_model(Model &M, int n_walkers) {
     M.W = n_walkers; M.NB = 5 * n_walkers + 1; M.NJ = 4 * n_walkers;
     M.continuous = 1;
+    M.poly_rev = 0;
     // active-manifold pool: observed maxima of simultaneously touching pairs over long random / collapsed rollouts are 18, 25, 34
     // for 2, 3, 4 walkers and 30 .. 44 for 5 .. 10 (6 per walker + 16 there); a pair past the pool is ignored for the step and raises the
     // sticky Hot::overflow bit
@@ -626,19 +628,36 @@ MW_HD float find_max_separation(int *edge_index, const Shape &p1, Xf xf1, const 
     return best_sep;
 }
 
-// b2CollidePolygons (2.3.0: reference face chosen with the 0.98 / 0.001 hysteresis)
-MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shape &pB, Xf xfB) {
+// ... and b2FindMaxSeparation as LATER 2.3.x revisions have it: every edge normal of poly1, taken to poly2's frame, against the deepest
+// vertex of poly2 -- no hill climbing, no centroids (Model::poly_rev = 1; which revision the authors' pybox2d wrapped is not recorded)
+MW_HD float find_max_separation_all_edges(int *edge_index, const Shape &p1, Xf xf1, const Shape &p2, Xf xf2) {
+    const Xf xf = mulT(xf2, xf1);
+    int best = 0;
+    float max_sep = -3.402823466e+38f;
+    for (int i = 0; i < p1.n; ++i) {
+        const V2 n = mul(xf.q, p1.nrm[i]), v1 = mul(xf, p1.v[i]);
+        float si = 3.402823466e+38f;
+        for (int j = 0; j < p2.n; ++j) { const float sij = dot(n, p2.v[j] - v1); if (sij < si) si = sij; }
+        if (si > max_sep) { max_sep = si; best = i; }
+    }
+    *edge_index = best;
+    return max_sep;
+}
+
+// b2CollidePolygons (rev 0 = 2.3.0: hill-climbing search, reference face chosen with the 0.98 / 0.001 hysteresis; rev 1 = later 2.3.x:
+// exhaustive search, poly1 = B only beyond 0.1 * b2_linearSlop)
+MW_HD void collide_polygons(ManifoldOut &mo, const Shape &pA, Xf xfA, const Shape &pB, Xf xfB, int rev) {
     MW_FLOPS(420);   // b2CollidePolygons: two b2FindMaxSeparation searches, incident edge, two clips
     mo.npts = 0;
     const float total_radius = 2.0f * POLY_RADIUS;
     int edgeA = 0, edgeB = 0;
-    const float sepA = find_max_separation(&edgeA, pA, xfA, pB, xfB);
+    const float sepA = rev ? find_max_separation_all_edges(&edgeA, pA, xfA, pB, xfB) : find_max_separation(&edgeA, pA, xfA, pB, xfB);
     if (sepA > total_radius) return;
-    const float sepB = find_max_separation(&edgeB, pB, xfB, pA, xfA);
+    const float sepB = rev ? find_max_separation_all_edges(&edgeB, pB, xfB, pA, xfA) : find_max_separation(&edgeB, pB, xfB, pA, xfA);
     if (sepB > total_radius) return;
     const Shape *p1, *p2; Xf xf1, xf2; int edge1, flip;
     const float k_relative_tol = 0.98f, k_absolute_tol = 0.001f;
-    if (sepB > k_relative_tol * sepA + k_absolute_tol) { p1 = &pB; p2 = &pA; xf1 = xfB; xf2 = xfA; edge1 = edgeB; mo.type = 1; flip = 1; }
+    if (rev ? (sepB > sepA + 0.1f * LINEAR_SLOP) : (sepB > k_relative_tol * sepA + k_absolute_tol)) { p1 = &pB; p2 = &pA; xf1 = xfB; xf2 = xfA; edge1 = edgeB; mo.type = 1; flip = 1; }
     else { p1 = &pA; p2 = &pB; xf1 = xfA; xf2 = xfB; edge1 = edgeA; mo.type = 0; flip = 0; }
     ClipV inc[2];
     {   // b2FindIncidentEdge
@@ -992,7 +1011,7 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, const ColdView &Cd, Scratch
     ManifoldOut mo; mo.npts = 0;
     const Xf xfA = body_xf(M, Wd.b[bA], bA), xfB = body_xf(M, Wd.b[bB], bB);
     const AABB ta = poly_aabb(sA, xfA), tb = poly_aabb(sB, xfB);
-    if (!(ta.lx > tb.hx + 0.1f || tb.lx > ta.hx + 0.1f || ta.ly > tb.hy + 0.1f || tb.ly > ta.hy + 0.1f)) collide_polygons(mo, sA, xfA, sB, xfB);
+    if (!(ta.lx > tb.hx + 0.1f || tb.lx > ta.hx + 0.1f || ta.ly > tb.hy + 0.1f || tb.ly > ta.hy + 0.1f)) collide_polygons(mo, sA, xfA, sB, xfB, M.poly_rev);
     const bool was = sl.touching != 0;
     const int ev = contact_update(sl, mo);
     if (ev == 1) contact_begin_flags(Wd, bA, bB);

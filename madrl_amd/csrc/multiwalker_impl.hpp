@@ -501,6 +501,7 @@ int k_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device
     memset(&M, 0, sizeof(M));
     mw::build_model(M, cfg->n_walkers);
     M.continuous = cfg->discrete_only ? 0 : 1;
+    M.poly_rev = cfg->polygon_revision ? 1 : 0;
 #ifdef MADRL_EXPERIMENTS   // measurement builds only (scripts/variants.sh): the production library takes nothing from the process environment
     if (const char *e = getenv("MADRL_MW_TOI")) M.continuous = atoi(e);  // 0 = no continuous pass, 2 = candidates only
 #endif

@@ -42,7 +42,7 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
     def __init__(self, n_walkers=2, position_noise=1e-3, angle_noise=1e-3, reward_mech='local', forward_reward=1.0,
                  fall_reward=-100.0, drop_reward=-100.0, terminate_on_fall=True, one_hot=False,
                  n_envs=1, device="cuda:0", seed=0, env_id_base=0, max_steps=0, auto_reset=False, max_blocks=0,
-                 continuous_physics=True):
+                 continuous_physics=True, box2d_polygon_revision=0):
         self._ctor = dict(locals())
         self._ctor.pop("self"); self._ctor.pop("__class__", None)
         self.n_walkers, self.position_noise, self.angle_noise = n_walkers, position_noise, angle_noise
@@ -52,6 +52,8 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         self._seed_value, self.env_id_base = int(seed), int(env_id_base)
         self.max_steps, self.auto_reset = int(max_steps), bool(auto_reset)   # (max_blocks: accepted for old call sites, unused -- a launch is one wavefront per group of envs)
         self.continuous_physics = bool(continuous_physics)  # b2World.continuousPhysics (Box2D default True; the reference never changes it)
+        # which b2CollidePolygons the hull / package contacts go through: 0 = Box2D 2.3.0 (default), 1 = later 2.3.x revisions (include/madrl_hip.h)
+        self.box2d_polygon_revision = int(box2d_polygon_revision)
         self._handle = None
         self.setup()
 
@@ -62,6 +64,7 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         c.terminate_on_fall, c.one_hot = int(bool(self.terminate_on_fall)), int(bool(self.one_hot))
         c.max_steps, c.auto_reset = self.max_steps, int(self.auto_reset)
         c.discrete_only = 0 if getattr(self, "continuous_physics", True) else 1
+        c.polygon_revision = 1 if getattr(self, "box2d_polygon_revision", 0) else 0
         c.position_noise, c.angle_noise = float(self.position_noise), float(self.angle_noise)
         c.forward_reward, c.fall_reward, c.drop_reward = float(self.forward_reward), float(self.fall_reward), float(self.drop_reward)
         c.seed, c.env_id_base = self._seed_value, self.env_id_base

@@ -36,7 +36,7 @@ def _p(a):
 class MultiWalkerOracle(object):
     def __init__(self, n_walkers=2, position_noise=1e-3, angle_noise=1e-3, reward_mech="local", forward_reward=1.0,
                  fall_reward=-100.0, drop_reward=-100.0, terminate_on_fall=True, one_hot=False, n_envs=1, seed=0,
-                 env_id_base=0, lanes_descending=False):
+                 env_id_base=0, lanes_descending=False, polygon_revision=0):
         L = lib(n_walkers)
         self.L = L
         L.mwo_create.restype = C.c_void_p
@@ -56,6 +56,8 @@ class MultiWalkerOracle(object):
         L.mwo_set_one_hot(self.h, int(bool(one_hot)))
         L.mwo_set_lane_order.argtypes = [C.c_void_p, C.c_int]
         L.mwo_set_lane_order(self.h, int(bool(lanes_descending)))   # order in which the emulated solver lanes run: must not matter
+        L.mwo_set_polygon_revision.argtypes = [C.c_void_p, C.c_int]
+        L.mwo_set_polygon_revision(self.h, int(polygon_revision))   # b2CollidePolygons: 0 = Box2D 2.3.0 (default), 1 = later 2.3.x revisions
         self.D = L.mwo_obs_dim(self.h)
         self.NB, self.NT = L.mwo_num_bodies(self.h), L.mwo_num_terrain(self.h)
         self.world_bytes = L.mwo_world_bytes()

@@ -34,6 +34,7 @@ extern "C" {
 int mwo_obs_dim(const MwOracle *o) { return mw::obs_dim_of(o->C); }
 void mwo_set_one_hot(MwOracle *o, int one_hot) { o->C.one_hot = one_hot ? 1 : 0; }
 void mwo_set_lane_order(MwOracle *o, int descending) { o->rev = descending != 0; }
+void mwo_set_polygon_revision(MwOracle *o, int rev) { o->M.poly_rev = rev ? 1 : 0; }   /* 0: b2CollidePolygons of Box2D 2.3.0 (default), 1: of later 2.3.x */
 void mwo_set_continuous(MwOracle *o, int on) { o->M.continuous = on ? 1 : 0; }  /* b2World continuousPhysics: experiments only */
 int mwo_world_bytes(void) { return (int)sizeof(mw::World); }
 /* layout figures the kernels' LDS blocks are computed from (multiwalker_impl.hpp k_create): sizeof(Hot), the solver's part of Scratch, Scratch without

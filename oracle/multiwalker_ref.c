@@ -365,19 +365,40 @@ static float find_max_separation(int *edgeIndex, const Shape *poly1, Xform xf1, 
     *edgeIndex = bestEdge;
     return bestSeparation;
 }
-static void collide_polygons(Manifold *m, const Shape *polyA, Xform xfA, const Shape *polyB, Xform xfB) {
+/* b2CollidePolygon.cpp as it reads in LATER 2.3.x revisions: b2FindMaxSeparation visits every edge normal of poly1 (in poly2's frame) and keeps the
+ * one whose deepest point of poly2 is the least deep -- no hill climbing, no centroids -- and b2CollidePolygons prefers poly1 = B only beyond
+ * 0.1 * b2_linearSlop.  Which revision the authors' pybox2d wrapped is not recorded anywhere: World::polygonRevision
+ * selects (0 = 2.3.0 above, the default; 1 = this one), so that whoever pins the dynamics against a real Box2D can try both. */
+static float find_max_separation_all_edges(int *edgeIndex, const Shape *poly1, Xform xf1, const Shape *poly2, Xform xf2) {
+    const Xform xf = xmulT_xx(xf2, xf1);
+    int bestIndex = 0;
+    float maxSeparation = -b2_maxFloat;
+    for (int i = 0; i < poly1->count; ++i) {
+        const Vec2 n = rmul(xf.q, poly1->n[i]);            /* poly1 normal in frame 2 */
+        const Vec2 v1 = xmul(xf, poly1->v[i]);
+        float si = b2_maxFloat;                            /* deepest point for normal i */
+        for (int j = 0; j < poly2->count; ++j) {
+            const float sij = vdot(n, vsub(poly2->v[j], v1));
+            if (sij < si) si = sij;
+        }
+        if (si > maxSeparation) { maxSeparation = si; bestIndex = i; }
+    }
+    *edgeIndex = bestIndex;
+    return maxSeparation;
+}
+static void collide_polygons(Manifold *m, const Shape *polyA, Xform xfA, const Shape *polyB, Xform xfB, int revision) {
     m->pointCount = 0;
     const float totalRadius = polyA->radius + polyB->radius;
     int edgeA = 0, edgeB = 0;
-    const float separationA = find_max_separation(&edgeA, polyA, xfA, polyB, xfB);
+    const float separationA = revision ? find_max_separation_all_edges(&edgeA, polyA, xfA, polyB, xfB) : find_max_separation(&edgeA, polyA, xfA, polyB, xfB);
     if (separationA > totalRadius) return;
-    const float separationB = find_max_separation(&edgeB, polyB, xfB, polyA, xfA);
+    const float separationB = revision ? find_max_separation_all_edges(&edgeB, polyB, xfB, polyA, xfA) : find_max_separation(&edgeB, polyB, xfB, polyA, xfA);
     if (separationB > totalRadius) return;
     const Shape *poly1, *poly2;
     Xform xf1, xf2;
     int edge1, flip;
     const float k_relativeTol = 0.98f, k_absoluteTol = 0.001f;
-    if (separationB > k_relativeTol * separationA + k_absoluteTol) {
+    if (revision ? (separationB > separationA + 0.1f * b2_linearSlop) : (separationB > k_relativeTol * separationA + k_absoluteTol)) {
         poly1 = polyB; poly2 = polyA; xf1 = xfB; xf2 = xfA; edge1 = edgeB; m->type = MF_FACE_B; flip = 1;
     } else {
         poly1 = polyA; poly2 = polyB; xf1 = xfA; xf2 = xfB; edge1 = edgeA; m->type = MF_FACE_A; flip = 0;
@@ -887,6 +908,7 @@ typedef struct World {
     int jointCount, jointList;
     Vec2 gravity;
     int allowSleep, continuousPhysics, warmStarting, newFixture, stepComplete;
+    int polygonRevision;   /* 0: b2CollidePolygons of 2.3.0 (hill-climbing b2FindMaxSeparation), 1: of later 2.3.x revisions (see collide_polygons) */
     float inv_dt0;
     ContactCallback listener;
     void *listenerUser;
@@ -991,7 +1013,7 @@ static int world_create_revolute(World *w, int bodyA, int bodyB, Vec2 anchorA, V
 static void contact_evaluate(World *w, Contact *c, Manifold *m) {
     Body *bA = &w->bodies[c->bodyA], *bB = &w->bodies[c->bodyB];
     if (bA->shape.type == SHAPE_EDGE) collide_edge_and_polygon(m, &bA->shape, bA->xf, &bB->shape, bB->xf);
-    else collide_polygons(m, &bA->shape, bA->xf, &bB->shape, bB->xf);
+    else collide_polygons(m, &bA->shape, bA->xf, &bB->shape, bB->xf, w->polygonRevision);
 }
 static void contact_update(World *w, int ci) {             /* b2Contact::Update */
     Contact *c = &w->contacts[ci];
@@ -1930,7 +1952,7 @@ static const double PACKAGE_POLY[4][2] = {{-120, 5}, {120, 5}, {120, -5}, {-120,
 enum { KIND_TERRAIN = 0, KIND_PACKAGE = 1, KIND_HULL = 2, KIND_UPPER = 3, KIND_LOWER = 4 };
 
 typedef struct {
-    int32_t n_walkers, reward_global, terminate_on_fall, one_hot, continuous_physics, reserved0;
+    int32_t n_walkers, reward_global, terminate_on_fall, one_hot, continuous_physics, polygon_revision;
     double position_noise, angle_noise, forward_reward, fall_reward, drop_reward;
     uint64_t seed;
     int64_t env_id_base;
@@ -1999,6 +2021,7 @@ static void mw_reset_world(const mwr_config *cfg, MwEnv *e, uint32_t gid, const 
     World *w = &e->world;
     world_init(w, V(0.0f, -10.0f));           /* Box2D.b2World(): gravity (0, -10), doSleep True (:280); a fresh world, see D1 */
     w->continuousPhysics = cfg->continuous_physics;
+    w->polygonRevision = cfg->polygon_revision ? 1 : 0;
     w->listener = mw_contact_listener; w->listenerUser = e;
     e->game_over = 0; e->prev_package_shaping = 0.0; e->t = 0;
     for (int i = 0; i < MW_MAX_WALKERS; ++i) { e->fallen[i] = 0; e->prev_shaping[i] = 0.0; e->hull[i] = -1; }

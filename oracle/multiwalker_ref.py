@@ -13,7 +13,7 @@ _LIBS = {}
 
 
 class MwrConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n_walkers", "reward_global", "terminate_on_fall", "one_hot", "continuous_physics", "reserved0")] + [
+    _fields_ = [(n, C.c_int32) for n in ("n_walkers", "reward_global", "terminate_on_fall", "one_hot", "continuous_physics", "polygon_revision")] + [
         (n, C.c_double) for n in ("position_noise", "angle_noise", "forward_reward", "fall_reward", "drop_reward")] + [
             ("seed", C.c_uint64), ("env_id_base", C.c_int64)]
 
@@ -51,10 +51,11 @@ class MultiWalkerRef(object):
     """Batched CPU MultiWalkerEnv; observations and rewards float64 like the reference's Python side."""
 
     def __init__(self, n_walkers=2, position_noise=1e-3, angle_noise=1e-3, reward_mech="local", forward_reward=1.0, fall_reward=-100.0,
-                 drop_reward=-100.0, terminate_on_fall=True, one_hot=False, n_envs=1, seed=0, env_id_base=0, continuous_physics=True, poly=False):
+                 drop_reward=-100.0, terminate_on_fall=True, one_hot=False, n_envs=1, seed=0, env_id_base=0, continuous_physics=True, poly=False,
+                 polygon_revision=0):
         self.L = lib(poly)
         self.cfg = MwrConfig(n_walkers=n_walkers, reward_global=int(reward_mech != "local"), terminate_on_fall=int(terminate_on_fall),
-                             one_hot=int(one_hot), continuous_physics=int(continuous_physics), position_noise=position_noise,
+                             one_hot=int(one_hot), continuous_physics=int(continuous_physics), polygon_revision=int(polygon_revision), position_noise=position_noise,
                              angle_noise=angle_noise, forward_reward=forward_reward, fall_reward=fall_reward, drop_reward=drop_reward,
                              seed=int(seed), env_id_base=int(env_id_base))
         self.N, self.W = int(n_envs), int(n_walkers)

@@ -303,3 +303,44 @@ def test_sleeping_and_waking():
             b = o.bodies()[0]
             assert (b[asleep][:, 3:] == 0).all(), "a sleeping body has zero velocity"
     assert slept > 0
+
+
+@pytest.mark.parametrize("n_walkers", [3, 10])
+def test_both_box2d_polygon_revisions_in_both_restatements(n_walkers):
+    """b2CollidePolygons changed inside Box2D 2.3.x (2.3.0: hill-climbing b2FindMaxSeparation + 0.98 / 0.001 hysteresis; later: every edge normal +
+    0.1 * b2_linearSlop), and the reference tree does not say which revision the authors' pybox2d wrapped.  Both restatements implement both
+    (`polygon_revision`): under EITHER one the product source equals the independent oracle bit for bit, free-running; and the two revisions
+    do differ -- hull / package contacts go through that routine every step -- on a share of env-steps that is worth knowing (a few per cent
+    once walkers lie on the ground; teacher-forced count)."""
+    from oracle import multiwalker_ref as mwr
+    W, N, T = n_walkers, 32, 220
+    kw = dict(n_walkers=W, n_envs=N, seed=17, position_noise=0, angle_noise=0, terminate_on_fall=False)
+    refs = [mwr.MultiWalkerRef(poly=True, polygon_revision=r, **kw) for r in (0, 1)]
+    core = [mwo.MultiWalkerOracle(position_noise=0.0, angle_noise=0.0, polygon_revision=r, lanes_descending=bool(r),
+                                  **{k: v for k, v in kw.items() if k not in ("position_noise", "angle_noise")}) for r in (0, 1)]
+    for o in refs + core:
+        o.reset()
+    probe = mwr.MultiWalkerRef(poly=True, polygon_revision=1, **kw)   # revision 1 teacher-forced on revision 0's states: how often ONE step differs
+    probe.reset()
+    rng = np.random.RandomState(5)
+    differ = 0
+    for t in range(T):
+        a = rng.uniform(-1, 1, (N, W, 4)).astype(np.float32)
+        if (t // 30) % 3 == 2:
+            a[:] = 0
+        probe.set_bodies(refs[0].bodies())
+        for r in (0, 1):
+            ro, rr, rd = refs[r].step(a)
+            co, cr, cd = core[r].step(a)
+            assert np.array_equal(refs[r].bodies(), core[r].bodies()[0]) and np.array_equal(rd, cd), (r, t)
+            assert np.array_equal(refs[r].joints(), core[r].joints()) and np.array_equal(refs[r].aux(), core[r].aux()), (r, t)
+            if rd.any():
+                refs[r].reset(mask=rd); core[r].reset(mask=rd)
+                if r == 0:
+                    probe.reset(mask=rd)
+        probe.step(a)
+        differ += int((probe.bodies() != refs[0].bodies()).any(axis=(1, 2)).sum())
+    assert not core[0].overflow().any() and not core[1].overflow().any()
+    share = differ / float(N * T)
+    print("n_walkers=%d: the two b2CollidePolygons revisions give different body states on %.2f %% of the env-steps" % (W, 100 * share))
+    assert 0.0 < share < 0.25

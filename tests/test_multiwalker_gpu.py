@@ -225,3 +225,25 @@ def test_the_reference_curriculum_walks_through_the_capacity_classes():
     assert len(obs) == 9 and len(one.agents) == 9
     o, r, d, info = one.step(np.zeros((9, 4)))
     assert len(o) == 9 and len(r) == 9
+
+
+@pytest.mark.parametrize("n_walkers", [3, 9])
+def test_later_box2d_polygon_revision_on_the_kernels(n_walkers):
+    """box2d_polygon_revision=1 (b2CollidePolygons as later Box2D 2.3.x revisions have it; include/madrl_hip.h madrl_multiwalker_config): the kernels
+    equal the CPU build of the same source byte for byte, as they do for the default"""
+    from oracle import multiwalker as mwo
+    N, W, T = 64, n_walkers, 80
+    env = _mk(N, n_walkers=W, seed=31, terminate_on_fall=False, box2d_polygon_revision=1)
+    orc = mwo.MultiWalkerOracle(n_walkers=W, position_noise=0.0, angle_noise=0.0, n_envs=N, seed=31, terminate_on_fall=False, polygon_revision=1)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.reset())
+    rng = np.random.RandomState(3)
+    for t in range(T):
+        a = rng.uniform(-1, 1, (N, W, 4)).astype(np.float32)
+        if t % 30 > 18:
+            a[:] = 0
+        obs, rew, done, _ = env.step(a)
+        oobs, orew, odone = orc.step(a)
+        assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone.astype(bool)), t
+        assert (env.state_buffer.cpu().numpy()[:, :orc.world_bytes] == orc.worlds()).all(), t
+        if odone.any():
+            orc.reset(mask=odone); env.reset(mask=odone)

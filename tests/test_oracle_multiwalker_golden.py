@@ -18,15 +18,18 @@ TOL = 1e-5
 
 @pytest.mark.skipif(not GOLDEN, reason="PARITY UNPINNED: no Box2D in the build image, tests/golden/multiwalker_box2d_*.npz were never generated "
                                        "(oracle/make_golden_multiwalker.py writes them where pybox2d imports)")
+@pytest.mark.parametrize("revision", [0, 1], ids=["b2CollidePolygons-2.3.0", "b2CollidePolygons-later-2.3.x"])
 @pytest.mark.parametrize("path", GOLDEN or ["none"], ids=[os.path.basename(p) for p in GOLDEN] or ["none"])
-def test_independent_oracle_reproduces_box2d_recordings(path):
+def test_independent_oracle_reproduces_box2d_recordings(path, revision):
+    """(Both revisions of b2CollidePolygons are tried: the one the recording's Box2D has passes, the other may fail on the first hull / package
+    contact it resolves differently -- whichever passes is the `polygon_revision` / `box2d_polygon_revision` to run with.)"""
     from oracle import multiwalker_ref as mwr
     g = np.load(path)
     W = int(g["n_walkers"])
     for ep in range(int(g["n_episodes"])):
         k = lambda name: g["ep%d_%s" % (ep, name)]
         ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=1, seed=0, position_noise=0, angle_noise=0, reward_mech="global" if int(g["reward_global"]) else "local",
-                                 poly=False)
+                                 poly=False, polygon_revision=revision)
         obs = ref.reset(terrain=k("terrain_y")[None], push=k("push")[None])
         assert np.abs(ref.bodies()[0] - k("bodies")[0]).max() <= TOL, "episode %d: state after reset" % ep
         assert np.abs(obs[0] - k("obs")[0]).max() <= TOL
