@@ -444,7 +444,8 @@ def bench_rollout(args, K, W, rank, world, dev):
     bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes) + 4 * P * R * R + 4 * P
     ms = dt / steps * 1e3
     region_ms = [x * calls / steps for x in region_ms]
-    roof = roofline(bytes_per, N, kernel_ms * calls / steps, ms, None, "pursuit_wave_kernel<16,16,8,30,7,1> + pursuit_policy_kernel (+ gae_kernel per horizon)", streams=S)
+    roof = roofline(bytes_per, N, kernel_ms * calls / steps, ms, measured_traffic(N // S, "pursuit_rollout", S),
+                    "pursuit_wave_kernel<16,16,8,30,7,1> + pursuit_policy_kernel (+ gae_kernel per horizon)", streams=S)
     cfg = {"workload": "policy-in-the-loop rollout: PursuitEvade 16x16, 8v30, %d envs per GPU, device chase policy, horizon %d, %d sub-batches, hipGraph per horizon"
                        % (N, T, S), "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world, "rccl_ranks": world,
            "streams_per_gpu": S, "envs_per_launch": N // S, "horizon": T, "collect_calls_per_region": calls}
