@@ -914,6 +914,7 @@ typedef struct World {
     void *listenerUser;
     int proxyCount;
     long stat_toi_events, stat_contacts_created;
+    long stat_rays, stat_rays_hit, stat_rays_multi;   /* lidar rays cast / with a hit / with hits on SEVERAL edges (where D2's "closest" and Box2D's "first in tree order" can differ) */
 } World;
 
 static void world_init(World *w, Vec2 gravity) {
@@ -963,7 +964,14 @@ static int world_create_body(World *w, int type, Vec2 position, float angle, con
     const AABB aabb = shape_aabb(&b->shape, b->xf);
     b->fatAABB.lo = V(aabb.lo.x - b2_aabbExtension, aabb.lo.y - b2_aabbExtension);
     b->fatAABB.hi = V(aabb.hi.x + b2_aabbExtension, aabb.hi.y + b2_aabbExtension);
-    b->proxyId = w->proxyCount++;
+    /* D1: creation order, as in a fresh b2World.  MWR_PROXY_ORDER=reverse in the environment (a sensitivity probe of the test infrastructure, DESIGN.md
+     * section 2) hands the ids out in DESCENDING order instead: the most different order a recycled b2DynamicTree node pool could produce */
+    {
+        static int reverse = -1;
+        if (reverse < 0) { const char *e = getenv("MWR_PROXY_ORDER"); reverse = (e && e[0] == 'r') ? 1 : 0; }
+        b->proxyId = reverse ? MWR_MAX_BODIES - 1 - w->proxyCount : w->proxyCount;
+        ++w->proxyCount;
+    }
     b->moved = 1;
     w->newFixture = 1;
     /* b2Body::ResetMassData */
@@ -1896,7 +1904,9 @@ static void world_step(World *w, float dt, int velocityIterations, int positionI
 }
 
 /* b2World::RayCast over the edge fixtures, closest hit (D2); b2EdgeShape::RayCast per fixture.  Returns the fraction, 1.0 without a hit. */
-static float world_raycast_closest(const World *w, Vec2 p1w, Vec2 p2w, uint16_t categoryMask) {
+static float world_raycast_closest(const World *w_, Vec2 p1w, Vec2 p2w, uint16_t categoryMask) {
+    World *w = (World *)w_;   /* (the counters) */
+    int hits = 0;
     float best = 1.0f;   /* LidarCallback.fraction starts at 1.0 (:210); input.maxFraction = 1 */
     for (int bi = 0; bi < w->bodyCount; ++bi) {
         const Body *b = &w->bodies[bi];
@@ -1917,8 +1927,10 @@ static float world_raycast_closest(const World *w, Vec2 p1w, Vec2 p2w, uint16_t 
         if (rr == 0.0f) continue;
         const float s = vdot(vsub(q, v1), r) / rr;
         if (s < 0.0f || 1.0f < s) continue;
+        ++hits;
         if (t < best) best = t;
     }
+    ++w->stat_rays; w->stat_rays_hit += hits > 0; w->stat_rays_multi += hits > 1;
     return best;
 }
 
@@ -2361,6 +2373,11 @@ int mwr_get_contacts(const mwr_handle *h, int64_t n, int32_t *ints, float *flts,
         }
     }
     return count;
+}
+/* lidar rays cast / with a hit / with hits on several terrain edges, summed over the envs */
+void mwr_get_ray_stats(const mwr_handle *h, int64_t *out3) {
+    out3[0] = out3[1] = out3[2] = 0;
+    for (int64_t n = 0; n < h->n_envs; ++n) { out3[0] += h->envs[n].world.stat_rays; out3[1] += h->envs[n].world.stat_rays_hit; out3[2] += h->envs[n].world.stat_rays_multi; }
 }
 void mwr_get_stats(const mwr_handle *h, int64_t *toi_events, int64_t *contacts_created) {
     *toi_events = 0; *contacts_created = 0;
