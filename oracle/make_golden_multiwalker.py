@@ -93,7 +93,7 @@ class ScriptedNormal(object):
         return loc + scale * self.queue.pop(0)
 
 
-def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed, prefix="multiwalker_box2d_", zero_from=44, noise=None, **env_kw):
+def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed, prefix="multiwalker_box2d_", zero_from=44, noise=None, fresh_world=False, **env_kw):
     """noise = (position_noise, angle_noise, seed, first env id): the observation noise on, scripted (ScriptedNormal); episode k is env id + k"""
     rng = np.random.RandomState(seed)
     out = []
@@ -125,6 +125,17 @@ def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed, pre
         for w in env.walkers:
             w._seed(int(rng.randint(2 ** 31 - 1)))          # (BipedalWalker seeds itself from the clock otherwise: recordings would not regenerate)
             w.np_random = SpyRandom(w.np_random)
+        if fresh_world:
+            # The recorded episode is the env object's SECOND reset (the constructor ran the first, :303).  In real Box2D the bodies of a second
+            # reset take recycled nodes off the dynamic tree's free list, so the proxy ids -- and with them the order of the contacts created in
+            # one FindNewContacts call, which decides bits from the first step on -- depend on the env object's history.  The
+            # restatements model the FIRST episode of an env object: give the module a brand-new b2World for the recorded reset, through its own
+            # attributes (nothing of the old world is touched: _destroy() returns at once when `terrain` / `hull` are unset, :98-100, :318-319).
+            import Box2D
+            env.world = Box2D.b2World()
+            env.terrain = None
+            for w in env.walkers:
+                w.world, w.hull = env.world, None
         obs0 = env.reset()
         for w in env.walkers:
             w.np_random = w.np_random.rs
@@ -242,8 +253,12 @@ def main():
     os.environ.setdefault("MPLBACKEND", "Agg")
     from madrl_environments.walker.multi_walker import MultiWalkerEnv
     if not envlayer:
-        run(MultiWalkerEnv, "w3_local", 3, "local", episodes=6, steps=200, seed=31)
-        run(MultiWalkerEnv, "w2_global", 2, "global", episodes=4, steps=200, seed=32)
+        # real Box2D: every recorded episode on a brand-new b2World (see run(): what the restatements model); one file WITHOUT that, whose episodes
+        # are second resets of their env objects -- if it replays too, recycled proxy ids do not matter in practice, if not, that is D1 showing
+        run(MultiWalkerEnv, "w3_local", 3, "local", episodes=6, steps=200, seed=31, fresh_world=True)
+        run(MultiWalkerEnv, "w2_global", 2, "global", episodes=4, steps=200, seed=32, fresh_world=True)
+        run(MultiWalkerEnv, "w10_local", 10, "local", episodes=2, steps=150, seed=41, fresh_world=True, zero_from=30)
+        run(MultiWalkerEnv, "w3_second_reset", 3, "local", episodes=3, steps=200, seed=33, fresh_world=False)
         return 0
     # the reference's env layer on the restated dynamics: BASELINE configs[3] (three walkers), the module's own example (two), one and
     # four walkers, both reward mechanisms, every reward coefficient changed, terminate_on_fall off (walkers keep falling, the package is dropped)
