@@ -416,7 +416,7 @@ def bench_rollout(args, K, W, rank, world, dev):
     from madrl_amd.sharded import StreamSharded
     MS, P, E, N0, mode = PURSUIT_VARIANTS["pursuit"]
     N, R, H = (args.envs or N0), 7, args.horizon
-    S = max(1, int(args.streams)) if args.streams else 2
+    S = max(1, int(args.streams)) if args.streams else 1   # step -> policy -> step is one chain: two sub-batches measure the same (102.9 against 102.0 us)
     if N % S or N // S < 64:
         S = 1
     T = max(1, min(K, 50))
@@ -450,6 +450,7 @@ def bench_rollout(args, K, W, rank, world, dev):
                        % (N, T, S), "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world, "rccl_ranks": world,
            "streams_per_gpu": S, "envs_per_launch": N // S, "horizon": T, "collect_calls_per_region": calls}
     cfg.update(region_stats(region_ms))
+    cfg["step_calls_in_process"] = (max(3, W // T) + cfg["timed_regions"] * calls) * T   # what a PMC pass of this command divides its sums by
     return {"metric": "env-steps/sec with the policy in the loop (PursuitEvade 16x16, 8v30)", "value": world * N * steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": steps, "warmup": W, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic", "data": "synthetic (chase policy on the env's own observations)",

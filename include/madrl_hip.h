@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MADRL_ABI_VERSION 5
+#define MADRL_ABI_VERSION 6
 
 #define MADRL_OK 0
 #define MADRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -461,11 +461,15 @@ int madrl_rollout_gae(const float *rew, const uint8_t *done, const float *values
  * obs[r * row_stride + ch_offset + (i * obs_range + j) * cell_stride]  (flatten rows: ch_offset = 2*R*R,
  * cell_stride = 1; (R,R,4) windows: ch_offset = 2, cell_stride = 4).  table_dev uint8 [R*R]: the action for
  * "nearest evader at window cell k" (255 = sample); empty window / 255 -> Philox(seed; row_id_base + r,
- * tick + *tick_dev) -- tick_dev (uint32 on the device, may be NULL) lets a captured hipGraph advance the draw
- * counter between replays.  actions int32 [n_rows] */
+ * tick + tick_dev[0]).  tick_dev: NULL, or MADRL_POLICY_COUNTER_WORDS zero-initialised uint32 words on the device -- [0]
+ * is the draw counter of a captured hipGraph and is advanced by one BY THE LAUNCH ITSELF when its last workgroup retires
+ * (the other words count retired workgroups and are zero again between launches), so launches that share a counter must
+ * be ordered on one stream.
+ * actions int32 [n_rows] */
+#define MADRL_POLICY_COUNTER_WORDS (32 * 65)
 int madrl_heuristic_pursuit(const float *obs, int64_t n_rows, int32_t obs_range, int64_t row_stride, int32_t cell_stride,
                             int32_t ch_offset, const uint8_t *table_dev, uint64_t seed, int64_t row_id_base,
-                            uint32_t tick, const uint32_t *tick_dev, int32_t *actions, void *stream);
+                            uint32_t tick, uint32_t *tick_dev, int32_t *actions, void *stream);
 /* WaterworldHeuristicPolicy.sample_actions, every row normalised on its own; cos_sin_dev float64 [K][2] with
  * K = obs_dim / 7 (np.linspace(0, 2 pi, K + 1)[:-1]); actions float32 [n_rows][2] */
 int madrl_heuristic_waterworld(const float *obs, int64_t n_rows, int32_t obs_dim, const double *cos_sin_dev,

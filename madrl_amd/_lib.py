@@ -15,7 +15,8 @@ import torch  # noqa: F401  (must precede CDLL, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MADRL_HIP_LIB") or os.path.join(_HERE, "libmadrl_hip.so")  # override: profiling variants only
-ABI_VERSION = 5
+ABI_VERSION = 6
+POLICY_COUNTER_WORDS = 32 * 65   # MADRL_POLICY_COUNTER_WORDS of include/madrl_hip.h
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
 

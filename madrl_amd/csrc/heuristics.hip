@@ -12,21 +12,71 @@ enum : uint32_t { TAG_HEURISTIC_ACT = 3 };
 // order among equals), then a direction from atan2 quadrants.  The quadrant logic is a table over the evader's window cell,
 // built on the host with the reference's own float64 expression (madrl_amd/heuristics.py); 255 in the table or an empty
 // window = the reference's action_space.sample(), here Philox(row id, tick).
-// 16 lanes per row: lane s looks at window cells s, s + 16, ... of the evader channel (four independent loads in flight, then the
-// comparisons), so the 16 lanes of a row read 64 consecutive bytes per pass (flatten rows; the (R, R, 4) layout strides by its four
-// channels); the packed (distance^2, cell) keys are min-reduced by shuffles.  A block walks the rows in strides of the grid: few,
-// long-lived wavefronts.  The kernel reads one channel of every row -- a third of the bytes -- but nowhere near a third of the time of a
-// full pass over the buffer (~50 us for its 310 MB at 65 536 envs).  Measured for those 524 288 rows (kernel under rocprofv3 / rollout
-// step of scripts/rollout_bench.py): round 4's mapping -- 8 lanes per row, a lane per window row, load - compare - branch per cell --
-// 44 us; the same with its loads batched: 133 us per rollout step; 16 lanes per row, one short-lived wavefront per four rows: 56 / 132;
-// this form: 51 / 125 (two sub-batches: 119).
+// 16 lanes per row.  Generic form (any obs_range, either layout): lane s looks at window cells s, s + 16, ... of the evader channel (four
+// independent loads in flight, then the comparisons); the packed (distance^2, cell) keys are min-reduced inside the DPP row of 16 lanes.
+// A block walks the rows in strides of the grid: few, long-lived wavefronts.  After its last row a launch advances the draw counter
+// itself (the last workgroup to retire, policy_retire), so a rollout step is two kernels, not three.
+// Measured for 524 288 rows (kernel under rocprofv3 / rollout step of scripts/rollout_bench.py): round 4's mapping -- 8 lanes per row, a
+// lane per window row, load - compare - branch per cell -- 44 us; the same with its loads batched: 133 us per rollout step; 16 lanes per
+// row, one short-lived wavefront per four rows: 56 / 132; the generic form below with a separate counter kernel behind it: 51 / 125 (two
+// sub-batches: 119); pursuit_policy_rows_kernel: 28.4 us / 99 - 102 per rollout step.
+__device__ __forceinline__ uint32_t min_row16(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+// the draw counter of this launch, read once per wavefront: the device word (it survives hipGraph replay) cannot move before every workgroup
+// of the launch has retired (policy_retire), so a plain cached load is enough -- a system-scope atomic load per row with an empty window
+// went to memory uncached and doubled the kernel's time
+__device__ __forceinline__ uint32_t policy_tick(uint32_t tick, const uint32_t *tick_dev) { return tick + (tick_dev ? *tick_dev : 0u); }
+
+__device__ __forceinline__ void policy_emit(uint32_t key, int64_t row, const uint8_t *__restrict__ table, uint32_t k0, uint32_t k1,
+                                            int64_t row_id_base, uint32_t tk, int32_t *__restrict__ actions) {
+    int act = 255;
+    if (key != 0xFFFFFFFFu) act = table[key & 0xFFFFu];
+    if (act == 255) {
+        const uint64_t id = (uint64_t)(row_id_base + row);
+        const u32x4 r = philox4x32_10((uint32_t)id, tk, (uint32_t)(id >> 32), TAG_HEURISTIC_ACT, k0, k1);
+        act = (int)__umulhi(r.x, 5u);
+    }
+    actions[row] = act;
+}
+
+// every row of this workgroup is done: the last workgroup of the launch advances the counter.  One shared count would be gridDim.x
+// same-address atomics arriving together at the end of a launch of persistent workgroups -- measured 8.5 ns each, one after the other: +17 us
+// with 2 048 workgroups, +35 us with 4 096 -- so the workgroups count in 64 groups on 64 cache lines, and the last one of each group counts
+// the groups: two chains of <= 64.  Layout of tick_dev (MADRL_POLICY_COUNTER_WORDS uint32): [0] draw counter, [1] groups done, [32 (1 + g)]
+// workgroups of group g done; all but [0] are zero again when the launch ends.
+__device__ __forceinline__ void policy_retire(uint32_t *tick_dev) {
+    if (!tick_dev) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // relaxed on purpose: an agent-scope release / acquire here is an L2 write-back + invalidate per workgroup (80 us per launch instead
+        // of 30, and the step kernel on the other stream loses its cache with it); nothing but the counters is ordered by them, and a
+        // workgroup has read tick_dev[0] (policy_tick) long before it arrives here
+        const uint32_t G = gridDim.x < 64u ? gridDim.x : 64u, g = blockIdx.x % G, n_g = (gridDim.x - 1u - g) / G + 1u;
+        uint32_t *mine = tick_dev + 32u * (1u + g);
+        if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_g - 1u) {
+            __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(tick_dev + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1u) {
+                __hip_atomic_store(tick_dev + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(tick_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__restrict__ obs, int64_t n_rows, int R, int64_t row_stride,
                                                              int cell_stride, int ch_offset, const uint8_t *__restrict__ table,
                                                              uint32_t k0, uint32_t k1, int64_t row_id_base, uint32_t tick,
-                                                             const uint32_t *__restrict__ tick_dev, int32_t *__restrict__ actions) {
+                                                             uint32_t *tick_dev, int32_t *__restrict__ actions) {
     const int sub = threadIdx.x & 15;
     const int c = R / 2;  // :23 (Python 2 integer division)
     const int cells = R * R;
+    const uint32_t tk = policy_tick(tick, tick_dev);
     for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += (int64_t)gridDim.x * 16) {
         uint32_t key = 0xFFFFFFFFu;
         const float *o = obs + row * row_stride + ch_offset;
@@ -42,22 +92,51 @@ __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__rest
                     key = min(key, (d2 << 16) | (uint32_t)k);
                 }
         }
-        key = min(key, (uint32_t)__shfl_xor((int)key, 8, 16));
-        key = min(key, (uint32_t)__shfl_xor((int)key, 1, 16));
-        key = min(key, (uint32_t)__shfl_xor((int)key, 2, 16));
-        key = min(key, (uint32_t)__shfl_xor((int)key, 4, 16));
-        if (sub == 0) {
-            int act = 255;
-            if (key != 0xFFFFFFFFu) act = table[key & 0xFFFFu];
-            if (act == 255) {
-                const uint64_t id = (uint64_t)(row_id_base + row);
-                const uint32_t tk = tick + (tick_dev ? *tick_dev : 0u);  // device counter: survives hipGraph replay
-                const u32x4 r = philox4x32_10((uint32_t)id, tk, (uint32_t)(id >> 32), TAG_HEURISTIC_ACT, k0, k1);
-                act = (int)__umulhi(r.x, 5u);
-            }
-            actions[row] = act;
-        }
+        key = min_row16(key);
+        if (sub == 0) policy_emit(key, row, table, k0, k1, row_id_base, tk, actions);
     }
+    policy_retire(tick_dev);
+}
+
+// Flatten rows with a window of 4 ... 64 cells (obs_range 3, 5, 7): the evader channel of a row is 4 * R * R consecutive bytes, lane s of
+// the row's 16 takes cells 4 s ... 4 s + 3 in ONE 16-byte load (4-byte aligned: rows are 12 R^2 + 4 bytes apart; the last lanes step back
+// to the final four cells, duplicates do not change a minimum); a lane's four (distance^2, cell) keys do not depend on the row and are
+// computed once.  Two rows per lane group in flight; lanes 0 and 1 finish one each.
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+
+__global__ __launch_bounds__(256) void pursuit_policy_rows_kernel(const float *__restrict__ obs, int64_t n_rows, int R, int64_t row_stride,
+                                                                  int ch_offset, const uint8_t *__restrict__ table, uint32_t k0, uint32_t k1,
+                                                                  int64_t row_id_base, uint32_t tick, uint32_t *tick_dev,
+                                                                  int32_t *__restrict__ actions) {
+    const int sub = threadIdx.x & 15;
+    const int c = R / 2, cells = R * R;
+    const uint32_t tk = policy_tick(tick, tick_dev);
+    const int base = min(4 * sub, cells - 4);
+    uint32_t keyq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = base + q, i = k / R, j = k - i * R;
+        keyq[q] = ((uint32_t)((i - c) * (i - c) + (j - c) * (j - c)) << 16) | (uint32_t)k;
+    }
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    const float *o = obs + ch_offset + base;
+    for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += 2 * stride) {
+        const int64_t row2 = row + stride;
+        const bool two = row2 < n_rows;
+        const f4u a = *reinterpret_cast<const f4u *>(o + row * row_stride);
+        const f4u b = *reinterpret_cast<const f4u *>(o + (two ? row2 : row) * row_stride);
+        uint32_t ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ka = min(ka, a.v[q] != 0.0f ? keyq[q] : 0xFFFFFFFFu);
+            kb = min(kb, b.v[q] != 0.0f ? keyq[q] : 0xFFFFFFFFu);
+        }
+        ka = min_row16(ka);
+        kb = min_row16(kb);
+        if (sub == 0 || (sub == 1 && two))
+            policy_emit(sub ? kb : ka, sub ? row2 : row, table, k0, k1, row_id_base, tk, actions);
+    }
+    policy_retire(tick_dev);
 }
 
 // ---- WaterworldHeuristicPolicy.sample_actions (waterworld.py:11-58), one row per thread group of 8 lanes: each lane sums
@@ -144,13 +223,21 @@ extern "C" {
 
 int madrl_heuristic_pursuit(const float *obs, int64_t n_rows, int32_t obs_range, int64_t row_stride, int32_t cell_stride,
                             int32_t ch_offset, const uint8_t *table_dev, uint64_t seed, int64_t row_id_base, uint32_t tick,
-                            const uint32_t *tick_dev, int32_t *actions, void *stream) {
+                            uint32_t *tick_dev, int32_t *actions, void *stream) {
     if (!obs || !table_dev || !actions || n_rows < 1 || obs_range < 1 || obs_range > 255) return fail(MADRL_EINVAL, "heuristic_pursuit: bad argument");
-    int64_t blocks = (n_rows + 15) / 16;
-    if (blocks > 256 * 16) blocks = 256 * 16;   // 16 four-wavefront blocks per CU: two rounds of resident wavefronts
-    hipLaunchKernelGGL(pursuit_policy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, obs, n_rows,
-                       (int)obs_range, row_stride, (int)cell_stride, (int)ch_offset, table_dev, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       row_id_base, tick, tick_dev, actions);
+    const int cells = obs_range * obs_range;
+    if (cell_stride == 1 && cells >= 4 && cells <= 64) {
+        int64_t blocks = (n_rows + 31) / 32;
+        if (blocks > 256 * 8) blocks = 256 * 8;   // 8 four-wavefront blocks per CU: every wavefront resident at once
+        hipLaunchKernelGGL(pursuit_policy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, obs, n_rows, (int)obs_range,
+                           row_stride, (int)ch_offset, table_dev, (uint32_t)seed, (uint32_t)(seed >> 32), row_id_base, tick, tick_dev, actions);
+    } else {
+        int64_t blocks = (n_rows + 15) / 16;
+        if (blocks > 256 * 16) blocks = 256 * 16;   // 16 four-wavefront blocks per CU: two rounds of resident wavefronts
+        hipLaunchKernelGGL(pursuit_policy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, obs, n_rows,
+                           (int)obs_range, row_stride, (int)cell_stride, (int)ch_offset, table_dev, (uint32_t)seed, (uint32_t)(seed >> 32),
+                           row_id_base, tick, tick_dev, actions);
+    }
     MADRL_HIP_TRY(hipGetLastError());
     return MADRL_OK;
 }

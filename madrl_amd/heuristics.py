@@ -58,7 +58,7 @@ class PursuitHeuristicPolicy(_DevicePolicy):
 
     def __init__(self, obs_range, flatten=True, seed=0, row_id_base=0):
         self.R, self.flatten, self.seed, self.row_id_base = int(obs_range), bool(flatten), int(seed), int(row_id_base)
-        self._tick = None  # uint32 draw counter on the device (a host counter would be frozen into a captured hipGraph)
+        self._tick = None  # [draw counter, workgroup counts ...] on the device: every launch advances the counter itself (a host counter would be frozen into a captured hipGraph)
         self._table_host = pursuit_decision_table(self.R)
         self._table = None
         self._act = None
@@ -77,13 +77,12 @@ class PursuitHeuristicPolicy(_DevicePolicy):
                 self._act = torch.empty(obs.shape[:2], dtype=torch.int32, device=obs.device)
             act = self._act
         if self._tick is None or self._tick.device != obs.device:
-            self._tick = torch.zeros(1, dtype=torch.int32, device=obs.device)
+            self._tick = torch.zeros(_lib.POLICY_COUNTER_WORDS, dtype=torch.int32, device=obs.device)
         row_stride = obs.numel() // n_rows
         cell_stride, ch_off = (1, 2 * R * R) if self.flatten else (4, 2)
         _lib.check(_lib.lib().madrl_heuristic_pursuit(_lib.ptr(obs), n_rows, R, row_stride, cell_stride, ch_off, _lib.ptr(self._table),
                                                       self.seed, self.row_id_base, 0, _lib.ptr(self._tick), _lib.ptr(act),
                                                       _lib.current_stream(obs.device)))
-        self._tick += 1
         return act, None
 
 

@@ -23,12 +23,16 @@ per_launch = line["config"].get("envs_per_launch", line["config"]["envs_per_gpu"
 # the PMC passes ran `--steps 10 --warmup 3` (MultiWalker: its own minimum of 200 warm-up steps): every region of the bench repeats the K steps
 pmc_line = None
 vals, kernels = {}, set()
+WIDE = ("pursuit_policy_rows_kernel",)   # kernels that read 16 bytes per lane: FETCH_SIZE under-counts those by 2 on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)
+wide_fetch = 0.0
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     tot = 0.0
     for f in glob.glob(os.path.join(out, "pmc_" + c, "**", "*counter_collection*.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if ksub in row["Kernel_Name"] and row["Counter_Name"] == c:
-                tot += float(row["Counter_Value"]); kernels.add(row["Kernel_Name"].split("(")[0][:120])
+                w = 2.0 if c == "FETCH_SIZE" and any(k in row["Kernel_Name"] for k in WIDE) else 1.0
+                tot += w * float(row["Counter_Value"]); kernels.add(row["Kernel_Name"].split("(")[0][:120])
+                wide_fetch += float(row["Counter_Value"]) if w == 2.0 else 0.0
     try:
         pmc_line = json.loads([l for l in open(os.path.join(out, "pmc_%s.log" % c)) if l.startswith("{")][-1])
     except Exception:
@@ -38,6 +42,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         n_steps = prep + pmc_line["warmup"] + pmc_line["config"]["timed_regions"] * pmc_line["steps"]   # step() calls of the whole batch (+ one reset launch: < 1 %)
         if S > 1 and "one_launch_per_step" in pmc_line["roofline"]:
             n_steps += prep + min(pmc_line["warmup"], 20) + pmc_line["config"]["timed_regions"] * pmc_line["steps"]   # the one-launch-per-step reference pass of the same run
+        n_steps = pmc_line["config"].get("step_calls_in_process", n_steps)   # the rollout workload counts its own (warm-up in horizons, not steps)
         vals[c] = tot / n_steps
 if len(vals) == 2:
     step_bytes = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
@@ -47,7 +52,10 @@ if len(vals) == 2:
              algorithmic_bytes_per_launch=line["roofline"]["algorithmic_bytes_per_env_step"] * per_launch,
              note="separate rocprofv3 --pmc passes (scripts/profile_workload.sh); counters in KiB, summed over every launch of the matching kernels and "
                   "divided by the step() calls of the run; reads of these kernels are <= 8 B per lane, so the gfx950 x2 correction for wide (16 B/lane) "
-                  "reads does not apply (obsnorm_pairs_kernel reads 16-byte words: its FETCH_SIZE is doubled below when it is the kernel asked for)")
+                  "reads does not apply, except: obsnorm_pairs_kernel (16-byte words: its FETCH_SIZE is doubled below when it is the kernel asked for) and "
+                  "pursuit_policy_rows_kernel (16-byte loads: its FETCH_SIZE is counted twice in the sums above)")
+    if wide_fetch:
+        j["FETCH_SIZE_KiB_raw_of_16_byte_readers_in_run"] = wide_fetch
     if "obsnorm_pairs" in ksub:   # 16 B/lane loads: FETCH_SIZE under-counts by 2 on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)
         j["FETCH_SIZE_KiB_per_step_corrected"] = 2 * vals["FETCH_SIZE"]
         j["traffic_bytes_per_step"] = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libmadrl_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "madrl_amd/_lib.py has no signature for %s" % n
-    assert L.madrl_abi_version() == _lib.ABI_VERSION == 5
+    assert L.madrl_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_host_philox_matches_published_vectors():

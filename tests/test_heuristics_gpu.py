@@ -77,3 +77,34 @@ def test_heuristic_rollouts_on_live_envs():
     assert np.abs(mp(o).cpu().numpy().reshape(-1, 4) - ho.multiwalker_actions(o.cpu().numpy().reshape(-1, o.shape[-1]))).max() < 1e-6
     tr = RolloutCollector(mw, mp, 30).collect()
     assert torch.isfinite(tr.rewards).all()
+
+
+@pytest.mark.parametrize("n_rows", [7, 16, 1000, 70000, 300001])
+def test_pursuit_policy_rows_kernel_any_row_count_and_its_own_draw_counter(n_rows):
+    """Flatten rows go through the 16-bytes-per-lane kernel (two rows per lane group in flight, the last lanes stepping back to the final
+    four cells): every row count -- fewer rows than lane groups, odd tails, more rows than one sweep of the grid -- against the NumPy
+    oracle; the launch advances the draw counter itself and leaves its workgroup counts at zero."""
+    from madrl_amd import _lib
+    from madrl_amd.heuristics import PursuitHeuristicPolicy
+    from oracle import heuristics_oracle as ho
+    R = 7
+    rng = np.random.RandomState(n_rows)
+    win = np.zeros((n_rows, R, R, 4), np.float32)
+    win[..., 2] = (rng.rand(n_rows, R, R) < 0.04) * rng.randint(1, 4, (n_rows, R, R))      # sparse evader counts, many empty windows
+    win[..., 0] = rng.rand(n_rows, R, R) < 0.2
+    win[..., 1] = rng.randint(0, 3, (n_rows, R, R))
+    ref = ho.pursuit_actions(win[:20000]) if n_rows > 20000 else ho.pursuit_actions(win)
+    rows = np.concatenate([np.transpose(win[..., :3], (0, 3, 1, 2)).reshape(n_rows, -1), np.full((n_rows, 1), 0.5, np.float32)], axis=1)
+    pol = PursuitHeuristicPolicy(R, flatten=True, seed=11)
+    obs = torch.as_tensor(rows, device=DEV).view(n_rows, 1, -1)
+    a = pol(obs).cpu().numpy()[:, 0]
+    det = ref >= 0
+    assert np.array_equal(a[:len(ref)][det], ref[det])
+    # the (R, R, 4) layout takes the generic kernel: same actions everywhere, the drawn ones included (same seed, row ids and tick)
+    b = PursuitHeuristicPolicy(R, flatten=False, seed=11)(torch.as_tensor(win, device=DEV).view(n_rows, 1, R, R, 4)).cpu().numpy()[:, 0]
+    assert np.array_equal(a, b)
+    for _ in range(4):
+        pol(obs)
+    torch.cuda.synchronize()
+    t = pol._tick.cpu().numpy()
+    assert len(t) == _lib.POLICY_COUNTER_WORDS and t[0] == 5 and not t[1:].any()
