@@ -84,4 +84,27 @@ for S in (2, 4):
         print("%d sub-batches, %4s workgroups each, one C call per step, free-running: min %.1f  median %.1f us" % ((S, blocks or "dflt") + timed(native(0, 0))), flush=True)
         print("%d sub-batches, %4s workgroups each, free-running streams:   min %.1f  median %.1f us" % ((S, blocks or "dflt") + timed(free)), flush=True)
         print("%d sub-batches, %4s workgroups each, joined after every step: min %.1f  median %.1f us" % ((S, blocks or "dflt") + timed(joined)), flush=True)
+        if blocks == 0:   # the same fork / join as edges of ONE captured hipGraph of 50 steps (the runtime places the nodes)
+            T = 50
+            g = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=dev)
+            keep = []
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=cap):
+                m = torch.cuda.current_stream(dev)
+                for i in range(T):
+                    ev0 = torch.cuda.Event(); ev0.record(m); keep.append(ev0)
+                    for j, (e, a, p) in enumerate(parts):
+                        if j == 0:
+                            L.madrl_pursuit_step(e._handle, _lib.ptr(a[i % 8]), None, *p, m.cuda_stream)
+                        else:
+                            streams[j].wait_event(ev0)
+                            L.madrl_pursuit_step(e._handle, _lib.ptr(a[i % 8]), None, *p, streams[j].cuda_stream)
+                            ev = torch.cuda.Event(); ev.record(streams[j]); m.wait_event(ev); keep.append(ev)
+
+            def graph_joined(k):
+                for _ in range(max(1, k // T)):
+                    g.replay()
+            print("%d sub-batches, %4s workgroups each, joined after every step, one hipGraph per %d steps: min %.1f  median %.1f us" % ((S, "dflt", T) + timed(graph_joined)), flush=True)
+            del g
         del parts
