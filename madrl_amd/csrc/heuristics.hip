@@ -101,9 +101,12 @@ __global__ __launch_bounds__(256) void pursuit_policy_kernel(const float *__rest
 // Flatten rows with a window of 4 ... 64 cells (obs_range 3, 5, 7): the evader channel of a row is 4 * R * R consecutive bytes, lane s of
 // the row's 16 takes cells 4 s ... 4 s + 3 in ONE 16-byte load (4-byte aligned: rows are 12 R^2 + 4 bytes apart; the last lanes step back
 // to the final four cells, duplicates do not change a minimum); a lane's four (distance^2, cell) keys do not depend on the row and are
-// computed once.  Two rows per lane group in flight; lanes 0 and 1 finish one each.
+// computed once.  U rows per lane group in flight, lane u of a group finishes row u.  Measured for the 524 288 rows of configs[1]: 28.0 - 29.1 us
+// with U = 2, 4, 8 and 4 or 8 blocks per CU alike (38.4 only with U = 2 and 4 blocks) -- not latency: the rows' 196 useful bytes at a
+// 592-byte stride touch 168 MB of 128-byte lines (PMC FETCH_SIZE), i.e. 5.9 TB/s; what is left is the reference's row layout.
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
 
+template <int U>
 __global__ __launch_bounds__(256) void pursuit_policy_rows_kernel(const float *__restrict__ obs, int64_t n_rows, int R, int64_t row_stride,
                                                                   int ch_offset, const uint8_t *__restrict__ table, uint32_t k0, uint32_t k1,
                                                                   int64_t row_id_base, uint32_t tick, uint32_t *tick_dev,
@@ -120,21 +123,24 @@ __global__ __launch_bounds__(256) void pursuit_policy_rows_kernel(const float *_
     }
     const int64_t stride = (int64_t)gridDim.x * 16;
     const float *o = obs + ch_offset + base;
-    for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += 2 * stride) {
-        const int64_t row2 = row + stride;
-        const bool two = row2 < n_rows;
-        const f4u a = *reinterpret_cast<const f4u *>(o + row * row_stride);
-        const f4u b = *reinterpret_cast<const f4u *>(o + (two ? row2 : row) * row_stride);
-        uint32_t ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
+    for (int64_t row0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row0 < n_rows; row0 += U * stride) {
+        f4u v[U];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ka = min(ka, a.v[q] != 0.0f ? keyq[q] : 0xFFFFFFFFu);
-            kb = min(kb, b.v[q] != 0.0f ? keyq[q] : 0xFFFFFFFFu);
+        for (int u = 0; u < U; ++u) {   // all U loads in flight before the first comparison
+            const int64_t r = row0 + u * stride;
+            v[u] = *reinterpret_cast<const f4u *>(o + (r < n_rows ? r : row0) * row_stride);
         }
-        ka = min_row16(ka);
-        kb = min_row16(kb);
-        if (sub == 0 || (sub == 1 && two))
-            policy_emit(sub ? kb : ka, sub ? row2 : row, table, k0, k1, row_id_base, tk, actions);
+        uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t k = 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k = min(k, v[u].v[q] != 0.0f ? keyq[q] : 0xFFFFFFFFu);
+            k = min_row16(k);
+            mine = sub == u ? k : mine;   // lane u of the group finishes row u
+        }
+        const int64_t my_row = row0 + sub * stride;
+        if (sub < U && my_row < n_rows) policy_emit(mine, my_row, table, k0, k1, row_id_base, tk, actions);
     }
     policy_retire(tick_dev);
 }
@@ -227,9 +233,10 @@ int madrl_heuristic_pursuit(const float *obs, int64_t n_rows, int32_t obs_range,
     if (!obs || !table_dev || !actions || n_rows < 1 || obs_range < 1 || obs_range > 255) return fail(MADRL_EINVAL, "heuristic_pursuit: bad argument");
     const int cells = obs_range * obs_range;
     if (cell_stride == 1 && cells >= 4 && cells <= 64) {
-        int64_t blocks = (n_rows + 31) / 32;
+        constexpr int U = 2;
+        int64_t blocks = (n_rows + 16 * U - 1) / (16 * U);
         if (blocks > 256 * 8) blocks = 256 * 8;   // 8 four-wavefront blocks per CU: every wavefront resident at once
-        hipLaunchKernelGGL(pursuit_policy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, obs, n_rows, (int)obs_range,
+        hipLaunchKernelGGL(pursuit_policy_rows_kernel<U>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, obs, n_rows, (int)obs_range,
                            row_stride, (int)ch_offset, table_dev, (uint32_t)seed, (uint32_t)(seed >> 32), row_id_base, tick, tick_dev, actions);
     } else {
         int64_t blocks = (n_rows + 15) / 16;
