@@ -25,6 +25,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), "libmadrl_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "madrl_amd/_lib.py has no signature for %s" % n
     assert L.madrl_abi_version() == _lib.ABI_VERSION == 6
+    hdr = open(os.path.join(ROOT, "include", "madrl_hip.h")).read()
+    assert int(re.search(r"#define MADRL_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
+    words = re.search(r"#define MADRL_POLICY_COUNTER_WORDS \((\d+) \* (\d+)\)", hdr)
+    assert int(words.group(1)) * int(words.group(2)) == _lib.POLICY_COUNTER_WORDS
 
 
 def test_host_philox_matches_published_vectors():
