@@ -31,7 +31,7 @@ def main():
     for k, v in cfg.items():
         out["cfg_" + k] = np.float64(v) if isinstance(v, float) else np.int64(v)
     out["pickled_keys"] = np.array(sorted(k for k in st if k in ("constraint_window", "n_evaders", "n_pursuers", "catchr")))
-    path = os.path.join(os.path.dirname(HERE), "tests", "golden", "curriculum_pursuit.npz")
+    path = os.path.join(os.environ.get("MADRL_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden"), "curriculum_pursuit.npz")
     np.savez_compressed(path, **out)
     print("curriculum: cw %.2f -> %.2f, pursuers %d -> %d, catchr %.2f -> %.2f (%d iterations, %.1f KB)" % (
         cfg["constraint_window"], rec["cw"][-1], cfg["n_pursuers"], rec["n_pursuers"][-1], cfg["catchr"], rec["catchr"][-1], T,

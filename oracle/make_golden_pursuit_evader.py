@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_loader  # noqa: E402
 from oracle.make_golden_pursuit import ScriptedController, free_cells  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.path.join(os.environ.get("MADRL_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden"))
 
 
 def run(R, name, maps, cfg, episodes, steps, seed):

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_loader  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "resetdist_pursuit.npz")
+OUT = os.path.join(os.environ.get("MADRL_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden"), "resetdist_pursuit.npz")
 CFG = dict(n_evaders=30, n_pursuers=8, obs_range=7, constraint_window=0.5, sample_maps=True)
 N_RESETS_PER_WORKER = 5000
 AGENTS = [0, 7, 8, 37]   # agent indices (pursuers first) whose single positions are histogrammed
