@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_loader  # noqa: E402
 from oracle.make_golden_hostage import run  # noqa: E402
 
-N_CASES = 8
+N_CASES = 16
 MASTER_SEED = 20260926
 
 

@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_loader  # noqa: E402
 from oracle.make_golden_pursuit import run_scenario  # noqa: E402
 
-N_CASES = 24
+N_CASES = 48
 MASTER_SEED = 20260924
 
 

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_loader  # noqa: E402
 from oracle.make_golden_waterworld import run_scenario  # noqa: E402
 
-N_CASES = 12
+N_CASES = 24
 MASTER_SEED = 20260925
 
 
