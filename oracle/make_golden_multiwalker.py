@@ -93,6 +93,9 @@ class ScriptedNormal(object):
         return loc + scale * self.queue.pop(0)
 
 
+N_DRAWN = 12
+
+
 def run(MultiWalkerEnv, name, n_walkers, reward_mech, episodes, steps, seed, prefix="multiwalker_box2d_", zero_from=44, noise=None, fresh_world=False, **env_kw):
     """noise = (position_noise, angle_noise, seed, first env id): the observation noise on, scripted (ScriptedNormal); episode k is env id + k"""
     rng = np.random.RandomState(seed)
@@ -283,6 +286,16 @@ def main():
     run(MultiWalkerEnv, "w6_global", 6, "global", episodes=2, steps=100, seed=43, prefix=pre, fall_reward=-20.0)
     run(MultiWalkerEnv, "w7_noterminate", 7, "local", episodes=2, steps=120, seed=44, prefix=pre, zero_from=20, terminate_on_fall=False, drop_reward=-50.0)
     run(MultiWalkerEnv, "w9_local", 9, "local", episodes=2, steps=100, seed=45, prefix=pre)
+    # drawn configurations: walker count, reward mechanism, every coefficient, terminate_on_fall, one-hot ids, the observation noise and the step
+    # from which the actions are zero all come from one seed -- combinations nobody wrote down get replayed too
+    frng = np.random.RandomState(20260927)
+    for i in range(N_DRAWN):
+        W = int(frng.randint(1, 11))
+        kw = dict(forward_reward=float(np.round(frng.uniform(0.5, 3.0), 3)), fall_reward=float(np.round(frng.uniform(-150.0, -1.0), 2)),
+                  drop_reward=float(np.round(frng.uniform(-150.0, -1.0), 2)), terminate_on_fall=bool(frng.rand() < 0.6), one_hot=bool(frng.rand() < 0.25))
+        noise = (float(10.0 ** frng.uniform(-4, -1.5)), float(10.0 ** frng.uniform(-4, -1.5)), int(frng.randint(1, 2 ** 31 - 1)), int(frng.randint(0, 5000))) if frng.rand() < 0.5 else None
+        run(MultiWalkerEnv, "fuzz_%02d" % i, W, "global" if frng.rand() < 0.5 else "local", episodes=2, steps=int(frng.randint(40, 110)), seed=int(frng.randint(1, 2 ** 31 - 1)),
+            prefix=pre, zero_from=int(frng.randint(5, 60)), noise=noise, **kw)
     # files named multiwalker_resetdraws_*: a different layout (no episodes), replayed by its own test
     record_philox_resets(MultiWalkerEnv, 3, seed=0x1234567890ABCDEF, gid0=1000, n=24, prefix="multiwalker_resetdraws_")
     record_philox_resets(MultiWalkerEnv, 2, seed=7, gid0=0, n=12, prefix="multiwalker_resetdraws_")

@@ -93,8 +93,13 @@ def test_kernels_env_layer_is_the_references(path):
     _replay("hip", path, 1e-6, 1e-6)
 
 
+def _noiseless(path):
+    g = np.load(path)
+    return float(g["cfg_position_noise"]) == 0.0 and float(g["cfg_angle_noise"]) == 0.0
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", [p for p in FILES if "noise" not in p], ids=[i for i in ids if "noise" not in i])
+@pytest.mark.parametrize("path", [p for p in FILES if _noiseless(p)], ids=[i for p, i in zip(FILES, ids) if _noiseless(p)])
 def test_kernels_env_layer_in_every_lane(path):
     """37 interleaved copies of every recorded episode: more than two wavefronts of envs per episode set, at every position of a wavefront"""
     _replay("hip", path, 1e-6, 1e-6, copies=37)
