@@ -5,10 +5,10 @@ import sys, numpy as np, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import multiwalker as mwo, multiwalker_ref as mwr
 import argparse
-ap = argparse.ArgumentParser(); ap.add_argument('--walkers', type=int, nargs='*', default=[3, 4, 2]); ap.add_argument('--steps', type=int, default=1500)
+ap = argparse.ArgumentParser(); ap.add_argument('--walkers', type=int, nargs='*', default=[3, 4, 2]); ap.add_argument('--steps', type=int, default=1500); ap.add_argument('--seed', type=int, default=0, help='added to the per-walker-count seeds: another soak')
 args = ap.parse_args()
 for W in args.walkers:
-    seed = {3: 101, 4: 102, 2: 103}.get(W, 100 + W)
+    seed = {3: 101, 4: 102, 2: 103}.get(W, 100 + W) + args.seed
     N, T = 64, args.steps
     ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=seed, position_noise=0, angle_noise=0, poly=True)
     core = mwo.MultiWalkerOracle(n_walkers=W, n_envs=N, seed=seed, position_noise=0.0, angle_noise=0.0, lanes_descending=(W == 4))
