@@ -1004,6 +1004,13 @@ MW_HD void collide_dyn_pair(const Model &M, Hot &Wd, const ColdView &Cd, Scratch
     Slot &sl = Cd.slot[M.dyn_slot_base + p];
     if (sl.edge < 0) return;
     if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) {   // Destroy (an EndContact would only clear lower-leg flags: none here)
+        // b2Contact::Destroy: "if (manifold.pointCount > 0 && no sensor) bodyA->SetAwake(true), bodyB->SetAwake(true)" -- a package thrown off
+        // a sleeping walker's hull within one step wakes that hull (once in ~10^7 env-steps: found by scripts/mw_soak.py --seed 1000 at six walkers)
+        if (sl.touching) {
+            BodyBits wake = BodyBits::none();
+            for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!Wd.awake.test(b)) { wake.set(b); Cd.sleep_time[b] = 0.0f; } }
+            if (wake.any()) par.or_bits(&Wd.awake, wake);
+        }
         sl.edge = -1; sl.npts = 0; sl.touching = 0;
         return;
     }
@@ -1066,13 +1073,17 @@ MW_HD void find_new_terrain_contacts(const Model &M, Hot &Wd, const ColdView &Cd
         sl.edge = (int16_t)e; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch; sl.reserved_ = tag;
     }
 }
-MW_HD void find_new_pair_contacts(const Model &M, const ColdView &Cd, BodyBits moved, uint32_t batch) {
+// (one lane runs this; b2ContactManager::AddPair of Box2D 2.3.0 ends with "Wake up the bodies": a hull put to sleep by this very step's
+// islands, or a sleeping package, is awake again when a moved proxy's fat AABB starts to overlap its own -- the terrain's pairs need nothing:
+// their dynamic body is the one that moved.  Found by scripts/mw_soak.py --seed 1000 at six walkers, env-step 127 913 of that run.)
+MW_HD void find_new_pair_contacts(const Model &M, Hot &Wd, const ColdView &Cd, BodyBits moved, uint32_t batch) {
     for (int p = 0; p < M.n_dyn_pairs; ++p) {
         const int bA = M.dyn_a[p], bB = M.dyn_b[p];
         Slot &sl = Cd.slot[M.dyn_slot_base + p];
         if (sl.edge >= 0 || !(moved.test(bA) || moved.test(bB))) continue;
         if (!aabb_overlap(body_fat(Cd, bA), body_fat(Cd, bB))) continue;
         sl.edge = 0; sl.npts = 0; sl.touching = 0; sl.batch = (uint16_t)batch;
+        for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!Wd.awake.test(b)) { Wd.awake.set(b); Cd.sleep_time[b] = 0.0f; } }
     }
 }
 
@@ -2314,7 +2325,7 @@ MW_HD_INLINE void step_post(const Model &M, Hot &Wd, const ColdView &Cd, Scratch
         if (mv.any()) par.or_bits(&S.moved, mv);
     }
     par.sync();
-    if (L0 == 0 && S.moved.any()) find_new_pair_contacts(M, Cd, S.moved, Wd.batch);
+    if (L0 == 0 && S.moved.any()) find_new_pair_contacts(M, Wd, Cd, S.moved, Wd.batch);
     par.sync();
 }
 
@@ -2465,7 +2476,7 @@ MW_HD void env_reset_world(const Model &M, const EnvCfg &C, Hot &Wd, const ColdV
         set_body_fat(Cd, b, fatten(poly_aabb(M.shape[shape_of_body(b)], body_xf(M, Wd.b[b], b))));
     }
     for (int b = 0; b < M.NB; ++b) find_new_terrain_contacts(M, Wd, Cd, b, 0);
-    find_new_pair_contacts(M, Cd, BodyBits::first(M.NB), 0);
+    find_new_pair_contacts(M, Wd, Cd, BodyBits::first(M.NB), 0);
     Wd.episode = tick + 1;
     Wd.tick = 0;
 }
