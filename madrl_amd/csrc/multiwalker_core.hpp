@@ -1842,6 +1842,11 @@ MW_HD void toi_body_chain(const Model &M, Hot &Wd, const ColdView &Cd, const Scr
                 if (si == min_slot) continue;
                 if (n_isl >= MAX_TOI_CONTACTS) break;
                 ManifoldOut o2;
+                // b2Contact::Update begins with "Re-enable this contact": a contact that an earlier event of this chain found not solid after
+                // all (disabled: bit 1 of its meta byte) is a candidate again once a later event's island has looked at it -- a leg tip
+                // on the vertex two edges share: the first edge's event is undone, the second one's is solid, and later in the step the
+                // first edge is hit for real (scripts/mw_soak.py --seed 5000 --steps 6000 at ten walkers, env-step 200 532 of that run)
+                TL.meta[si - base] &= (uint8_t)~2u;
                 if (toi_update_contact(M, Wd, Cd, Cd.slot[si], mover, o2)) add_manifold(o2, si);
             }
         }
