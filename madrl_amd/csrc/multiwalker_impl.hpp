@@ -299,7 +299,7 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
     lds_sync();
     if (!fresh) {
         if (lane < W) io.rew[env * W + lane] = s_rew[lane];
-        if (lane == 0) io.done[env] = (uint8_t)*s_done;
+        if (lane == 0) io.done[env] = (uint8_t)(*s_done | (Wd.overflow ? 0x80u : 0u));   // bit 7: this episode ran out of a capacity (sticky, Hot::overflow)
         if ((*s_done >> 8) == 1) {   // the episode ended and the next one is ready: it becomes the live record
             const uint32_t *sp = d.spare_state + env * (int64_t)d.world_dw;
             uint32_t *dst = reinterpret_cast<uint32_t *>(&Wd);

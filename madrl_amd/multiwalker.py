@@ -153,8 +153,12 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
 
     def step(self, actions, rew_out=None, done_out=None):
         """multi_walker.py:359-428.  done = bit 0 of the kernel's done byte (game over / package dropped, :404-424); bit 1 =
-        the max_steps time limit.  With auto_reset ANY bit starts a new episode, so info carries the raw bits like
-        BatchedPursuitEvade does (the rollout collector and the wrappers cut episodes on info['done_bits']).
+        the max_steps time limit.  With auto_reset either of them starts a new episode, so info carries the raw bits like
+        BatchedPursuitEvade does (the rollout collector and the wrappers cut episodes on info['done_bits']).  Bit 7 (info['overflow']) =
+        the episode ran out of a capacity -- a contact did not fit its cache or the step's manifold pool and was ignored; sticky until
+        the env's next reset, starts no episode by itself.  The pools are sized for walking and falling walkers (the largest
+        manifold count seen in random and gait rollouts is about two thirds of them); every walker of eight lying in a heap with
+        terminate_on_fall off exceeds them after a few hundred steps.
         rew_out float32 [N, W] / done_out uint8 [N]: optional destinations the kernel writes instead of the env's buffers."""
         N, W = self.n_envs, int(self.n_walkers)
         a = torch.as_tensor(actions, device=self.device)
@@ -166,7 +170,7 @@ class BatchedMultiWalkerEnv(AbstractMAEnv):
         assert rew.dtype == torch.float32 and rew.numel() == N * W and dn.dtype == torch.uint8 and dn.numel() == N
         _lib.check(_lib.lib().madrl_multiwalker_step(self._handle, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(rew),
                                                      _lib.ptr(dn), _lib.current_stream(self.device)))
-        return self._obs, rew, (dn & 1).bool(), {"done_bits": dn, "truncated": (dn & 2).bool()}
+        return self._obs, rew, (dn & 1).bool(), {"done_bits": dn, "truncated": (dn & 2).bool(), "overflow": (dn & 128).bool()}
 
     def bodies(self):
         N, W, dev = self.n_envs, int(self.n_walkers), self.device

@@ -247,3 +247,39 @@ def test_later_box2d_polygon_revision_on_the_kernels(n_walkers):
         assert (env.state_buffer.cpu().numpy()[:, :orc.world_bytes] == orc.worlds()).all(), t
         if odone.any():
             orc.reset(mask=odone); env.reset(mask=odone)
+
+
+@pytest.mark.parametrize("n_walkers,capacity", [(3, 4), (6, 8), (10, 10)])
+def test_capacity_overflow_is_reported_in_the_done_byte(n_walkers, capacity):
+    """A contact that does not fit its cache or the step's manifold pool is ignored and the env's sticky Hot::overflow flag set (in gait
+    rollouts with terminate_on_fall off and eight walkers lying in a heap: twice in 192 000 env-steps, scripts/mw_soak.py).  The env must
+    SAY so in-band: bit 7 of the done byte / info['overflow'] -- the flag get_state returns -- every step until the env is reset, no other
+    bit set by it, no new episode started.  (The flag is poked into the raw record here; its offset is checked against the CPU build.)"""
+    import ctypes as C
+    from oracle import multiwalker as mwo
+    N, W = 64, n_walkers
+    off = 24 * (5 * capacity + 1) + 4 * capacity
+    off = (off + 7) // 8 * 8 + 8 * capacity + 8 + 3 * capacity + 1     # Hot: bodies, push_x, prev_shaping[], prev_package_shaping, fallen, ground, game_over, overflow
+    orc = mwo.MultiWalkerOracle(n_walkers=W, n_envs=2, seed=1, position_noise=0.0, angle_noise=0.0)
+    orc.reset()
+    w = orc.worlds().copy()
+    assert not w[:, off].any()
+    w[1, off] = 1
+    orc.L.mwo_set_worlds(orc.h, w.ctypes.data_as(C.c_void_p))
+    assert list(orc.overflow() != 0) == [False, True], "the offset of Hot::overflow"
+    env = _mk(N, n_walkers=W, seed=3, auto_reset=True, max_steps=0)
+    env.reset()
+    zero = torch.zeros((N, W, 4), device=DEV)
+    obs, rew, done, info = env.step(zero)
+    assert not info["overflow"].any()
+    marked = torch.zeros(N, dtype=torch.bool, device=DEV)
+    marked[[5, 40]] = True
+    env.state_buffer[marked, off] = 1
+    for _ in range(3):
+        obs, rew, done, info = env.step(zero)
+        assert torch.equal(info["overflow"], marked) and torch.equal(env.get_state()["flags"][:, -1] != 0, marked)
+        assert not ((info["done_bits"] & 0x7C) != 0).any() and torch.equal((info["done_bits"] & 1).bool(), done)
+        assert not done[marked].any()      # standing walkers, zero actions: nothing ends, and the flag ends nothing
+    env.reset(mask=marked.to(torch.uint8))
+    obs, rew, done, info = env.step(zero)
+    assert not info["overflow"].any(), "reset clears the flag"
