@@ -6,6 +6,8 @@ PARITY UNPINNED: Box2D, where the reference's arithmetic for this env lives, is 
     that independent restatement, step by step: every body pose / velocity BIT FOR BIT, every contact of Box2D's world list
     (pair, order, touching, feature ids, warm-start impulses), every joint impulse, every ContactDetector flag, done, rewards;
   * physical invariants and the env logic around the solver."""
+import os
+
 import numpy as np
 import pytest
 
@@ -344,3 +346,28 @@ def test_both_box2d_polygon_revisions_in_both_restatements(n_walkers):
     share = differ / float(N * T)
     print("n_walkers=%d: the two b2CollidePolygons revisions give different body states on %.2f %% of the env-steps" % (W, 100 * share))
     assert 0.0 < share < 0.25
+
+
+@pytest.mark.parametrize("case", ["addpair_wakes", "update_reenables"])
+def test_the_two_env_steps_a_longer_soak_caught(case):
+    """tests/fixtures/mw_soak_finds.npz (oracle/make_fixture_mw_soak_finds.py): the product's world record of one env just before a step on
+    which the product's source once disagreed with the independent restatement, and what the independent restatement has after that step.
+    1. AddPair wakes both bodies (a hull the step's islands had just put to sleep); 2. b2Contact::Update re-enables a contact that an
+    earlier event of the continuous pass had disabled (a leg tip on the vertex two terrain edges share).  The CPU build must land on the
+    independent restatement's bits: bodies, joints, fat AABBs / sleep times / awake flags, contact flags."""
+    import ctypes as C
+    from oracle import multiwalker as mwo
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "mw_soak_finds.npz"))
+    k = lambda name: g["%s_%s" % (case, name)]
+    W = int(k("n_walkers"))
+    for descending in (False, True):
+        core = mwo.MultiWalkerOracle(n_walkers=W, n_envs=1, seed=int(k("seed")), position_noise=0.0, angle_noise=0.0, lanes_descending=descending)
+        core.reset()
+        w = np.ascontiguousarray(k("world")[None])
+        assert w.shape == core.worlds().shape
+        core.L.mwo_set_worlds(core.h, w.ctypes.data_as(C.c_void_p))
+        core.step(k("actions")[None])
+        bodies, flags = core.bodies()
+        assert np.array_equal(bodies[0], k("bodies")), "body states"
+        assert np.array_equal(core.joints()[0], k("joints")) and np.array_equal(core.aux()[0], k("aux")), "joints / fat AABBs, sleep times, awake flags"
+        assert np.array_equal(np.asarray(flags[0], np.uint8), k("flags")) and not core.overflow().any()
