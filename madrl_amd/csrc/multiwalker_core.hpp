@@ -2043,6 +2043,7 @@ MW_HD void solve_toi(const Model &M, Hot &Wd, const ColdView &Cd, Scratch &S, To
                     AABB A, B; A.lx = fa[0]; A.ly = fa[1]; A.hx = fa[2]; A.hy = fa[3]; B.lx = fb[0]; B.ly = fb[1]; B.hx = fb[2]; B.hy = fb[3];
                     if (!aabb_overlap(A, B)) continue;
                     ps.edge = 0; ps.npts = 0; ps.touching = 0; ps.batch = (uint16_t)(T.batch_base + 1u + (uint32_t)r);
+                    for (int q = 0; q < 2; ++q) { const int b = q ? bB : bA; if (!Wd.awake.test(b)) { Wd.awake.set(b); Cd.sleep_time[b] = 0.0f; } }   // AddPair: "Wake up the bodies"
                     MW_STAT(toi_pairs, 1);
                 }
             }

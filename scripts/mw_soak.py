@@ -36,7 +36,8 @@ for W in args.walkers:
         assert np.array_equal(ref.bodies(), core.bodies()[0]) and np.array_equal(rd, cd), (W, t)
         assert np.array_equal(ref.joints(), core.joints()) and np.array_equal(ref.aux(), core.aux()), (W, t)
         # the env layer on top (float64 on the reference's side, float32 in the product): observations incl. lidar, rewards
-        assert np.abs(np.asarray(ro, np.float64).reshape(co.shape) - co).max() <= 1e-5 and np.abs(np.asarray(rr, np.float64).reshape(cr.shape) - cr).max() <= 1e-4 * max(1.0, float(np.abs(rr).max())), (W, t, 'obs / rewards')
+        ro64, rr64 = np.asarray(ro, np.float64).reshape(co.shape), np.asarray(rr, np.float64).reshape(cr.shape)
+        assert (np.abs(ro64 - co) <= 1e-6 * np.maximum(1.0, np.abs(ro64))).all() and (np.abs(rr64 - cr) <= 1e-6 * np.maximum(1.0, np.abs(rr64))).all(), (W, t, 'obs / rewards')
         nd += int(rd.sum())
         if rd.any(): ref.reset(mask=rd); core.reset(mask=rd)
     print("W=%d: %d free-running env-steps identical, %d episodes, %d continuous-pass events, %d capacity overflows (env restarted), %.0f s" % (W, N * T, nd, ref.stats()["toi_events"], n_ov, time.time() - t0), flush=True)
