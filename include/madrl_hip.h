@@ -385,7 +385,8 @@ int madrl_multiwalker_reset(madrl_multiwalker *h, const uint8_t *mask_dev, float
 /* MultiWalkerEnv.step (:359-428): actions float32 [N][W][4]; rew float32 [N][W]; done uint8 [N]
  * (bit0 = the reference's done, bit1 = max_steps reached, bit7 = capacity overflow, sticky until the env is reset: a contact did
  * not fit its cache or the step's manifold pool -- sized for walking and falling walkers, not for all of them lying in a heap with
- * terminate_on_fall off -- and was ignored, so this episode is no longer Box2D's; the same flag as get_state's).  With auto_reset an env whose episode ended continues with its next
+ * terminate_on_fall off -- and was ignored, or the episode has outlasted the 16-bit creation stamps of its contacts (65 280 FindNewContacts
+ * calls: some 45 000 steps of walking, 9 000 with ten fallen walkers), so this episode is no longer Box2D's; the same flag as get_state's).  With auto_reset an env whose episode ended continues with its next
  * episode (reset + trailing step, :330-357) and obs holds that episode's first observation; the result is the same as
  * reset(mask = done) after the call, whichever way the library gets there (a prepared spare record or a second pass) */
 int madrl_multiwalker_step(madrl_multiwalker *h, const float *actions_dev, float *obs_dev, float *rew_dev,

@@ -482,7 +482,7 @@ struct Hot {
     Body b[MAXB];
     float push_x[MAX_WALKERS];    // ApplyForceToCenter pending until the first Step (:130-131)
     double prev_shaping[MAX_WALKERS], prev_package_shaping;   // float64 like the reference's Python side (:403-411)
-    uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, overflow;   // overflow: sticky, a contact did not fit its cache / the pool
+    uint8_t fallen[MAX_WALKERS], ground[MAX_WALKERS][2], game_over, overflow;   // overflow: sticky; bit 0 a contact did not fit its cache / the pool, 1 a stale cache entry evicted, 2 the continuous pass's logs, 3 more FindNewContacts calls in one episode than Slot::batch counts
     uint8_t pad_[2 + (4 - (3 * MAX_WALKERS) % 4) % 4];
     uint32_t tick;                // observations of the current episode so far (noise draws)
     uint32_t episode;             // resets of this env so far (a reset's draws)
@@ -2316,6 +2316,10 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
                 }
         }
         Wd.batch += 1;   // this step's FindNewContacts call (step_post)
+        // A contact remembers its call in 16 bits (Slot::batch): past 65 535 calls in ONE episode -- some 45 000 steps of walking, 9 000 with
+        // ten fallen walkers and half a dozen continuous-pass events per step (found by scripts/mw_soak.py --gait 0.9 --no-terminate at ten
+        // walkers, step 9 141) -- new contacts would sort before old ones.  Said in-band instead (sticky bit 3, a margin of one step's events early).
+        if (Wd.batch >= 0xFF00u) Wd.overflow |= 8;
     }
     par.sync();
 }

@@ -110,7 +110,8 @@ void mwo_set_worlds(MwOracle *o, const void *in) { memcpy(o->worlds.data(), in, 
 
 /* body kinematics for tests: [N][NB][6] = cx, cy, angle, vx, vy, w ; flags [N][2+2W] */
 /* sticky Hot::overflow per env: bit 0 a contact found no room (cache slot or manifold pool), bit 1 a stale cache entry was evicted, bit 2 the
- * event log of a continuous pass was full -- all zero means every contact Box2D would have had was simulated */
+ * event log of a continuous pass was full, bit 3 the episode has had more FindNewContacts calls than a contact's 16-bit creation stamp counts --
+ * all zero means every contact Box2D would have had was simulated, in Box2D's order */
 void mwo_get_overflow(const MwOracle *o, uint8_t *out) { for (int64_t n = 0; n < o->n_envs; ++n) out[n] = o->worlds[n].h.overflow; }
 void mwo_get_bodies(const MwOracle *o, float *out, uint8_t *flags) {
     const int NB = o->M.NB, W = o->M.W;
