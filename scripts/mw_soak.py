@@ -6,7 +6,7 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 from oracle import multiwalker as mwo, multiwalker_ref as mwr
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument('--walkers', type=int, nargs='*', default=[3, 4, 2]); ap.add_argument('--steps', type=int, default=1500); ap.add_argument('--seed', type=int, default=0, help='added to the per-walker-count seeds: another soak')
-ap.add_argument('--no-terminate', action='store_true', help='terminate_on_fall off: fallen walkers stay (more sleeping bodies, package dropped)'); ap.add_argument('--rev', type=int, default=0, help='b2CollidePolygons revision'); ap.add_argument('--hold', type=int, default=1, help='actions drawn anew every HOLD steps (held in between: other gaits)'); ap.add_argument('--scale', type=float, default=1.0, help='action amplitude'); ap.add_argument('--descending', action='store_true', help='the CPU build runs an env\'s lanes in descending order (the result must not depend on it)'); ap.add_argument('--gait', type=float, default=0.0, help='fraction of the walkers that follow the reference\'s hand-written gait (heuristics/multi_walker.py) instead of random actions')
+ap.add_argument('--no-terminate', action='store_true', help='terminate_on_fall off: fallen walkers stay (more sleeping bodies, package dropped)'); ap.add_argument('--rev', type=int, default=0, help='b2CollidePolygons revision'); ap.add_argument('--hold', type=int, default=1, help='actions drawn anew every HOLD steps (held in between: other gaits)'); ap.add_argument('--scale', type=float, default=1.0, help='action amplitude'); ap.add_argument('--contacts', type=int, default=0, help='every CONTACTS steps also compare every env\'s whole contact list: pairs in list order, touching, feature ids, warm-start impulses'); ap.add_argument('--descending', action='store_true', help='the CPU build runs an env\'s lanes in descending order (the result must not depend on it)'); ap.add_argument('--gait', type=float, default=0.0, help='fraction of the walkers that follow the reference\'s hand-written gait (heuristics/multi_walker.py) instead of random actions')
 args = ap.parse_args()
 for W in args.walkers:
     seed = {3: 101, 4: 102, 2: 103}.get(W, 100 + W) + args.seed
@@ -38,6 +38,10 @@ for W in args.walkers:
         # the env layer on top (float64 on the reference's side, float32 in the product): observations incl. lidar, rewards
         ro64, rr64 = np.asarray(ro, np.float64).reshape(co.shape), np.asarray(rr, np.float64).reshape(cr.shape)
         assert (np.abs(ro64 - co) <= 1e-6 * np.maximum(1.0, np.abs(ro64))).all() and (np.abs(rr64 - cr) <= 1e-6 * np.maximum(1.0, np.abs(rr64))).all(), (W, t, 'obs / rewards')
+        if args.contacts and t % args.contacts == 0:
+            for e in range(N):
+                (ri, rf), (ci, cf) = ref.contacts(e, 1024), core.contacts(e, 1024)
+                assert len(ri) == len(ci) and np.array_equal(ri[:, :7], ci[:, :7]) and np.array_equal(rf, cf), (W, t, e, 'contact lists')
         nd += int(rd.sum())
         if rd.any(): ref.reset(mask=rd); core.reset(mask=rd)
     print("W=%d: %d free-running env-steps identical, %d episodes, %d continuous-pass events, %d capacity overflows (env restarted), %.0f s" % (W, N * T, nd, ref.stats()["toi_events"], n_ov, time.time() - t0), flush=True)
