@@ -6,13 +6,13 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 from oracle import multiwalker as mwo, multiwalker_ref as mwr
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument('--walkers', type=int, nargs='*', default=[3, 4, 2]); ap.add_argument('--steps', type=int, default=1500); ap.add_argument('--seed', type=int, default=0, help='added to the per-walker-count seeds: another soak')
-ap.add_argument('--no-terminate', action='store_true', help='terminate_on_fall off: fallen walkers stay (more sleeping bodies, package dropped)'); ap.add_argument('--rev', type=int, default=0, help='b2CollidePolygons revision'); ap.add_argument('--hold', type=int, default=1, help='actions drawn anew every HOLD steps (held in between: other gaits)'); ap.add_argument('--scale', type=float, default=1.0, help='action amplitude'); ap.add_argument('--noise', type=float, default=0.0, help='position_noise = angle_noise (the reference\'s default is 1e-3)'); ap.add_argument('--contacts', type=int, default=0, help='every CONTACTS steps also compare every env\'s whole contact list: pairs in list order, touching, feature ids, warm-start impulses'); ap.add_argument('--descending', action='store_true', help='the CPU build runs an env\'s lanes in descending order (the result must not depend on it)'); ap.add_argument('--gait', type=float, default=0.0, help='fraction of the walkers that follow the reference\'s hand-written gait (heuristics/multi_walker.py) instead of random actions')
+ap.add_argument('--no-terminate', action='store_true', help='terminate_on_fall off: fallen walkers stay (more sleeping bodies, package dropped)'); ap.add_argument('--rev', type=int, default=0, help='b2CollidePolygons revision'); ap.add_argument('--hold', type=int, default=1, help='actions drawn anew every HOLD steps (held in between: other gaits)'); ap.add_argument('--scale', type=float, default=1.0, help='action amplitude'); ap.add_argument('--global-reward', action='store_true'); ap.add_argument('--one-hot', action='store_true'); ap.add_argument('--noise', type=float, default=0.0, help='position_noise = angle_noise (the reference\'s default is 1e-3)'); ap.add_argument('--contacts', type=int, default=0, help='every CONTACTS steps also compare every env\'s whole contact list: pairs in list order, touching, feature ids, warm-start impulses'); ap.add_argument('--descending', action='store_true', help='the CPU build runs an env\'s lanes in descending order (the result must not depend on it)'); ap.add_argument('--gait', type=float, default=0.0, help='fraction of the walkers that follow the reference\'s hand-written gait (heuristics/multi_walker.py) instead of random actions')
 args = ap.parse_args()
 for W in args.walkers:
     seed = {3: 101, 4: 102, 2: 103}.get(W, 100 + W) + args.seed
     N, T = 64, args.steps
-    ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=seed, position_noise=args.noise, angle_noise=args.noise, poly=True, terminate_on_fall=not args.no_terminate, polygon_revision=args.rev)
-    core = mwo.MultiWalkerOracle(n_walkers=W, n_envs=N, seed=seed, position_noise=args.noise, angle_noise=args.noise, lanes_descending=(W == 4) != args.descending, terminate_on_fall=not args.no_terminate, polygon_revision=args.rev)
+    ref = mwr.MultiWalkerRef(n_walkers=W, n_envs=N, seed=seed, position_noise=args.noise, angle_noise=args.noise, poly=True, terminate_on_fall=not args.no_terminate, polygon_revision=args.rev, reward_mech='global' if args.global_reward else 'local', one_hot=args.one_hot)
+    core = mwo.MultiWalkerOracle(n_walkers=W, n_envs=N, seed=seed, position_noise=args.noise, angle_noise=args.noise, lanes_descending=(W == 4) != args.descending, terminate_on_fall=not args.no_terminate, polygon_revision=args.rev, reward_mech='global' if args.global_reward else 'local', one_hot=args.one_hot)
     ref.reset(); core.reset()
     rng = np.random.RandomState(seed); gait_rng = np.random.RandomState(seed + 1); pick = None
     t0 = time.time(); nd = 0; n_ov = 0
