@@ -44,6 +44,8 @@ void mwo_sizes(int32_t *out) {
     out[3] = (int32_t)sizeof(mw::ToiWork); out[4] = (int32_t)sizeof(mw::Manifold); out[5] = (int32_t)sizeof(mw::World); out[6] = (int32_t)sizeof(mw::Cold);
 }
 int mwo_capacity(void) { return mw::MAX_WALKERS; }
+/* byte offsets inside the world record, for tests that poke it: Hot::overflow, Hot::batch */
+void mwo_hot_offsets(int32_t *out) { out[0] = (int32_t)offsetof(mw::Hot, overflow); out[1] = (int32_t)offsetof(mw::Hot, batch); }
 int mwo_lanes(void) { return mw::SOLVE_LANES; }
 
 MwOracle *mwo_create(int n_walkers, int reward_global, int terminate_on_fall, float position_noise, float angle_noise,

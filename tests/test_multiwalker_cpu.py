@@ -371,3 +371,29 @@ def test_the_two_env_steps_a_longer_soak_caught(case):
         assert np.array_equal(bodies[0], k("bodies")), "body states"
         assert np.array_equal(core.joints()[0], k("joints")) and np.array_equal(core.aux()[0], k("aux")), "joints / fat AABBs, sleep times, awake flags"
         assert np.array_equal(np.asarray(flags[0], np.uint8), k("flags")) and not core.overflow().any()
+
+
+@pytest.mark.parametrize("n_walkers", [3, 6, 10])
+def test_an_episode_that_outlasts_its_contacts_creation_stamps_says_so(n_walkers):
+    """A contact remembers the FindNewContacts call that created it in 16 bits (its place in Box2D's lists).  An episode with more calls than
+    that -- ten fallen walkers with half a dozen continuous-pass events per step get there in 9 141 steps (scripts/mw_soak.py), walking
+    ones in some 45 000 -- raises the record's sticky overflow flag (bit 3) 256 calls early instead of letting new contacts sort before
+    old ones.  The call counter is poked into the raw record here."""
+    import ctypes as C
+    core = mwo.MultiWalkerOracle(n_walkers=n_walkers, n_envs=2, seed=5, position_noise=0.0, angle_noise=0.0)
+    core.reset()
+    off = (C.c_int32 * 2)()
+    core.L.mwo_hot_offsets(off)
+    w = core.worlds().copy()
+    assert int(w[1, off[1]:off[1] + 4].view(np.uint32)[0]) < 100 and not w[:, off[0]].any()
+    w[1, off[1]:off[1] + 4] = np.frombuffer(np.uint32(0xFEFE).tobytes(), np.uint8)
+    core.L.mwo_set_worlds(core.h, w.ctypes.data_as(C.c_void_p))
+    zero = np.zeros((2, n_walkers, 4), np.float32)
+    core.step(zero)
+    assert list(core.overflow()) == [0, 0]          # 0xFEFF calls: not yet
+    core.step(zero)
+    assert list(core.overflow() & 8) == [0, 8], "sticky bit 3 from 0xFF00 calls on"
+    core.step(zero)
+    assert list(core.overflow() & 8) == [0, 8]
+    core.reset(mask=np.array([0, 1], np.uint8))
+    assert not core.overflow().any()
