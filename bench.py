@@ -261,7 +261,7 @@ PURSUIT_VARIANTS = {
 }
 
 
-def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True):
+def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True, api_leg=None):
     import numpy as np
     import torch
     from madrl_amd.maps import rectangle_map
@@ -354,11 +354,29 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     torch.cuda.synchronize()
     dt, kernel_ms, region_ms = Timer(world, dev, hip_streams).run(one_step, K, W, tail, prepare)
     kernel_kind = envs[0].kernel_kind
+    api = None
+    if (bool(cpu_budget) if api_leg is None else api_leg) and not coll:
+        # The same K-step regions through the DROP-IN API instead of the raw C ABI: BatchedPursuitEvade.step(actions) per sub-batch (as
+        # StreamSharded.step(fork=False, join=False), the free-running form the ABI loop above has) -- argument checks, the ctypes call and
+        # the result tuple / info dict, whose tensors are views of what the launch wrote (madrl_amd/pursuit.py _step_result).
+        from madrl_amd.sharded import StreamSharded
+        sh = StreamSharded.from_envs(envs, dev)
+        act_parts = [[a[j * per:(j + 1) * per] for j in range(S)] for a in actions]
+
+        def api_step(i, record):
+            if S == 1:
+                envs[0].step(actions[i % n_act])            # one launch per step, on the current stream
+            else:
+                sh.step(act_parts[i % n_act], fork=False, join=False)
+        adt, akms, aregion = Timer(world, dev, hip_streams).run(api_step, K, min(W, 20))
+        api = {"python_api_ms_per_step": adt / K * 1e3, "python_api_region_ms_per_step": [round(x, 6) for x in aregion],
+               "python_api_is": "BatchedPursuitEvade.step(actions) on every sub-batch (StreamSharded.step, fork=False, join=False), same actions, same K"}
+        del sh
     del envs, outs, hs
     one = None
     if reference_pass and S > 1 and not coll:
         # the same batch as ONE launch per step on one stream, in the same process: what the sub-batch streams are compared with
-        one = bench_pursuit(args, variant, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False)
+        one = bench_pursuit(args, variant, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False, api_leg=bool(cpu_budget))
     if rank != 0:
         return None
     bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
@@ -396,6 +414,13 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
                         "horizon_resets_per_step": N / float(H), "horizon_resets_per_launch": per / float(H)}, **region_stats(region_ms)),
         "roofline": roof,
     }
+    if api is not None and not cpu_budget:
+        out["python_api"] = api
+    elif api is not None:
+        api["python_api_over_abi"] = api["python_api_ms_per_step"] / out["ms_per_step"]
+        if one is not None and "python_api" in one:
+            api["python_api_one_launch_ms"] = one["python_api"]["python_api_ms_per_step"]
+        out["python_api"] = api
     if cpu_budget:
         c2 = variant == "pursuit"
         attach_cpu_baselines(out, "pursuit" if c2 else None, "pursuit_c1" if c2 else None, lambda: cpu_baseline_port(maps, kw, cpu_budget))
@@ -462,7 +487,7 @@ def C_void(v):
     return ctypes.c_void_p(v)
 
 
-def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True):
+def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True, api_leg=None):
     """Waterworld (BASELINE configs[2]; `waterworld_std` = the same env under StandardizedEnv, which is how every reference run
     wraps it, runners/run_waterworld.py / run_pursuit.py:57-58), MultiWalker (configs[3]) and the hostage world on the same contract."""
     import numpy as np
@@ -644,10 +669,25 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
     age()
     dt, kernel_ms, region_ms = Timer(world, dev, hip_streams).run(step, K, W)
     n_ended = float((done_rows[:K] != 0).sum().item()) / N if workload.startswith("multiwalker") else None
+    api = None
+    if (bool(cpu_budget) if api_leg is None else api_leg) and workload in ("waterworld", "hostage") and not collective_on(world):
+        # the drop-in API instead of the raw C ABI (see bench_pursuit): Batched*.step(action) per sub-batch on its stream
+        from madrl_amd.sharded import StreamSharded
+        sh = StreamSharded.from_envs(envs, dev)
+
+        def api_step(i, record):
+            if S == 1:
+                envs[0].step(acts[0][i % 8])
+            else:
+                sh.step([acts[j][i % 8] for j in range(S)], fork=False, join=False)
+        adt, _, aregion = Timer(world, dev, hip_streams).run(api_step, K, min(W, 20))
+        api = {"python_api_ms_per_step": adt / K * 1e3, "python_api_region_ms_per_step": [round(x, 6) for x in aregion],
+               "python_api_is": "Batched*.step(action) on every sub-batch (StreamSharded.step, fork=False, join=False), same actions, same K"}
+        del sh
     del envs
     one = None
     if reference_pass and S > 1 and world == 1:
-        one = bench_other(args, workload, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False)
+        one = bench_other(args, workload, K, min(W, 20), rank, world, dev, 0, streams=1, reference_pass=False, api_leg=bool(cpu_budget))
     if rank != 0:
         return None
     roof = roofline(bytes_per, N, kernel_ms, dt / K * 1e3, measured_traffic(per, traffic_key, S), kernel, streams=S, binding_resource=binding)
@@ -668,6 +708,12 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if workload != "waterworld_std" else "f32 simulation, f64 running statistics",
            "data": "synthetic (uniform random actions resident in HBM, in-kernel Philox, fused auto-reset, steady-state episode ages)",
            "config": cfg, "roofline": roof}
+    if api is not None:
+        if cpu_budget:
+            api["python_api_over_abi"] = api["python_api_ms_per_step"] / out["ms_per_step"]
+            if one is not None and "python_api" in one:
+                api["python_api_one_launch_ms"] = one["python_api"]["python_api_ms_per_step"]
+        out["python_api"] = api
     if cpu_budget:
         attach_cpu_baselines(out, live_key, rec_key, cpu_fn)
     return out
@@ -703,6 +749,10 @@ def compact_line(out):
                                         "trajectory_gather_in_timed_region") if k in c}
     line["config"]["region_ms_per_step"] = [_r(float(x)) for x in c["region_ms_per_step"]]
     line["roofline"] = compact_roofline(out["roofline"])
+    if "python_api" in out:   # the same regions through Batched*.step() instead of the raw C ABI
+        for k in ("python_api_ms_per_step", "python_api_one_launch_ms"):
+            if k in out["python_api"]:
+                line[k] = _r(float(out["python_api"][k]))
     if "cpu_baseline" in out:
         b = out["cpu_baseline"]
         line["cpu_baseline"] = {"value": _r(float(b["value"])), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "sample": b["sample"][:160]}
@@ -719,6 +769,8 @@ def compact_line(out):
                  "envs": w["config"]["envs_per_gpu"], "streams": w["config"]["streams_per_gpu"], "roofline": compact_roofline(w["roofline"], side=True)}
             if "cpu_baseline" in w:
                 e["cpu_baseline"] = {"value": _r(float(w["cpu_baseline"]["value"])), "cores": w["cpu_baseline"]["cores"], "kind": w["cpu_baseline"]["kind"]}
+            if "python_api" in w:
+                e["python_api_ms"] = _r(float(w["python_api"]["python_api_ms_per_step"]))
             line["workloads"][name] = e
     return line
 
@@ -809,12 +861,12 @@ def main():
         # (their own step counts, whatever --steps says: the contract's K is the headline's; a 20-step region of a two-stream pipeline is a third
         # fill and drain -- Waterworld reads 51 us per step at K = 20 and 42 at K = 200)
         for name, k, w in (("waterworld", 200, 20), ("multiwalker", 50, 20), ("pursuit_c5", 200, 20), ("pursuit_colocate", 200, 20), ("waterworld_std", 100, 20),
-                           ("multiwalker_w10", 20, 20), ("pursuit_rollout", 200, 20)):
+                           ("multiwalker_w10", 20, 20), ("pursuit_rollout", 200, 20), ("hostage", 200, 20)):
             try:
                 r = bench_rollout(args, k, w, rank, world, dev) if name == "pursuit_rollout" else \
                     bench_pursuit(args, name, k, w, rank, world, dev, side_cpu) if name.startswith("pursuit") else \
                     bench_other(args, name, k, w, rank, world, dev, side_cpu)
-                wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline") if f in r}
+                wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "python_api") if f in r}
             except Exception as e:  # a failing side workload must not take the headline down; it shows up as an error entry
                 wl[name] = {"error": repr(e)}
         out["workloads"] = wl

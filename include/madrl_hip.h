@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MADRL_ABI_VERSION 6
+#define MADRL_ABI_VERSION 7
 
 #define MADRL_OK 0
 #define MADRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -92,9 +92,16 @@ int madrl_pursuit_obs_dim(const madrl_pursuit_config *cfg, int32_t *out_dim);
 /* Bytes of per-env state the caller must allocate (and zero: an all-zero state is the
  * reference's constructor state -- every agent at (0,0) on map 0, pursuit_evade.py:69-75).
  * Layout: n_envs packed records of madrl_pursuit_record_bytes() each, padding to 256 bytes, then -- for shapes with a
- * compiled fast path -- the stale-zero masks of that path (256 bytes per env and wavefront, see obs_dev below).
+ * compiled fast path -- the stale-zero masks of that path (256 bytes per env, wavefront and mask word, see obs_dev below), then the
+ * flag plane (one dword per env, madrl_pursuit_flags_offset).
  * Everything the library knows about an env lives in this buffer and in the observation buffer: copying both clones it. */
 int madrl_pursuit_state_bytes(const madrl_pursuit_config *cfg, int64_t n_envs, uint64_t *out_bytes);
+/* Byte offset, inside the state buffer, of the FLAG PLANE: uint32 [n_envs], written by every step launch next to done_dev.
+ * Word n = the done byte of env n split into one 0 / 1 byte per meaning (little endian): byte 0 = bit0 (is_terminal, the `done`
+ * PursuitEvade.step returns, pursuit_evade.py:259), byte 1 = bit1 (max_steps reached), byte 2 = bit7 (count overflow), byte 3 = the
+ * done byte itself.  A host binding hands these bytes out as strided bool arrays (madrl_amd/pursuit.py: the `done` and `info` tensors
+ * of step() are views of this plane) instead of launching kernels that mask bits of done_dev after every step. */
+int madrl_pursuit_flags_offset(const madrl_pursuit_config *cfg, int64_t n_envs, uint64_t *out_offset);
 /* bytes of one packed record: [u32 tick][u32 t][u32 map_id][u32 0][u8 x,y per agent, pursuers first][u32 gone bits][u32 terminal bits], 16-B aligned */
 int madrl_pursuit_record_bytes(const madrl_pursuit_config *cfg, int32_t *out_bytes);
 
@@ -421,7 +428,9 @@ int madrl_multiwalker_reset_with(madrl_multiwalker *h, const uint8_t *mask_dev, 
 /* ------------------------------------------------------------------------------------------
  * Env wrappers as epilogue kernels (reference: madrl_environments/__init__.py:143-389).
  * Every env instance carries its own wrapper state (caller-owned device buffers, zero / one
- * initialised as noted); `mask` / `reset_mask` are uint8 [n_envs] or NULL.
+ * initialised as noted); `mask` / `reset_mask` are uint8 [n_envs] or NULL.  Where a kernel reads DONE BYTES of a step launch as episode
+ * boundaries (obsbuffer's reset_mask, diagnostics' done, madrl_rollout_gae's done) bit 7 -- the sticky overflow report of the Pursuit and
+ * MultiWalker kernels, which resets nothing -- is ignored.
  * ---------------------------------------------------------------------------------------- */
 /* StandardizedEnv.standardize_obs (:242-263): mean/var float64 [n_elems] (init 0 / 1, :229-230) */
 int madrl_wrap_obsnorm(const float *obs_in, double *mean, double *var, float *obs_out, int64_t n_elems,
@@ -435,7 +444,7 @@ int madrl_wrap_rewnorm(const float *rew_in, double *mean, double *var, float *re
 int madrl_wrap_obsbuffer(const float *obs, float *buf, int64_t n_elems, int64_t elems_per_env, int32_t k,
                          const uint8_t *reset_mask, const uint8_t *active_mask, void *stream);
 /* DiagnosticsWrapper.step (:335-369): per-env accumulators ep_reward float64 [N][A], ep_len int32 [N],
- * disc_ret / disc_pow float64 [N] (all init 0); on episode end (any done bit or max_traj_len) the out_* rows
+ * disc_ret / disc_pow float64 [N] (all init 0); on episode end (done bit 0 or 1, or max_traj_len) the out_* rows
  * receive episode_reward_agent*, episode_disc_return, episode_length and out_finished = 1 */
 int madrl_wrap_diagnostics(const float *rew, const uint8_t *done, double *ep_reward, int32_t *ep_len,
                            double *disc_ret, double *disc_pow, int64_t n_envs, int32_t n_agents, double discount,
@@ -446,7 +455,7 @@ int madrl_wrap_diagnostics(const float *rew, const uint8_t *done, double *ep_rew
  * Rollout post-processing: what the external samplers the runners hand the env to do with a batch of
  * paths (runners/rurllab.py:298-305 discount / gae_lambda; runners/rurltools.py:196-209), as one reverse
  * scan in time over the time-major trajectory tensors of the collector.
- *   rew float32 [T][N][A], done uint8 [T][N] (any bit = episode boundary after step t),
+ *   rew float32 [T][N][A], done uint8 [T][N] (bit 0 or 1 = episode boundary after step t; bit 7, the overflow report, is none),
  *   values float32 [T+1][N][A] or NULL (baseline predictions; row T bootstraps the unfinished tail),
  *   returns[t] = rew[t] + gamma * (done[t] ? 0 : returns[t+1]),      returns[T] = values[T] or 0
  *   delta[t]   = rew[t] + gamma * (done[t] ? 0 : values[t+1]) - values[t]

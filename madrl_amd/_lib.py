@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MADRL_HIP_LIB") or os.path.join(_HERE, "libmadrl_hip.so")  # override: profiling variants only
-ABI_VERSION = 6
+ABI_VERSION = 7
 POLICY_COUNTER_WORDS = 32 * 65   # MADRL_POLICY_COUNTER_WORDS of include/madrl_hip.h
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
@@ -90,6 +90,7 @@ SIGNATURES = {
     "madrl_pursuit_obs_dim": (C.c_int, [_vp, _vp]),
     "madrl_pursuit_state_bytes": (C.c_int, [_vp, C.c_int64, _vp]),
     "madrl_pursuit_record_bytes": (C.c_int, [_vp, _vp]),
+    "madrl_pursuit_flags_offset": (C.c_int, [_vp, C.c_int64, _vp]),
     "madrl_pursuit_invalidate_obs": (C.c_int, [_vp]),
     "madrl_pursuit_declare_obs_zero": (C.c_int, [_vp, _vp, _vp]),
     "madrl_pursuit_set_params": (C.c_int, [_vp, C.c_double, C.c_double]),

@@ -94,6 +94,13 @@ __host__ __device__ inline double u53(uint32_t hi, uint32_t lo) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The flag plane of a step launch (include/madrl_hip.h, madrl_pursuit_flags_offset): the done byte split into one 0 / 1 byte per
+// meaning, so that the host side hands out bool views of it instead of launching kernels that mask bits.
+//   byte 0 = bit 0 (episode over)   byte 1 = bit 1 (max_steps reached)   byte 2 = bit 7 (a capacity overflowed)   byte 3 = the done byte
+__host__ __device__ inline uint32_t done_flag_word(uint32_t done_byte) {
+    return (done_byte & 1u) | ((done_byte & 2u) << 7) | ((done_byte & 0x80u) << 9) | (done_byte << 24);
+}
+
 // XCD-aware walk of the env range by a grid of persistent one-wavefront workgroups.  Workgroups are dealt round-robin to
 // the 8 XCDs (block b runs on XCD b % 8, each with its own L2), so the plain walk env = b + k * gridDim hands NEIGHBOURING
 // envs to DIFFERENT L2s: every cache line shared by two envs' rows / records / reward words is then written back partially

@@ -58,6 +58,7 @@ struct PursuitDev {
     const double *cw_env;     // per-env constraint_window / catchr (curriculum, pursuit_evade.py:264-272) or nullptr: the scalars above
     const double *catchr_env;
     uint8_t *state;
+    uint32_t *flags;         // [n_envs] flag words (done_flag_word, common.hpp): in the caller's state buffer, behind the stale-zero masks
 };
 
 struct PursuitIO {
@@ -425,6 +426,7 @@ __global__ void pursuit_kernel(const PursuitDev d, const PursuitIO io, const int
             if (tid == 0) {
                 io.done[env] = (uint8_t)(done_bits | overflow);
                 io.removed[env] = (int32_t)s_misc[4];
+                d.flags[env] = done_flag_word(done_bits | overflow);
             }
             do_reset = d.auto_reset && done_bits != 0;
         }
@@ -619,7 +621,7 @@ struct madrl_pursuit {
     int walk_mode = 0;        // 0 auto (alternate above ~375 MB per launch), 1 always alternate, 2 always forward; fixed at create
     void *wtables;
     int kernel_kind;  // MADRL_KERNEL_AUTO / _GENERIC / _WAVE (requested)
-    hipEvent_t ev_fork = nullptr, ev_done = nullptr;   // madrl_pursuit_step_sharded: created on first use, destroyed with the handle
+    hipEvent_t ev_fork = nullptr, ev_done = nullptr;   // madrl_pursuit_step_sharded: made by madrl_pursuit_create on the handle's device, destroyed with the handle
 };
 
 namespace {
@@ -631,6 +633,7 @@ struct WaveGeom {
     int rec_bytes, off_gone, off_term;
     int waves;  // wavefronts per env: 1 = pursuit_wave_kernel, > 1 = pursuit_group_kernel
     int occ;    // resident wavefronts per SIMD the kernel's registers are allocated for
+    int mwords; // stale-zero mask dwords per lane (1: one bit per float4 slot in each byte, up to 8 slots per lane; the row-loop kernel: P / 8)
 };
 }  // namespace
 
@@ -671,7 +674,7 @@ void group_launch(const pw::WaveDev &d, const pw::WaveIO &io, int mode, int64_t 
 template <class S>
 constexpr WaveGeom wave_geom(int waves = 1, int occ = 4) {
     return WaveGeom{S::XS, S::YS, S::P, S::E, S::R, S::FLATTEN, S::GW, S::PAD, S::GSZ, S::D, S::X_ID, S::X_SKIP,
-                    S::REC_BYTES, S::OFF_GONE, S::OFF_TERM, waves, occ};
+                    S::REC_BYTES, S::OFF_GONE, S::OFF_TERM, waves, occ, S::MWORDS};
 }
 
 #define X(XS, YS, NP, NE, R, FL) {wave_geom<pw::Shape<XS, YS, NP, NE, R, FL>>(1, pw::Shape<XS, YS, NP, NE, R, FL>::OCC), wave_launch<pw::Shape<XS, YS, NP, NE, R, FL>>},
@@ -682,6 +685,7 @@ const WaveEntry WAVE_TABLE[] = {
 #include "pursuit_specializations.local.def"
 #endif
 #undef X
+#undef XG
 #define X(XS, YS, NP, NE, R, FL)
 #define XG(XS, YS, NP, NE, R, FL, NW) {wave_geom<pw::GShape<XS, YS, NP, NE, R, FL, NW>>(NW), group_launch<pw::GShape<XS, YS, NP, NE, R, FL, NW>>},
 #include "pursuit_specializations.def"
@@ -817,7 +821,7 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
         pw::WaveDev wd = h->wdev;
         wd.catchr = h->dev.catchr; wd.cw = h->dev.cw; wd.cw_env = h->dev.cw_env; wd.catchr_env = h->dev.catchr_env;  // curriculum
         if (h->zmask_obs != (const void *)io.obs) {  // unknown buffer contents: every cell "not known to be zero"
-            MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0xFF, (size_t)h->dev.n_envs * 256 * h->wave->g.waves, s));
+            MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0xFF, (size_t)h->dev.n_envs * 256 * h->wave->g.waves * h->wave->g.mwords, s));
             h->zmask_obs = io.obs;
         }
         if (mode == 1) {
@@ -845,12 +849,14 @@ int launch(madrl_pursuit *h, const PursuitIO &io, int mode, void *stream) {
     return MADRL_OK;
 }
 
-// caller-owned state buffer = [n_envs packed records][pad to 256 B][stale-zero masks of the fast path, 256 B per env and wavefront]
+// caller-owned state buffer = [n_envs packed records][pad to 256 B][stale-zero masks of the fast path, 256 B per env, wavefront and
+// mask word][flag plane, one dword per env]
 uint64_t zmask_offset(int rec_bytes, int64_t n_envs) { return align_up((uint64_t)rec_bytes * (uint64_t)n_envs, 256); }
 uint64_t zmask_bytes(const madrl_pursuit_config *cfg, int64_t n_envs) {
     const WaveEntry *w = find_wave(cfg);
-    return w ? (uint64_t)n_envs * 256u * (uint64_t)w->g.waves : 0u;
+    return w ? (uint64_t)n_envs * 256u * (uint64_t)w->g.waves * (uint64_t)w->g.mwords : 0u;
 }
+uint64_t flags_offset(const madrl_pursuit_config *cfg, int rec_bytes, int64_t n_envs) { return zmask_offset(rec_bytes, n_envs) + zmask_bytes(cfg, n_envs); }
 
 int pick_threads(const PursuitDev &d, int requested) {
     int thr = requested;
@@ -881,7 +887,17 @@ int madrl_pursuit_state_bytes(const madrl_pursuit_config *cfg, int64_t n_envs, u
     if (n_envs < 1 || !out_bytes) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_bytes non-NULL");
     PursuitDev d;
     layout(cfg, &d);
-    *out_bytes = zmask_offset(d.rec_bytes, n_envs) + zmask_bytes(cfg, n_envs);
+    *out_bytes = flags_offset(cfg, d.rec_bytes, n_envs) + 4u * (uint64_t)n_envs;
+    return MADRL_OK;
+}
+
+int madrl_pursuit_flags_offset(const madrl_pursuit_config *cfg, int64_t n_envs, uint64_t *out_offset) {
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (n_envs < 1 || !out_offset) return fail(MADRL_EINVAL, "n_envs must be >= 1 and out_offset non-NULL");
+    PursuitDev d;
+    layout(cfg, &d);
+    *out_offset = flags_offset(cfg, d.rec_bytes, n_envs);
     return MADRL_OK;
 }
 
@@ -912,6 +928,7 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
     PursuitDev &d = h->dev;
     d.n_envs = n_envs;
     d.state = (uint8_t *)state_dev;
+    d.flags = reinterpret_cast<uint32_t *>((uint8_t *)state_dev + flags_offset(cfg, d.rec_bytes, n_envs));
     const int xs = d.xs, ys = d.ys, pad = d.pad, GW = d.GW;
     const size_t cells = (size_t)xs * ys;
 
@@ -1082,6 +1099,7 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             w.cnt_tmpl = reinterpret_cast<const uint32_t *>(h->wtables) + w_tmpl;
             w.slot_tab = reinterpret_cast<const uint32_t *>(h->wtables) + w_slots;
             w.state = d.state;
+            w.flags = d.flags;
             h->zmask = (uint8_t *)state_dev + zmask_offset(d.rec_bytes, n_envs);  // caller-owned, like the records
             w.zmask = reinterpret_cast<uint32_t *>(h->zmask);
         } else {
@@ -1092,6 +1110,13 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
     h->walk_mode = 0;
     h->max_blocks = 0;
     rc = madrl_pursuit_set_launch(h, 0, 0);
+    // the fork / join events of madrl_pursuit_step_sharded, on this handle's device (hipSetDevice above), each checked on its own
+    if (!rc && (hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess)) {
+        if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        rc = fail(MADRL_EHIP, "create: hipEventCreateWithFlags failed");
+    }
     if (rc) {
         if (h->wtables) (void)hipFree(h->wtables);
         (void)hipFree(h->tables);
@@ -1190,30 +1215,32 @@ int madrl_pursuit_step_sharded(madrl_pursuit *const *hs, const madrl_pursuit_sha
     if (!hs || !io || n_shards < 1) return fail(MADRL_EINVAL, "step_sharded: NULL argument or n_shards < 1");
     for (int j = 0; j < n_shards; ++j) {
         if (!hs[j] || !io[j].actions || !io[j].obs || !io[j].rew || !io[j].done || !io[j].removed) return fail(MADRL_EINVAL, "step_sharded: shard %d has a NULL argument", j);
-        if (!hs[j]->ev_done) {
-            MADRL_HIP_TRY(hipEventCreateWithFlags(&hs[j]->ev_done, hipEventDisableTiming));
-            MADRL_HIP_TRY(hipEventCreateWithFlags(&hs[j]->ev_fork, hipEventDisableTiming));
-        }
+        if (!hs[j]->ev_done || !hs[j]->ev_fork) return fail(MADRL_EINVAL, "step_sharded: shard %d's handle has no events (madrl_pursuit_create makes them)", j);
     }
     hipStream_t cs = (hipStream_t)caller_stream;
     if (fork) {   // every sub-batch stream waits for what the caller's stream holds so far (the actions)
         MADRL_HIP_TRY(hipEventRecord(hs[0]->ev_fork, cs));
         for (int j = 0; j < n_shards; ++j) if ((hipStream_t)io[j].stream != cs) MADRL_HIP_TRY(hipStreamWaitEvent((hipStream_t)io[j].stream, hs[0]->ev_fork, 0));
     }
-    for (int j = 0; j < n_shards; ++j) {
+    int rc = MADRL_OK, launched = 0;
+    for (; launched < n_shards && rc == MADRL_OK; ++launched) {
+        const int j = launched;
         PursuitIO p;
         memset(&p, 0, sizeof(p));
         p.actions = io[j].actions; p.inj_eact = io[j].inj_evader_actions; p.obs = io[j].obs; p.rew = io[j].rew; p.done = io[j].done; p.removed = io[j].removed;
-        const int rc = launch(hs[j], p, 1, io[j].stream);
-        if (rc) return rc;
+        rc = launch(hs[j], p, 1, io[j].stream);
+        if (rc) break;
     }
-    if (join)     // ... and the caller's stream waits for every sub-batch
-        for (int j = 0; j < n_shards; ++j) {
+    // ... and the caller's stream waits for every sub-batch -- also when a launch failed half way: the shards launched before it are
+    // running, and the caller's stream must not be left unordered against them
+    if (join || rc != MADRL_OK)
+        for (int j = 0; j < launched; ++j) {
             if ((hipStream_t)io[j].stream == cs) continue;
-            MADRL_HIP_TRY(hipEventRecord(hs[j]->ev_done, (hipStream_t)io[j].stream));
-            MADRL_HIP_TRY(hipStreamWaitEvent(cs, hs[j]->ev_done, 0));
+            if (hipEventRecord(hs[j]->ev_done, (hipStream_t)io[j].stream) != hipSuccess || hipStreamWaitEvent(cs, hs[j]->ev_done, 0) != hipSuccess) {
+                if (rc == MADRL_OK) rc = fail(MADRL_EHIP, "step_sharded: joining shard %d failed", j);
+            }
         }
-    return MADRL_OK;
+    return rc;
 }
 
 int madrl_pursuit_get_state(madrl_pursuit *h, int32_t *pos_p, int32_t *pos_e, uint8_t *gone, uint8_t *term_p,
@@ -1249,7 +1276,7 @@ int madrl_pursuit_invalidate_obs(madrl_pursuit *h) {
 int madrl_pursuit_declare_obs_zero(madrl_pursuit *h, const float *obs_dev, void *stream) {
     if (!h || !obs_dev) return fail(MADRL_EINVAL, "declare_obs_zero: NULL argument");
     if (h->zmask) {   // every cell of that buffer is known to hold +0.0f: no stale cell can need protecting
-        MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0, (size_t)h->dev.n_envs * 256 * h->wave->g.waves, (hipStream_t)stream));
+        MADRL_HIP_TRY(hipMemsetAsync(h->zmask, 0, (size_t)h->dev.n_envs * 256 * h->wave->g.waves * h->wave->g.mwords, (hipStream_t)stream));
         h->zmask_obs = obs_dev;
     }
     return MADRL_OK;

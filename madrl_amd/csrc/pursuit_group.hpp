@@ -43,6 +43,7 @@ struct GShape {
     static constexpr int DV = D / 4;
     static constexpr int NQ = P * DV;
     static constexpr int NS = (NQ + NT - 1) / NT;                // float4 slots per thread
+    static constexpr int MWORDS = 1;                             // stale-zero mask dwords per thread
     static constexpr int X_FILL = 3 * GSZ;
     static constexpr int X_SKIP = 3 * GSZ + 1;
     static constexpr int X_ID = 3 * GSZ + 2;
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                 if (fresh(tid) == 0) {
                     io.done[env] = (uint8_t)done_bits;
                     io.removed[env] = n_removed;
+                    cold_args()->d.flags[env] = done_flag_word(done_bits);
                 }
             }
             // ---------------------------------------------------------- registers -> state record

@@ -64,6 +64,7 @@ struct WaveDev {
     const double *cw_env;      // per-env constraint_window / catchr (curriculum) or nullptr: the scalars above.  Read with scalar loads
     const double *catchr_env;  // (constant address space): written by the host or an earlier launch, never by these kernels
     uint8_t *state;
+    uint32_t *flags;         // [n_envs] flag words of the step launches (done_flag_word, common.hpp)
     uint32_t *zmask;         // [n_envs][64]: per lane, which of its observation cells hold a NON-ZERO stale value (see "stale-zero mask")
 };
 
@@ -113,6 +114,7 @@ struct Shape {
     static constexpr int DV = D / 4;                             // float4 per pursuer row
     static constexpr int NQ = P * DV;                            // float4 slots per env
     static constexpr int NS = (NQ + 63) / 64;                    // slots per lane
+    static constexpr int MWORDS = 1;                             // stale-zero mask dwords per lane
     static constexpr int OCC = NS <= 5 ? MADRL_PW_WAVES : (MADRL_PW_WAVES < 4 ? MADRL_PW_WAVES : 4);  // resident wavefronts per SIMD aimed at
     static constexpr int X_FILL = 3 * GSZ;                       // extras after the layers
     static constexpr int X_SKIP = 3 * GSZ + 1;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
     // PIPE: the exact-wait prefetch above (production step kernel); the reset kernel (envs may be skipped) and the parity
     // harness variant keep compiler-managed loads and the mid-iteration hinge.
     constexpr bool PIPE = (MODE == 1) && !INJECT && !(MADRL_ABLATE & (1 | 8 | 16 | 64));
-    constexpr int VM_PER_ENV = 5 * NS + 5;  // stores every step iteration issues: NS x (4 dword + 1 float4), reward, done, removed, record, mask
+    constexpr int VM_PER_ENV = 5 * NS + 6;  // stores every step iteration issues: NS x (4 dword + 1 float4), reward, done, removed, flag word, record, mask
     static_assert(!PIPE || VM_PER_ENV < 64, "vmcnt range");
     const uint32_t rec_off = (ulane < (uint32_t)S::REC_DW ? ulane : (uint32_t)S::REC_DW - 1u) * 4u;
     const uint32_t act_off = (ulane < (uint32_t)P ? ulane : (uint32_t)P - 1u) * 4u;
@@ -740,6 +742,7 @@ __global__ __launch_bounds__(64) MADRL_PW_OCC void pursuit_wave_kernel(const Wav
                 if (fresh(lane) == 0) {
                     io.done[env] = (uint8_t)done_bits;
                     io.removed[env] = n_removed;
+                    cold_args()->d.flags[env] = done_flag_word(done_bits);   // (the pointer is not kept in SGPRs across the env loop)
                 }
             }
             // ---------------------------------------------------------- registers -> state record

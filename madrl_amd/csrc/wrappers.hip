@@ -96,7 +96,7 @@ __global__ void obsbuffer_kernel(const float *obs, float *buf, int64_t n, int64_
         if (active_mask != nullptr && active_mask[i / per_env] == 0) continue;  // partial reset: the other envs keep their history
         float *b = buf + i * k;
         const float x = obs[i];
-        if (reset_mask != nullptr && reset_mask[i / per_env] != 0) {
+        if (reset_mask != nullptr && (reset_mask[i / per_env] & 0x7Fu) != 0) {   // a done byte's bit 7 (overflow report) resets nothing
             for (int j = 0; j < k; ++j) b[j] = x;                           // reset :190-192
         } else {
             for (int j = 0; j + 1 < k; ++j) b[j] = b[j + 1];               // step :179-181
@@ -112,7 +112,7 @@ __global__ void obsbuffer4_kernel(const float *obs, float4 *buf, int64_t n, int6
         if (active_mask != nullptr && active_mask[i / per_env] == 0) continue;
         const float x = obs[i];
         float4 b;
-        if (reset_mask != nullptr && reset_mask[i / per_env] != 0) { b.x = x; b.y = x; b.z = x; b.w = x; }   // reset :190-192
+        if (reset_mask != nullptr && (reset_mask[i / per_env] & 0x7Fu) != 0) { b.x = x; b.y = x; b.z = x; b.w = x; }   // reset :190-192
         else { const float4 o = buf[i]; b.x = o.y; b.y = o.z; b.z = o.w; b.w = x; }                           // step :179-181
         buf[i] = b;
     }
@@ -133,7 +133,9 @@ __global__ void diagnostics_kernel(const float *rew, const uint8_t *done, double
     disc_ret[n] += (s / (double)A) * disc_pow[n];                           // :360-361 accumulated step by step
     disc_pow[n] *= discount;
     ep_len[n] += 1;                                                         // :351
-    const bool fin = (done[n] != 0) || ep_len[n] >= max_traj_len;           // :354
+    // bits 0 / 1 of a done byte end an episode (terminal, time limit); bit 7 is the sticky "a capacity overflowed" report of the
+    // Pursuit / MultiWalker kernels (include/madrl_hip.h) and starts no episode by itself
+    const bool fin = ((done[n] & 0x03u) != 0) || ep_len[n] >= max_traj_len;   // :354
     out_finished[n] = fin ? 1 : 0;
     if (fin) {
         for (int a = 0; a < A; ++a) { out_ep_reward[n * A + a] = ep_reward[n * A + a]; ep_reward[n * A + a] = 0.0; }
@@ -163,7 +165,7 @@ __global__ void gae_kernel(const float *__restrict__ rew, const uint8_t *__restr
     double ret = values ? (double)values[T * row + i] : 0.0, a = 0.0;
     double vnext = ret;
     for (int64_t t = T - 1; t >= 0; --t) {
-        const bool cut = done[t * n_envs + n] != 0;
+        const bool cut = (done[t * n_envs + n] & 0x03u) != 0;   // (bit 7 = overflow report: no episode boundary)
         const double r = (double)rew[t * row + i];
         ret = r + (cut ? 0.0 : gamma * ret);
         returns[t * row + i] = (float)ret;

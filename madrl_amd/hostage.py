@@ -161,7 +161,7 @@ class BatchedContinuousHostageWorld(AbstractMAEnv):
             r = torch.as_tensor(respawn, device=self.device).reshape(N, self.n_bad, 4).to(torch.float32).contiguous()
         _lib.check(_lib.lib().madrl_hostage_step(self._handle, _lib.ptr(a), _lib.ptr(r), _lib.ptr(self._obs), _lib.ptr(self._rew),
                                                  _lib.ptr(self._done), _lib.ptr(self._info), _lib.current_stream(self.device)))
-        return self._obs, self._rew, self._done.bool(), {"ho_saved": self._info[:, 0], "cr_encs": self._info[:, 1]}
+        return self._obs, self._rew, self._done.view(torch.bool), {"ho_saved": self._info[:, 0], "cr_encs": self._info[:, 1], "done_bits": self._done}
 
     @property
     def is_gate_open(self):

@@ -25,3 +25,24 @@ def as_map_pool(map_pool):
     if not np.isin(pool, (0, -1)).all():
         raise ValueError("map cells must be 0 (free) or -1 (building)")
     return pool
+
+
+def resize(scale, maps):
+    """utils/TwoDMaps.py:90-94 for an integer scale: `scipy.ndimage.zoom(mat, scale, order=0)` replicates every cell scale x scale
+    times (how the survey builds a 32 x 32 pool from the tree's only map file, `resize(2, map_pool16)`)."""
+    scale = int(scale)
+    return np.stack([np.repeat(np.repeat(np.asarray(m), scale, axis=0), scale, axis=1) for m in maps])
+
+
+def synthetic_map_pool(n_maps, xs, ys, seed=0, n_rect=(2, 5), side=(0.1, 0.4)):
+    """A pool of random maps for benchmarks on boxes without the reference tree (the authors' `map_pool32.npy` / `map_pool128.npy` are
+    not in it either): a few axis-aligned buildings per map, about a quarter of the cells built over like `maps/map_pool16.npy`, with
+    buildings that may touch row / column 0 (quirk Q4 of need_to_surround).  Synthetic data, not a restatement of a reference file."""
+    rng = np.random.RandomState(seed)
+    pool = np.zeros((n_maps, xs, ys), dtype=np.int32)
+    for m in pool:
+        for _ in range(rng.randint(n_rect[0], n_rect[1] + 1)):
+            w, h = max(1, int(round(xs * rng.uniform(*side)))), max(1, int(round(ys * rng.uniform(*side))))
+            x0, y0 = rng.randint(0, xs - w + 1), rng.randint(0, ys - h + 1)
+            m[x0:x0 + w, y0:y0 + h] = -1
+    return pool

@@ -129,6 +129,8 @@ class BatchedPursuitEvade(AbstractMAEnv):
         _lib.check(L.madrl_pursuit_state_bytes(C.byref(cfg), self.n_envs, C.byref(nbytes)))
         _lib.check(L.madrl_pursuit_record_bytes(C.byref(cfg), C.byref(rbytes)))
         self.record_bytes = rbytes.value
+        foff = C.c_uint64()
+        _lib.check(L.madrl_pursuit_flags_offset(C.byref(cfg), self.n_envs, C.byref(foff)))
         N, P, E, D = self.n_envs, int(self.n_pursuers), int(self.n_evaders), dim.value
         shape_key = (N, P, E, D, nbytes.value)
         if getattr(self, "_shape_key", None) != shape_key:
@@ -139,6 +141,10 @@ class BatchedPursuitEvade(AbstractMAEnv):
             self._rew = torch.zeros((N, P), dtype=torch.float32, device=dev)
             self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
             self._removed = torch.zeros(N, dtype=torch.int32, device=dev)
+            # the flag plane of the step launches (include/madrl_hip.h, madrl_pursuit_flags_offset): uint8 [N, 4] inside the state buffer;
+            # step()'s `done` / `truncated` / `count_overflow` are bool VIEWS of its columns -- no torch kernel runs after the launch
+            self._flags = self._state[foff.value:foff.value + 4 * N].view(N, 4)
+            self._flag_views = tuple(self._flags[:, k].view(torch.bool) for k in range(3))   # done, truncated, count_overflow
             self._shape_key = shape_key
             self._obs_is_fresh = True   # every element +0.0f, like the reference's local_obs at construction (:119-120)
             self._obs_version = None    # (no launch has written this tensor yet: nothing to compare its version counter with)
@@ -275,7 +281,7 @@ class BatchedPursuitEvade(AbstractMAEnv):
         _lib.check(_lib.lib().madrl_pursuit_reset(self._handle, _lib.ptr(mask), _lib.ptr(pos), _lib.ptr(mid),
                                                   _lib.ptr(self._obs), self._stream()))
         self._was_reset, self._needs_reset, self._obs_is_fresh = True, False, False
-        self._obs_version = self._obs._version
+        self._obs_version = self._version_of_obs()
         return self._obs_view()
 
     def _check_obs_untouched(self):
@@ -286,10 +292,22 @@ class BatchedPursuitEvade(AbstractMAEnv):
         buffer, the masks are reset to "nothing known" before the next launch.  The edit itself stays in the stale cells, exactly as an
         edit of local_obs would in the reference; writes PyTorch cannot see (another library writing through the raw pointer) still need
         invalidate_obs()."""
-        if getattr(self, "_obs_version", None) is not None and self._obs._version != self._obs_version:
+        v = self._version_of_obs()
+        if v is None or (getattr(self, "_obs_version", None) is not None and v != self._obs_version):
             _lib.check(_lib.lib().madrl_pursuit_invalidate_obs(self._handle))
             self._obs_is_fresh = False
-        self._obs_version = self._obs._version
+        self._obs_version = v
+
+    def _version_of_obs(self):
+        """the observation tensor's in-place operation count, or None where PyTorch keeps none: a tensor allocated under
+        torch.inference_mode() ("Inference tensors do not track version counter") -- edits of such a buffer cannot be noticed, so the
+        stale-zero masks are reset before EVERY launch then (correct, the slower "nothing known" state of the fast path).  Under hipGraph
+        capture this host-side check runs once, at capture: a replayed graph neither re-checks nor re-invalidates -- do not edit the
+        observation buffer in place between replays (or call invalidate_obs() and re-capture)."""
+        try:
+            return self._obs._version
+        except RuntimeError:
+            return None
 
     def step(self, actions, evader_actions=None, rew_out=None, done_out=None):
         """pursuit_evade.py:209-262.  actions: int [N, P] (0..4).  evader_actions: optional int
@@ -300,7 +318,10 @@ class BatchedPursuitEvade(AbstractMAEnv):
         if getattr(self, "_needs_reset", False):
             raise RuntimeError("update_curriculum / set_param_values changed the agent counts: the running episodes cannot continue "
                                "(the reference applies new counts at the next reset(), pursuit_evade.py:173-199) -- call reset() first")
-        act = self._i32(actions, (N, P), "actions")
+        if type(actions) is torch.Tensor and actions.dtype is torch.int32 and actions.shape == (N, P) and actions.device == self.device and actions.is_contiguous():
+            act = actions   # the sampler's own tensor, already what the kernel reads
+        else:
+            act = self._i32(actions, (N, P), "actions")
         # evader control (train_pursuit=False): the opponents are the pursuers, one injected action per pursuer
         eact = self._i32(evader_actions, (N, E if self.train_pursuit else P), "evader_actions")
         self._check_obs_untouched()
@@ -330,11 +351,12 @@ class BatchedPursuitEvade(AbstractMAEnv):
         return self._obs_view()
 
     def _step_result(self, rew, dn):
-        done = (dn & 1).bool()
-        # bit 7: more than 253 agents of one kind stood on ONE cell of this env (byte count grids of the generic kernel; possible only
-        # with more than 253 pursuers or evaders) -- its results are void until its next reset
-        info = {"removed": self._removed, "truncated": (dn & 2).bool(), "done_bits": dn, "count_overflow": (dn & 0x80).bool()}
-        return self._obs_view(), rew, done, info
+        """Every returned tensor is a view of a buffer the step launch itself wrote (no torch kernel runs here: the drop-in API costs what
+        the C ABI call costs, bench.py `python_api_ms_per_step`) and, like `obs` and `rew`, holds this step's values until the next step().
+        bit 7 / count_overflow: more than 253 agents of one kind stood on ONE cell of this env (byte count grids of the generic kernel;
+        possible only with more than 253 pursuers or evaders) -- its results are void until its next reset"""
+        done, trunc, ovf = self._flag_views
+        return self._obs_view(), rew, done, {"removed": self._removed, "truncated": trunc, "done_bits": dn, "count_overflow": ovf}
 
     def obs_rows_valid(self):
         """bool [N, P]: which observation rows the last reset / step wrote.  All of them with train_pursuit; in evader control

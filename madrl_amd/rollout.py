@@ -116,7 +116,10 @@ class RolloutCollector(object):
     def _step(self, t):
         env, obs = self.env, self._obs
         if self._policy_out and self._buf is not None:   # the policy writes its actions straight into their trajectory slot
-            act, val = self.policy(obs, out=self._buf["actions"][t]), None
+            out = self.policy(obs, out=self._buf["actions"][t])
+            act, val = out if isinstance(out, tuple) else (out, None)   # (a policy with `out=` may return values too: they are stored below)
+            if act.data_ptr() != self._buf["actions"][t].data_ptr():    # ... or ignore `out` and return its own tensor
+                self._buf["actions"][t].copy_(act)
         else:
             act, val = self._act(obs)
             if self._buf is None:

@@ -44,6 +44,18 @@ class StreamSharded(object):
         self.n_envs, self.n_streams, self.per = int(n_envs), int(n_streams), int(n_envs) // int(n_streams)
         self.envs = [make_env(n_envs=self.per, env_id_base=int(env_id_base) + j * self.per, device=self.device) for j in range(self.n_streams)]
         self.streams = shared_streams(self.device, self.n_streams)
+        self._nat = None
+
+    @classmethod
+    def from_envs(cls, envs, device=None):
+        """the same over env objects that exist already (equal sizes, env_id_base advanced by the caller), e.g. bench.py's sub-batches"""
+        self = cls.__new__(cls)
+        self.device = torch.device(device if device is not None else envs[0].device)
+        self.envs, self.n_streams, self.per = list(envs), len(envs), int(envs[0].n_envs)
+        self.n_envs = self.per * self.n_streams
+        self.streams = shared_streams(self.device, self.n_streams)
+        self._nat = None
+        return self
 
     @property
     def agents(self):
@@ -128,10 +140,17 @@ class StreamSharded(object):
             if getattr(e, "_needs_reset", False) or e.handle_generation != gens[j]:
                 self._nat = None   # the handle was re-created (curriculum): take the general path this once, rebuild the table next time
                 return self._step_general(parts, fork, join)
-            a = e._i32(a, (e.n_envs, int(e.n_pursuers)), "actions")
+            # Nothing of this path may run on the CALLER's stream unordered against the sub-batch launches.  Actions that need a
+            # conversion kernel (another dtype / device / layout) go through the general path, which converts on the sub-batch's own
+            # stream; step()'s result tensors are views of buffers the launch itself writes (BatchedPursuitEvade._step_result: no torch
+            # kernel), so with join=False they hold the step's values exactly when the sub-batch stream has run the launch.
+            if not (torch.is_tensor(a) and a.dtype == torch.int32 and a.device == e.device and a.is_contiguous()
+                    and a.numel() == e.n_envs * int(e.n_pursuers)):
+                return self._step_general(parts, fork, join)
+            acts.append(a)
+        for j, (e, a) in enumerate(zip(self.envs, acts)):
             e._check_obs_untouched()
             e._obs_is_fresh = False
-            acts.append(a)
             io[j].actions = _lib.ptr(a).value
             if not join:
                 a.record_stream(self.streams[j])
@@ -147,6 +166,8 @@ class StreamSharded(object):
         for env, s, a in zip(self.envs, self.streams, parts):
             with torch.cuda.stream(s):
                 out.append(env.step(a))
+            if not join and torch.is_tensor(a):
+                a.record_stream(s)
         if join:
             self.join()
         return out

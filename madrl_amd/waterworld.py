@@ -230,10 +230,11 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         _lib.check(_lib.lib().madrl_waterworld_step(self._handle, _lib.ptr(a), _lib.ptr(r), None if std else _lib.ptr(self._obs),
                                                     _lib.ptr(self._rew), _lib.ptr(self._done), _lib.ptr(self._info),
                                                     _lib.current_stream(self.device)))
-        info = {"evcatches": self._info[:, 0], "pocatches": self._info[:, 1]}
+        # `done` is a bool VIEW of the byte the kernel wrote (0 / 1): no torch kernel runs after the launch
+        info = {"evcatches": self._info[:, 0], "pocatches": self._info[:, 1], "done_bits": self._done}
         if std:  # fused StandardizedEnv: standardised observations and scaled / normalised rewards straight from the kernel
-            return std["obs_out"], std["rew_out"], self._done.bool(), info
-        return self._obs, self._rew, self._done.bool(), info
+            return std["obs_out"], std["rew_out"], self._done.view(torch.bool), info
+        return self._obs, self._rew, self._done.view(torch.bool), info
 
     @property
     def is_terminal(self):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libmadrl_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "madrl_amd/_lib.py has no signature for %s" % n
-    assert L.madrl_abi_version() == _lib.ABI_VERSION == 6
+    assert L.madrl_abi_version() == _lib.ABI_VERSION == 7
     hdr = open(os.path.join(ROOT, "include", "madrl_hip.h")).read()
     assert int(re.search(r"#define MADRL_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
     words = re.search(r"#define MADRL_POLICY_COUNTER_WORDS \((\d+) \* (\d+)\)", hdr)
@@ -67,10 +67,14 @@ def test_obs_dim_and_state_bytes():
     r = C.c_int32()
     assert L.madrl_pursuit_record_bytes(C.byref(_cfg()), C.byref(r)) == 0
     assert r.value == 112  # 16 B header + 76 B positions + masks, 16-B aligned
-    assert b.value == 65536 * (112 + 256)  # records, then the fast path's stale-zero masks (256 B per env): all caller-owned
-    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(n_pursuers=7)), 65536, C.byref(b)) == 0 and b.value == 65536 * 112  # no fast path
-    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(control_evaders=1)), 1000, C.byref(b)) == 0 and b.value == 112128 + 1000 * 256  # records padded to 256 B, then the masks
-    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(n_pursuers=16, n_evaders=60, xs=32, ys=32, control_evaders=1)), 1000, C.byref(b)) == 0 and b.value % 256 == 0 \
+    # records, then the fast path's stale-zero masks (256 B per env), then the flag plane (ABI 7: one dword per env): all caller-owned
+    assert b.value == 65536 * (112 + 256 + 4)
+    f = C.c_uint64()
+    assert L.madrl_pursuit_flags_offset(C.byref(_cfg()), 65536, C.byref(f)) == 0 and f.value == 65536 * (112 + 256)
+    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(n_pursuers=7)), 65536, C.byref(b)) == 0 and b.value == 65536 * (112 + 4)  # no fast path
+    assert L.madrl_pursuit_flags_offset(C.byref(_cfg(n_pursuers=7)), 65536, C.byref(f)) == 0 and f.value == 65536 * 112
+    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(control_evaders=1)), 1000, C.byref(b)) == 0 and b.value == 112128 + 1000 * 256 + 4000  # records padded to 256 B, then the masks, then the flags
+    assert L.madrl_pursuit_state_bytes(C.byref(_cfg(n_pursuers=16, n_evaders=60, xs=32, ys=32, control_evaders=1)), 1000, C.byref(b)) == 0 and (b.value - 4000) % 256 == 0 \
         and b.value < 1000 * 512   # evader control above one wavefront of agents: generic kernel only, no masks
 
 

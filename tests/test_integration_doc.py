@@ -31,7 +31,7 @@ def test_documented_struct_is_the_library_struct():
     L = _lib.lib()
     b = C.c_uint64()
     assert L.madrl_pursuit_state_bytes(C.byref(ns["cfg"]), 65536, C.byref(b)) == 0, L.madrl_last_error()
-    assert b.value == 65536 * (112 + 256)
+    assert b.value == 65536 * (112 + 256 + 4)   # records, stale-zero masks, flag plane
 
 
 @pytest.mark.gpu
