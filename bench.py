@@ -244,7 +244,7 @@ def roofline(bytes_per, N, kernel_ms, wall_ms, traffic, kernel, streams=1, **mor
 
 # sub-batches per GPU, each on its own HIP stream, when --streams is not given: what scripts/stream_sweep.sh measured fastest on MI355X
 # (the one-launch-per-step figure is reported next to it in every line: roofline.one_launch_per_step)
-DEFAULT_STREAMS = {"pursuit": 2, "pursuit_c5": 2, "pursuit_colocate": 2, "waterworld": 2, "waterworld_std": 2, "hostage": 2, "multiwalker": 4, "multiwalker_w10": 4}
+DEFAULT_STREAMS = {"pursuit": 2, "pursuit_c5": 2, "pursuit_colocate": 2, "pursuit_authors": 2, "waterworld": 2, "waterworld_std": 2, "hostage": 2, "multiwalker": 4, "multiwalker_w10": 4}
 
 
 def shard_count(args, N, workload):
@@ -258,6 +258,9 @@ PURSUIT_VARIANTS = {
     "pursuit_c5": (32, 16, 60, 32768, dict(n_catch=2, surround=True, flatten=True)),          # configs[4], one GPU's shard
     # SURVEY 8 preamble's secondary mode: heuristics/pursuit.py:66-67 (co-location catch, (R, R, 4) observations)
     "pursuit_colocate": (16, 8, 30, 65536, dict(n_catch=4, surround=False, flatten=False)),
+    # the authors' own training shape (runners/old/rllab/pursuit.sh:1: 30 pursuers / 50 evaders, obs_range 11, --sample_maps --flatten --surround
+    # on a 32x32 map pool; their map_pool32.npy is not in the tree -> a synthetic pool of ten maps, madrl_amd/maps.py)
+    "pursuit_authors": (32, 30, 50, 16384, dict(n_catch=2, surround=True, flatten=True, obs_range=11, sample_maps=True, pool=10)),
 }
 
 
@@ -268,11 +271,17 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     from madrl_amd.pursuit import BatchedPursuitEvade
     from madrl_amd import _lib
     MS, P, E, N0, mode = PURSUIT_VARIANTS[variant]
-    N, R = (args.envs or N0), 7
+    mode = dict(mode)
+    N, R = (args.envs or N0), mode.pop("obs_range", 7)
     H = args.horizon
     S = shard_count(args, N, variant) if streams is None else streams
     per = N // S
-    maps = [rectangle_map(MS, MS)]
+    n_pool = mode.pop("pool", 0)
+    if n_pool:
+        from madrl_amd.maps import synthetic_map_pool
+        maps = list(synthetic_map_pool(n_pool, MS, MS, seed=0))
+    else:
+        maps = [rectangle_map(MS, MS)]
     kw = dict(n_pursuers=P, n_evaders=E, obs_range=R, reward_mech="local", **mode)
     # the batch as S independent sub-batches, each on its own HIP stream (madrl_amd/sharded.py): env ids continue across them
     envs = [BatchedPursuitEvade(maps, n_envs=per, device=dev, seed=0, env_id_base=rank * N + j * per, max_steps=H,
@@ -380,7 +389,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     if rank != 0:
         return None
     bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
-    fast = ("pursuit_group_kernel<%d,%d,%d,%d,%d,%d,2>" if P + E > 64 else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))
+    fast = ("pursuit_group_kernel<%d,%d,%d,%d,%d,%d,2>" if (P + E > 64 or P * D > 2048) else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))
     kname = fast if kernel_kind == "wave" else "pursuit_kernel<NT>"
     catch = "surround, n_catch 2" if mode["surround"] else "co-location catch, n_catch %d" % mode["n_catch"]
     roof = roofline(bytes_per, N, kernel_ms, dt / K * 1e3, measured_traffic(per, variant, S), kname, streams=S)
@@ -402,8 +411,9 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
         "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset; episode ages "
                 "start uniform over [0, %d): every step resets ~%d of its %d envs through the two-observation-pass path; %d untimed "
                 "steps before the warm-up bring the stale-zero masks of the observation rows to their equilibrium)" % (H, N // H, N, args.prep),
-        "config": dict({"workload": "PursuitEvade %dx%d rectangle_map, %d pursuers / %d evaders, obs_range 7, %s, %s, local reward, "
-                                    "%d envs per GPU, horizon %d" % (MS, MS, P, E, catch, "flatten" if mode["flatten"] else "(R,R,4) observations", N, H),
+        "config": dict({"workload": "PursuitEvade %dx%d %s, %d pursuers / %d evaders, obs_range %d, %s, %s, local reward, "
+                                    "%d envs per GPU, horizon %d" % (MS, MS, ("synthetic pool of %d maps, sample_maps" % n_pool) if n_pool else "rectangle_map", P, E, R, catch,
+                                                                     "flatten" if mode["flatten"] else "(R,R,4) observations", N, H),
                         "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world,
                         "streams_per_gpu": S, "envs_per_launch": per, "prep_steps": args.prep,
                         "step_is": ("one pass of the step kernel over all %d envs of the GPU: %d launches of %d envs, one per HIP stream, not ordered "
@@ -789,7 +799,7 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
-WORKLOADS = ["pursuit", "pursuit_c5", "pursuit_colocate", "pursuit_rollout", "waterworld", "waterworld_std", "multiwalker", "multiwalker_w10", "hostage"]
+WORKLOADS = ["pursuit", "pursuit_c5", "pursuit_colocate", "pursuit_authors", "pursuit_rollout", "waterworld", "waterworld_std", "multiwalker", "multiwalker_w10", "hostage"]
 
 
 def main():
@@ -861,7 +871,7 @@ def main():
         # (their own step counts, whatever --steps says: the contract's K is the headline's; a 20-step region of a two-stream pipeline is a third
         # fill and drain -- Waterworld reads 51 us per step at K = 20 and 42 at K = 200)
         for name, k, w in (("waterworld", 200, 20), ("multiwalker", 50, 20), ("pursuit_c5", 200, 20), ("pursuit_colocate", 200, 20), ("waterworld_std", 100, 20),
-                           ("multiwalker_w10", 20, 20), ("pursuit_rollout", 200, 20), ("hostage", 200, 20)):
+                           ("multiwalker_w10", 20, 20), ("pursuit_rollout", 200, 20), ("hostage", 200, 20), ("pursuit_authors", 100, 20)):
             try:
                 r = bench_rollout(args, k, w, rank, world, dev) if name == "pursuit_rollout" else \
                     bench_pursuit(args, name, k, w, rank, world, dev, side_cpu) if name.startswith("pursuit") else \

@@ -39,16 +39,22 @@ def pursuit_fast_path(xs, ys, n_pursuers, n_evaders, obs_range, flatten, include
         return None, "flatten without the id: rows are not whole float4s"
     if P > 64 or E > 64 or A > 128:
         return None, "more than 64 pursuers or evaders (or 128 agents)"
-    nw = 1 if A <= 64 else 2
     D = 3 * R * R + 1 if flatten else 4 * R * R
     if D % 4:
         return None, "observation row is not a whole number of float4"
-    if (P * (D // 4) + 64 * nw - 1) // (64 * nw) > 8:
-        return None, "more than 8 float4 slots per lane (n_pursuers x row length too large)"
+    # one wavefront per env when the agents fit its lanes AND the row fits 8 float4 slots per lane (slot constants in registers,
+    # pursuit_wave.hpp); otherwise two wavefronts (pursuit_group.hpp), up to 32 slots per thread -- above 8 from an LDS table ("LONG ROWS")
+    slots = lambda n: (P * (D // 4) + 64 * n - 1) // (64 * n)
+    nw = 1 if (A <= 64 and slots(1) <= 8) else 2
+    if slots(nw) > 32:
+        return None, "more than 32 float4 slots per thread (n_pursuers x row length too large)"
     pad = max((R - 1) // 2, 1)
     gsz = ((xs + 2 * pad) * (ys + 2 * pad) + 3) // 4 * 4
-    if (3 * gsz + 2 + P + 72 + (xs * ys + 3) // 4 + 2 * P + 16) * 4 > 64 * 1024:
+    tabled = slots(nw) > 8
+    if (3 * gsz + 2 + P + 72 + (xs * ys + 3) // 4 + 2 * P + 16 + (2 * (D // 4) if tabled else 0)) * 4 > 64 * 1024:
         return None, "map too large for the LDS layers"
+    if tabled and 3 * gsz + 2 + P >= 32768:
+        return None, "map too large for the 15-bit offsets of the long-row table"
     ngw, ntw = max((E + 31) // 32, 1), (A + 31) // 32
     rec = ((16 + 2 * A + 3) // 4 * 4 + 4 * ngw + 4 * ntw + 15) // 16 * 16
     if rec > 256:

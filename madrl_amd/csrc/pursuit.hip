@@ -687,7 +687,7 @@ const WaveEntry WAVE_TABLE[] = {
 #undef X
 #undef XG
 #define X(XS, YS, NP, NE, R, FL)
-#define XG(XS, YS, NP, NE, R, FL, NW) {wave_geom<pw::GShape<XS, YS, NP, NE, R, FL, NW>>(NW), group_launch<pw::GShape<XS, YS, NP, NE, R, FL, NW>>},
+#define XG(XS, YS, NP, NE, R, FL, NW) {wave_geom<pw::GShape<XS, YS, NP, NE, R, FL, NW>>(NW, pw::GShape<XS, YS, NP, NE, R, FL, NW>::OCC), group_launch<pw::GShape<XS, YS, NP, NE, R, FL, NW>>},
 #include "pursuit_specializations.def"
 #if __has_include("pursuit_specializations.local.def")   // shapes added on this machine by `python -m madrl_amd.build --pursuit-shape ...` (git-ignored)
 #include "pursuit_specializations.local.def"
@@ -1015,10 +1015,12 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
         const int need_words = ((int)cells + 3) / 4;
         const int fstride = g.GSZ + need_words;
         const size_t w_codes = (size_t)fstride * d.n_maps;
-        // after the maps: slot codes [D] | empty count layer [GSZ] | per-thread slot table [NS][6][NT]
+        // after the maps: slot codes [D] | empty count layer [GSZ] | per-thread slot table [NS][6][NT] -- or, for shapes with more than 8
+        // slots per thread (pursuit_group.hpp, TABLED), one packed entry of two dwords per float4 of a pursuer's row [DV][2]
         const int NT = 64 * g.waves, DV = d.D / 4, NQ = d.P * DV, NS = (NQ + NT - 1) / NT;
+        const bool tabled = NS > 8;
         const size_t w_tmpl = w_codes + (size_t)d.D, w_slots = w_tmpl + (size_t)g.GSZ;
-        std::vector<uint32_t> wh(w_slots + (size_t)NS * 6 * NT, 0u);
+        std::vector<uint32_t> wh(w_slots + (tabled ? (size_t)2 * DV : (size_t)NS * 6 * NT), 0u);
         const float wallv = (float)1 / (float)cfg->layer_norm;  // |-1| / layer_norm in float32
         uint32_t wall_bits, fill_bits;
         memcpy(&wall_bits, &wallv, 4);
@@ -1061,7 +1063,23 @@ int madrl_pursuit_create(const madrl_pursuit_config *cfg, const int8_t *map_pool
             const int gx = k / g.GW - g.PAD, gy = k % g.GW - g.PAD;
             wh[w_tmpl + k] = (gx >= 0 && gx < xs && gy >= 0 && gy < ys) ? 0u : pw::SENT;
         }
-        for (int sl = 0; sl < NS; ++sl)
+        if (tabled) {
+            // entry f: dword 0 = off0 | off1 << 16, dword 1 = off2 | id3 << 15 | off3 << 16 | abs3 << 31 -- dword offsets into the LDS array,
+            // relative to the window origin unless abs3 (element 3 only: the skip cell, or with id3 the id cell of pursuer 0 + pursuer)
+            if (3 * g.GSZ + 2 + d.P >= 32768 || g.mwords != (NS + 7) / 8) eligible = false;
+            for (int f = 0; f < DV && eligible; ++f) {
+                uint32_t off[4], abs3 = 0u, id3 = 0u;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = wc[4 * f + k];
+                    off[k] = c & 0x7FFFFFFFu;
+                    if (k == 3 && !(c >> 31)) { abs3 = 1u; id3 = ((int)off[k] == g.X_ID) ? 1u : 0u; }
+                    if (off[k] >= 32768u) eligible = false;
+                }
+                wh[w_slots + 2 * (size_t)f] = off[0] | (off[1] << 16);
+                wh[w_slots + 2 * (size_t)f + 1] = off[2] | (id3 << 15) | (off[3] << 16) | (abs3 << 31);
+            }
+        }
+        for (int sl = 0; sl < (tabled ? 0 : NS); ++sl)
             for (int t = 0; t < NT; ++t) {
                 const int q = t + NT * sl, pidx = q / DV, f = q % DV;
                 uint32_t *row = wh.data() + w_slots + (size_t)sl * 6 * NT + t;

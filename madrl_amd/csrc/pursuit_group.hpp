@@ -17,6 +17,13 @@
 //     live in wavefront 0 only;
 //   * every wavefront loads the whole record (dword k in lane k) and stores the dwords it owns.
 // Requirements: n_pursuers <= 64, n_evaders <= 64, record <= 64 dwords, odd obs_range, row length % 4 == 0.
+//
+// LONG ROWS (round 6; the authors' own training shapes, runners/old/rllab/pursuit.sh:1 -- 30 pursuers, obs_range 11: 2 730 float4 per
+// env, 22 slots per thread): with more than 8 slots per thread the per-slot constants no longer live in registers (6 VGPRs per slot).
+// Such a shape is TABLED: slot q = tid + NT s still belongs to thread tid (every store instruction writes NT consecutive float4, whole
+// 64-byte chunks), but its constants come from a table in LDS indexed by the float4's position f = q mod DV inside its row -- four
+// 15-bit dword offsets relative to the window origin, packed in two dwords, identical for every pursuer -- and (pursuer, f) advance
+// from slot to slot by constants.  The stale-zero mask grows to MWORDS = ceil(NS / 8) dwords per thread (one bit per slot in each byte).
 #pragma once
 
 #include "pursuit_wave.hpp"
@@ -43,7 +50,8 @@ struct GShape {
     static constexpr int DV = D / 4;
     static constexpr int NQ = P * DV;
     static constexpr int NS = (NQ + NT - 1) / NT;                // float4 slots per thread
-    static constexpr int MWORDS = 1;                             // stale-zero mask dwords per thread
+    static constexpr int MWORDS = (NS + 7) / 8;                  // stale-zero mask dwords per thread: one bit per slot in each byte, 8 slots per dword
+    static constexpr bool TABLED = NS > 8;                       // slot constants from an LDS table indexed by the position in the row (see above)
     static constexpr int X_FILL = 3 * GSZ;
     static constexpr int X_SKIP = 3 * GSZ + 1;
     static constexpr int X_ID = 3 * GSZ + 2;
@@ -52,7 +60,8 @@ struct GShape {
     static constexpr int X_NEED = X_VTAB + NVT;
     static constexpr int X_ORG = X_NEED + (XS * YS + 3) / 4;     // P window origins
     static constexpr int X_XCH = (X_ORG + P + 3) / 4 * 4;        // 2 dwords per wavefront: ballot exchange
-    static constexpr int LDS_DWORDS = X_XCH + 2 * NW;
+    static constexpr int X_TAB = (X_XCH + 2 * NW + 3) / 4 * 4;   // TABLED: DV entries of two dwords (8-byte aligned)
+    static constexpr int LDS_DWORDS = X_TAB + (TABLED ? 2 * DV : 0);
     static constexpr int NGW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
     static constexpr int NTW = (A + 31) / 32;
     static constexpr int OFF_GONE = (16 + 2 * A + 3) / 4 * 4;
@@ -65,7 +74,11 @@ struct GShape {
     static_assert(R % 2 == 1, "odd obs_range only");
     static_assert(D % 4 == 0, "observation row must be a whole number of float4");
     static_assert(LDS_DWORDS * 4 <= 64 * 1024, "LDS budget");
-    static_assert(NS <= 8, "stale-zero mask: one bit per slot in each byte of the thread's mask dword");
+    // resident wavefronts per SIMD: what the registers are allocated for, capped by what the LDS of a CU (160 KB) admits
+    static constexpr int OCC_LDS = (160 * 1024 / (LDS_DWORDS * 4)) * NW / 4;
+    static constexpr int OCC = OCC_LDS < MADRL_PG_WAVES ? (OCC_LDS < 1 ? 1 : OCC_LDS) : MADRL_PG_WAVES;
+    static_assert(MWORDS <= 4, "at most 32 float4 slots per thread");
+    static_assert(!TABLED || 3 * GSZ + 2 + P < 32768, "TABLED: dword offsets of the layers must fit 15 bits");
 };
 
 // LDS-only workgroup barrier: the DS queue of this wavefront is drained, global stores stay in flight.
@@ -76,7 +89,7 @@ __device__ __forceinline__ void group_sync() {
 }
 
 template <class S, int MODE, bool INJECT>
-__global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_WAVES, MADRL_PG_WAVES))) void pursuit_group_kernel(const WaveDev d, const WaveIO io) {
+__global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(S::OCC, S::OCC))) void pursuit_group_kernel(const WaveDev d, const WaveIO io) {
     constexpr int P = S::P, E = S::E, A = S::A, GW = S::GW, PAD = S::PAD, GSZ = S::GSZ, NS = S::NS, NT = S::NT;
     __shared__ __attribute__((aligned(16))) uint32_t L[S::LDS_DWORDS];
     const int tid = threadIdx.x;            // = agent index for tid < A
@@ -98,17 +111,23 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
     }
     if (tid < P) L[S::X_ID + tid] = __float_as_uint((float)((double)tid / (double)P));
     for (int k = tid; k < S::NVT; k += NT) L[S::X_VTAB + k] = __float_as_uint(d.vtab[k]);
-    int s_cst[NS][4];
-    int s_rel3[NS];
-    int s_org[NS];    // LDS index of the owning pursuer's window origin
+    constexpr int NSR = S::TABLED ? 1 : NS;   // slots whose constants live in registers
+    int s_cst[NSR][4];
+    int s_rel3[NSR];
+    int s_org[NSR];    // LDS index of the owning pursuer's window origin
+    if constexpr (S::TABLED) {
+        for (int k = tid; k < 2 * S::DV; k += NT) L[S::X_TAB + k] = d.slot_tab[k];   // host-built (pursuit.hip): [DV][2] packed offsets
+    } else {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const uint32_t *t = d.slot_tab + s * 6 * NT + tid;  // host-built (pursuit.hip), see WaveDev
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t *t = d.slot_tab + s * 6 * NT + tid;  // host-built (pursuit.hip), see WaveDev
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_cst[s][k] = (int)t[NT * k];
-        s_rel3[s] = (int)t[NT * 4];
-        s_org[s] = S::X_ORG + (int)t[NT * 5];
+            for (int k = 0; k < 4; ++k) s_cst[s][k] = (int)t[NT * k];
+            s_rel3[s] = (int)t[NT * 4];
+            s_org[s] = S::X_ORG + (int)t[NT * 5];
+        }
     }
+    const int q0_p = tid / S::DV, q0_f = tid % S::DV;   // TABLED: (pursuer, float4 position in its row) of this thread's slot 0
     // map 0 is staged with the tables above (pursuit_wave.hpp); the group_sync before the env loop publishes it
     for (int k = tid; k < GSZ; k += NT) L[k] = d.fmaps[k];
     for (int k = tid; k < (S::XS * S::YS + 3) / 4; k += NT) L[S::X_NEED + k] = d.fmaps[GSZ + k];
@@ -154,8 +173,14 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
             return ((uint64_t)hi << 32) | lo;
         }
     };
-    auto fetch_zm = [&](int64_t env) -> uint32_t { return uniform_ptr(d.zmask + env * NT)[utid]; };  // stale-zero mask, pursuit_wave.hpp
-    uint32_t cur_rec = 0, cur_zm = 0xFFFFFFFFu;
+    constexpr int MW = S::MWORDS;
+    auto fetch_zm = [&](int64_t env, uint32_t (&zmw)[MW]) {   // stale-zero masks, pursuit_wave.hpp: [env][MWORDS][NT]
+#pragma unroll
+        for (int w = 0; w < MW; ++w) zmw[w] = uniform_ptr(d.zmask + (env * MW + w) * NT)[utid];
+    };
+    uint32_t cur_rec = 0, cur_zm[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) cur_zm[w] = 0xFFFFFFFFu;
     int cur_act = 4;
     // env indices are 32-bit (the fast path is not taken for n_envs >= 2^31 - 2^20), byte offsets 64-bit
     const int n_envs = (int)d.n_envs, stride = (int)gridDim.x;
@@ -163,21 +188,25 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
     if ((int)blockIdx.x < n_envs) {
         cur_rec = fetch_rec(phys(blockIdx.x));
         cur_act = fetch_act(phys(blockIdx.x));
-        cur_zm = fetch_zm(phys(blockIdx.x));
+        fetch_zm(phys(blockIdx.x), cur_zm);
     }
-    asm volatile("" : "+v"(cur_rec), "+v"(cur_act), "+v"(cur_zm));
+    asm volatile("" : "+v"(cur_rec), "+v"(cur_act));
+#pragma unroll
+    for (int w = 0; w < MW; ++w) asm volatile("" : "+v"(cur_zm[w]));
     group_sync();
 
     for (int e = blockIdx.x; e < n_envs; e += stride) {
         const int64_t env = phys(e);
         const bool has_next = e + stride < n_envs;
         const int64_t nenv = phys(has_next ? e + stride : e);
-        uint32_t nxt_rec = 0, nxt_zm = 0xFFFFFFFFu;
+        uint32_t nxt_rec = 0, nxt_zm[MW];
+#pragma unroll
+        for (int w = 0; w < MW; ++w) nxt_zm[w] = 0xFFFFFFFFu;
         int nxt_act = 4;
         if (has_next) {
             nxt_rec = fetch_rec(nenv);
             nxt_act = fetch_act(nenv);
-            nxt_zm = fetch_zm(nenv);
+            fetch_zm(nenv, nxt_zm);
         }
         bool skip = false;
         if constexpr (MODE == 0) skip = (io.mask != nullptr && io.mask[env] == 0);
@@ -310,8 +339,13 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                 n_removed = __popcll(caught_mask);
             }
 
-            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act), "+v"(nxt_zm));  // pipeline hinge (pursuit_wave.hpp)
-            uint32_t zm = cur_zm;
+            asm volatile("" : "+v"(nxt_rec), "+v"(nxt_act));  // pipeline hinge (pursuit_wave.hpp)
+            uint32_t zm[MW];
+#pragma unroll
+            for (int w = 0; w < MW; ++w) {
+                asm volatile("" : "+v"(nxt_zm[w]));
+                zm[w] = cur_zm[w];
+            }
 
             const int npass = (MODE == 1 && do_reset) ? 2 : 1;
             for (int pass = 0; pass < npass; ++pass) {
@@ -378,28 +412,26 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                 if (alive) cnt = layer[cell] & 0xFFFFu;
                 group_sync();
                 if (alive) layer[cell] = L[S::X_VTAB + cnt];
-                if (isP()) L[S::X_ORG + tid] = (uint32_t)((x - S::OFF + PAD) * GW + (y - S::OFF + PAD));
+                // window origin of pursuer tid: a dword index into L (a byte offset for TABLED shapes)
+                if (isP()) L[S::X_ORG + tid] = (uint32_t)((x - S::OFF + PAD) * GW + (y - S::OFF + PAD)) * (S::TABLED ? 4u : 1u);
                 group_sync();
                 {
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     v4f *orow = reinterpret_cast<v4f *>(io.obs + env * (int64_t)(P * S::D));
-                    uint32_t acc = 0u;
+                    uint32_t acc[MW];
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        const int q = tid + NT * s;
-                        const int base = (int)L[s_org[s]];
-                        const uint32_t v0 = L[base + s_cst[s][0]];
-                        const uint32_t v1 = L[base + s_cst[s][1]];
-                        const uint32_t v2 = L[base + s_cst[s][2]];
-                        const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
-                        // stale-zero mask: see pursuit_wave.hpp
+                    for (int w = 0; w < MW; ++w) acc[w] = 0u;
+                    // what happens to the four cells of one slot (stale-zero mask: see pursuit_wave.hpp).  Slot s = bit (slots of its word - 1 - s % 8)
+                    // of every byte of mask word s / 8; `wc` is that word (a compile-time index: the words live in registers), `sh` the bit
+                    auto finish_slot = [&](auto wc, int sh, int q, bool valid, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+                        constexpr int w = decltype(wc)::value;
                         const uint32_t top = __builtin_amdgcn_perm(v1, v0, 0x0C0C0703u) | __builtin_amdgcn_perm(v3, v2, 0x07030C0Cu);
                         const uint32_t out4 = (top >> 7) & 0x01010101u;
                         const uint32_t nz4 = ((top >> 5) | (top >> 6)) & 0x01010101u;
-                        const uint32_t old4 = (zm >> (NS - 1 - s)) & 0x01010101u;
+                        const uint32_t old4 = (zm[w] >> sh) & 0x01010101u;
                         const uint32_t dirty = out4 & old4;
-                        acc = (acc << 1) | (dirty | (~out4 & nz4));
-                        if ((NT * (s + 1) <= S::NQ) ? true : (fresh(tid) + NT * s < S::NQ)) {
+                        acc[w] = (acc[w] << 1) | (dirty | (~out4 & nz4));
+                        if (valid) {
                             if (dirty == 0u) {
                                 if (out4 != 0x01010101u) {
                                     const v4f val = {__uint_as_float((uint32_t)max((int)v0, 0)), __uint_as_float((uint32_t)max((int)v1, 0)),
@@ -414,8 +446,49 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                                 if (v3 != SENT) o[3] = __uint_as_float(v3);
                             }
                         }
+                    };
+                    if constexpr (S::TABLED) {
+                        // a ROLLED loop per mask word (fully unrolled, the 22 slots of the authors' shape cost 241 VGPRs: two wavefronts per SIMD)
+                        int pq = q0_p, fq = q0_f, q = tid;   // (pursuer, position in its row) and index of the slot, advanced by constants
+                        const char *Lb = reinterpret_cast<const char *>(L);
+                        auto cell_b = [&](int byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(Lb + byte_off); };
+                        static_for<0, MW>([&](auto wc) {
+                            constexpr int w = decltype(wc)::value, nsw = (NS - 8 * w) < 8 ? (NS - 8 * w) : 8;
+#pragma unroll 2
+                            for (int i = 0; i < nsw; ++i) {
+                                const bool valid = q < S::NQ;
+                                const int pp = valid ? pq : 0;                                   // threads past the end of the rows read harmless cells
+                                const uint2 t = *reinterpret_cast<const uint2 *>(&L[S::X_TAB + 2 * fq]);
+                                const int base = (int)L[S::X_ORG + pp];                          // byte offset of the window origin
+                                const uint32_t v0 = cell_b(base + (int)((t.x & 0xFFFFu) << 2));
+                                const uint32_t v1 = cell_b(base + (int)((t.x >> 16) << 2));
+                                const uint32_t v2 = cell_b(base + (int)((t.y & 0x7FFFu) << 2));
+                                // element 3: relative like the others, or absolute (bit 31: the skip cell / the id cells; bit 15: + pursuer)
+                                const int b3 = ((int)t.y < 0) ? 0 : base;
+                                const int id3 = (t.y & 0x8000u) ? pp : 0;
+                                const uint32_t v3 = cell_b(b3 + (int)((((t.y >> 16) & 0x7FFFu) + (uint32_t)id3) << 2));
+                                finish_slot(wc, nsw - 1 - i, q, valid, v0, v1, v2, v3);
+                                q += NT;
+                                fq += NT % S::DV;
+                                pq += NT / S::DV;
+                                if (fq >= S::DV) { fq -= S::DV; pq += 1; }
+                            }
+                        });
+                    } else {
+                        static_for<0, NS>([&](auto sc) {
+                            constexpr int s = decltype(sc)::value;
+                            const int q = tid + NT * s;
+                            const bool valid = (NT * (s + 1) <= S::NQ) ? true : (fresh(tid) + NT * s < S::NQ);
+                            const int base = (int)L[s_org[s]];
+                            const uint32_t v0 = L[base + s_cst[s][0]];
+                            const uint32_t v1 = L[base + s_cst[s][1]];
+                            const uint32_t v2 = L[base + s_cst[s][2]];
+                            const uint32_t v3 = L[(int)__umul24((uint32_t)base, (uint32_t)s_rel3[s]) + s_cst[s][3]];
+                            finish_slot(std::integral_constant<int, 0>{}, NS - 1 - s, q, valid, v0, v1, v2, v3);
+                        });
                     }
-                    zm = acc;
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) zm[w] = acc[w];
                 }
                 group_sync();
                 if (alive) layer[cell] = 0u;
@@ -444,12 +517,14 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(MADRL_PG_
                 if (own_term) w = ((lane - S::OFF_TERM / 4) & 1) ? (uint32_t)(term >> 32) : (uint32_t)term;
                 if (lane >= S::OFF_TERM / 4 + S::NTW) w = 0u;  // padding dwords
                 if (own_dw) uniform_ptr(reinterpret_cast<uint32_t *>(d.state + env * (int64_t)S::REC_BYTES))[ulane] = w;
-                uniform_ptr(d.zmask + env * NT)[utid] = zm;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) uniform_ptr(d.zmask + (env * MW + w) * NT)[utid] = zm[w];
             }
         }
         cur_rec = nxt_rec;
         cur_act = nxt_act;
-        cur_zm = nxt_zm;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) cur_zm[w] = nxt_zm[w];
     }
 }
 

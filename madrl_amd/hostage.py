@@ -152,15 +152,29 @@ class BatchedContinuousHostageWorld(AbstractMAEnv):
         """hostage.py:228-430.  action: float [N, n_good, 2] (or anything that reshapes to it, :229-230).
         respawn: optional float [N, n_bad, 4] injected respawn uniforms (parity hook)."""
         N, Nr = self.n_envs, self.n_good
-        a = torch.as_tensor(action, device=self.device)
-        if a.numel() != N * Nr * 2:
-            raise AssertionError("action has %d elements, expected %d" % (a.numel(), N * Nr * 2))  # :234
-        a = a.reshape(N, Nr, 2).to(torch.float32).contiguous()
+        if not self._conforming(action):
+            a = torch.as_tensor(action, device=self.device)
+            if a.numel() != N * Nr * 2:
+                raise AssertionError("action has %d elements, expected %d" % (a.numel(), N * Nr * 2))  # :234
+            action = a.reshape(N, Nr, 2).to(torch.float32).contiguous()
         r = None
         if respawn is not None:
             r = torch.as_tensor(respawn, device=self.device).reshape(N, self.n_bad, 4).to(torch.float32).contiguous()
+        return self._launch_step(action, r, _lib.current_stream(self.device))
+
+    def _conforming(self, a):
+        return (type(a) is torch.Tensor and a.dtype is torch.float32 and a.device == self.device and a.is_contiguous()
+                and a.numel() == self.n_envs * self.n_good * 2)
+
+    def step_on_stream(self, action, stream):
+        """step() launched on `stream` without making it the current stream (madrl_amd/waterworld.py step_on_stream); None = needs a conversion"""
+        if not self._conforming(action):
+            return None
+        return self._launch_step(action, None, C.c_void_p(stream.cuda_stream))
+
+    def _launch_step(self, a, r, stream_ptr):
         _lib.check(_lib.lib().madrl_hostage_step(self._handle, _lib.ptr(a), _lib.ptr(r), _lib.ptr(self._obs), _lib.ptr(self._rew),
-                                                 _lib.ptr(self._done), _lib.ptr(self._info), _lib.current_stream(self.device)))
+                                                 _lib.ptr(self._done), _lib.ptr(self._info), stream_ptr))
         return self._obs, self._rew, self._done.view(torch.bool), {"ho_saved": self._info[:, 0], "cr_encs": self._info[:, 1], "done_bits": self._done}
 
     @property

@@ -219,17 +219,33 @@ class BatchedMAWaterWorld(AbstractMAEnv):
         """waterworld.py:220-436.  action: float [N, Np, 2] (or anything that reshapes to it, :221-222).
         respawn: optional float [N, NP, 4] injected respawn outcomes (parity hook)."""
         N, Np = self.n_envs, self.n_pursuers
-        a = torch.as_tensor(action, device=self.device)
-        if a.numel() != N * Np * 2:
-            raise AssertionError("action has %d elements, expected %d" % (a.numel(), N * Np * 2))  # :227
-        a = a.reshape(N, Np, 2).to(torch.float32).contiguous()
+        if not self._conforming(action):
+            a = torch.as_tensor(action, device=self.device)
+            if a.numel() != N * Np * 2:
+                raise AssertionError("action has %d elements, expected %d" % (a.numel(), N * Np * 2))  # :227
+            action = a.reshape(N, Np, 2).to(torch.float32).contiguous()
         r = None
         if respawn is not None:
             r = torch.as_tensor(respawn, device=self.device).reshape(N, self.n_particles, 4).to(torch.float32).contiguous()
+        return self._launch_step(action, r, _lib.current_stream(self.device))
+
+    def _conforming(self, a):
+        """an action tensor the kernel can read as it is (float32, contiguous, on the device, N * Np * 2 elements): no torch kernel needed"""
+        return (type(a) is torch.Tensor and a.dtype is torch.float32 and a.device == self.device and a.is_contiguous()
+                and a.numel() == self.n_envs * self.n_pursuers * 2)
+
+    def step_on_stream(self, action, stream):
+        """step() launched on `stream` (a torch.cuda.Stream) without making it the current stream -- for callers that drive sub-batches on
+        their own streams (madrl_amd/sharded.py): entering a `with torch.cuda.stream(...)` block costs the host more than this launch.
+        Returns None when the action needs a conversion kernel (the caller then takes step() under the stream context)."""
+        if not self._conforming(action):
+            return None
+        return self._launch_step(action, None, C.c_void_p(stream.cuda_stream))
+
+    def _launch_step(self, a, r, stream_ptr):
         std = getattr(self, "_std", None)
         _lib.check(_lib.lib().madrl_waterworld_step(self._handle, _lib.ptr(a), _lib.ptr(r), None if std else _lib.ptr(self._obs),
-                                                    _lib.ptr(self._rew), _lib.ptr(self._done), _lib.ptr(self._info),
-                                                    _lib.current_stream(self.device)))
+                                                    _lib.ptr(self._rew), _lib.ptr(self._done), _lib.ptr(self._info), stream_ptr))
         # `done` is a bool VIEW of the byte the kernel wrote (0 / 1): no torch kernel runs after the launch
         info = {"evcatches": self._info[:, 0], "pocatches": self._info[:, 1], "done_bits": self._done}
         if std:  # fused StandardizedEnv: standardised observations and scaled / normalised rewards straight from the kernel

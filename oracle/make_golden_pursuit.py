@@ -283,6 +283,16 @@ def main():
     run_scenario(R, "crowd_260v40_global", [TM.rectangle_map(20, 20)],
                  dict(n_evaders=40, n_pursuers=260, obs_range=5, n_catch=3, surround=False, flatten=True,
                       reward_mech="global", catchr=0.1, urgency_reward=-0.05), episodes=2, steps_per_episode=10, seed=14)
+    # O, P: the authors' own training shapes -- runners/old/rllab/pursuit.sh:1 (30 pursuers / 50 evaders, obs_range 11, --sample_maps
+    #    --flatten --surround, local reward) and runners/old/rltools/pursuit.sh:1 (30 v 30, --catchr 0.0 --term_pursuit 5.0).  Their
+    #    map_pool32.npy is not in the tree: the survey's substitute, TwoDMaps.resize(2, map_pool16) (32 x 32, walls in row / column 0)
+    pool32 = list(TM.resize(2, pool16))
+    run_scenario(R, "authors_30v50_obs11", pool32,
+                 dict(n_evaders=50, n_pursuers=30, obs_range=11, n_catch=2, surround=True, flatten=True, reward_mech="local",
+                      sample_maps=True), episodes=4, steps_per_episode=24, seed=15, chase=0.8)
+    run_scenario(R, "authors_30v30_obs11", pool32,
+                 dict(n_evaders=30, n_pursuers=30, obs_range=11, n_catch=2, surround=True, flatten=True, reward_mech="local",
+                      sample_maps=True, catchr=0.0, term_pursuit=5.0), episodes=4, steps_per_episode=24, seed=16, chase=0.8)
 
 
 if __name__ == "__main__":

@@ -85,7 +85,7 @@ def test_default_batch_line_carries_every_baseline_config():
     j = _last_json(r.stdout)
     assert KEYS <= set(j) and j["config"]["envs_per_gpu"] == 65536 and j["data"] == "synthetic"
     wl = j["workloads"]
-    assert set(wl) == {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std", "multiwalker_w10", "pursuit_rollout"}
+    assert set(wl) >= {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std", "multiwalker_w10", "pursuit_rollout", "hostage"}
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
     rf = j["roofline"]
     # `frac` is priced by the wall clock of the timed region (ms_per_step), `frac_kernel` by the HIP events around the launches

@@ -5,6 +5,8 @@ env of the batch, free-running with fused auto-resets inside the compared region
   * the same at 98 304 envs: more than 375 MB per launch, so successive launches really walk the env range in opposite
     directions (pursuit.hip `launch`)                                                          bit-exact
   * configs[4]  32x32, 16 v 60, one GPU's shard of 32 768 envs      pursuit_group_kernel     bit-exact
+  * the authors' training shape (runners/old/rllab/pursuit.sh:1): 32x32 pool, 30 v 50, obs_range 11, sample_maps, 16 384 envs
+                                                                    pursuit_group_kernel, LDS slot table   bit-exact
   * configs[2]  MAWaterWorld 5 / 10 / 30 sensors, 32 768 envs       waterworld_kernel<1,5,10,10,30>  == the float32 oracle
 
 The oracles are the C restatements pinned to the unmodified reference by tests/test_oracle_*.py; the reference's own draws
@@ -22,6 +24,7 @@ PURSUIT = {
     "c2_65536": (16, 8, 30, 65536, 30, 11),
     "c2_98304_alternating_walk": (16, 8, 30, 98304, 14, 6),
     "c5_shard_32768": (32, 16, 60, 32768, 16, 7),
+    "authors_30v50_obs11_16384": ("pool32", 30, 50, 16384, 12, 5),
 }
 
 
@@ -31,8 +34,14 @@ def test_pursuit_full_batch_bit_exact(case):
     from madrl_amd.pursuit import BatchedPursuitEvade
     from oracle import pursuit as po
     side, P, E, N, T, H = PURSUIT[case]
-    maps = [rectangle_map(side, side)]
-    kw = dict(n_pursuers=P, n_evaders=E, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local")
+    if side == "pool32":   # TwoDMaps.resize(2, map_pool16) as recorded in the golden of this shape; sample_maps like the authors' launch line
+        import os
+        from conftest import GOLDEN
+        maps = list(np.load(os.path.join(GOLDEN, "pursuit_authors_30v50_obs11.npz"))["maps"])
+        kw = dict(n_pursuers=P, n_evaders=E, obs_range=11, n_catch=2, surround=True, flatten=True, reward_mech="local", sample_maps=True)
+    else:
+        maps = [rectangle_map(side, side)]
+        kw = dict(n_pursuers=P, n_evaders=E, obs_range=7, n_catch=2, surround=True, flatten=True, reward_mech="local")
     env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=99, env_id_base=7, max_steps=H, auto_reset=True, **kw)
     assert env.kernel_kind == "wave"
     orc = po.PursuitOracle(maps, n_envs=N, seed=99, env_id_base=7, **kw)
@@ -69,7 +78,7 @@ def test_pursuit_full_batch_bit_exact(case):
     assert n_resets >= N and n_removed > 0, (n_resets, n_removed)   # every env went through the fused reset at least once
 
 
-@pytest.mark.parametrize("mode", ["headline", "secondary_hwc"])
+@pytest.mark.parametrize("mode", ["headline", "secondary_hwc", "authors_long_rows"])
 @pytest.mark.parametrize("start", ["declared_zero", "nothing_known"])
 def test_long_rollout_into_the_mask_equilibrium_is_bit_exact(mode, start):
     """The fast path decides per 16-byte slot between one whole store (cells outside the map that are KNOWN to hold 0.0 are written as
@@ -84,6 +93,12 @@ def test_long_rollout_into_the_mask_equilibrium_is_bit_exact(mode, start):
     maps = [rectangle_map(16, 16)]
     kw = dict(n_pursuers=P, n_evaders=E, obs_range=7, reward_mech="local")
     kw.update(dict(n_catch=2, surround=True, flatten=True) if mode == "headline" else dict(n_catch=2, surround=False, flatten=False))
+    if mode == "authors_long_rows":   # the two-wavefront kernel with the LDS slot table: three stale-zero mask words per thread
+        import os
+        from conftest import GOLDEN
+        N, P, E, T = 192, 30, 50, 500
+        maps = list(np.load(os.path.join(GOLDEN, "pursuit_authors_30v50_obs11.npz"))["maps"])
+        kw = dict(n_pursuers=P, n_evaders=E, obs_range=11, n_catch=2, surround=True, flatten=True, reward_mech="local", sample_maps=True)
     env = BatchedPursuitEvade(maps, n_envs=N, device=DEV, seed=5, env_id_base=1 << 20, max_steps=H, auto_reset=True, **kw)
     assert env.kernel_kind == "wave"
     if start == "nothing_known":

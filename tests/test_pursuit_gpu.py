@@ -31,6 +31,7 @@ WAVE_GOLDEN = {"pursuit_c1_surround_local", "pursuit_c1_surround_global", "pursu
                "pursuit_pool16_sample_maps", "pursuit_tiny5_dense", "pursuit_in_building",
                "pursuit_nonsquare_12x20", "pursuit_window_gt_map", "pursuit_random_opponents",
                "pursuit_c5_32x32",  # two wavefronts per env (pursuit_group.hpp)
+               "pursuit_authors_30v50_obs11", "pursuit_authors_30v30_obs11",   # ... with 22 float4 slots per thread (the LDS slot table, round 6)
                "pursuit_fuzz_13", "pursuit_fuzz_20"}  # the drawn configurations whose shape the one-wavefront kernel can take (odd obs_range, <= 8 float4 slots per lane)
 
 
@@ -92,6 +93,12 @@ CASES = {
     # map_pool128.npy is not in the tree -> rectangle_map(128, 128))
     "authors_cnn_100v300": dict(maps="rect128", n_pursuers=100, n_evaders=300, obs_range=21, n_catch=2, surround=True, flatten=False,
                                 reward_mech="local", n_envs=6, steps=20, expect_catches=False),   # (random pursuers surround nobody on a 128 x 128 map in 20 steps)
+    # the authors' own training shapes (runners/old/rllab/pursuit.sh:1, runners/old/rltools/pursuit.sh:1) on resize(2, map_pool16): the
+    # two-wavefront kernel with the LDS slot table (22 slots per thread, three stale-zero mask words)
+    "authors_30v50_obs11": dict(maps="pool32", n_pursuers=30, n_evaders=50, obs_range=11, n_catch=2, surround=True, flatten=True,
+                                reward_mech="local", sample_maps=True, n_envs=192, steps=90),
+    "authors_30v30_obs11": dict(maps="pool32", n_pursuers=30, n_evaders=30, obs_range=11, n_catch=2, surround=True, flatten=True,
+                                reward_mech="local", sample_maps=True, catchr=0.0, term_pursuit=5.0, n_envs=192, steps=60),
     "tiny_window": dict(maps="open6", n_pursuers=5, n_evaders=4, obs_range=5, n_catch=2, surround=True, flatten=True,
                         reward_mech="global", constraint_window=0.5),
 }
@@ -107,6 +114,9 @@ def _maps(name):
         return [rectangle_map(128, 128)]
     if name == "open6":
         return [np.zeros((6, 6), np.int32)]
+    if name == "pool32":   # TwoDMaps.resize(2, map_pool16), as recorded in the authors' shape goldens
+        g = np.load(pursuit_golden_files()[[golden_id(p) for p in pursuit_golden_files()].index("pursuit_authors_30v50_obs11")])
+        return list(g["maps"])
     if name == "pool16":
         g = np.load(pursuit_golden_files()[[golden_id(p) for p in pursuit_golden_files()].index("pursuit_pool16_sample_maps")])
         return list(g["maps"])
