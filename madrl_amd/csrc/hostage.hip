@@ -110,7 +110,7 @@ __device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_
 template <int MODE, int TNr, int TNh, int TNc, int TK, int TD = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MADRL_HW_WAVES : 1, TNr > 0 ? MADRL_HW_WAVES : 8))) void hostage_kernel(const HwDev d, const HwIO io) {
     // specialised shape: compile-time LDS layout in a static array, launched with 0 dynamic bytes (see waterworld.hip)
-    constexpr int SPEC_DW = TNr > 0 ? ((4 * (TNr + TNh + TNc) + 9 + 3) / 4 * 4 + (TNr * (TD > 0 ? TD : 1) + 3) / 4 * 4 + (2 * TK + 3) / 4 * 4) : 0;
+    constexpr int SPEC_DW = TNr > 0 ? ((4 * (TNr + TNh + TNc) + 9 + 3) / 4 * 4 + ((TNr + 1) * (TD > 0 ? TD : 1) + 3) / 4 * 4 + (2 * TK + 3) / 4 * 4) : 0;   // (TNr + 1: the spare row of the sensing phase)
     constexpr int SPEC_BYTES = TNr > 0 ? (SPEC_DW * 4 + 8 * TNr + TNr * (TNh + TNc) + 2 * TNh + TNc + 15) / 16 * 16 : 16;
     static_assert(TNr == 0 || TD > 0, "a specialised shape fixes the observation width too");
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
     const int OFF_KEY = 4 * NP, OFF_BOMB = 4 * NP + 2, OFF_SAVED = 4 * NP + 4, OFF_FLAGS = 4 * NP + 6, OFF_T = 4 * NP + 7, OFF_TICK = 4 * NP + 8;
     const int rec_dw = TNr > 0 ? (4 * (TNr + TNh + TNc) + 9 + 3) / 4 * 4 : d.rec_dw;
     float *O = S + ((rec_dw + 3) & ~3);                // observation staging [Nr][D]
-    float *SEN = O + ((Nr * D + 3) & ~3);              // sensor unit vectors [K][2]
+    float *const O_SPARE = O + Nr * D;                 // one more row: where the sensing lanes without a (rescuer, sensor) pair write
+    float *SEN = O + (((Nr + 1) * D + 3) & ~3);        // sensor unit vectors [K][2]
     uint64_t *NEAR = reinterpret_cast<uint64_t *>(SEN + ((2 * K + 3) & ~3));  // per rescuer: particles (bit j), key (bit NP), bomb (bit NP + 1) in sensing reach
     uint8_t *COLH = reinterpret_cast<uint8_t *>(NEAR + Nr);  // [Nr][Nh]
     uint8_t *COLC = COLH + Nr * Nh;                    // [Nr][Nc]
@@ -317,7 +318,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                     constexpr int PPP = ALIGNED ? 64 / (TK > 0 ? TK : 1) : 1;
                     const int n_pass = ALIGNED ? (Nr + PPP - 1) / PPP : (Nr * K + 63) / 64;
                     constexpr int N_PASS_T = TNr > 0 ? (ALIGNED ? (TNr + PPP - 1) / PPP : (TNr * TK + 63) / 64) : 3;
-                    constexpr int PCH = N_PASS_T < 3 ? N_PASS_T : 3;
                     const float srange = DA.sensor_range, rad2 = DA.radius * DA.radius;  // G1
                     const float part_x = fresh(lane) < NP ? X[2 * lane] : 0.f, part_y = fresh(lane) < NP ? X[2 * lane + 1] : 0.f;
                     // Conservative cull (as in waterworld.hip): NEAR[i] = objects with d2 <= (rad2 + range^2) * (1 + 1e-4); all others
@@ -332,101 +332,97 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TNr > 0 ? MA
                         }
                         wave_sync();
                     }
-                    for (int p0 = 0; p0 < n_pass; p0 += PCH) {
-                        int ii[PCH], kk[PCH];
-                        bool ok[PCH];
-                        float sx[PCH], sy[PCH], px[PCH], py[PCH];
-                        float b_cr[PCH], b_ho[PCH], b_ke[PCH], b_bo[PCH];
-                        int a_cr[PCH];
-                        uint64_t reach[PCH];  // wave-uniform: objects in reach of any rescuer of pass q
+                    // ONE PASS AT A TIME (round 6, as in waterworld.hip): a pass walks the set bits of ITS OWN reach mask (ascending = the
+                    // reference's index order: the first minimum wins as in np.argmin) instead of the union of the passes' masks with a
+                    // test-and-skip per pass and object -- scalar work on the CU's one scalar pipe; lanes without a (rescuer, sensor) pair write
+                    // to a spare row instead of branching around the stores.
 #pragma unroll
-                        for (int q = 0; q < PCH; ++q) {
-                            const int pass_q = p0 + q;
-                            int i_first, i_last;  // rescuers of this pass
-                            if constexpr (ALIGNED) {
-                                const int li = lane / K;
-                                i_first = pass_q * PPP; i_last = min(i_first + PPP, Nr) - 1;
-                                ok[q] = li < PPP && i_first + li <= i_last;
-                                ii[q] = ok[q] ? i_first + li : 0;
-                                kk[q] = ok[q] ? lane - li * K : 0;
-                            } else {
-                                const int idx = 64 * pass_q + lane;
-                                ok[q] = idx < Nr * K;
-                                ii[q] = ok[q] ? idx / K : 0;
-                                kk[q] = ok[q] ? idx - ii[q] * K : 0;
-                                i_first = 64 * pass_q / K; i_last = min(64 * pass_q + 63, Nr * K - 1) / K;
-                            }
-                            sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
-                            px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
-                            b_cr[q] = INFINITY; b_ho[q] = INFINITY; a_cr[q] = 0;
-                            uint64_t u = 0ull;
-                            if (pass_q < n_pass)
-                                for (int i = i_first; i <= i_last; ++i) u |= NEAR[i];
-                            reach[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
-                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
+                    for (int pass_q = 0; pass_q < (TNr > 0 ? N_PASS_T : n_pass); ++pass_q) {
+                        int i_first, i_last;  // rescuers of this pass
+                        bool okq;
+                        int iq, kq;
+                        if constexpr (ALIGNED) {
+                            const int li = lane / K;
+                            i_first = pass_q * PPP; i_last = min(i_first + PPP, Nr) - 1;
+                            okq = li < PPP && i_first + li <= i_last;
+                            iq = okq ? i_first + li : 0;
+                            kq = okq ? lane - li * K : 0;
+                        } else {
+                            const int idx = 64 * pass_q + lane;
+                            okq = idx < Nr * K;
+                            iq = okq ? idx / K : 0;
+                            kq = okq ? idx - iq * K : 0;
+                            i_first = 64 * pass_q / K; i_last = min(64 * pass_q + 63, Nr * K - 1) / K;
                         }
-                        uint64_t reach_any = 0ull;
-#pragma unroll
-                        for (int q = 0; q < PCH; ++q) reach_any |= reach[q];
-                        auto sense = [&](int q, float qx, float qy) -> float {
-                            const float rx = qx - px[q], ry = qy - py[q];
-                            const float sv = sx[q] * rx + sy[q] * ry;
+                        const float sxq = SEN[2 * kq], syq = SEN[2 * kq + 1];
+                        const float pxq = X[2 * iq], pyq = X[2 * iq + 1];
+                        uint64_t u = 0ull;
+                        for (int i = i_first; i <= i_last; ++i) u |= NEAR[i];
+                        // wave-uniform: objects in reach of any rescuer of this pass
+                        const uint64_t reach = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
+                                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
+                        auto sense = [&](float qx, float qy) -> float {
+                            const float rx = qx - pxq, ry = qy - pyq;
+                            const float sv = sxq * rx + syq * ry;
                             const float d2 = rx * rx + ry * ry;
-                            const bool out = (sv < 0.f) | (sv > srange) | (d2 - sv * sv > rad2);
+                            // sv < 0 || sv > srange as ONE compare: the median of (sv, 0, srange) is sv exactly when 0 <= sv <= srange (waterworld.hip)
+                            const bool out = (__builtin_amdgcn_fmed3f(sv, 0.f, srange) != sv) | (d2 - sv * sv > rad2);
                             return out ? INFINITY : sv;
                         };
-                        // Objects are visited by walking the SET BITS of the reach mask (ascending = the reference's index order, so the
-                        // first minimum wins as in np.argmin): no test-and-skip per object, which is scalar work on the CU's one scalar pipe.
+                        float b_cr = INFINITY, b_ho = INFINITY;
+                        int a_cr = 0;
+                        if (TNr > 0 && Nc <= 32 && Nh <= 32) {   // 32-bit class masks: half the scalar work of the walk
+                            uint32_t todo = (uint32_t)(reach >> (Nr + Nh)) & (Nc >= 32 ? 0xFFFFFFFFu : ((1u << Nc) - 1u));
+#pragma nounroll
+                            while (todo != 0u) {
+                                const int m = __builtin_ctz(todo);
+                                todo &= todo - 1u;
+                                const float sv = sense(bcast(part_x, Nr + Nh + m), bcast(part_y, Nr + Nh + m));
+                                const bool better = sv < b_cr;
+                                b_cr = better ? sv : b_cr;
+                                a_cr = better ? m : a_cr;
+                            }
+                            // hostages: the saved ones (mask from before this step's processing, G5, :296) are not sensed
+                            todo = (uint32_t)(reach >> Nr) & (Nh >= 32 ? 0xFFFFFFFFu : ((1u << Nh) - 1u)) & ~(uint32_t)saved;
+#pragma nounroll
+                            while (todo != 0u) {
+                                const int m = __builtin_ctz(todo);
+                                todo &= todo - 1u;
+                                const float sv = sense(bcast(part_x, Nr + m), bcast(part_y, Nr + m));
+                                b_ho = sv < b_ho ? sv : b_ho;
+                            }
+                        } else {
+                            uint64_t todo = reach & ((((Nc >= 64) ? ~0ull : ((1ull << Nc) - 1ull))) << (Nr + Nh));
+#pragma nounroll
+                            while (todo != 0ull) {
+                                const int bit = __builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                                const float sv = sense(bcast(part_x, bit), bcast(part_y, bit));
+                                const bool better = sv < b_cr;
+                                b_cr = better ? sv : b_cr;
+                                a_cr = better ? bit - (Nr + Nh) : a_cr;
+                            }
+                            todo = reach & (((((Nh >= 64) ? ~0ull : ((1ull << Nh) - 1ull))) & ~saved) << Nr);
+#pragma nounroll
+                            while (todo != 0ull) {
+                                const int bit = __builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                                const float sv = sense(bcast(part_x, bit), bcast(part_y, bit));
+                                b_ho = sv < b_ho ? sv : b_ho;
+                            }
+                        }
+                        const float b_ke = ((reach >> NP) & 1ull) ? sense(kx, ky) : INFINITY;
+                        const float b_bo = ((reach >> (NP + 1)) & 1ull) ? sense(bx, by) : INFINITY;
                         {
-                            uint64_t todo = reach_any & ((((Nc >= 64) ? ~0ull : ((1ull << Nc) - 1ull))) << (Nr + Nh));
-#pragma nounroll
-                            while (todo != 0ull) {
-                                const int bit = __builtin_ctzll(todo);
-                                todo &= todo - 1ull;
-                                const int m = bit - (Nr + Nh);
-                                const float qx = bcast(part_x, bit), qy = bcast(part_y, bit);
-#pragma unroll
-                                for (int q = 0; q < PCH; ++q) {
-                                    if (!((reach[q] >> bit) & 1ull)) continue;
-                                    const float sv = sense(q, qx, qy);
-                                    const bool better = sv < b_cr[q];
-                                    b_cr[q] = better ? sv : b_cr[q];
-                                    a_cr[q] = better ? m : a_cr[q];
-                                }
-                            }
-                        }
-                        {   // hostages: the saved ones (mask from before this step's processing, G5, :296) are not sensed
-                            uint64_t todo = reach_any & (((((Nh >= 64) ? ~0ull : ((1ull << Nh) - 1ull))) & ~saved) << Nr);
-#pragma nounroll
-                            while (todo != 0ull) {
-                                const int bit = __builtin_ctzll(todo);
-                                todo &= todo - 1ull;
-                                const float qx = bcast(part_x, bit), qy = bcast(part_y, bit);
-#pragma unroll
-                                for (int q = 0; q < PCH; ++q) {
-                                    if (!((reach[q] >> bit) & 1ull)) continue;
-                                    const float sv = sense(q, qx, qy);
-                                    b_ho[q] = sv < b_ho[q] ? sv : b_ho[q];
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q < PCH; ++q) {
-                            b_ke[q] = ((reach[q] >> NP) & 1ull) ? sense(q, kx, ky) : INFINITY;
-                            b_bo[q] = ((reach[q] >> (NP + 1)) & 1ull) ? sense(q, bx, by) : INFINITY;
-                        }
-#pragma unroll
-                        for (int q = 0; q < PCH; ++q) {
-                            if (!ok[q]) continue;
-                            const int i = ii[q], k = kk[q];
-                            float *o = O + i * D;
-                            const bool fin = b_cr[q] < INFINITY;
-                            const int j = Nr + Nh + a_cr[q];
-                            o[k] = fin ? b_cr[q] : 0.f;
-                            o[K + k] = fin ? (sx[q] * (V[2 * j] - V[2 * i]) + sy[q] * (V[2 * j + 1] - V[2 * i + 1])) : 0.f;  // :204-226
-                            o[2 * K + k] = (gate0 && b_ho[q] < INFINITY) ? b_ho[q] : 0.f;   // :320-322
-                            o[3 * K + k] = (!gate0 && b_ke[q] < INFINITY) ? b_ke[q] : 0.f;  // :338-340
-                            o[4 * K + k] = (b_bo[q] < INFINITY) ? b_bo[q] : 0.f;
+                            float *o = okq ? O + iq * D : O_SPARE;
+                            const bool fin = b_cr < INFINITY;
+                            const int j = Nr + Nh + a_cr;   // (a_cr = 0 without a hit: a valid particle, its value is not used)
+                            const float raw = sxq * (V[2 * j] - V[2 * iq]) + syq * (V[2 * j + 1] - V[2 * iq + 1]);   // :204-226; loaded and computed unconditionally: a select, no branch
+                            o[kq] = fin ? b_cr : 0.f;
+                            o[K + kq] = fin ? raw : 0.f;
+                            o[2 * K + kq] = (gate0 && b_ho < INFINITY) ? b_ho : 0.f;   // :320-322
+                            o[3 * K + kq] = (!gate0 && b_ke < INFINITY) ? b_ke : 0.f;  // :338-340
+                            o[4 * K + kq] = (b_bo < INFINITY) ? b_bo : 0.f;
                         }
                     }
                 }
@@ -625,7 +621,7 @@ void hw_layout(const madrl_hostage_config *c, HwDev *d) {
 }
 
 size_t hw_lds_bytes(const HwDev &d) {
-    size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)d.Nr * d.D, 4) + align_up((size_t)2 * d.K, 4);
+    size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)(d.Nr + 1) * d.D, 4) + align_up((size_t)2 * d.K, 4);   // (Nr + 1: the spare row of the sensing phase)
     size_t b = f * 4 + 8 * (size_t)d.Nr + (size_t)d.Nr * (d.Nh + d.Nc) + 2 * (size_t)d.Nh + d.Nc;
     return align_up(b, 16);
 }

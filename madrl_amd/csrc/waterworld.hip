@@ -107,6 +107,20 @@ __device__ __forceinline__ int fresh(int v) {
     return v;
 }
 
+// The same for the SPECIALISED shapes, one instruction cheaper (round 6): fresh() costs a v_mov before its v_cmp; here the compare is written
+// out (volatile: it stays where it is used and its mask dies there), its right-hand side an inline constant of the shape (<= 64), and the
+// wave-uniform mask becomes the lane predicate without an instruction (inverse ballot).
+__device__ __forceinline__ bool lane_lt_imm(int lane, int n) {   // lane < n; n must fold to a constant in -16 .. 64
+    unsigned long long m;
+    asm volatile("v_cmp_gt_i32_e64 %0, %1, %2" : "=s"(m) : "i"(n), "v"(lane));
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+}
+__device__ __forceinline__ bool lane_eq_imm(int lane, int n) {
+    unsigned long long m;
+    asm volatile("v_cmp_eq_i32_e64 %0, %1, %2" : "=s"(m) : "i"(n), "v"(lane));
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
     // The specialised shape has a compile-time LDS layout in a STATIC array (launched with 0 dynamic bytes): every LDS address is
     // "lane-dependent register + immediate offset".  With the dynamic array the base is a link-time symbol the compiler adds in
     // registers, hoists out of the env loop per access pattern and -- at 5 waves per SIMD -- spills.
-    constexpr int SPEC_DW = TNp > 0 ? ((4 * (TNp + TNe + TNpo) + 4 + 3) / 4 * 4 + (TNp * (TD > 0 ? TD : 1) + 3) / 4 * 4 + (2 * TK + 3) / 4 * 4) : 0;
+    constexpr int SPEC_DW = TNp > 0 ? ((4 * (TNp + TNe + TNpo) + 4 + 3) / 4 * 4 + ((TNp + 1) * (TD > 0 ? TD : 1) + 3) / 4 * 4 + (2 * TK + 3) / 4 * 4) : 0;   // (TNp + 1: the spare row)
     constexpr int SPEC_BYTES = TNp > 0 ? (SPEC_DW * 4 + 8 * TNp + TNp * (TNe + TNpo) + 2 * TNe + TNpo + 15) / 16 * 16 : 16;
     static_assert(TNp == 0 || TD > 0, "a specialised shape fixes the observation width too");
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
@@ -160,6 +174,9 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
     const uint32_t ulane = threadIdx.x;
 #define DA (ww_args()->d)
 #define IOA (ww_args()->io)
+    static_assert(TNp == 0 || TNp + TNe + TNpo + 1 <= 64, "lane predicates of a specialised shape compare against inline constants");
+#define LANE_LT(n) (TNp > 0 ? lane_lt_imm(lane, (n)) : (fresh(lane) < (n)))
+#define LANE_EQ(n) (TNp > 0 ? lane_eq_imm(lane, (n)) : (fresh(lane) == (n)))
     const int Np = TNp > 0 ? TNp : d.Np, Ne = TNp > 0 ? TNe : d.Ne, Npo = TNp > 0 ? TNpo : d.Npo, K = TNp > 0 ? TK : d.K;
     const int NP = Np + Ne + Npo, D = TD > 0 ? TD : d.D;  // TD: the observation width of the specialised shape (7 K + 3)
     // ---- LDS carve
@@ -167,7 +184,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
     float *X = S, *V = S + 2 * NP;
     float *OB = S + 4 * NP;
     float *O = S + (((TNp > 0 ? 4 * (TNp + TNe + TNpo) + 4 : d.rec_dw) + 3) & ~3);  // observation staging [Np][D]
-    float *SEN = O + ((Np * D + 3) & ~3);               // sensor unit vectors [K][2]
+    float *const O_SPARE = O + Np * D;                  // one more row: where the sensing lanes without a (pursuer, sensor) pair write
+    float *SEN = O + (((Np + 1) * D + 3) & ~3);         // sensor unit vectors [K][2]
     uint64_t *NEAR = reinterpret_cast<uint64_t *>(SEN + ((2 * K + 3) & ~3));  // per pursuer: particles (bit j) / obstacle (bit NP) in sensing reach
     uint8_t *COL = reinterpret_cast<uint8_t *>(NEAR + Np);  // col_ev[Np][Ne] | col_po[Np][Npo]
     uint8_t *COLP = COL + Np * Ne;
@@ -247,8 +265,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                         }
                         X[2 * lane] = x;
                         X[2 * lane + 1] = y;
-                        V[2 * lane] = fresh(lane) < Np ? 0.0f : (u0 - 0.5f) * DA.ev_speed;      // :164, :170 (W9)
-                        V[2 * lane + 1] = fresh(lane) < Np ? 0.0f : (u1 - 0.5f) * DA.ev_speed;
+                        V[2 * lane] = LANE_LT(Np) ? 0.0f : (u0 - 0.5f) * DA.ev_speed;      // :164, :170 (W9)
+                        V[2 * lane + 1] = LANE_LT(Np) ? 0.0f : (u1 - 0.5f) * DA.ev_speed;
                     }
                     tick += 1;
                     act_lane = 0.0f;  // reset ends with step(zeros) (:172, W11)
@@ -259,8 +277,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 // phase A: particles
                 float reward = 0.0f;
                 {
-                    const float a_raw0 = __shfl(act_lane, 2 * (fresh(lane) < Np ? lane : 0));
-                    const float a_raw1 = __shfl(act_lane, 2 * (fresh(lane) < Np ? lane : 0) + 1);
+                    const float a_raw0 = __shfl(act_lane, 2 * (LANE_LT(Np) ? lane : 0));
+                    const float a_raw1 = __shfl(act_lane, 2 * (LANE_LT(Np) ? lane : 0) + 1);
                     const float a0 = a_raw0 * DA.action_scale, a1 = a_raw1 * DA.action_scale;  // :224
                     float pen_local = DA.control_penalty * (a0 * a0 + a1 * a1);
                     if (DA.reward_global) {  // (actions**2).sum(), row-major (:234-235, W12)
@@ -272,10 +290,10 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                         }
                         pen_local = DA.control_penalty * s;
                     }
-                    if (fresh(lane) < NP) {
+                    if (LANE_LT(NP)) {
                         float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
                         float sq_obst = DA.sq_obst_po, f = -1.0f;
-                        if (fresh(lane) < Np) {
+                        if (LANE_LT(Np)) {
                             vx = vx + a0; vy = vy + a1;  // :229-231
                             x = x + vx; y = y + vy;
                             reward = 0.0f + pen_local;   // :233-237
@@ -285,7 +303,7 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                             if (y != cy) vy = 0.f;
                             x = cx; y = cy;
                             sq_obst = DA.sq_obst_pu; f = -0.5f;
-                        } else if (fresh(lane) < Np + Ne) {
+                        } else if (LANE_LT(Np + Ne)) {
                             sq_obst = DA.sq_obst_ev; f = -0.5f;
                         }
                         if (dist2_le(x, y, ox, oy, sq_obst)) {  // dist <= pr + obst_r, :247-270 (W1, W2)
@@ -314,14 +332,14 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
 #pragma unroll
                     for (int w = 0; w < WE; ++w) {
                         const int li = lane / Ne, i0 = w * GE + li;
-                        const bool in = fresh(lane) < GE * Ne && i0 < Np;
+                        const bool in = LANE_LT(GE * Ne) && i0 < Np;
                         const int i = in ? i0 : 0, m = in ? lane - li * Ne : 0, j = Np + m;
                         col_ev[w] = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_ev));
                     }
 #pragma unroll
                     for (int w = 0; w < WP; ++w) {
                         const int li = lane / Npo, i0 = w * GP + li;
-                        const bool in = fresh(lane) < GP * Npo && i0 < Np;
+                        const bool in = LANE_LT(GP * Npo) && i0 < Np;
                         const int i = in ? i0 : 0, m = in ? lane - li * Npo : 0, j = Np + Ne + m;
                         col_po[w] = __ballot(in && dist2_le(X[2 * i], X[2 * i + 1], X[2 * j], X[2 * j + 1], DA.sq_hit_po));
                     }
@@ -335,8 +353,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                     for (int r = 0; r < GE; ++r) cm_ev |= 1ull << (r * Ne);
 #pragma unroll
                     for (int r = 0; r < GP; ++r) cm_po |= 1ull << (r * Npo);
-                    if (fresh(lane) >= Np && fresh(lane) < NP) {
-                        const bool is_ev = fresh(lane) < Np + Ne;
+                    if ((!LANE_LT(Np) && LANE_LT(NP))) {
+                        const bool is_ev = LANE_LT(Np + Ne);
                         const int m = is_ev ? lane - Np : lane - Np - Ne;
                         int sc = 0;
                         if (is_ev) {
@@ -363,8 +381,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 }
                 wave_sync();
                 // _caught (:180-193): evader lanes / poison lanes count their column
-                if (fresh(lane) >= Np && fresh(lane) < NP) {
-                    const bool is_ev = fresh(lane) < Np + Ne;
+                if ((!LANE_LT(Np) && LANE_LT(NP))) {
+                    const bool is_ev = LANE_LT(Np + Ne);
                     const int m = is_ev ? lane - Np : lane - Np - Ne;
                     const uint8_t *col = is_ev ? COL : COLP;
                     const int n2 = is_ev ? Ne : Npo;
@@ -397,114 +415,123 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 constexpr int PPP = ALIGNED ? 64 / (TK > 0 ? TK : 1) : 1;  // pursuers per pass
                 const int n_pass = ALIGNED ? (Np + PPP - 1) / PPP : (Np * K + 63) / 64;
                 constexpr int N_PASS_T = TNp > 0 ? (ALIGNED ? (TNp + PPP - 1) / PPP : (TNp * TK + 63) / 64) : 3;
-                constexpr int PCH = N_PASS_T < 3 ? N_PASS_T : 3;
-                const float part_x = fresh(lane) < NP ? X[2 * lane] : 0.f, part_y = fresh(lane) < NP ? X[2 * lane + 1] : 0.f;
+                const float part_x = LANE_LT(NP) ? X[2 * lane] : 0.f, part_y = LANE_LT(NP) ? X[2 * lane + 1] : 0.f;
                 // Conservative cull: a sensor of pursuer i can only return a finite value for an object with
                 // d2 <= rad2 + sv^2 <= rad2 + range^2; NEAR[i] marks the objects within that reach plus a 1e-4 relative margin
                 // (d2 is computed exactly as in the test below), everything else would yield INFINITY and is skipped per pass.
                 {
                     const float thr2 = (rad2 + srange * srange) * 1.0001f + 1e-9f;
-                    const float mx = fresh(lane) == NP ? ox : part_x, my = fresh(lane) == NP ? oy : part_y;
+                    const float mx = LANE_EQ(NP) ? ox : part_x, my = LANE_EQ(NP) ? oy : part_y;
                     for (int i = 0; i < Np; ++i) {
                         const float rx = mx - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), i));
                         const float ry = my - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), i));
-                        const uint64_t mk = __ballot((fresh(lane) <= NP) && (rx * rx + ry * ry <= thr2));
-                        if (fresh(lane) == 0) NEAR[i] = mk;
+                        const uint64_t mk = __ballot((LANE_LT(NP + 1)) && (rx * rx + ry * ry <= thr2));
+                        if (LANE_EQ(0)) NEAR[i] = mk;
                     }
                     wave_sync();
                 }
 #if MADRL_WW_ABLATE & 1
                 if (DA.n_envs < 0)
 #endif
-                for (int p0 = 0; p0 < n_pass; p0 += PCH) {
-                    int ii[PCH], kk[PCH];
-                    bool ok[PCH];
-                    float sx[PCH], sy[PCH], px[PCH], py[PCH];
-                    uint64_t reach[PCH];  // wave-uniform: objects in reach of any pursuer of pass q
+                // ONE PASS AT A TIME (round 6).  A pass walks the set bits of ITS OWN reach mask, class by class -- ascending = the reference's
+                // index order: the first minimum wins as in np.argmin.  Round 5 held three passes in registers, walked the union of their
+                // masks once and tested per object which of the passes it concerns: 17 scalar instructions per object (loop control +
+                // three test-and-skip branches) on the CU's single scalar pipe, the resource this kernel is bound by.  Per (object, pass)
+                // visit the walk now costs 6 (32-bit class masks where a class has at most 32 members), nothing is tested and skipped, and
+                // one pass's lane constants and ONE running minimum are all that is live in the object loop.
 #pragma unroll
-                    for (int q = 0; q < PCH; ++q) {
-                        const int pass_q = p0 + q;
-                        int i_first, i_last;  // pursuers of this pass
-                        if constexpr (ALIGNED) {
-                            const int li = lane / K;
-                            i_first = pass_q * PPP; i_last = min(i_first + PPP, Np) - 1;
-                            ok[q] = li < PPP && i_first + li <= i_last;
-                            ii[q] = ok[q] ? i_first + li : 0;
-                            kk[q] = ok[q] ? lane - li * K : 0;
-                        } else {
-                            const int idx = 64 * pass_q + lane;
-                            ok[q] = idx < Np * K;
-                            ii[q] = ok[q] ? idx / K : 0;
-                            kk[q] = ok[q] ? idx - ii[q] * K : 0;
-                            i_first = 64 * pass_q / K; i_last = min(64 * pass_q + 63, Np * K - 1) / K;
-                        }
-                        sx[q] = SEN[2 * kk[q]]; sy[q] = SEN[2 * kk[q] + 1];
-                        px[q] = X[2 * ii[q]]; py[q] = X[2 * ii[q] + 1];
-                        uint64_t u = 0ull;
-                        if (pass_q < n_pass)
-                            for (int i = i_first; i <= i_last; ++i) u |= NEAR[i];
-                        reach[q] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
-                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
+                for (int pass_q = 0; pass_q < (TNp > 0 ? N_PASS_T : n_pass); ++pass_q) {
+                    int i_first, i_last;  // pursuers of this pass
+                    bool okq;
+                    int iq, kq;
+                    if constexpr (ALIGNED) {
+                        const int li = lane / K;
+                        i_first = pass_q * PPP; i_last = min(i_first + PPP, Np) - 1;
+                        okq = li < PPP && i_first + li <= i_last;
+                        iq = okq ? i_first + li : 0;
+                        kq = okq ? lane - li * K : 0;
+                    } else {
+                        const int idx = 64 * pass_q + lane;
+                        okq = idx < Np * K;
+                        iq = okq ? idx / K : 0;
+                        kq = okq ? idx - iq * K : 0;
+                        i_first = 64 * pass_q / K; i_last = min(64 * pass_q + 63, Np * K - 1) / K;
                     }
-                    uint64_t reach_any = 0ull;
-#pragma unroll
-                    for (int q = 0; q < PCH; ++q) reach_any |= reach[q];
+                    const float sxq = SEN[2 * kq], syq = SEN[2 * kq + 1];
+                    const float pxq = X[2 * iq], pyq = X[2 * iq + 1];
+                    uint64_t u = 0ull;
+                    for (int i = i_first; i <= i_last; ++i) u |= NEAR[i];
+                    // wave-uniform: objects in reach of any pursuer of this pass
+                    const uint64_t reach = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)) |
+                                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
+                    // (a specialised shape fixes the row width, and with it whether the speed features are in the row: 7 K + 2 (+ 1) against 4 K + 2 (+ 1))
+                    const bool speed = TNp > 0 ? (TD >= 7 * TK + 2) : (bool)DA.speed_features;
+                    // lanes without a (pursuer, sensor) pair -- 4 of 64 in a pass of two pursuers, 34 in the last pass of C3 -- write their features
+                    // to a spare row behind the staging rows instead of branching around the stores (an exec-mask round trip per (pass, class))
+                    float *const orow_l = okq ? O + iq * D : O_SPARE;
 #pragma unroll
                     for (int cls = 0; cls < 4; ++cls) {
-                        const int lo = cls == 1 ? Np : (cls == 2 ? Np + Ne : 0);
+                        const int lo = cls == 0 ? NP : (cls == 1 ? Np : (cls == 2 ? Np + Ne : 0));
                         const int cnt = cls == 0 ? 1 : (cls == 1 ? Ne : (cls == 2 ? Npo : Np));
-                        float b[PCH];
-                        int bi[PCH];
-#pragma unroll
-                        for (int q = 0; q < PCH; ++q) { b[q] = INFINITY; bi[q] = 0; }
-                        // the class's objects in reach of any pass, visited by walking the SET BITS of the mask (ascending = the reference's
-                        // index order: the first minimum wins as in np.argmin) -- no test-and-skip per object on the scalar pipe
-                        uint64_t todo = reach_any & (cls == 0 ? (1ull << NP) : ((((cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull))) << lo));
+                        float b = INFINITY;
+                        int bi = 0;
+                        auto visit = [&](int m, float qx, float qy) {
+                            const float rx = qx - pxq, ry = qy - pyq;
+                            const float sv = sxq * rx + syq * ry;
+                            const float d2 = rx * rx + ry * ry;
+                            // branch-free (bitwise |, selects): no exec-mask round trips in the inner loop
+                            // sv < 0 || sv > srange as ONE compare: the median of (sv, 0, srange) is sv exactly when 0 <= sv <= srange (sv is finite;
+                            // -0.0 compares equal to the +0.0 the median may return, as it passes `sv < 0`)
+                            const bool out = (__builtin_amdgcn_fmed3f(sv, 0.f, srange) != sv) | (d2 - sv * sv > rad2) | ((cls == 3) & (m == iq));
+                            // (the reference sets an excluded ray to +inf and takes the first minimum: an excluded ray is never "better", a kept one
+                            // is when it is smaller -- the same minimum and the same first index without materialising the +inf)
+                            const bool better = !out & (sv < b);
+                            b = better ? sv : b;
+                            bi = better ? m : bi;
+                        };
+                        if (cls == 0) {
+                            if ((reach >> NP) & 1ull) visit(0, ox, oy);
+                        } else if (TNp > 0 && cnt <= 32) {
+                            uint32_t todo = (uint32_t)(reach >> lo) & (cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u));
 #pragma nounroll
-                        while (todo != 0ull) {
-                            const int bit = __builtin_ctzll(todo);
-                            todo &= todo - 1ull;
-                            const int m = cls == 0 ? 0 : bit - lo;
-                            const float qx = cls == 0 ? ox : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), bit));
-                            const float qy = cls == 0 ? oy : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), bit));
-#pragma unroll
-                            for (int q = 0; q < PCH; ++q) {
-                                if (!((reach[q] >> bit) & 1ull)) continue;
-                                const float rx = qx - px[q], ry = qy - py[q];
-                                float sv = sx[q] * rx + sy[q] * ry;
-                                const float d2 = rx * rx + ry * ry;
-                                // branch-free (bitwise |, selects): no exec-mask round trips in the inner loop
-                                const bool out = (sv < 0.f) | (sv > srange) | (d2 - sv * sv > rad2) | ((cls == 3) & (m == ii[q]));
-                                sv = out ? INFINITY : sv;
-                                const bool better = sv < b[q];
-                                b[q] = better ? sv : b[q];
-                                bi[q] = better ? m : bi[q];
+                            while (todo != 0u) {
+                                const int m = __builtin_ctz(todo);
+                                todo &= todo - 1u;
+                                // the object's position: ONE uniform-address LDS read (a broadcast) instead of two v_readlane + their wait states --
+                                // the LDS pipe has room, the VALU port is what this kernel is bound by since the scalar work went
+                                const float2 qp = *reinterpret_cast<const float2 *>(&X[2 * (lo + m)]);
+                                visit(m, qp.x, qp.y);
+                            }
+                        } else {
+                            uint64_t todo = reach & ((((cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull))) << lo);
+#pragma nounroll
+                            while (todo != 0ull) {
+                                const int bit = __builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                                visit(bit - lo, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_x), bit)),
+                                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part_y), bit)));
                             }
                         }
-                        // the class's features go to the staging row now (not after all four classes): nothing but the running
-                        // minimum of ONE class is held in registers across the object loop
-                        const bool speed = DA.speed_features;
-#pragma unroll
-                        for (int q = 0; q < PCH; ++q) {
-                            if (!ok[q]) continue;
-                            const int i = ii[q], k = kk[q];
-                            float *o = O + i * D;
-                            const bool fin = b[q] < INFINITY;
-                            const float fd = fin ? b[q] : 0.f;  // W4: raw distance or 0
+                        // the features of (pass, class) go to the staging row now: nothing but ONE running minimum is held in registers
+                        {
+                            float *o = orow_l;
+                            const bool fin = b < INFINITY;
+                            const float fd = fin ? b : 0.f;  // W4: raw distance or 0
                             if (cls == 0) {
-                                o[k] = fd;
+                                o[kq] = fd;
                             } else {
-                                const int j = lo + bi[q];
-                                const float fs = fin ? (sx[q] * (V[2 * j] - V[2 * i]) + sy[q] * (V[2 * j + 1] - V[2 * i + 1])) : 0.f;  // W5
-                                if (speed) { o[(2 * cls - 1) * K + k] = fd; o[2 * cls * K + k] = fs; }
-                                else o[cls * K + k] = fd;
+                                const int j = lo + bi;   // (bi = 0 without a hit: a valid particle, its value is not used)
+                                const float raw = sxq * (V[2 * j] - V[2 * iq]) + syq * (V[2 * j + 1] - V[2 * iq + 1]);   // loaded and computed
+                                const float fs = fin ? raw : 0.f;  // W5                                                  unconditionally: a select, no branch
+                                if (speed) { o[(2 * cls - 1) * K + kq] = fd; o[2 * cls * K + kq] = fs; }
+                                else o[cls * K + kq] = fd;
                             }
                         }
                     }
                 }
                 // pursuer lanes: collision flags, id, who-caught tests for the local rewards
                 bool wc = false, wp = false, we = false;
-                if (fresh(lane) < Np) {
+                if (LANE_LT(Np)) {
                     bool tev = false, tpo = false;
                     if constexpr (BITROWS) {
                         uint64_t we_ = col_ev[0], wp_ = col_po[0];  // the word that holds this pursuer's row
@@ -539,8 +566,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 }
                 wave_sync();
                 // phase E: respawn caught evaders / poisons (:355-374)
-                if (fresh(lane) >= Np && fresh(lane) < NP && my_caught) {
-                    const bool is_ev = fresh(lane) < Np + Ne;
+                if ((!LANE_LT(Np) && LANE_LT(NP)) && my_caught) {
+                    const bool is_ev = LANE_LT(Np + Ne);
                     float x, y, u0, u1;
                     if (MODE == 1 && IOA.inj_resp != nullptr && !do_init) {
                         const float *r = IOA.inj_resp + (env * NP + lane) * 4;
@@ -563,7 +590,7 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 }
                 tick += 1;
                 // phase F: rewards (:376-385)
-                if (fresh(lane) < Np) {
+                if (LANE_LT(Np)) {
                     if (DA.reward_global) {
                         reward += ((float)n_evc * DA.food_reward) + ((float)n_poc * DA.poison_reward) +
                                   ((float)n_enc * DA.encounter_reward);
@@ -575,7 +602,7 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 }
                 wave_sync();
                 // phase G: evaders / poisons move; velocity flips only if BOTH coordinates left [0,1] (W6)
-                if (fresh(lane) >= Np && fresh(lane) < NP) {
+                if ((!LANE_LT(Np) && LANE_LT(NP))) {
                     float x = X[2 * lane], y = X[2 * lane + 1], vx = V[2 * lane], vy = V[2 * lane + 1];
                     x = x + vx; y = y + vy;
                     const bool outx = !(x >= 0.f && x <= 1.f), outy = !(y >= 0.f && y <= 1.f);
@@ -590,8 +617,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                 if (pass == 0) asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_act));  // pipeline hinge
                 // ---------------------------------------------------- outputs
                 if (MODE == 1 && !do_init) {
-                    if (fresh(lane) < Np) uniform_ptr(IOA.rew + env * Np)[ulane] = reward;
-                    if (FUSED && IOA.st->rew_out != nullptr && fresh(lane) < Np) {  // StandardizedEnv.step :283-291
+                    if (LANE_LT(Np)) uniform_ptr(IOA.rew + env * Np)[ulane] = reward;
+                    if (FUSED && IOA.st->rew_out != nullptr && LANE_LT(Np)) {  // StandardizedEnv.step :283-291
                         const WwStd &st = *IOA.st;
                         const int64_t i = env * Np + lane;
                         double r = (double)reward;
@@ -605,7 +632,7 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
                         }
                         st.rew_out[i] = (float)(st.scale * r);                                           // :290
                     }
-                    if (fresh(lane) == 0) {
+                    if (LANE_EQ(0)) {
                         IOA.done[env] = (uint8_t)is_done;
                         IOA.info[2 * env] = n_evc;
                         IOA.info[2 * env + 1] = n_poc;
@@ -621,8 +648,16 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
 #if MADRL_WW_ABLATE & 2
                     if (DA.n_envs < 0)
 #endif
-                    if (obs_p != nullptr)   // the raw row may be dropped when the fused wrapper output is all the caller reads
-                    for (uint32_t e = ulane; e < (uint32_t)(Np * D); e += 64u) orow[e] = O[e];
+                    if (obs_p != nullptr) {  // the raw row may be dropped when the fused wrapper output is all the caller reads
+                        // 16 bytes per lane (ds_read_b128 + one 16-byte store; an env's rows start on a 4-byte boundary only -- gfx950 under HSA runs
+                        // global accesses in unaligned mode -- and the rows of neighbouring envs are contiguous, so whole lines leave the chip anyway)
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+                        const uint32_t n4 = (uint32_t)(Np * D) / 4u;
+                        for (uint32_t e = ulane; e < n4; e += 64u)
+                            *reinterpret_cast<__attribute__((address_space(1))) f4u *>(orow + 4 * e) = *reinterpret_cast<const f4a *>(O + 4 * e);
+                        for (uint32_t e = 4u * n4 + ulane; e < (uint32_t)(Np * D); e += 64u) orow[e] = O[e];
+                    }
                     if (FUSED) {  // StandardizedEnv.standardize_obs :242-263
                         const WwStd &st = *IOA.st;
                         const int64_t base = env * (int64_t)(Np * D);
@@ -681,6 +716,8 @@ __global__ __launch_bounds__(64) MADRL_WW_OCC void waterworld_kernel(const WwDev
 }
 #undef DA
 #undef IOA
+#undef LANE_LT
+#undef LANE_EQ
 
 }  // namespace
 // =================================================================== host side / C ABI
@@ -751,7 +788,7 @@ void ww_layout(const madrl_waterworld_config *c, WwDev *d) {
 }
 
 size_t ww_lds_bytes(const WwDev &d) {
-    size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)d.Np * d.D, 4) + align_up((size_t)2 * d.K, 4);
+    size_t f = align_up((size_t)d.rec_dw, 4) + align_up((size_t)(d.Np + 1) * d.D, 4) + align_up((size_t)2 * d.K, 4);   // (Np + 1: the spare row of the sensing phase)
     size_t b = f * 4 + 8 * (size_t)d.Np + (size_t)d.Np * (d.Ne + d.Npo) + 2 * (size_t)d.Ne + d.Npo;
     return align_up(b, 16);
 }

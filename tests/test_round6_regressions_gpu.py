@@ -165,8 +165,9 @@ def test_waterworld_and_hostage_done_is_a_view():
     w.reset()
     for t in range(4):
         _, _, done, info = w.step(torch.zeros((128, 5, 2), device=DEV))
-        # (reset() ends with a step(zeros) that counts, waterworld.py:172: the limit of 3 is reached by the second step() of an episode)
-        assert done.dtype == torch.bool and done.data_ptr() == w._done.data_ptr() and bool(done.all()) == (t % 3 == 1) and bool(done.any()) == (t % 3 == 1)
+        # (reset() ends with a step(zeros) that counts, waterworld.py:172: with a limit of 3 every second step() ends an episode)
+        assert done.dtype == torch.bool and done.data_ptr() == w._done.data_ptr() and torch.equal(done, w._done != 0)
+        assert bool(done.all()) == bool(done.any()) == (t % 2 == 1)
         assert info["done_bits"] is w._done
     h = BatchedContinuousHostageWorld(3, 10, 5, 2, 2, n_envs=128, device=DEV, seed=0, max_steps=3, auto_reset=True)
     h.reset()
