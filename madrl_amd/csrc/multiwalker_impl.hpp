@@ -159,11 +159,15 @@ constexpr uint32_t SPARE_BUSY = 0xFFFFFFFFu;
 // split step the schedule (the solver's part of mw::Scratch) waits in front of the manifold pool in the state buffer.
 enum { PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 4, PH_ALL = 7 };
 // The one-launch form is not built for the sixteen-lane class: set_mode(fused) then runs the three launches (same results).  hipcc 7.2
-// compiles that kernel -- and only that one -- into code that faults: the per-env record pointer is parked in accumulation registers
-// over the solver loop and read back inside the joints' write-back block, where the lanes past n_walkers are masked off; those lanes'
-// copies stay whatever temporaries were there, and step_post's body loop, which runs on all sixteen lanes, then loads through them
-// (rocgdb with precise-memory: profiles/r05_multiwalker/rocgdb_c10_fused.txt).  The three-launch kernels of this class and every kernel
-// of the other two match the CPU build byte for byte in every lane (tests/test_multiwalker_gpu.py).
+// miscompiles that kernel -- and only that one.  Root cause (round 6, profiles/r06_multiwalker/c10_fused_masked_spill.txt, readable off the
+// emitted code without a GPU): the register allocator splits the live range of the per-lane record pointer at the control-flow join that
+// follows the joints' InitVelocityConstraints and emits its copies into accumulation registers (a32 / a33) at the head of the join block,
+// AHEAD of the `s_or_b64 exec` that re-enables the lanes the region had masked off -- the lanes without joints, lane >= n_walkers.  Those
+// lanes never write their copy; after the velocity iterations the pointer is read back under the full mask and step_post's body loop, which
+// runs on all sixteen lanes, loads through the stale registers (the fault rocgdb showed: profiles/r05_multiwalker/rocgdb_c10_fused.txt).
+// The source reads nothing uninitialised: every lane computes the pointer at the top of the kernel.  scripts/find_masked_spills.py finds
+// such copies in a .s file; the kernels that ARE built are clean (profiles/r06_multiwalker/masked_spill_scan.txt) and match the CPU build
+// byte for byte in every lane (tests/test_multiwalker_gpu.py).
 constexpr bool HAVE_FUSED = NL < 16;
 template <int PH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_MW_SOLVE_WAVES, MADRL_MW_SOLVE_WAVES)))
