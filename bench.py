@@ -618,7 +618,6 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
         # solve + continuous-pass time, not the slowest wavefront's of every phase): 3.4 against 4.0 ms per step at four sub-batches;
         # alone on the chip the two forms take the same 4.6 ms (scripts/stream_sweep.sh)
         mw_fused = (S > 1) if "MADRL_BENCH_MW_FUSED" not in os.environ else os.environ["MADRL_BENCH_MW_FUSED"] == "1"
-        mw_fused = mw_fused and envs[0].lanes_per_env < 16   # (the one-launch kernel is not built for the sixteen-lane class)
         if mw_fused:
             for e in envs:
                 e.set_mode(fused=True)

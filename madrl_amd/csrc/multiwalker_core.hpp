@@ -902,6 +902,9 @@ struct SerialPar {
     MW_HD void or_bits(uint32_t *p, uint32_t v) const { *p |= v; }
     template <class B> MW_HD void or_bits(B *p, B v) const { p->join(v); }
     MW_HD uint32_t reduce_or(uint32_t v) const { return v; }   // OR over the lanes of the env: this one lane has seen everything
+    // (the HIP build of the sixteen-lane class finds its record again from the lane id here, see GroupPar in multiwalker_impl.hpp)
+    MW_HD ColdView cold_again(const ColdView &c) const { return c; }
+    MW_HD Manifold *pool_again(Manifold *p) const { return p; }
 };
 
 // b2Contact::Update of one contact whose new manifold is `mo`: impulses carried over by feature id, touching state, e_enabledFlag
@@ -2094,6 +2097,37 @@ MW_HD_INLINE void manifold_position_part(Manifold &m, const Manifold &src) {
     m.bA = src.bA; m.bB = src.bB; m.type = src.type; m.island = src.island;
     m.local_normal = src.local_normal; m.local_point = src.local_point; m.lp[0] = src.lp[0]; m.lp[1] = src.lp[1];
 }
+// what SolveVelocityConstraints reads of a manifold (b2ContactVelocityConstraint after InitializeVelocityConstraints), and the four
+// accumulated impulses it leaves behind.  PM: a pointer to the working copy -- in the HIP build one that says which memory it points
+// into (MW_LDS: were both kinds handed over as plain pointers, hipcc would fold the two fetches into one flat load through a selected
+// pointer); scalar by scalar because a struct cannot be copied out of a qualified address space
+template <class PM>
+MW_HD_INLINE void manifold_velocity_part_from(Manifold &m, PM s) {
+    m.bA = s->bA; m.bB = s->bB; m.npts = s->npts; m.block = s->block;
+    m.normal.x = s->normal.x; m.normal.y = s->normal.y;
+    MW_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        m.rA[i].x = s->rA[i].x; m.rA[i].y = s->rA[i].y; m.rB[i].x = s->rB[i].x; m.rB[i].y = s->rB[i].y;
+        m.nm[i] = s->nm[i]; m.tm[i] = s->tm[i]; m.ni[i] = s->ni[i]; m.ti[i] = s->ti[i];
+    }
+    m.friction = s->friction;
+    m.k11 = s->k11; m.k12 = s->k12; m.k22 = s->k22; m.im11 = s->im11; m.im12 = s->im12; m.im22 = s->im22;
+}
+template <class PM>
+MW_HD_INLINE void manifold_store_impulses_to(PM d, const Manifold &m) {
+    d->ni[0] = m.ni[0]; d->ni[1] = m.ni[1]; d->ti[0] = m.ti[0]; d->ti[1] = m.ti[1];
+}
+template <class PM>
+MW_HD_INLINE void manifold_position_part_from(Manifold &m, PM s) {
+    m.bA = s->bA; m.bB = s->bB; m.type = s->type; m.island = s->island;
+    m.local_normal.x = s->local_normal.x; m.local_normal.y = s->local_normal.y;
+    m.local_point.x = s->local_point.x; m.local_point.y = s->local_point.y;
+    MW_UNROLL
+    for (int i = 0; i < 2; ++i) { m.lp[i].x = s->lp[i].x; m.lp[i].y = s->lp[i].y; }
+}
+#ifndef MW_LDS
+#define MW_LDS   // the qualifier of a pointer into the solver's LDS working copies (multiwalker_impl.hpp: address_space(3)); nothing on the CPU
+#endif
 MW_HD_INLINE void joint_position_part(const Model &M, const Scratch &S, int ji, JointCache &c) {
     const JointDef &jd = M.jd[ji];
     const MassAB q = mass_of_pair(S, jd.bA, jd.bB);
@@ -2168,11 +2202,36 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
         for (int l2 = 0; l2 < sl_; ++l2) { const int c2 = S.lane_cnt[l2]; if (c2 > Par::MREG) ls.mo_base += c2 - Par::MREG; }
         for (int r = Par::MREG; r < ls.cnt; ++r) { const int o = ls.mo_base + r - Par::MREG; if (o < mo_cap) MO[o] = MP[S.lane_list[sl_][r]]; }
     }
-#define MW_POOL_MANIFOLD(r_) (ls.mo_base + (r_) - Par::MREG < mo_cap ? MO[ls.mo_base + (r_) - Par::MREG] : MP[S.lane_list[sl_][r_]])
+    Manifold *MP_ = MP;   // (re-pointed after the velocity iterations, see par.pool_again below)
+    MW_LDS Manifold *const MOL = (MW_LDS Manifold *)MO;
+#define MW_POOL_MANIFOLD(r_) (ls.mo_base + (r_) - Par::MREG < mo_cap ? MO[ls.mo_base + (r_) - Par::MREG] : MP_[S.lane_list[sl_][r_]])
     // One contact sweep: round by round, inside a round position by position of the lanes' lists, all lanes at once (build_islands made
     // sure two constraints of one (round, position) never share a body, and that the order of any two that do is the island's).  F_ is
     // a statement over the manifold `m_` and its mass data `q_`.
-#define MW_CONTACT_SWEEP(F_)                                                                                              \
+    // Past the lane-private copies a manifold sits in MO (LDS) or, when that is full, in the pool (HBM).  POOL_ says how F_ gets at it:
+    //   MW_POOL_IN_PLACE   a reference to wherever it sits (InitializeVelocityConstraints: once per step, writes most of it);
+    //   MW_POOL_VELOCITY   a register copy of the part the velocity sweeps read, fetched in one go at the top of the position; the four
+    //                      accumulated impulses go back afterwards.  (In place, the 180 sweeps went through a pointer that may be LDS or
+    //                      HBM -- flat loads one field at a time, re-fetched after every store through the same pointer: a position past
+    //                      the register copies cost 2.5 times one inside them.)
+    //   MW_POOL_POSITION   a register copy of the part the position sweeps read; nothing goes back.
+#define MW_POOL_IN_PLACE(F_)  { Manifold &m_ = MW_POOL_MANIFOLD(r_); const MassAB q_ = mass_of_pair(S, m_.bA, m_.bB); F_; }
+#define MW_POOL_VELOCITY(F_)  {                                                                                           \
+        const int o_ = ls.mo_base + r_ - Par::MREG;                                                                       \
+        Manifold m_;                                                                                                      \
+        if (o_ < mo_cap) manifold_velocity_part_from(m_, MOL + o_); else manifold_velocity_part_from(m_, MP_ + k_);       \
+        const MassAB q_ = mass_of_pair(S, m_.bA, m_.bB);                                                                  \
+        F_;                                                                                                               \
+        if (o_ < mo_cap) manifold_store_impulses_to(MOL + o_, m_); else manifold_store_impulses_to(MP_ + k_, m_);         \
+    }
+#define MW_POOL_POSITION(F_)  {                                                                                           \
+        const int o_ = ls.mo_base + r_ - Par::MREG;                                                                       \
+        Manifold m_;                                                                                                      \
+        if (o_ < mo_cap) manifold_position_part_from(m_, MOL + o_); else manifold_position_part_from(m_, MP_ + k_);       \
+        const MassAB q_ = mass_of_pair(S, m_.bA, m_.bB);                                                                  \
+        F_;                                                                                                               \
+    }
+#define MW_CONTACT_SWEEP(F_, POOL_)                                                                                       \
     for (int rd_ = 0; rd_ < n_rounds; ++rd_) {                                                                            \
         MW_UNROLL                                                                                                         \
         for (int r_ = 0; r_ < NREG; ++r_) {                                                                               \
@@ -2180,21 +2239,19 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
             MW_LANES { MW_LANE if (ls.mrd[r_] == rd_) { Manifold &m_ = ls.mc[r_]; const MassAB &q_ = ls.mq[r_]; F_; } }    \
             par.sync();                                                                                                   \
         }                                                                                                                 \
-        for (int r_ = Par::MREG; r_ < max_cnt; ++r_) {   /* past the lane-private copies: in place in the pool */         \
+        for (int r_ = Par::MREG; r_ < max_cnt; ++r_) {   /* past the lane-private copies */                               \
             MW_LANES { MW_LANE                                                                                            \
                 if (r_ >= ls.cnt) continue;                                                                               \
                 const int k_ = S.lane_list[sl_][r_];                                                                      \
                 if (S.m_round[k_] != rd_) continue;                                                                       \
-                Manifold &m_ = MW_POOL_MANIFOLD(r_);                                                                      \
-                const MassAB q_ = mass_of_pair(S, m_.bA, m_.bB);                                                          \
-                F_;                                                                                                       \
+                POOL_(F_)                                                                                                 \
             }                                                                                                             \
             par.sync();                                                                                                   \
         }                                                                                                                 \
     }
     // ---- contact constraints: b2ContactSolver::InitializeVelocityConstraints + WarmStart, in the island's order
     MW_TSTAMP(0, 1); MW_TVAL(0, 0, max_cnt); MW_TVAL(0, 1, n_rounds);
-    MW_CONTACT_SWEEP(contact_init_warm(Wd, m_, q_))
+    MW_CONTACT_SWEEP(contact_init_warm(Wd, m_, q_), MW_POOL_IN_PLACE)
     // ---- joints: InitVelocityConstraints (+ warm start)
     MW_LANES { MW_LANE
         MW_UNROLL
@@ -2209,15 +2266,26 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
             for (int q = 0; q < 4; ++q) if (q < ls.jn) joint_solve_velocity(Wd, ls.jc[q]);
         }
         par.sync();
-        MW_CONTACT_SWEEP(contact_solve_velocity(Wd, m_, q_))
+        MW_CONTACT_SWEEP(contact_solve_velocity(Wd, m_, q_), MW_POOL_VELOCITY)
     }
     MW_TSTAMP(0, 3);
+    // From here on the record is addressed through pointers found again from the lane id (par.cold_again / pool_again: the identity
+    // everywhere but in the one-launch kernel of the sixteen-lane class): no per-lane pointer is then live across the sweeps above, which
+    // is where hipcc 7.2 parked them under a narrowed exec mask (multiwalker_impl.hpp, HAVE_FUSED).
+    const ColdView CdW = par.cold_again(Cd);
+    Manifold *const MPW = par.pool_again(MP);
+    MP_ = MPW;
+    // (the joint ids too: read again from the schedule instead of being carried over the sweeps -- one more value the join could park)
+    MW_LANES { MW_LANE
+        MW_UNROLL
+        for (int q = 0; q < 4; ++q) ls.ji[q] = q < ls.jn ? S.jorder[sl_][q] : 0;
+    }
     // the accumulated joint impulses and limit states go back to the world (warm start of the next step)
     MW_LANES { MW_LANE
         MW_UNROLL
         for (int q = 0; q < 4; ++q) {
             if (q >= ls.jn) continue;
-            Joint &j = Cd.j[ls.ji[q]];
+            Joint &j = CdW.j[ls.ji[q]];
             const JointCache &c = ls.jc[q];
             j.ix = c.ix; j.iy = c.iy; j.iz = c.iz; j.motor_impulse = c.motor_impulse; j.limit_state = c.limit_state;
         }
@@ -2228,13 +2296,13 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
         for (int r = 0; r < NREG; ++r) {
             if (r >= Par::MREG || ls.mix[r] < 0) continue;
             const Manifold &m = ls.mc[r];
-            Slot &sl = Cd.slot[m.slot];
+            Slot &sl = CdW.slot[m.slot];
             MW_UNROLL
             for (int i = 0; i < 2; ++i) if (i < m.npts) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }   // (constant indices: mc stays in registers)
         }
         for (int r = Par::MREG; r < ls.cnt; ++r) {
             const Manifold &m = MW_POOL_MANIFOLD(r);
-            Slot &sl = Cd.slot[m.slot];
+            Slot &sl = CdW.slot[m.slot];
             for (int i = 0; i < m.npts; ++i) { sl.ni[i] = m.ni[i]; sl.ti[i] = m.ti[i]; }
         }
     }
@@ -2242,7 +2310,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
     // limits), the velocity iterations above did not: it is fetched again here instead of being carried through them in registers.
     MW_LANES { MW_LANE
         MW_UNROLL
-        for (int r = 0; r < NREG; ++r) if (r < Par::MREG && ls.mix[r] >= 0) manifold_position_part(ls.mc[r], MP[ls.mix[r]]);
+        for (int r = 0; r < NREG; ++r) if (r < Par::MREG && ls.mix[r] >= 0) manifold_position_part(ls.mc[r], MPW[ls.mix[r]]);
         MW_UNROLL
         for (int q = 0; q < 4; ++q) if (q < ls.jn) joint_position_part(M, S, ls.ji[q], ls.jc[q]);
     }
@@ -2272,7 +2340,7 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
         pos_its_ = it + 1;
         MW_STAT(pos_iters, 1); MW_STAT(pos_iters_step, 1);
         uint32_t not_yet = 0;
-        MW_CONTACT_SWEEP(if (!((isl_done >> m_.island) & 1u)) { if (!(contact_solve_position(Wd, m_, q_) >= -3.0f * LINEAR_SLOP)) not_yet |= 1u << m_.island; })
+        MW_CONTACT_SWEEP(if (!((isl_done >> m_.island) & 1u)) { if (!(contact_solve_position(Wd, m_, q_) >= -3.0f * LINEAR_SLOP)) not_yet |= 1u << m_.island; }, MW_POOL_POSITION)
         MW_LANES { MW_LANE
             MW_UNROLL
             for (int q = 0; q < 4; ++q) {
@@ -2290,6 +2358,9 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
     par.sync();
     MW_TSTAMP(0, 5); MW_TVAL(0, 2, pos_its_);
 #undef MW_CONTACT_SWEEP
+#undef MW_POOL_IN_PLACE
+#undef MW_POOL_VELOCITY
+#undef MW_POOL_POSITION
 #undef MW_POOL_MANIFOLD
 #undef MW_LANES
 #undef MW_LANE
@@ -2302,16 +2373,16 @@ MW_HD_INLINE void step_solve(const Model &M, Hot &Wd, const ColdView &Cd, Scratc
                 if (S.island_of[bi] != c) continue;
                 const Body &b = Wd.b[bi];
                 if (b.w * b.w > ANGULAR_SLEEP_TOLERANCE * ANGULAR_SLEEP_TOLERANCE || dot(b.v, b.v) > LINEAR_SLEEP_TOLERANCE * LINEAR_SLEEP_TOLERANCE) {
-                    Cd.sleep_time[bi] = 0.0f; min_sleep = 0.0f;
+                    CdW.sleep_time[bi] = 0.0f; min_sleep = 0.0f;
                 } else {
-                    Cd.sleep_time[bi] += h;
-                    min_sleep = mnf(min_sleep, Cd.sleep_time[bi]);
+                    CdW.sleep_time[bi] += h;
+                    min_sleep = mnf(min_sleep, CdW.sleep_time[bi]);
                 }
             }
             if (min_sleep >= TIME_TO_SLEEP && S.isl_pos_solved[c])
                 for (int bi = 0; bi < NB; ++bi) {
                     if (S.island_of[bi] != c) continue;
-                    Wd.awake.clear(bi); Cd.sleep_time[bi] = 0.0f;
+                    Wd.awake.clear(bi); CdW.sleep_time[bi] = 0.0f;
                     Wd.b[bi].v = v2(0, 0); Wd.b[bi].w = 0.0f;
                 }
         }

@@ -38,6 +38,7 @@ static __device__ unsigned long long g_mw_acc[MW_DBG_BLOCKS][8];
         if ((int)threadIdx.x == __ffsll((long long)__ballot(1)) - 1 && blockIdx.x < MW_DBG_BLOCKS) atomicAdd(&g_mw_acc[blockIdx.x][k], n_ - v); \
         v = n_; } while (0)
 #endif
+#define MW_LDS __attribute__((address_space(3)))   // mw::step_solve: its working copies of manifolds past the registers are in LDS
 #include "multiwalker_core.hpp"
 
 #include <new>
@@ -113,6 +114,28 @@ struct GroupPar {
     static constexpr int SOLVE_EMU = 1;                    // mw::step_solve: this lane IS one solver lane
     static constexpr int MREG = MADRL_MW_SOLVE_MREG;
     int l;
+    // Wave-uniform values from which a lane finds its env's record again with nothing but its lane id (sixteen-lane class: no per-lane
+    // pointer has to stay live across the solver's sweeps, see HAVE_FUSED below): the records (live or spare), the list that maps a
+    // spare slot to its env (or nullptr), the first env of this wavefront, the record stride and where the manifold pool starts in it
+    const uint32_t *rec_base;
+    const uint32_t *slot_env;
+    int64_t first_env;
+    int32_t world_dw, pool_off_dw;
+    __device__ __forceinline__ int64_t env_again() const {
+        const int lid = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // the lane id, whatever exec is
+        int64_t env = first_env + lid / NL;
+        if (slot_env) env = slot_env[env];
+        return env;
+    }
+    __device__ __forceinline__ uint32_t *rec_again() const { return const_cast<uint32_t *>(rec_base) + env_again() * (int64_t)world_dw; }
+    __device__ __forceinline__ mw::ColdView cold_again(const mw::ColdView &c) const {
+        if constexpr (NL < 16) return c;
+        else { mw::ColdView v = mw::cold_view(*reinterpret_cast<mw::Cold *>(rec_again() + sizeof(mw::Hot) / 4)); v.ty = c.ty; return v; }
+    }
+    __device__ __forceinline__ mw::Manifold *pool_again(mw::Manifold *p) const {
+        if constexpr (NL < 16) return p;
+        else return reinterpret_cast<mw::Manifold *>(rec_again() + pool_off_dw);
+    }
     __device__ __forceinline__ int solve_lane(int) const { return l; }
     __device__ __forceinline__ int lane() const { return l; }
     __device__ __forceinline__ int n() const { return NL; }
@@ -158,24 +181,26 @@ constexpr uint32_t SPARE_BUSY = 0xFFFFFFFFu;
 // loops, which is what the instruction caches, shared by the eight wavefronts of two CUs, are sized for).  Between the launches of a
 // split step the schedule (the solver's part of mw::Scratch) waits in front of the manifold pool in the state buffer.
 enum { PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 4, PH_ALL = 7 };
-// The one-launch form is not built for the sixteen-lane class: set_mode(fused) then runs the three launches (same results).  hipcc 7.2
-// miscompiles that kernel -- and only that one.  Root cause (round 6, profiles/r06_multiwalker/c10_fused_masked_spill.txt, readable off the
-// emitted code without a GPU): the register allocator splits the live range of the per-lane record pointer at the control-flow join that
-// follows the joints' InitVelocityConstraints and emits its copies into accumulation registers (a32 / a33) at the head of the join block,
-// AHEAD of the `s_or_b64 exec` that re-enables the lanes the region had masked off -- the lanes without joints, lane >= n_walkers.  Those
-// lanes never write their copy; after the velocity iterations the pointer is read back under the full mask and step_post's body loop, which
-// runs on all sixteen lanes, loads through the stale registers (the fault rocgdb showed: profiles/r05_multiwalker/rocgdb_c10_fused.txt).
-// The source reads nothing uninitialised: every lane computes the pointer at the top of the kernel.  scripts/find_masked_spills.py finds
-// such copies in a .s file; the kernels that ARE built are clean (profiles/r06_multiwalker/masked_spill_scan.txt) and match the CPU build
-// byte for byte in every lane (tests/test_multiwalker_gpu.py).
-constexpr bool HAVE_FUSED = NL < 16;
+// The one-launch form and hipcc 7.2.  Up to round 5 it was not built for the sixteen-lane class: the compiler emitted faulting code for that
+// kernel -- and only that one.  Root cause (round 6, profiles/r06_multiwalker/c10_fused_masked_spill.txt, readable off the emitted code
+// without a GPU): the register allocator split the live range of the per-lane record pointers at the control-flow join that follows the
+// joints' InitVelocityConstraints and emitted its copies into accumulation registers at the head of the join block, AHEAD of the
+// `s_or_b64 exec` that re-enables the lanes the region had masked off -- the lanes without joints, lane >= n_walkers.  Those lanes never
+// wrote their copy; after the velocity iterations the pointer was read back under the full mask and step_post's body loop, which runs on
+// all sixteen lanes, loaded through the stale registers (the fault rocgdb showed: profiles/r05_multiwalker/rocgdb_c10_fused.txt).  The
+// source read nothing uninitialised: every lane computes the pointer at the top of the kernel.
+// What is built now keeps no per-lane pointer (and no joint id) live across that join: after the sweeps every lane finds its env's record
+// again from its lane id and wave-uniform values (GroupPar::rec_again, mw::step_solve's cold_again / pool_again).  The one-launch kernel of
+// every class is then clean under scripts/find_masked_spills.py -- tests/test_kernel_metadata.py compiles the three classes and runs that
+// scan, so a later change that brings such a copy back fails the CPU suite -- and matches the CPU build byte for byte in every lane
+// (tests/test_multiwalker_gpu.py, the "fused" cases at 3, 8, 9 and 10 walkers).
+constexpr bool HAVE_FUSED = true;
 template <int PH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_MW_SOLVE_WAVES, MADRL_MW_SOLVE_WAVES)))
 void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pending_only) {
     const mw::Model &M = *d.model;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int g = threadIdx.x / NL, lane = threadIdx.x % NL;
-    const GroupPar par{lane};
     constexpr int PHI = PH == PH_ALL ? 0 : (PH == PH_COLLIDE ? 1 : (PH == PH_SOLVE ? 2 : 3));
     constexpr bool TERRAIN = PH != PH_SOLVE;   // the solver never looks at the terrain
     const int tyb = TERRAIN ? d.ty_bytes : 0;
@@ -202,6 +227,8 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
         if (active && mode == 1) active = pending_only ? d.pending[env] != 0 : (io.mask ? io.mask[env] != 0 : true);
     }
     if (!active) return;   // (a whole group: the lanes that stay only ever synchronise inside their wavefront)
+    const GroupPar par{lane, spare ? d.spare_state : d.state, spare ? d.dirty_list + cur * d.n_envs : nullptr,
+                       ((int64_t)blockIdx.x - (mode == 0 && !spare ? d.spare_blocks : 0)) * EPW, d.world_dw, d.scratch_off_dw + SOLVE_HDR_BYTES / 4};
     const bool fresh = spare || mode == 1;   // reset first, then the trailing zero-action step (:357)
     if (PH == PH_SOLVE) MW_TSTAMP(0, 0);
     if (PH == PH_TOI) MW_TSTAMP(1, 0);
@@ -250,6 +277,14 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
     }
     // every lane copies the manifolds it owns from the pool into registers (and LDS: the bytes the collide phase's summaries were in)
     if (PH & PH_SOLVE) { mw::step_solve(M, Wd, Cd, S, pool, reinterpret_cast<mw::Manifold *>(work), MADRL_MW_SOLVE_OVERFLOW, par); lds_sync(); }
+    if constexpr (NL >= 16 && PH == PH_ALL) {   // the record found again from the lane id: nothing of the above stays live over the solver (GroupPar)
+        env = par.env_again();
+        rec = par.rec_again();
+        cold_g = reinterpret_cast<mw::Cold *>(rec + sizeof(mw::Hot) / 4);
+        Cd = par.cold_again(Cd);
+        sched_g = rec + d.scratch_off_dw;
+        pool = par.pool_again(pool);
+    }
     if (PH != PH_ALL && !(PH & PH_TOI)) {   // hand the step on to the next launch
         if (PH & PH_COLLIDE) { const uint32_t *sd = reinterpret_cast<const uint32_t *>(&S); for (int k = lane; k < SOLVE_HDR_BYTES / 4; k += NL) sched_g[k] = sd[k]; }
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&Wd);

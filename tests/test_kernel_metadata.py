@@ -78,10 +78,43 @@ def test_multiwalker_launches_have_no_scratch():
     accesses inside GJK, a kernel with a few hundred bytes of scratch per lane made the runtime re-allocate scratch around every other
     kernel on the stream: +3 ms per step next to a policy's torch kernels."""
     ks = {n: k for n, k in _kernels().items() if "mw_step_kernel" in n}
-    # three capacity classes (mwk_c4 / _c8 / _c10: 4 / 8 / 16 lanes per env) x (collide | solve | continuous pass) + the one-launch form of
-    # the first two (multiwalker_impl.hpp HAVE_FUSED)
-    assert len(ks) == 11 and sum("mwk_c10" in n for n in ks) == 3, sorted(ks)
+    # three capacity classes (mwk_c4 / _c8 / _c10: 4 / 8 / 16 lanes per env) x (collide | solve | continuous pass | the whole step in one
+    # launch -- since round 6 for the sixteen-lane class too, see test_no_spill_copy_runs_under_a_narrowed_exec_mask)
+    assert len(ks) == 12 and sum("mwk_c10" in n for n in ks) == 4, sorted(ks)
     for n, k in ks.items():
         # (.vgpr_spill_count may be non-zero with no private segment: at one wavefront per SIMD the allocator parks values in the 256
         # accumulation registers, a register copy each way -- what must not happen is a private segment, i.e. memory)
         assert k["scratch"] == 0, (n, k)
+
+
+def test_no_spill_copy_runs_under_a_narrowed_exec_mask():
+    """hipcc 7.2 may split the live range of a per-lane value at a control-flow join and emit the copy (VGPR -> accumulation register) at
+    the head of the join block, AHEAD of the `s_or_b64 exec` that re-enables the lanes the region had masked off; those lanes never get
+    their copy and read a stale register afterwards.  That is what made the one-launch MultiWalker kernel of the sixteen-lane class fault
+    (profiles/r05_multiwalker/rocgdb_c10_fused.txt, profiles/r06_multiwalker/c10_fused_masked_spill.txt).  Round 6 removed the values
+    that were live across that join (the record is found again from the lane id after the sweeps: GroupPar::rec_again) -- this test keeps
+    it that way: the three capacity classes are compiled to assembly with the build's own flags and scanned (scripts/find_masked_spills.py)."""
+    import importlib.util
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, root)
+    from madrl_amd import build as B
+    if not os.path.exists(B.HIPCC):
+        pytest.skip("no hipcc")
+    spec = importlib.util.spec_from_file_location("find_masked_spills", os.path.join(root, "scripts", "find_masked_spills.py"))
+    fms = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fms)
+    with tempfile.TemporaryDirectory() as tmp:
+        def asm(c):
+            out = os.path.join(tmp, c + ".s")
+            subprocess.run([B.HIPCC] + [f for f in B.FLAGS if f != "-Wall"] + B.EXTRA_FLAGS["multiwalker_c"] +
+                           ["--cuda-device-only", "-S", os.path.join(B.CSRC, "multiwalker_%s.hip" % c), "-o", out], check=True, capture_output=True)
+            return out
+        with ThreadPoolExecutor(3) as ex:
+            files = list(ex.map(asm, ("c4", "c8", "c10")))
+        for f in files:
+            text = open(f).read()
+            assert text.count("mw_step_kernelILi7E") > 0, "the one-launch kernel is missing from " + f
+            hits = fms.scan(f)
+            assert not hits, [(h[0], h[1], h[2]) for h in hits]

@@ -24,7 +24,9 @@ def _mk(n_envs, **kw):
 @pytest.mark.parametrize("n_walkers,reward_mech", [(3, "local"), (2, "global"), (4, "local"), (1, "local"), (3, "one_hot"),
                                                    # the capacity classes beyond four walkers (lessons/multiwalker/env.yaml runs 2 .. 10):
                                                    # eight lanes per env for 5 .. 8 walkers, sixteen for 9 and 10
-                                                   (5, "local"), (6, "global"), (7, "local"), (8, "local"), (9, "global"), (10, "local"), (10, "one_hot")])
+                                                   (5, "local"), (6, "global"), (7, "local"), (8, "local"), (9, "global"), (10, "local"), (10, "one_hot"),
+                                                   # the whole step as ONE launch, every capacity class (since round 6 the sixteen-lane one too)
+                                                   (3, "fused"), (8, "fused"), (9, "fused"), (10, "fused")])
 def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
     """The GPU execution (four lanes per env, sixteen envs per wavefront, the step in three launches, contact cache in HBM) against the
     CPU build of the same source (the lanes one after the other): the WHOLE per-env world record -- bodies, joints, every contact with its list position and impulses,
@@ -33,8 +35,11 @@ def test_hip_matches_cpu_build_bit_for_bit(n_walkers, reward_mech):
     from oracle import multiwalker as mwo
     N, T = 96, 70
     one_hot = reward_mech == "one_hot"   # ids as np.eye(MAX_AGENTS)[i] (multi_walker.py:397-398): 71-wide rows
-    reward_mech = "local" if one_hot else reward_mech
+    fused = reward_mech == "fused"
+    reward_mech = "local" if one_hot or fused else reward_mech
     env = _mk(N, n_walkers=n_walkers, reward_mech=reward_mech, seed=11, env_id_base=7, one_hot=one_hot)
+    if fused:
+        env.set_mode(fused=True)
     orc = mwo.MultiWalkerOracle(n_walkers=n_walkers, position_noise=0.0, angle_noise=0.0, reward_mech=reward_mech,
                                 n_envs=N, seed=11, env_id_base=7, one_hot=one_hot)
     if one_hot:
