@@ -14,7 +14,10 @@ auto-resets (the two-observation-pass path), as in a steady rollout.
 N > 1: one rank per GPU -- started by torch.distributed.run (the driver's command line), or by this script itself when it is
 invoked as plain `python bench.py --gpus N` (it re-executes itself under torch.distributed.run on 127.0.0.1).  Env index
 ranges are sharded by rank (weak scaling), the compact trajectory (actions, rewards, dones) of the timed region is
-all-gathered over RCCL at the end, inside the timed region.
+exchanged over RCCL in chunks that overlap with the stepping and waited for at the end, inside the timed region: `--gather root`
+(default) gathers it on rank 0 -- north_star's "RCCL gather of trajectory buffers at episode end" -- `all` on every rank
+(all-gather), `stats` exchanges per-episode returns only.  At N = 1 `workloads.pursuit_collective` runs that code path in a
+one-rank group (the headline config with recording + exchange in the timed region; `over_headline` = its step time / the headline's).
 
 Timing: W untimed warm-up steps, then REPEATS regions of EXACTLY K steps, each bracketed by barrier + synchronize on both
 sides, max over ranks; `value` / `ms_per_step` are the MEDIAN region, `config.region_ms_per_step` lists all of them.
@@ -161,9 +164,9 @@ class Timer(object):
     """the bench contract: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + synchronize on both sides;
     HIP events on the launch stream give the average launch duration"""
 
-    def __init__(self, world, dev, streams=None):
+    def __init__(self, world, dev, streams=None, coll=None):
         self.world, self.dev, self.streams = world, dev, streams
-        self.coll = collective_on(world)
+        self.coll = collective_on(world) if coll is None else coll
 
     def barrier(self):
         import torch
@@ -264,7 +267,27 @@ PURSUIT_VARIANTS = {
 }
 
 
-def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True, api_leg=None):
+def ensure_group(dev):
+    """a process group for the trajectory exchange: the launcher's when there is one, else a ONE-rank group of this process (how a one-GPU box
+    takes the RCCL code path: workloads.pursuit_collective, MADRL_BENCH_FORCE_COLLECTIVE=1); -> True when this call created it"""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return False
+    if "MASTER_ADDR" not in os.environ:
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+        sk.close()
+    backend = os.environ.get("MADRL_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    return True
+
+
+def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=None, reference_pass=True, api_leg=None, coll=None):
     import numpy as np
     import torch
     from madrl_amd.maps import rectangle_map
@@ -300,7 +323,8 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     actions = [torch.randint(0, 5, (N, P), generator=gen, device=dev, dtype=torch.int32) for _ in range(n_act)]
     # compact trajectory of the timed region (what a sampler returns to the learner), cut into
     # chunks whose all-gather over RCCL/xGMI overlaps with the stepping of the next chunk
-    coll = collective_on(world)
+    coll = collective_on(world) if coll is None else coll
+    gather_mode = getattr(args, "gather", "root")
     CH = 50
     n_chunks = (K + CH - 1) // CH
     chunk_len = [min(CH, K - c * CH) for c in range(n_chunks)]
@@ -319,7 +343,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     gatherer = None
     if coll:
         from madrl_amd.dist import ChunkedTrajectoryGather
-        gatherer = ChunkedTrajectoryGather(always_collective=True)
+        gatherer = ChunkedTrajectoryGather(always_collective=True, mode=gather_mode)
 
     def prepare():
         if gatherer is not None:
@@ -347,8 +371,17 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
         if gatherer is not None:
             if K % CH:
                 submit(traj[-1])
-            gathered = gatherer.finish()            # episode end: every rank holds every rank's trajectory
-            assert sum(t.shape[1] for t in gathered["rewards"]) == K and gathered["rewards"][0].shape[0] == world
+            gathered = gatherer.finish()            # episode end: the learner's rank (--gather root) or every rank (all) holds every rank's trajectory
+            if gatherer.receives:
+                assert sum(t.shape[1] for t in gathered["rewards"]) == K and gathered["rewards"][0].shape[0] == world
+            elif gather_mode == "stats":
+                # nothing but per-episode statistics crosses xGMI: the episodes this rank finished in the region (returns per pursuer, lengths are
+                # the horizon here) -- a few KB, ragged over the ranks
+                from madrl_amd.dist import gather_episode_stats
+                ended = torch.cat([t["dones"] for t in traj]) != 0
+                ret = torch.cat([t["rewards"] for t in traj]).sum(0)[ended.any(0)]
+                st = gather_episode_stats(ret, torch.full((ret.shape[0],), H, dtype=torch.int32, device=dev))
+                assert len(st["returns"]) == world
 
     for j, env in enumerate(envs):
         env.reset()
@@ -361,7 +394,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     for i in range(args.prep):
         one_step(i, False)
     torch.cuda.synchronize()
-    dt, kernel_ms, region_ms = Timer(world, dev, hip_streams).run(one_step, K, W, tail, prepare)
+    dt, kernel_ms, region_ms = Timer(world, dev, hip_streams, coll=coll).run(one_step, K, W, tail, prepare)
     kernel_kind = envs[0].kernel_kind
     api = None
     if (bool(cpu_budget) if api_leg is None else api_leg) and not coll:
@@ -419,7 +452,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
                         "step_is": ("one pass of the step kernel over all %d envs of the GPU: %d launches of %d envs, one per HIP stream, not ordered "
                                     "against each other (independent env instances)" % (N, S, per)) if S > 1 else "one launch of the step kernel over all %d envs" % N,
                         "rccl_ranks": world, "collective_backend": (os.environ.get("MADRL_BENCH_BACKEND", "nccl") if coll else None),
-                        "trajectory_gather_in_timed_region": bool(coll),
+                        "trajectory_gather_in_timed_region": bool(coll), "trajectory_gather": (gather_mode if coll else None),
                         "horizon_resets_per_env_in_timed_region": K / float(H),
                         "horizon_resets_per_step": N / float(H), "horizon_resets_per_launch": per / float(H)}, **region_stats(region_ms)),
         "roofline": roof,
@@ -755,7 +788,7 @@ def compact_line(out):
     line["data"] = "synthetic"
     c = out["config"]
     line["config"] = {k: c[k] for k in ("workload", "envs_per_gpu", "envs_total", "parallelism", "streams_per_gpu", "rccl_ranks", "collective_backend",
-                                        "trajectory_gather_in_timed_region") if k in c}
+                                        "trajectory_gather_in_timed_region", "trajectory_gather") if k in c}
     line["config"]["region_ms_per_step"] = [_r(float(x)) for x in c["region_ms_per_step"]]
     line["roofline"] = compact_roofline(out["roofline"])
     if "python_api" in out:   # the same regions through Batched*.step() instead of the raw C ABI
@@ -780,6 +813,9 @@ def compact_line(out):
                 e["cpu_baseline"] = {"value": _r(float(w["cpu_baseline"]["value"])), "cores": w["cpu_baseline"]["cores"], "kind": w["cpu_baseline"]["kind"]}
             if "python_api" in w:
                 e["python_api_ms"] = _r(float(w["python_api"]["python_api_ms_per_step"]))
+            if "over_headline" in w:   # pursuit_collective: the N > 1 code path (trajectory recording + RCCL exchange) in a one-rank group
+                e["over_headline"] = _r(float(w["over_headline"]))
+                e["gather"] = w["config"].get("trajectory_gather")
             line["workloads"][name] = e
     return line
 
@@ -819,6 +855,10 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="root", choices=("root", "all", "stats"),
+                    help="N > 1: who receives the compact trajectory (actions, rewards, dones) of the timed region, exchanged in chunks that overlap with the "
+                         "stepping -- root = rank 0 only (default: north_star's gather at episode end, the sampler workers returning their paths to one learner), "
+                         "all = every rank (all-gather: a learner data-parallel over the same ranks), stats = nobody (per-episode returns only)")
     ap.add_argument("--full", action="store_true", help="print the long record (every key, prose included) instead of the compact line")
     ap.add_argument("--full-record", default="", help="also write the long record to this file (default: gpurun_out/bench_full.json when that directory exists)")
     ap.add_argument("--no-workloads", action="store_true", help="headline only: do not time the other BASELINE configs")
@@ -841,17 +881,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if collective_on(world):
-        import torch.distributed as dist
-        if world == 1 and "MASTER_ADDR" not in os.environ:   # MADRL_BENCH_FORCE_COLLECTIVE: a one-rank group needs a rendezvous too
-            import socket
-            sk = socket.socket()
-            sk.bind(("127.0.0.1", 0))
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
-            sk.close()
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        ensure_group(dev)   # the launcher's group, or (MADRL_BENCH_FORCE_COLLECTIVE with one rank) a one-rank group with its own rendezvous
 
     K, W = args.steps, args.warmup
     cpu = (not args.no_cpu_baseline) and not collective_on(world)   # the CPU baselines are reported with the plain 1-GPU line only
@@ -878,6 +908,19 @@ def main():
                 wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "python_api") if f in r}
             except Exception as e:  # a failing side workload must not take the headline down; it shows up as an error entry
                 wl[name] = {"error": repr(e)}
+        # What the N > 1 code path costs, measured where it can be: the headline config again with the trajectory recording and the RCCL
+        # exchange (--gather) in the timed region, in a ONE-rank group (two ranks on one device are refused by RCCL).  The collectives are then
+        # device-local copies made by the backend: this prices the recording, the chunking and the backend's launches, not xGMI.
+        try:
+            import torch.distributed as dist
+            made = ensure_group(dev)
+            r = bench_pursuit(args, "pursuit", 200, 20, rank, world, dev, 0, reference_pass=False, api_leg=False, coll=True)
+            wl["pursuit_collective"] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline") if f in r}
+            wl["pursuit_collective"]["over_headline"] = r["ms_per_step"] / out["ms_per_step"]
+            if made:
+                dist.destroy_process_group()
+        except Exception as e:
+            wl["pursuit_collective"] = {"error": repr(e)}
         out["workloads"] = wl
     if rank == 0:
         full_path = args.full_record or (os.path.join(ROOT, "gpurun_out", "bench_full.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)

@@ -52,6 +52,26 @@ def main():
             exp_r = torch.randn((5, N, P), generator=gr)
             exp_d = torch.randint(0, 2, (5, N), generator=gr, dtype=torch.uint8)
             assert torch.equal(got["rewards"][c][r], exp_r) and torch.equal(got["dones"][c][r], exp_d), (c, r)
+    # mode "root" (bench.py's default): rank 1 -- not 0, to see that dst is honoured -- receives every rank's chunks, the others only send;
+    # mode "stats": nothing is exchanged, finish() hands back the local chunks
+    for mode in ("root", "stats"):
+        cg = ChunkedTrajectoryGather(mode=mode, dst=1)
+        cg.reserve(chunks)
+        for ch in chunks:
+            cg.submit(ch)
+        got = cg.finish()
+        if mode == "stats":
+            assert not cg.receives and all(torch.equal(got["rewards"][c][0], chunks[c]["rewards"]) for c in range(3))
+        elif rank == 1:
+            assert cg.receives and len(got["dones"]) == 3 and got["rewards"][0].shape == (world, 5, N, P)
+            for c in range(3):
+                for r in range(world):
+                    gr = torch.Generator().manual_seed(1000 * r + c)
+                    exp_r = torch.randn((5, N, P), generator=gr)
+                    exp_d = torch.randint(0, 2, (5, N), generator=gr, dtype=torch.uint8)
+                    assert torch.equal(got["rewards"][c][r], exp_r) and torch.equal(got["dones"][c][r], exp_d), (mode, c, r)
+        else:
+            assert not cg.receives and got["rewards"] == [] and got["dones"] == []
     # ragged: every rank finished a different number of episodes / owns an uneven env shard
     ne = 4 + 3 * rank
     st = gather_episode_stats(torch.full((ne, P), float(rank)), torch.full((ne,), rank, dtype=torch.int32))
