@@ -137,6 +137,32 @@ def cpu_baseline_port(maps, kw, budget_s=10.0):
                 sample="C oracle (oracle/pursuit_oracle.c, OpenMP), %d envs x %d steps, same config, %.1f s" % (n, steps, dt))
 
 
+def cpu_baseline_rollout(budget_s=3.0):
+    """The policy-in-the-loop workload on the host: the C oracle's step (OpenMP over envs) and the NumPy restatement of the reference's chase
+    policy (heuristics/pursuit.py:18-54, one row at a time as the reference calls it) choosing every action from the observation the step
+    just wrote.  Bounded sample: 256 envs, ~budget_s seconds."""
+    import numpy as np
+    from madrl_amd.maps import rectangle_map
+    from oracle import pursuit as po
+    from oracle.heuristics_oracle import pursuit_actions
+    MS, P, E, _, mode = PURSUIT_VARIANTS["pursuit"]
+    n, R = 256, 7
+    orc = po.PursuitOracle([rectangle_map(MS, MS)], n_envs=n, seed=0, n_pursuers=P, n_evaders=E, obs_range=R, reward_mech="local", **mode)
+    obs = orc.reset()
+    rng = np.random.RandomState(0)
+    t0 = time.time()
+    steps = 0
+    while time.time() - t0 < budget_s or steps < 2:
+        win = np.asarray(obs).reshape(n * P, -1)[:, :3 * R * R].reshape(n * P, 3, R, R).transpose(0, 2, 3, 1)   # flattened rows: channel-major (:448-449)
+        a = pursuit_actions(win)
+        a = np.where(a < 0, rng.randint(5, size=a.shape), a).astype(np.int32).reshape(n, P)
+        obs = orc.step(a)[0]
+        steps += 1
+    dt = time.time() - t0
+    return dict(value=n * steps / dt, unit="env-steps/s", cores=po.lib().po_num_threads(), kind="port",
+                sample="C oracle step (OpenMP) + NumPy chase policy row by row (oracle/heuristics_oracle.py, one Python thread), %d envs x %d steps, %.1f s" % (n, steps, dt))
+
+
 def attach_cpu_baselines(out, live_ref_key, record_key, port_fn):
     """cpu_baseline is always a LIVE measurement on this host (the reference when a checkout is reachable through
     MADRL_REFERENCE_ROOT, else the C port); the committed record of the reference goes under its own key."""
@@ -470,7 +496,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     return out
 
 
-def bench_rollout(args, K, W, rank, world, dev):
+def bench_rollout(args, K, W, rank, world, dev, cpu_budget=0):
     """Policy in the loop (the sampler loop the reference's runners drive, runners/rurllab.py:298-305; in-tree instance heuristics/pursuit.py:71-85):
     BASELINE configs[1]'s batch, the device chase policy (madrl_amd/heuristics.py) choosing every action from the observation the step
     kernel just wrote, trajectory tensors filled in place, returns scanned at the end of each horizon -- ShardedRolloutCollector over
@@ -519,10 +545,13 @@ def bench_rollout(args, K, W, rank, world, dev):
            "streams_per_gpu": S, "envs_per_launch": N // S, "horizon": T, "collect_calls_per_region": calls}
     cfg.update(region_stats(region_ms))
     cfg["step_calls_in_process"] = (max(3, W // T) + cfg["timed_regions"] * calls) * T   # what a PMC pass of this command divides its sums by
-    return {"metric": "env-steps/sec with the policy in the loop (PursuitEvade 16x16, 8v30)", "value": world * N * steps / dt, "unit": "env-steps/s", "n_gpus": world,
-            "steps": steps, "warmup": W, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic", "data": "synthetic (chase policy on the env's own observations)",
-            "config": cfg, "roofline": roof}
+    out = {"metric": "env-steps/sec with the policy in the loop (PursuitEvade 16x16, 8v30)", "value": world * N * steps / dt, "unit": "env-steps/s", "n_gpus": world,
+           "steps": steps, "warmup": W, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8/int32 grid state, f32 observations, f64 reward arithmetic", "data": "synthetic (chase policy on the env's own observations)",
+           "config": cfg, "roofline": roof}
+    if cpu_budget:
+        out["cpu_baseline"] = cpu_baseline_rollout(cpu_budget)
+    return out
 
 
 def C_void(v):
@@ -775,8 +804,8 @@ def compact_roofline(r, side=False):
     for k in ("valu_frac", "flop_per_env_step"):
         if k in r:
             out[k] = _r(r[k])
-    if side:
-        out.pop("peak", None); out.pop("unit", None); out.pop("bound", None)
+    if side:   # (achieved = frac x the headline's peak)
+        out.pop("peak", None); out.pop("unit", None); out.pop("bound", None); out.pop("achieved", None)
     return out
 
 
@@ -807,7 +836,7 @@ def compact_line(out):
             if "error" in w:
                 line["workloads"][name] = {"error": w["error"][:200]}
                 continue
-            e = {"value": _r(float(w["value"])), "ms_per_step": _r(float(w["ms_per_step"])), "steps": w["steps"], "workload": w["config"]["workload"][:100],
+            e = {"value": _r(float(w["value"])), "ms_per_step": _r(float(w["ms_per_step"])), "steps": w["steps"], "workload": w["config"]["workload"][:72],
                  "envs": w["config"]["envs_per_gpu"], "streams": w["config"]["streams_per_gpu"], "roofline": compact_roofline(w["roofline"], side=True)}
             if "cpu_baseline" in w:
                 e["cpu_baseline"] = {"value": _r(float(w["cpu_baseline"]["value"])), "cores": w["cpu_baseline"]["cores"], "kind": w["cpu_baseline"]["kind"]}
@@ -869,6 +898,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)   # does not return
+    # The contract: rank 0 prints ONE JSON line.  Libraries write to file descriptor 1 behind Python's back -- RCCL prints a version banner
+    # through C stdio when its first communicator comes up, and a redirected C stream is flushed at process exit, i.e. AFTER the line.  So
+    # descriptor 1 is pointed at stderr for the life of the process and the line goes to a private copy of the real stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -888,7 +923,7 @@ def main():
     scale = float(os.environ.get("MADRL_BENCH_CPU_BUDGET", "1"))   # tests shorten the CPU samples
     head_cpu, side_cpu = (10.0 * scale, 3.0 * scale) if cpu else (0, 0)
     if args.workload == "pursuit_rollout":
-        out = bench_rollout(args, K, W, rank, world, dev)
+        out = bench_rollout(args, K, W, rank, world, dev, head_cpu)
     elif args.workload.startswith("pursuit"):
         out = bench_pursuit(args, args.workload, K, W, rank, world, dev, head_cpu)
     else:
@@ -902,7 +937,7 @@ def main():
         for name, k, w in (("waterworld", 200, 20), ("multiwalker", 50, 20), ("pursuit_c5", 200, 20), ("pursuit_colocate", 200, 20), ("waterworld_std", 100, 20),
                            ("multiwalker_w10", 20, 20), ("pursuit_rollout", 200, 20), ("hostage", 200, 20), ("pursuit_authors", 100, 20)):
             try:
-                r = bench_rollout(args, k, w, rank, world, dev) if name == "pursuit_rollout" else \
+                r = bench_rollout(args, k, w, rank, world, dev, side_cpu) if name == "pursuit_rollout" else \
                     bench_pursuit(args, name, k, w, rank, world, dev, side_cpu) if name.startswith("pursuit") else \
                     bench_other(args, name, k, w, rank, world, dev, side_cpu)
                 wl[name] = {f: r[f] for f in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "python_api") if f in r}
@@ -930,8 +965,8 @@ def main():
                     json.dump(out, f, indent=1)
             except OSError:
                 pass
-        print(json.dumps(out if args.full else compact_line(out), separators=(",", ":")))
-        sys.stdout.flush()
+        json_out.write(json.dumps(out if args.full else compact_line(out), separators=(",", ":")) + "\n")
+        json_out.flush()
     if collective_on(world):
         import torch.distributed as dist
         dist.barrier()

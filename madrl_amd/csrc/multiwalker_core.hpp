@@ -158,8 +158,8 @@ struct V2 { float x, y; };
 MW_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
 MW_HD V2 operator+(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
 MW_HD V2 operator-(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
-MW_HD V2 operator-(V2 a) { return v2(-a.x, -a.y); }
 MW_HD V2 operator*(float s, V2 a) { return v2(s * a.x, s * a.y); }
+MW_HD V2 operator-(V2 a) { return v2(-a.x, -a.y); }
 MW_HD float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
 MW_HD float cross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
 MW_HD V2 cross(V2 a, float s) { return v2(s * a.y, -s * a.x); }

@@ -85,7 +85,8 @@ def test_default_batch_line_carries_every_baseline_config():
     j = _last_json(r.stdout)
     assert KEYS <= set(j) and j["config"]["envs_per_gpu"] == 65536 and j["data"] == "synthetic"
     wl = j["workloads"]
-    assert set(wl) >= {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std", "multiwalker_w10", "pursuit_rollout", "hostage"}
+    assert set(wl) >= {"waterworld", "multiwalker", "pursuit_c5", "pursuit_colocate", "waterworld_std", "multiwalker_w10", "pursuit_rollout", "hostage",
+                       "pursuit_authors", "pursuit_collective"}
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
     rf = j["roofline"]
     # `frac` is priced by the wall clock of the timed region (ms_per_step), `frac_kernel` by the HIP events around the launches
@@ -95,7 +96,9 @@ def test_default_batch_line_carries_every_baseline_config():
     for name, w in wl.items():
         assert "error" not in w, (name, w)
         assert w["value"] > 1e5 and w["roofline"]["frac"] > 0 and w["workload"], name
-        if name != "pursuit_rollout":
+        if name == "pursuit_collective":   # the N > 1 code path in a one-rank group: recording + RCCL exchange in the timed region
+            assert w["gather"] == "root" and 0.9 < w["over_headline"] < 3.0, w
+        else:
             cb = w["cpu_baseline"]
             assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port", name
     assert wl["pursuit_colocate"]["roofline"]["kernel"].startswith("pursuit_wave_kernel")
