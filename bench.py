@@ -679,7 +679,9 @@ def bench_other(args, workload, K, W, rank, world, dev, cpu_budget, streams=None
         # several sub-batches in flight: the whole b2World::Step of a sub-batch as ONE launch (a wavefront then pays its own collide +
         # solve + continuous-pass time, not the slowest wavefront's of every phase): 3.4 against 4.0 ms per step at four sub-batches;
         # alone on the chip the two forms take the same 4.6 ms (scripts/stream_sweep.sh)
-        mw_fused = (S > 1) if "MADRL_BENCH_MW_FUSED" not in os.environ else os.environ["MADRL_BENCH_MW_FUSED"] == "1"
+        # (the sixteen-lane class -- 9 / 10 walkers, 4 envs per wavefront -- is the other way round: as three launches its solver runs two
+        # wavefronts per SIMD, which the one-launch kernel's registers do not allow: 7.5 against 8.4 ms per step at ten walkers)
+        mw_fused = (S > 1 and envs[0].lanes_per_env < 16) if "MADRL_BENCH_MW_FUSED" not in os.environ else os.environ["MADRL_BENCH_MW_FUSED"] == "1"
         if mw_fused:
             for e in envs:
                 e.set_mode(fused=True)

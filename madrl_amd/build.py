@@ -43,9 +43,9 @@ def pursuit_fast_path(xs, ys, n_pursuers, n_evaders, obs_range, flatten, include
     if D % 4:
         return None, "observation row is not a whole number of float4"
     # one wavefront per env when the agents fit its lanes AND the row fits 8 float4 slots per lane (slot constants in registers,
-    # pursuit_wave.hpp); otherwise two wavefronts (pursuit_group.hpp), up to 32 slots per thread -- above 8 from an LDS table ("LONG ROWS")
+    # pursuit_wave.hpp); otherwise two wavefronts (pursuit_group.hpp) -- four for long rows, whose slot constants come from an LDS table ("LONG ROWS": more than 8 slots per thread of two wavefronts), up to 32 slots per thread
     slots = lambda n: (P * (D // 4) + 64 * n - 1) // (64 * n)
-    nw = 1 if (A <= 64 and slots(1) <= 8) else 2
+    nw = 1 if (A <= 64 and slots(1) <= 8) else (2 if slots(2) <= 8 else 4)   # long rows: four wavefronts share the env's LDS (occupancy is LDS-bound there)
     if slots(nw) > 32:
         return None, "more than 32 float4 slots per thread (n_pursuers x row length too large)"
     pad = max((R - 1) // 2, 1)

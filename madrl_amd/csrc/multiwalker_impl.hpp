@@ -94,6 +94,21 @@ struct MwIO {
 #ifndef MADRL_MW_SOLVE_OVERFLOW
 #define MADRL_MW_SOLVE_OVERFLOW 5   // manifolds per env the solver launch can hold in LDS on top of the lanes' register copies
 #endif
+// which phases a launch runs (see mw_step_kernel)
+enum { PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 4, PH_ALL = 7 };
+// THE SOLVER LAUNCH OF THE SIXTEEN-LANE CLASS RUNS TWO WAVEFRONTS PER SIMD (round 6).  With 9 / 10 walkers a wavefront holds 4 envs: 16 384
+// envs are 4 096 wavefronts, four rounds over the chip at one wavefront per SIMD -- the launch is bound by how much of a SIMD's time ONE
+// wavefront of dependent float32 updates can use (about half: the rest waits for LDS round trips and branches), so a second resident
+// wavefront is worth more than manifolds in registers.  That launch therefore keeps NO manifold in registers (228 VGPRs instead of 385, no
+// scratch): every position of a sweep works on a register copy fetched from the LDS working copies in one go (mw::step_solve,
+// MW_POOL_VELOCITY), of which it holds 14 per env instead of 5 (20 KB of LDS per wavefront: eight wavefronts per CU).  The other classes
+// have one wavefront per SIMD's worth of work at the BASELINE batch (16 envs per wavefront) and keep three manifolds per lane in registers.
+#ifndef MADRL_MW_SOLVE_2W
+#define MADRL_MW_SOLVE_2W (MW_NLANES >= 16)
+#endif
+constexpr int waves_of(int ph) { return (ph == PH_SOLVE && MADRL_MW_SOLVE_2W) ? 2 : MADRL_MW_SOLVE_WAVES; }
+constexpr int mreg_of(int ph) { return (ph == PH_SOLVE && MADRL_MW_SOLVE_2W) ? 0 : MADRL_MW_SOLVE_MREG; }
+constexpr int overflow_of(int ph) { return (ph == PH_SOLVE && MADRL_MW_SOLVE_2W) ? 14 : MADRL_MW_SOLVE_OVERFLOW; }
 constexpr int EPW = 64 / mw::SOLVE_LANES;   // envs per wavefront: one lane per walker
 constexpr int NL = mw::SOLVE_LANES;
 constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
@@ -110,9 +125,10 @@ __device__ __forceinline__ void lds_sync() {
 }
 
 // the cooperating lanes of multiwalker_core.hpp's `Par` = one group of NL (4, 8 or 16) neighbouring lanes of the wavefront
+template <int MREG_>
 struct GroupPar {
     static constexpr int SOLVE_EMU = 1;                    // mw::step_solve: this lane IS one solver lane
-    static constexpr int MREG = MADRL_MW_SOLVE_MREG;
+    static constexpr int MREG = MREG_;
     int l;
     // Wave-uniform values from which a lane finds its env's record again with nothing but its lane id (sixteen-lane class: no per-lane
     // pointer has to stay live across the solver's sweeps, see HAVE_FUSED below): the records (live or spare), the list that maps a
@@ -180,7 +196,6 @@ constexpr uint32_t SPARE_BUSY = 0xFFFFFFFFu;
 // PH: which phases this launch runs (all of them, or one: the step as three launches -- every wavefront of a launch then runs the same
 // loops, which is what the instruction caches, shared by the eight wavefronts of two CUs, are sized for).  Between the launches of a
 // split step the schedule (the solver's part of mw::Scratch) waits in front of the manifold pool in the state buffer.
-enum { PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 4, PH_ALL = 7 };
 // The one-launch form and hipcc 7.2.  Up to round 5 it was not built for the sixteen-lane class: the compiler emitted faulting code for that
 // kernel -- and only that one.  Root cause (round 6, profiles/r06_multiwalker/c10_fused_masked_spill.txt, readable off the emitted code
 // without a GPU): the register allocator split the live range of the per-lane record pointers at the control-flow join that follows the
@@ -196,7 +211,7 @@ enum { PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 4, PH_ALL = 7 };
 // (tests/test_multiwalker_gpu.py, the "fused" cases at 3, 8, 9 and 10 walkers).
 constexpr bool HAVE_FUSED = true;
 template <int PH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MADRL_MW_SOLVE_WAVES, MADRL_MW_SOLVE_WAVES)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(waves_of(PH), waves_of(PH))))
 void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pending_only) {
     const mw::Model &M = *d.model;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -227,7 +242,7 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
         if (active && mode == 1) active = pending_only ? d.pending[env] != 0 : (io.mask ? io.mask[env] != 0 : true);
     }
     if (!active) return;   // (a whole group: the lanes that stay only ever synchronise inside their wavefront)
-    const GroupPar par{lane, spare ? d.spare_state : d.state, spare ? d.dirty_list + cur * d.n_envs : nullptr,
+    const GroupPar<mreg_of(PH)> par{lane, spare ? d.spare_state : d.state, spare ? d.dirty_list + cur * d.n_envs : nullptr,
                        ((int64_t)blockIdx.x - (mode == 0 && !spare ? d.spare_blocks : 0)) * EPW, d.world_dw, d.scratch_off_dw + SOLVE_HDR_BYTES / 4};
     const bool fresh = spare || mode == 1;   // reset first, then the trailing zero-action step (:357)
     if (PH == PH_SOLVE) MW_TSTAMP(0, 0);
@@ -276,7 +291,7 @@ void mw_step_kernel(const MwDev d, const MwIO io, const int mode, const int pend
         lds_sync();
     }
     // every lane copies the manifolds it owns from the pool into registers (and LDS: the bytes the collide phase's summaries were in)
-    if (PH & PH_SOLVE) { mw::step_solve(M, Wd, Cd, S, pool, reinterpret_cast<mw::Manifold *>(work), MADRL_MW_SOLVE_OVERFLOW, par); lds_sync(); }
+    if (PH & PH_SOLVE) { mw::step_solve(M, Wd, Cd, S, pool, reinterpret_cast<mw::Manifold *>(work), overflow_of(PH), par); lds_sync(); }
     if constexpr (NL >= 16 && PH == PH_ALL) {   // the record found again from the lane id: nothing of the above stays live over the solver (GroupPar)
         env = par.env_again();
         rec = par.rec_again();
@@ -581,9 +596,9 @@ int k_create(const madrl_multiwalker_config *cfg, int64_t n_envs, int32_t device
     d.toi_lane0_bytes = (int32_t)align_up((size_t)(M.slot_cap[0] > mw::EDGE_SLOTS_HULL ? M.slot_cap[0] : mw::EDGE_SLOTS_HULL) * 5, 16);
     {
         const int wc = SCR_HDR_BYTES - SOLVE_HDR_BYTES + (int32_t)align_up(4 * 4 * mw::MAX_WALKERS, 16);            // collide
-        const int ws = MADRL_MW_SOLVE_OVERFLOW * (int32_t)sizeof(mw::Manifold);                                       // solve
+        const int ws = overflow_of(PH_SOLVE) * (int32_t)sizeof(mw::Manifold), wsa = overflow_of(PH_ALL) * (int32_t)sizeof(mw::Manifold);   // solve: its own launch, inside the one-launch kernel
         const int wt = TOI_WORK_BYTES + d.toi_lane0_bytes + (NL - 1) * TOI_LANE_BYTES;                                // continuous pass
-        const int wa = wc > ws ? (wc > wt ? wc : wt) : (ws > wt ? ws : wt);
+        const int wa = wc > wsa ? (wc > wt ? wc : wt) : (wsa > wt ? wsa : wt);
         const int common = HOT_BYTES + SOLVE_HDR_BYTES;
         d.lds_stride[0] = common + d.ty_bytes + (int32_t)align_up((size_t)wa, 16);
         d.lds_stride[1] = common + d.ty_bytes + (int32_t)align_up((size_t)wc, 16);

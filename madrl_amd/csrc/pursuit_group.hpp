@@ -35,6 +35,9 @@ namespace pw {
 #ifndef MADRL_PG_WAVES
 #define MADRL_PG_WAVES 4
 #endif
+#ifndef MADRL_PG_UNROLL
+#define MADRL_PG_UNROLL 2   // LONG ROWS: slots of one mask word in flight together (their LDS reads issued side by side)
+#endif
 
 template <int XS_, int YS_, int P_, int E_, int R_, int FLATTEN_, int NW_>
 struct GShape {
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(S::NT) __attribute__((amdgpu_waves_per_eu(S::OCC, S
                         auto cell_b = [&](int byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(Lb + byte_off); };
                         static_for<0, MW>([&](auto wc) {
                             constexpr int w = decltype(wc)::value, nsw = (NS - 8 * w) < 8 ? (NS - 8 * w) : 8;
-#pragma unroll 2
+#pragma unroll MADRL_PG_UNROLL
                             for (int i = 0; i < nsw; ++i) {
                                 const bool valid = q < S::NQ;
                                 const int pp = valid ? pq : 0;                                   // threads past the end of the rows read harmless cells

@@ -161,7 +161,7 @@ def test_which_shapes_can_have_a_fast_path_and_how_they_are_added(tmp_path, monk
     assert b.pursuit_fast_path(16, 16, 8, 30, 7, 0) == ("X", None) and b.pursuit_fast_path(20, 8, 7, 1, 3, 0) == ("X", None)
     # the authors' own training shapes (runners/old/rllab/pursuit.sh:1, runners/old/rltools/pursuit.sh:1): 22 float4 slots per thread on two
     # wavefronts -- also at 30 v 30, where the agents alone would fit one
-    assert b.pursuit_fast_path(32, 32, 30, 50, 11, 1) == ("XG", 2) and b.pursuit_fast_path(32, 32, 30, 30, 11, 1) == ("XG", 2)
+    assert b.pursuit_fast_path(32, 32, 30, 50, 11, 1) == ("XG", 4) and b.pursuit_fast_path(32, 32, 30, 30, 11, 1) == ("XG", 4)   # long rows: four wavefronts
     assert b.pursuit_fast_path(5, 10, 16, 7, 7, 1) == ("XG", 2)   # 23 agents, but 10 slots per lane of one wavefront: two wavefronts, 5 each
     for shape, why in (((10, 10, 4, 4, 4, 1), "even"), ((128, 128, 100, 300, 21, 0), "more than 64"), ((16, 16, 64, 10, 21, 0), "slots"),
                        ((200, 200, 8, 30, 7, 1), "LDS"), ((24, 24, 70, 58, 3, 1), "more than 64")):
