@@ -448,7 +448,7 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
     if rank != 0:
         return None
     bytes_per = algorithmic_bytes_per_env_step(P, E, D, rec_bytes)
-    fast = ("pursuit_group_kernel<%d,%d,%d,%d,%d,%d,2>" if (P + E > 64 or P * D > 2048) else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))
+    fast = (("pursuit_group_kernel<%%d,%%d,%%d,%%d,%%d,%%d,%d>" % (4 if P * D > 4096 else 2)) if (P + E > 64 or P * D > 2048) else "pursuit_wave_kernel<%d,%d,%d,%d,%d,%d>") % (MS, MS, P, E, R, int(mode["flatten"]))   # (long rows: four wavefronts per env, madrl_amd/build.py pursuit_fast_path)
     kname = fast if kernel_kind == "wave" else "pursuit_kernel<NT>"
     catch = "surround, n_catch 2" if mode["surround"] else "co-location catch, n_catch %d" % mode["n_catch"]
     roof = roofline(bytes_per, N, kernel_ms, dt / K * 1e3, measured_traffic(per, variant, S), kname, streams=S)
