@@ -470,8 +470,8 @@ def bench_pursuit(args, variant, K, W, rank, world, dev, cpu_budget, streams=Non
         "data": "synthetic (uniform random pursuer actions resident in HBM, in-kernel Philox evaders, fused auto-reset; episode ages "
                 "start uniform over [0, %d): every step resets ~%d of its %d envs through the two-observation-pass path; %d untimed "
                 "steps before the warm-up bring the stale-zero masks of the observation rows to their equilibrium)" % (H, N // H, N, args.prep),
-        "config": dict({"workload": "PursuitEvade %dx%d %s, %d pursuers / %d evaders, obs_range %d, %s, %s, local reward, "
-                                    "%d envs per GPU, horizon %d" % (MS, MS, ("synthetic pool of %d maps, sample_maps" % n_pool) if n_pool else "rectangle_map", P, E, R, catch,
+        "config": dict({"workload": "PursuitEvade %dx%d, %d pursuers / %d evaders, obs_range %d, %s, %s, %s, local reward, "
+                                    "%d envs per GPU, horizon %d" % (MS, MS, P, E, R, ("synthetic pool of %d maps, sample_maps" % n_pool) if n_pool else "rectangle_map", catch,
                                                                      "flatten" if mode["flatten"] else "(R,R,4) observations", N, H),
                         "envs_per_gpu": N, "envs_total": N * world, "parallelism": "env-sharded x%d" % world,
                         "streams_per_gpu": S, "envs_per_launch": per, "prep_steps": args.prep,
@@ -838,7 +838,7 @@ def compact_line(out):
             if "error" in w:
                 line["workloads"][name] = {"error": w["error"][:200]}
                 continue
-            e = {"value": _r(float(w["value"])), "ms_per_step": _r(float(w["ms_per_step"])), "steps": w["steps"], "workload": w["config"]["workload"][:72],
+            e = {"value": _r(float(w["value"])), "ms_per_step": _r(float(w["ms_per_step"])), "steps": w["steps"], "workload": w["config"]["workload"][:56],
                  "envs": w["config"]["envs_per_gpu"], "streams": w["config"]["streams_per_gpu"], "roofline": compact_roofline(w["roofline"], side=True)}
             if "cpu_baseline" in w:
                 e["cpu_baseline"] = {"value": _r(float(w["cpu_baseline"]["value"])), "cores": w["cpu_baseline"]["cores"], "kind": w["cpu_baseline"]["kind"]}
