@@ -108,7 +108,10 @@ enum { PH_COLLIDE = 1, PH_SOLVE = 2, PH_TOI = 4, PH_ALL = 7 };
 #endif
 constexpr int waves_of(int ph) { return (ph == PH_SOLVE && MADRL_MW_SOLVE_2W) ? 2 : MADRL_MW_SOLVE_WAVES; }
 constexpr int mreg_of(int ph) { return (ph == PH_SOLVE && MADRL_MW_SOLVE_2W) ? 0 : MADRL_MW_SOLVE_MREG; }
-constexpr int overflow_of(int ph) { return (ph == PH_SOLVE && MADRL_MW_SOLVE_2W) ? 14 : MADRL_MW_SOLVE_OVERFLOW; }
+#ifndef MADRL_MW_SOLVE_2W_COPIES
+#define MADRL_MW_SOLVE_2W_COPIES 14   // LDS working copies per env of that launch
+#endif
+constexpr int overflow_of(int ph) { return (ph == PH_SOLVE && MADRL_MW_SOLVE_2W) ? MADRL_MW_SOLVE_2W_COPIES : MADRL_MW_SOLVE_OVERFLOW; }
 constexpr int EPW = 64 / mw::SOLVE_LANES;   // envs per wavefront: one lane per walker
 constexpr int NL = mw::SOLVE_LANES;
 constexpr int HOT_BYTES = (int)((sizeof(mw::Hot) + 15) / 16 * 16);
