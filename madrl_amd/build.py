@@ -22,7 +22,8 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmadrl_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-Wno-pass-failed"]   # (`#pragma unroll` on loops whose bounds are only known in the specialised instantiations: the generic ones stay rolled)
 # per-source additions.  multiwalker: the SLP vectorizer pairs the solver's scalar float math into packed-fp32 instructions, which
 # need every loop constant replicated into register pairs -- the 180-sweep loop then runs out of VGPRs (AGPR copies, scratch)
 EXTRA_FLAGS = {"multiwalker_c": ["-fno-slp-vectorize"]}   # file-name prefix -> flags (the capacity classes multiwalker_c4 / _c8 / _c10.hip)
