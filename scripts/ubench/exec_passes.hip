@@ -1,3 +1,4 @@
+// (Read exec_passes3.hip with this: the 4x found here for masks of <= 8 lanes sets in only after ~0.3 ms of NOTHING BUT narrow masks on a SIMD.)
 // Does a wave64 VALU instruction cost fewer cycles when whole 16-lane quarters of the exec mask are off?  One wavefront per SIMD runs a chain of
 // dependent v_mul_f32 / v_add_f32 under exec masks with 1, 2, 3, 4 non-empty quarters (and with the active lanes SPREAD over all quarters).
 //   hipcc --offload-arch=gfx950 -O3 -o exec_passes exec_passes.hip && ./exec_passes
