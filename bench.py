@@ -44,6 +44,9 @@ if ROOT not in sys.path:
 # the sub-batch streams of a GPU (madrl_amd/sharded.py) must not share a hardware queue: ROCm multiplexes HIP streams onto
 # GPU_MAX_HW_QUEUES queues (4 by default); read by the HIP runtime when it starts, so set before torch is imported
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (without it RCCL fails with `hipIpcGetMemHandle: invalid argument`);
+# already exported on the build and GPU boxes -- set here too so that a bare shell gets it, before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0  # the same guide's measured copy rate (MI355X_MICROARCH.md:34-35): what a pure streaming kernel reaches
